@@ -1,0 +1,238 @@
+/*
+ * vitcap_hip.h -- C ABI of libvitcap_hip.so, the MI355X (gfx950) implementation of the ViTCAP
+ * captioning hot path (BASELINE.json north_star).
+ *
+ * The reference (jacobswan1/ViTCAP) is 100 % Python: it has no FFI/operator boundary at all, every
+ * "kernel" is a stock torch op.  Each entry point below therefore cites the
+ * reference *Python* code it replaces (file:line relative to the reference root), which is what a
+ * maintainer would swap for a ctypes call.
+ *
+ * Conventions
+ *   - plain `extern "C"`; raw device pointers; explicit sizes; no torch types.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*): no allocation, no
+ *     synchronisation, no ownership transfer -> hipGraph-capturable.
+ *   - returns 0 on success, a negative VITCAP_E* code otherwise; vitcap_last_error() returns a
+ *     thread-local message for the last failure.
+ *   - matrices are row-major; "bf16" is the 16-bit truncated-exponent brain float stored as
+ *     uint16_t; weights keep the nn.Linear layout W[N][K] (out_features x in_features).
+ */
+#ifndef VITCAP_HIP_H
+#define VITCAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITCAP_OK 0
+#define VITCAP_EINVAL (-1)   /* bad shape / alignment / null pointer        */
+#define VITCAP_ELAUNCH (-2)  /* hipLaunch / HIP runtime failure              */
+#define VITCAP_EWORKSPACE (-3) /* caller workspace too small                 */
+#define VITCAP_ESTATE (-4)   /* engine used before weights were bound        */
+
+/* epilogue activation of vitcap_gemm_bias_act */
+#define VITCAP_ACT_NONE 0
+#define VITCAP_ACT_GELU_ERF 1 /* x*0.5*(1+erf(x/sqrt2)): nn.GELU (timm vision_transformer.py:142-158) and
+                                 activations.py:16-24 `_gelu_python`                                        */
+#define VITCAP_ACT_TANH 2     /* BertPooler (modeling_bert.py:515-527)                                       */
+
+/* output dtype */
+#define VITCAP_OUT_BF16 0
+#define VITCAP_OUT_F32 1
+
+const char* vitcap_last_error(void);
+int vitcap_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] = act( A[M,K] . W[N,K]^T + bias[N] ) (+ residual)
+ *   replaces nn.Linear + activation + residual add in
+ *     timm Attention.qkv/proj, Mlp.fc1/fc2 (vision_transformer.py:150-158, 176-200, 246-247),
+ *     BertSelfAttention.query/key/value, BertSelfOutput.dense, BertIntermediate, BertOutput
+ *     (modeling_bert.py:307-313, 353-357, 402-405, 415-419), BertPooler, BertPredictionHeadTransform,
+ *     BertLMPredictionHead.decoder (modeling_bert.py:515-563) and the PatchEmbed conv written as a GEMM
+ *     (vision_transformer.py:253-275).
+ *   A, W: bf16, K % 64 == 0, lda/ldw in elements (multiples of 8, 16-byte aligned bases).
+ *   bias: fp32[N] or NULL.  residual: fp32, same row mapping as C, ldr in elements, or NULL.
+ *   C: bf16 or fp32 (out_dtype), N % 4 == 0, ldc % 4 == 0.
+ *   Row remap (patch embed writes rows b*577+1+p, adds pos_embed[1+p]):
+ *     if row_group > 0: out_row = (r / row_group) * out_group_rows + out_row_off + r % row_group
+ *                       res_row = res_periodic ? (r % row_group) : out_row
+ *     else out_row = res_row = r.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int act;
+  int out_dtype;
+  int row_group, out_group_rows, out_row_off, res_periodic;
+} vitcap_gemm_desc;
+
+int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
+                         void* C, const vitcap_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (768): y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 statistics.
+ *   replaces nn.LayerNorm in timm Block.norm1/norm2 (eps 1e-6, vision_transformer.py:352, 233-247)
+ *   and BertSelfOutput/BertOutput/BertEmbeddings/BertPredictionHeadTransform LayerNorm (eps 1e-12,
+ *   modeling_bert.py:235, 356, 418, 543).
+ *   x: fp32 [M, ldx]; y_bf16 and/or y_f32 may be NULL (at least one non-NULL), both [M,768] dense.
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                         void* y_bf16, float* y_f32, int M, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Patch gather: image [B,3,384,384] (fp32 or bf16) -> A matrix [B*576, 768] bf16 with
+ *   K index = c*256 + kh*16 + kw (the Conv2d(3,768,16,16) weight flattened), rows in (h,w) order.
+ *   replaces the implicit im2col of PatchEmbed.proj (vision_transformer.py:273-274).
+ *   Also writes the cls rows: x[b*577 + 0] = cls_token + pos_embed[0]   (vision_transformer.py:423-426)
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_patch_gather(const void* image, int image_is_bf16, void* patches_bf16, int B, void* stream);
+int vitcap_cls_rows(const float* cls_token, const float* pos_embed, float* x, int B, int rows_per_image,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense (unmasked) multi-head self-attention over packed qkv, flash style.
+ *   qkv: bf16 [B*S, 3*768], column = which*768 + head*64 + d  (timm Attention.forward reshape
+ *   (B,N,3,12,64), vision_transformer.py:176-177; decoder Q/K/V weights concatenated give the same layout)
+ *   out: bf16 [B*S, 768] = softmax(q k^T * scale) v per head, heads concatenated
+ *   (vision_transformer.py:179-200 with the all-zero mask of modeling_bert.py:1415 dropped;
+ *    modeling_bert.py:320-340 for the visual rows of the decoder, which attend visual rows only).
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Incremental decoder attention for one greedy step t (1..19), 2 query rows per sequence:
+ *   row 0 = last real token (position t-1), row 1 = [MASK] (position t).
+ *   qkv_step: bf16 [B*2, 2304]; vis_qkv: bf16 [B*S_vis, 2304] (K/V sections are the prefill cache);
+ *   text_kv: bf16 [B, max_len, 2, 768] cache of text-row K/V for this layer, row t-1 is written here.
+ *   out: bf16 [B*2, 768].
+ *   Row 0 attends visual + text rows 0..t-1; row 1 additionally attends itself
+ *   (mask of dataset.py:377-390 sliced as in modeling_bert.py:853-871; scores / 8 then softmax,
+ *   modeling_bert.py:320-336).  `vis_image_stride_rows`: rows between consecutive images in vis_qkv;
+ *   `seq_per_image` > 1 shares one image's visual K/V between several sequences (beams).
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out,
+                            int B, int S_vis, int t, int max_len, int seq_per_image, float scale,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Text embedding for step t: rows (b,0)=word[ids[b][t-1]]+pos[t-1]+type[0], (b,1)=word[MASK]+pos[t]+type[0],
+ * followed by LayerNorm(eps)   (BertEmbeddings.forward, modeling_bert.py:222-237).
+ *   word/pos/type tables bf16; ids int64 [B, max_len]; outputs x_f32 [B*2,768], x_bf16 [B*2,768].
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mask_token,
+                      const void* word_emb, const void* pos_emb, const void* type_emb,
+                      const float* gamma, const float* beta, float eps,
+                      float* x_f32, void* x_bf16, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy bookkeeping for step t over fp32 logits [B, ldl] (first V columns valid):
+ *   tok = argmax (lowest index on ties); lp = log_softmax(logits)[tok];
+ *   add = unfinished ? tok : pad; ids[b][t] = add; sum_lp += lp*unf; cnt += unf; unf &= (add != eos);
+ *   at t == max_len-1 additionally ids[b][t] = eos where still unfinished, and
+ *   logprob[b] = sum_lp / cnt is written          (modeling_utils.py:836-877).
+ *   state: int32 unfinished[B]; float sum_lp[B]; float cnt[B].  t == 1 expects the caller to have run
+ *   vitcap_greedy_init.
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_lp, float* cnt, int B, int max_len,
+                       int bos, int pad, void* stream);
+int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
+                       int max_len, int eos, int pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tag head tail: prob = sigmoid(logit); top-k (largest, sorted, lowest index first on ties);
+ *   topk_len = #(prob_topk >= thresh)        (modeling_bert.py:1428-1432)
+ *   logits fp32 [B, ldl]; out_ids int64 [B,k]; out_prob fp32 [B,k]; out_len int64 [B].  k <= 64.
+ * ---------------------------------------------------------------------------------------------- */
+int vitcap_sigmoid_topk(const float* logits, int ldl, int V, int k, float thresh, int64_t* out_ids,
+                        float* out_prob, int64_t* out_len, int B, void* stream);
+
+/* small data movers used by the engine and exposed for tests */
+int vitcap_assemble_visual(const float* hidden, const float* tag_hidden, float* vis_f32, void* vis_bf16,
+                           int B, int n_tok, void* stream);  /* modeling_bert.py:1493 */
+int vitcap_gather_rows_bf16(const float* x, int ldx_rows, void* out_bf16, int B, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine: the whole greedy captioning forward (ImageCaptioning.forward test branch,
+ *   ..._bertemb.py:87-184 -> ViTCAP.generate, modeling_bert.py:928-1059 ->
+ *   _generate_no_beam_search, modeling_utils.py:768-886) enqueued by ONE call.
+ * Weights are bound once as device pointers (packed by the host side: matrices bf16 in nn.Linear
+ * layout, decoder query/key/value concatenated to [2304,768], vocab padded to VITCAP_VOCAB_PAD rows,
+ * vectors fp32).
+ * ---------------------------------------------------------------------------------------------- */
+#define VITCAP_VOCAB 30522
+#define VITCAP_VOCAB_PAD 30592 /* 239 * 128 */
+#define VITCAP_HID 768
+#define VITCAP_NVIS 577
+#define VITCAP_MAXLEN 20
+
+typedef struct {
+  const void* qkv_w;  const float* qkv_b;    /* [2304,768] bf16, [2304] */
+  const void* proj_w; const float* proj_b;   /* [768,768]               */
+  const void* fc1_w;  const float* fc1_b;    /* [3072,768]              */
+  const void* fc2_w;  const float* fc2_b;    /* [768,3072]              */
+  const float* n1_g; const float* n1_b; const float* n2_g; const float* n2_b;
+} vitcap_vit_block_w;
+
+typedef struct {
+  const void* qkv_w;  const float* qkv_b;    /* query|key|value stacked: [2304,768] */
+  const void* ao_w;   const float* ao_b;     /* attention.output.dense [768,768]   */
+  const float* ao_g;  const float* ao_beta;  /* attention.output.LayerNorm        */
+  const void* i_w;    const float* i_b;      /* intermediate.dense [3072,768]     */
+  const void* o_w;    const float* o_b;      /* output.dense [768,3072]           */
+  const float* o_g;   const float* o_beta;   /* output.LayerNorm                  */
+} vitcap_bert_layer_w;
+
+typedef struct {
+  const void* dense_w; const float* dense_b; /* transform.dense [768,768]          */
+  const float* ln_g;   const float* ln_b;    /* transform.LayerNorm                */
+  const void* dec_w;                          /* decoder.weight [VOCAB_PAD,768], pad rows zero */
+  const float* dec_b;                         /* predictions.bias [VOCAB_PAD], pad = -1e30    */
+} vitcap_lm_head_w;
+
+typedef struct {
+  const void* patch_w; const float* patch_b;       /* [768, 768(c,kh,kw)] bf16, [768]            */
+  const float* cls_token; const float* pos_embed;  /* fp32 [768], [577,768]                      */
+  vitcap_vit_block_w blocks[12];
+  vitcap_vit_block_w tag_blocks[4];
+  const void* pooler_w; const float* pooler_b;     /* bert.pooler.dense                          */
+  vitcap_lm_head_w tag_logit;
+  const void* word_emb; const void* pos_emb; const void* type_emb; /* bf16 [VOCAB_PAD|512|2, 768] */
+  const float* emb_ln_g; const float* emb_ln_b;
+  vitcap_bert_layer_w dec[4];
+  vitcap_lm_head_w cls;
+} vitcap_weights;
+
+typedef struct vitcap_engine vitcap_engine;
+
+int vitcap_engine_create(vitcap_engine** out);
+void vitcap_engine_destroy(vitcap_engine* e);
+int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w);
+size_t vitcap_engine_workspace_bytes(int B);
+
+/* image: [B,3,384,384] fp32 or bf16, normalised as the reference's Normalize(.5,.5)
+ * out_ids int64 [B,1,20]; out_logprobs fp32 [B,1]  (what ImageCaptioning.forward returns at test time).
+ * Optional taps (may be NULL): tag_logits fp32 [B,30522], tag_topk int64 [B,50]. */
+int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B,
+                         void* workspace, size_t workspace_bytes,
+                         int64_t* out_ids, float* out_logprobs,
+                         float* tag_logits_out, int64_t* tag_topk_out, void* stream);
+
+/* Debug/parity taps into the workspace after vitcap_engine_greedy (device pointers, valid until the next
+ * call): name in {"img_feats","hidden","tag_hidden","vis","logits_last","margins"} */
+const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B);
+
+/* Stages, for profiling and per-stage parity: encoder only / prefill only / one decode step. */
+int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
+int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes,
+                         int64_t* out_ids, float* out_logprobs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITCAP_HIP_H */

@@ -1,0 +1,476 @@
+"""CPU oracle for the ViTCAP captioning hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-PyTorch (CPU, fp32) restatement of the reference algorithm for the path named by
+BASELINE.json ``north_star``.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the shipped package ``vitcap_amd``
+never does (it fails loudly when the HIP library is missing).
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference itself
+(/root/reference, with the container-only shims of SURVEY.md section 8c) on the seeded weights of
+``vitcap_amd/weights.py`` and commits its outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks every function here against those vectors.
+
+Weights are addressed by the reference's checkpoint key names (``module.bert...``,
+``module.cls...``, ``image_encoder.module...``) in a flat dict of torch
+tensors.  All dense arithmetic is delegated to ATen (nn.functional), as in the reference
+(SURVEY.md section 8c "third-party arithmetic").
+
+Two formulations of the greedy decoder are provided:
+
+* ``greedy_as_written``   -- what the reference executes: the whole 16-block ViT and the whole
+  joint sequence are recomputed at each of the 19 steps (modeling_utils.py:798-867 with
+  ``past=None``; SURVEY.md headline 4).
+* ``greedy_incremental``  -- the algebraically identical incremental form the HIP path computes
+  (encoder + visual-row decoder prefill once, 2 query rows per step against cached K/V).  With
+  ``emulate_bf16=True`` it rounds operands to bfloat16 at exactly the points where the HIP
+  kernels store bf16, so device token ids can be compared bit-for-bit.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+HID = 768
+HEADS = 12
+HD = 64
+V = 30522
+N_VIS = 577
+MAX_LEN = 20
+OD_LEN = 50
+BOS, EOS, PAD, MASK = 101, 102, 0, 103
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+def to_torch(sd_np):
+    """numpy state dict (vitcap_amd.weights.make_state_dict) -> torch fp32 tensors (shared storage kept)."""
+    out, seen = {}, {}
+    for k, v in sd_np.items():
+        if id(v) not in seen:
+            seen[id(v)] = torch.from_numpy(v)
+        out[k] = seen[id(v)]
+    return out
+
+
+def gelu_erf(x):
+    """src/layers/bert/activations.py:16-24 (`_gelu_python`) and nn.GELU in timm Mlp."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + '.weight'], sd.get(p + '.bias'))
+
+
+def _ln(sd, p, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + '.weight'], sd[p + '.bias'], eps)
+
+
+# --------------------------------------------------------------------------------------------
+# a1  patch embed + cls + pos   (timm vision_transformer.py:253-275, 411-426)
+# --------------------------------------------------------------------------------------------
+def patch_embed(sd, image):
+    p = 'image_encoder.module.'
+    x = F.conv2d(image, sd[p + 'patch_embed.proj.weight'], sd[p + 'patch_embed.proj.bias'], stride=16)
+    x = x.flatten(2).transpose(1, 2)                                        # (B,576,768) row-major (h,w)
+    cls = sd[p + 'cls_token'].expand(x.shape[0], -1, -1)
+    x = torch.cat((cls, x), dim=1) + sd[p + 'pos_embed']
+    return x                                                                # blocks=[], norm=Identity
+
+
+# --------------------------------------------------------------------------------------------
+# a2-a4  ViT block   (timm vision_transformer.py:142-250; LayerNorm eps 1e-6 at :352)
+# --------------------------------------------------------------------------------------------
+def vit_attention(sd, p, x):
+    B, N, C = x.shape
+    qkv = _lin(sd, p + '.qkv', x).reshape(B, N, 3, HEADS, C // HEADS).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (HD ** -0.5)                         # mask is all-zero (bert:1415)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    return _lin(sd, p + '.proj', x)
+
+
+def vit_mlp(sd, p, x):
+    return _lin(sd, p + '.fc2', F.gelu(_lin(sd, p + '.fc1', x)))
+
+
+def vit_block(sd, p, x):
+    x = x + vit_attention(sd, p + '.attn', _ln(sd, p + '.norm1', x, 1e-6))
+    x = x + vit_mlp(sd, p + '.mlp', _ln(sd, p + '.norm2', x, 1e-6))
+    return x
+
+
+# --------------------------------------------------------------------------------------------
+# a5  split encoder   (modeling_bert.py:458-478)
+# --------------------------------------------------------------------------------------------
+def split_encoder(sd, img_feats, depth=12, split_blocks=4):
+    h = img_feats
+    tag_h = None
+    for i in range(depth):
+        if i == depth - split_blocks:
+            tag_h = h
+        h = vit_block(sd, 'module.bert.encoder.blocks.%d' % i, h)
+    for i in range(split_blocks):
+        tag_h = vit_block(sd, 'module.bert.encoder.tag_blocks.%d' % i, tag_h)
+    return h, tag_h
+
+
+# --------------------------------------------------------------------------------------------
+# a6 / a10  pooler + LM-style head   (modeling_bert.py:515-563, 651-658)
+# --------------------------------------------------------------------------------------------
+def pooler(sd, p, hidden):
+    return torch.tanh(_lin(sd, p + '.dense', hidden[:, 0]))
+
+
+def lm_head(sd, p, x):
+    h = _lin(sd, p + '.predictions.transform.dense', x)
+    h = gelu_erf(h)
+    h = _ln(sd, p + '.predictions.transform.LayerNorm', h, 1e-12)
+    return F.linear(h, sd[p + '.predictions.decoder.weight']) + sd[p + '.predictions.bias']
+
+
+def tag_head(sd, tag_hidden, topk=50):
+    """modeling_bert.py:1424-1432.  Returns (logit, prob_topk, pred_topk, topk_len)."""
+    logit = lm_head(sd, 'module.bert.tag_logit', pooler(sd, 'module.bert.pooler', tag_hidden))
+    prob, pred = torch.sigmoid(logit).topk(topk, dim=1, largest=True)
+    return logit, prob, pred, (prob >= 0.2).sum(dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# a7  text embeddings   (modeling_bert.py:208-237, 1381-1406)
+# --------------------------------------------------------------------------------------------
+def bert_embeddings(sd, p, input_ids, position_ids=None, token_type_ids=None):
+    if position_ids is None:
+        position_ids = torch.arange(input_ids.shape[1]).unsqueeze(0).expand_as(input_ids)
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    e = (sd[p + '.word_embeddings.weight'][input_ids]
+         + sd[p + '.position_embeddings.weight'][position_ids]
+         + sd[p + '.token_type_embeddings.weight'][token_type_ids])
+    return _ln(sd, p + '.LayerNorm', e, 1e-12)
+
+
+def encode_tag_to_embedding(sd, pred_topk, cls_emb_weight=None, caption_len=20):
+    p = 'module.bert.embeddings'
+    w = cls_emb_weight if cls_emb_weight is not None else sd[p + '.word_embeddings.weight']
+    pos = (torch.arange(pred_topk.shape[1]) + caption_len).unsqueeze(0).expand_as(pred_topk)
+    e = w[pred_topk] + sd[p + '.position_embeddings.weight'][pos] + sd[p + '.token_type_embeddings.weight'][0]
+    return _ln(sd, p + '.LayerNorm', e, 1e-12)
+
+
+# --------------------------------------------------------------------------------------------
+# a9  post-LN BERT layer   (modeling_bert.py:275-437)
+# --------------------------------------------------------------------------------------------
+def bert_layer(sd, p, x, ext_mask):
+    B, S, _ = x.shape
+
+    def heads(t):
+        return t.view(B, S, HEADS, HD).permute(0, 2, 1, 3)
+    q = heads(_lin(sd, p + '.attention.self.query', x))
+    k = heads(_lin(sd, p + '.attention.self.key', x))
+    v = heads(_lin(sd, p + '.attention.self.value', x))
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(HD)
+    s = s + ext_mask
+    pr = torch.softmax(s, dim=-1)                                           # attention dropout: eval
+    ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).contiguous().view(B, S, HID)
+    a = _ln(sd, p + '.attention.output.LayerNorm', _lin(sd, p + '.attention.output.dense', ctx) + x, 1e-12)
+    i = gelu_erf(_lin(sd, p + '.intermediate.dense', a))
+    return _ln(sd, p + '.output.LayerNorm', _lin(sd, p + '.output.dense', i) + a, 1e-12)
+
+
+# --------------------------------------------------------------------------------------------
+# a8  masks   (tagger_caption_uni_pipeline_expanding_bertemb.py:57-85; dataset.py:377-390 test mode)
+# --------------------------------------------------------------------------------------------
+def test_text_inputs(batch, max_len=MAX_LEN, od_len=OD_LEN):
+    """What CaptionTensorizer emits at test time (dataset.py:218-219, 326, 377-390; notebook cell 15)."""
+    T = max_len + od_len
+    input_ids = torch.zeros(batch, T, dtype=torch.long)
+    input_ids[:, 0] = BOS
+    input_ids[:, 1:max_len - 1] = MASK
+    input_ids[:, max_len - 1] = EOS
+    am = torch.zeros(T, T)
+    am[:max_len, :max_len] = torch.tril(torch.ones(max_len, max_len))
+    attention_mask = am.unsqueeze(0).expand(batch, T, T).clone()
+    return input_ids, attention_mask
+
+
+def construct_attn_mask(attention_mask, num_img_feats):
+    """seq2seq branch of ImageCaptioning.construct_attn_mask (..._bertemb.py:57-85)."""
+    B, T, _ = attention_mask.shape
+    top = torch.cat((attention_mask, torch.ones(B, T, num_img_feats)), dim=2)
+    bottom = torch.cat((torch.zeros(B, num_img_feats, T), torch.ones(B, num_img_feats, num_img_feats)), dim=2)
+    return torch.cat((top, bottom), dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# ViTSplitCLSEmbModel.forward as written   (modeling_bert.py:1408-1516)
+# --------------------------------------------------------------------------------------------
+def joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_type_ids,
+                  tagemb='cls', topk=50, enc=None):
+    """Returns (sequence_output (B,S,768), tag_logit (B,V)).  ``enc`` may carry a precomputed
+    (hidden, tag_hidden) pair -- the encoder is a pure function of img_feats."""
+    input_ids = input_ids.clone()
+    hidden, tag_hidden = enc if enc is not None else split_encoder(sd, img_feats)
+    logit, prob, pred_topk, topk_len = tag_head(sd, tag_hidden, topk)
+    pred_topk = pred_topk.clone()
+    cls_w = sd['module.cls.predictions.decoder.weight']
+    L = input_ids.shape[1]
+    if int(topk_len[0]) + 20 <= L:                                           # :1435 branch A
+        pred_topk[:, -1] = EOS
+        emb = bert_embeddings(sd, 'module.bert.embeddings', input_ids, position_ids, token_type_ids)
+        if tagemb == 'cls':
+            tag_emb = cls_w[pred_topk]                                       # raw F.embedding (:1456)
+        else:
+            tag_emb = encode_tag_to_embedding(sd, pred_topk, None)
+        emb[:, -pred_topk.shape[1]:] = tag_emb
+    else:                                                                    # :1473 branch B
+        start_id = L - topk_len
+        input_ids[:, start_id] = EOS
+        pred_topk[:, -1] = EOS
+        if tagemb == 'cls':
+            tag_emb = encode_tag_to_embedding(sd, pred_topk, cls_w)
+        else:
+            tag_emb = bert_embeddings(sd, 'module.bert.extra_embeddings', pred_topk,
+                                      position_ids[:, -pred_topk.shape[1]:])
+        emb = bert_embeddings(sd, 'module.bert.embeddings', input_ids, position_ids, token_type_ids)
+        emb[:, -pred_topk.shape[1]:] = tag_emb
+    enc_out = torch.cat([tag_hidden[:, 0, :].unsqueeze(1), hidden], 1)       # :1493
+    am = torch.cat([attention_mask, attention_mask[:, -1].unsqueeze(1)], dim=1)
+    am = torch.cat([am, torch.ones(am.shape[0], am.shape[1], 1)], dim=2)
+    ext = (1.0 - am.unsqueeze(1)) * -10000.0                                 # :1498-1501
+    x = torch.cat((emb, enc_out), 1)
+    for i in range(4):
+        x = bert_layer(sd, 'module.bert.decoder.layer.%d' % i, x, ext)
+    return x, logit
+
+
+def encode_forward_infer(sd, input_ids, img_feats, attention_mask, position_ids, token_type_ids,
+                         tagemb='cls', enc=None):
+    """ViTCAP.encode_forward(is_training=False): class logits on all text rows (modeling_bert.py:808-812)."""
+    seq, _ = joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_type_ids, tagemb, enc=enc)
+    return lm_head(sd, 'module.cls', seq[:, :input_ids.shape[1]])
+
+
+# --------------------------------------------------------------------------------------------
+# a11/a12  greedy decode, as written   (modeling_bert.py:825-1001; modeling_utils.py:768-886)
+# --------------------------------------------------------------------------------------------
+def _remove_rows_cols(t, rs, re, cs, ce):
+    t00, t01 = t[:, :rs, :cs], t[:, :rs, ce:]
+    t10, t11 = t[:, re:, :cs], t[:, re:, ce:]
+    return torch.cat([torch.cat([t00, t01], dim=2), torch.cat([t10, t11], dim=2)], dim=1)
+
+
+def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_start_posid=20,
+                      reuse_encoder=False, return_trace=False):
+    """Reference greedy decode.  ``reuse_encoder=True`` computes the (step-invariant) ViT encoder
+    once instead of 19 times -- same numbers, used only to keep CPU tests fast."""
+    B = image.shape[0]
+    img_feats = patch_embed(sd, image)
+    input_ids0, am = test_text_inputs(B, max_length)
+    full_mask = construct_attn_mask(am, img_feats.shape[1])
+    od_label_ids = input_ids0[:, max_length:]
+    od_len = od_label_ids.shape[1]
+    od_start = max(od_labels_start_posid, max_length)
+    pos = torch.cat([torch.arange(max_length), torch.arange(od_start, od_start + od_len)])
+    full_pos = pos.unsqueeze(0).expand(B, -1)
+    full_tt = torch.zeros(B, max_length + od_len, dtype=torch.long)
+    enc = split_encoder(sd, img_feats) if reuse_encoder else None
+
+    ids = torch.full((B, 1), BOS, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    logprobs, unf_hist, trace = [], [], []
+    cur_len = 1
+    while cur_len < max_length:
+        step_ids = torch.cat([ids, torch.full((B, 1), MASK, dtype=torch.long)], dim=1)
+        curr = step_ids.shape[1]
+        mask = _remove_rows_cols(full_mask, curr, max_length, curr, max_length)
+        tt = torch.cat([full_tt[:, :curr], full_tt[:, max_length:]], dim=1)
+        pp = torch.cat([full_pos[:, :curr], full_pos[:, max_length:]], dim=1)
+        step_ids = torch.cat([step_ids, od_label_ids], dim=1)
+        logits = encode_forward_infer(sd, step_ids, img_feats, mask, pp, tt, tagemb, enc=enc)
+        nxt_logits = logits[:, cur_len, :]
+        nxt = torch.argmax(nxt_logits, dim=-1)
+        sc = torch.gather(F.log_softmax(nxt_logits, dim=-1), -1, nxt.unsqueeze(-1))
+        if return_trace:
+            top2 = nxt_logits.topk(2, dim=-1).values
+            trace.append({'logits_row': nxt_logits.clone(), 'margin': (top2[:, 0] - top2[:, 1]).clone()})
+        logprobs.append(sc)
+        unf_hist.append(unfinished)
+        add = nxt * unfinished + PAD * (1 - unfinished)
+        ids = torch.cat([ids, add.unsqueeze(-1)], dim=-1)
+        unfinished = unfinished * add.ne(EOS).long()
+        cur_len += 1
+        if unfinished.max() == 0:
+            break
+    if cur_len == max_length:
+        ids[:, -1].masked_fill_(unfinished.bool(), EOS)
+    lp = torch.cat(logprobs, dim=1)
+    uh = torch.stack(unf_hist, dim=1).float()
+    lp = (lp * uh).sum(dim=1) / uh.sum(dim=1)
+    if ids.shape[1] < max_length:
+        ids = torch.cat([ids, ids.new_full((B, max_length - ids.shape[1]), PAD)], dim=1)
+    out = (ids.unsqueeze(1), lp.unsqueeze(1))
+    return out + (trace,) if return_trace else out
+
+
+# --------------------------------------------------------------------------------------------
+# incremental formulation (what the HIP path computes); optional bf16 rounding emulation
+# --------------------------------------------------------------------------------------------
+class _R:
+    """Rounding policy: identity (fp32) or round-to-nearest-even to bfloat16 and back."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __call__(self, t):
+        return t.to(torch.bfloat16).to(torch.float32) if self.on else t
+
+
+def _rw(sd, r):
+    """Weights as the device holds them: matrices/embeddings in bf16, biases and LN params fp32."""
+    if not r.on:
+        return sd
+    out, seen = {}, {}
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            if id(v) not in seen:
+                seen[id(v)] = r(v)
+            out[k] = seen[id(v)]
+        else:
+            out[k] = v
+    return out
+
+
+def encoder_incremental(sdw, image, r):
+    """Device pipeline for a1-a5 with its rounding points.
+
+    residual stream x: fp32.  LN output, qkv, attention output, GELU output: bf16.
+    GEMMs: bf16 operands, fp32 accumulate, fp32 bias/residual epilogue.
+    Softmax: scores fp32, P rounded to bf16 before P.V, row sum accumulated from the unrounded fp32 P.
+    """
+    p = 'image_encoder.module.'
+    B = image.shape[0]
+    img = r(image)
+    patches = img.reshape(B, 3, 24, 16, 24, 16).permute(0, 2, 4, 1, 3, 5).reshape(B, 576, 768)
+    w = sdw[p + 'patch_embed.proj.weight'].reshape(768, 768)
+    x = patches @ w.t() + sdw[p + 'patch_embed.proj.bias']
+    x = torch.cat((sdw[p + 'cls_token'].expand(B, -1, -1), x), dim=1) + sdw[p + 'pos_embed']
+
+    def block(pref, x):
+        h = r(_ln(sdw, pref + '.norm1', x, 1e-6))
+        qkv = r(_lin(sdw, pref + '.attn.qkv', h))
+        o = r(attn_rounded(qkv, x.shape[1], r))
+        x = x + _lin(sdw, pref + '.attn.proj', o)
+        h = r(_ln(sdw, pref + '.norm2', x, 1e-6))
+        g = r(F.gelu(_lin(sdw, pref + '.mlp.fc1', h)))
+        return x + _lin(sdw, pref + '.mlp.fc2', g)
+
+    tag = None
+    for i in range(12):
+        if i == 8:
+            tag = x
+        x = block('module.bert.encoder.blocks.%d' % i, x)
+    for i in range(4):
+        tag = block('module.bert.encoder.tag_blocks.%d' % i, tag)
+    return x, tag
+
+
+def attn_rounded(qkv, S, r, n_q=None):
+    """softmax(QK^T/8)V over packed (B,S,2304) qkv; P rounded to bf16 for the PV product only."""
+    B = qkv.shape[0]
+    q, k, v = qkv.view(B, S, 3, HEADS, HD).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    m = s.max(dim=-1, keepdim=True).values
+    e = torch.exp(s - m)
+    o = (r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    return o.transpose(1, 2).reshape(B, S, HID)
+
+
+def _dec_w(sdw, i):
+    p = 'module.bert.decoder.layer.%d' % i
+    wqkv = torch.cat([sdw[p + '.attention.self.%s.weight' % n] for n in ('query', 'key', 'value')], 0)
+    bqkv = torch.cat([sdw[p + '.attention.self.%s.bias' % n] for n in ('query', 'key', 'value')], 0)
+    return p, wqkv, bqkv
+
+
+def _post(sdw, p, ctx, x, r):
+    """BertSelfOutput + BertIntermediate + BertOutput on rows (..., 768) with device rounding points."""
+    a = _ln(sdw, p + '.attention.output.LayerNorm', _lin(sdw, p + '.attention.output.dense', r(ctx)) + x, 1e-12)
+    i = r(gelu_erf(_lin(sdw, p + '.intermediate.dense', r(a))))
+    return _ln(sdw, p + '.output.LayerNorm', _lin(sdw, p + '.output.dense', i) + a, 1e-12)
+
+
+def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False):
+    """Greedy caption via encoder-once + visual prefill + 2-row incremental steps.
+
+    Equivalent to ``greedy_as_written`` under the shipped test mask: caption row i attends caption
+    rows <= i and all 578 visual rows; visual rows attend visual rows only; the 50 tag slots are
+    attended by nothing and their outputs are unused (SURVEY.md headline 5), so they are skipped.
+    """
+    r = _R(emulate_bf16)
+    sdw = _rw(sd, r)
+    B = image.shape[0]
+    hidden, tag_hidden = encoder_incremental(sdw, image, r)
+    vis = torch.cat([tag_hidden[:, :1], hidden], dim=1)                      # (B,578,768) fp32
+    S = vis.shape[1]
+    # ---- prefill: visual rows through the 4 decoder layers, keep per-layer K/V --------------
+    kv = []
+    x = vis
+    for i in range(4):
+        p, wqkv, bqkv = _dec_w(sdw, i)
+        qkv = r(F.linear(r(x), wqkv, bqkv))
+        kv.append((qkv[..., 768:1536].clone(), qkv[..., 1536:].clone()))
+        ctx = attn_rounded(qkv, S, r)
+        x = _post(sdw, p, ctx, x, r)
+    # ---- steps -------------------------------------------------------------------------------
+    e = 'module.bert.embeddings'
+    ids = torch.full((B, max_length), PAD, dtype=torch.long)
+    ids[:, 0] = BOS
+    unf = torch.ones(B, dtype=torch.long)
+    sum_lp = torch.zeros(B)
+    cnt = torch.zeros(B)
+    tk = [torch.zeros(B, max_length, HID) for _ in range(4)]                 # text K cache per layer
+    tv = [torch.zeros(B, max_length, HID) for _ in range(4)]
+    trace = []
+    for t in range(1, max_length):
+        tok = torch.stack([ids[:, t - 1], torch.full((B,), MASK, dtype=torch.long)], dim=1)   # (B,2)
+        pos = torch.tensor([t - 1, t])
+        x = (sdw[e + '.word_embeddings.weight'][tok] + sdw[e + '.position_embeddings.weight'][pos]
+             + sdw[e + '.token_type_embeddings.weight'][0])
+        x = _ln(sdw, e + '.LayerNorm', x, 1e-12)                             # (B,2,768) fp32
+        for i in range(4):
+            p, wqkv, bqkv = _dec_w(sdw, i)
+            qkv = r(F.linear(r(x), wqkv, bqkv))                              # (B,2,2304)
+            q = qkv[..., :768].view(B, 2, HEADS, HD).transpose(1, 2)         # (B,H,2,64)
+            tk[i][:, t - 1] = qkv[:, 0, 768:1536]
+            tv[i][:, t - 1] = qkv[:, 0, 1536:]
+            # keys: visual 578, cached text rows 0..t-1, MASK row (visible to itself only)
+            K = torch.cat([kv[i][0], tk[i][:, :t], qkv[:, 1:2, 768:1536]], dim=1)
+            Vv = torch.cat([kv[i][1], tv[i][:, :t], qkv[:, 1:2, 1536:]], dim=1)
+            Kh = K.view(B, -1, HEADS, HD).transpose(1, 2)
+            Vh = Vv.view(B, -1, HEADS, HD).transpose(1, 2)
+            s = (q @ Kh.transpose(-1, -2)) * 0.125                           # (B,H,2,S+t+1)
+            s[:, :, 0, -1] = float('-inf')                                   # row t-1 cannot see MASK row t
+            m = s.max(dim=-1, keepdim=True).values
+            ex = torch.exp(s - m)
+            ctx = (r(ex) @ Vh) / ex.sum(dim=-1, keepdim=True)
+            ctx = ctx.transpose(1, 2).reshape(B, 2, HID)
+            x = _post(sdw, p, ctx, x, r)
+        hrow = x[:, 1]                                                       # MASK row
+        c = 'module.cls.predictions'
+        h = _ln(sdw, c + '.transform.LayerNorm', gelu_erf(_lin(sdw, c + '.transform.dense', r(hrow))), 1e-12)
+        logits = F.linear(r(h), sdw[c + '.decoder.weight']) + sdw[c + '.bias']
+        nxt = torch.argmax(logits, dim=-1)
+        lp = torch.gather(F.log_softmax(logits, dim=-1), -1, nxt.unsqueeze(-1)).squeeze(-1)
+        if return_trace:
+            top2 = logits.topk(2, dim=-1).values
+            trace.append({'logits_row': logits.clone(), 'margin': (top2[:, 0] - top2[:, 1]).clone()})
+        sum_lp += lp * unf
+        cnt += unf
+        add = nxt * unf + PAD * (1 - unf)
+        ids[:, t] = add
+        unf = unf * add.ne(EOS).long()
+    ids[:, -1].masked_fill_(unf.bool(), EOS)
+    out = (ids.unsqueeze(1), (sum_lp / cnt).unsqueeze(1))
+    return out + (trace,) if return_trace else out

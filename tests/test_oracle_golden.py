@@ -1,0 +1,126 @@
+"""Pins the CPU oracle (oracle/vitcap_oracle.py) against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitcap_oracle as O
+from vitcap_amd import weights as W
+
+TOL = dict(rtol=2e-4, atol=2e-5)   # same ATen build, same op order -> differences are summation-order only
+
+
+@pytest.fixture(scope='module')
+def img():
+    return torch.from_numpy(W.gen_image_batch(2, 1234))
+
+
+@pytest.fixture(scope='module')
+def enc_out(sd_t, img):
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        feats = O.patch_embed(sd_t, img)
+        hid, tag = O.split_encoder(sd_t, feats)
+    return feats, hid, tag
+
+
+def test_recipe_matches_reference_layout(golden, sd_np):
+    vec, meta = golden
+    assert meta['keys_missing_in_reference'] == []
+    assert meta['reference_keys_not_in_recipe'] == []
+    assert meta['n_keys'] == len(sd_np) == 288
+    for k, shp in meta['key_shapes'].items():
+        assert list(sd_np[k].shape) == shp
+    for k, dg in meta['digests'].items():
+        assert W.tensor_digest(sd_np[k]) == dg, k
+
+
+def test_a1_patch_embed(golden, enc_out):
+    vec, meta = golden
+    feats = enc_out[0]
+    np.testing.assert_allclose(feats[0, :4].numpy(), vec['a1_img_feats_b0'], **TOL)
+    assert abs(float(feats.double().mean()) - meta['a1']['mean']) < 1e-6
+
+
+def test_a4_block(golden, sd_t, enc_out):
+    vec, _ = golden
+    with torch.no_grad():
+        y = O.vit_block(sd_t, 'module.bert.encoder.blocks.0', enc_out[0])
+    np.testing.assert_allclose(y[0, :3].numpy(), vec['a4_block0_rows'], **TOL)
+
+
+def test_a5_split_encoder(golden, enc_out):
+    vec, meta = golden
+    _, hid, tag = enc_out
+    np.testing.assert_allclose(hid[:, :2].numpy(), vec['a5_hidden_rows'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(tag[:, 0].numpy(), vec['a5_tag_hidden_cls'], rtol=1e-3, atol=1e-4)
+    assert abs(float(hid.double().std()) - meta['a5_hidden']['std']) < 1e-4
+
+
+def test_a6_tag_head(golden, sd_t, enc_out):
+    vec, _ = golden
+    with torch.no_grad():
+        logit, prob, pred, tl = O.tag_head(sd_t, enc_out[2])
+    np.testing.assert_allclose(logit[:, :64].numpy(), vec['a6_logit_head'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_array_equal(pred.numpy(), vec['a6_pred_topk'])
+    np.testing.assert_array_equal(tl.numpy(), vec['a6_topk_len'])
+
+
+def test_a9_bert_layer_and_a10_head(golden, sd_t):
+    vec, _ = golden
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(1, 630, 768, generator=g) * 0.5
+    m = torch.ones(1, 630, 630)
+    m[:, :52, :52] = 0
+    m[:, :2, :2] = torch.tril(torch.ones(2, 2))
+    m[:, 52:, :52] = 0
+    ext = (1.0 - m.unsqueeze(1)) * -10000.0
+    with torch.no_grad():
+        y = O.bert_layer(sd_t, 'module.bert.decoder.layer.0', xs, ext)
+        z = O.lm_head(sd_t, 'module.cls', xs[:, :3])
+    np.testing.assert_allclose(y[0, [0, 1, 2, 52, 629]].numpy(), vec['a9_rows'], **TOL)
+    np.testing.assert_allclose(z[0, :, :128].numpy(), vec['a10_logits_head'], **TOL)
+
+
+def test_step1_logits_row(golden, sd_t, img, enc_out):
+    """One full `encode_forward(is_training=False)` call of the reference (decode step 1)."""
+    vec, _ = golden
+    input_ids, am = O.test_text_inputs(1)
+    full = O.construct_attn_mask(am, 577)
+    step_ids = torch.cat([torch.tensor([[101, 103]]), input_ids[:, 20:]], 1)
+    mask = O._remove_rows_cols(full, 2, 20, 2, 20)
+    pos = torch.cat([torch.arange(2), torch.arange(20, 70)]).unsqueeze(0)
+    with torch.no_grad():
+        logits = O.encode_forward_infer(sd_t, step_ids, enc_out[0][:1], mask, pos,
+                                        torch.zeros(1, 52, dtype=torch.long),
+                                        enc=(enc_out[1][:1], enc_out[2][:1]))
+    np.testing.assert_allclose(logits[0, 1].numpy(), vec['step1_logits_row'], rtol=1e-3, atol=2e-4)
+
+
+def test_greedy_as_written_token_exact(golden, sd_t, img):
+    vec, _ = golden
+    with torch.no_grad():
+        ids, lp = O.greedy_as_written(sd_t, img, reuse_encoder=True)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_b2_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_b2_logprobs'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(ids[:1].numpy(), vec['greedy_b1_ids'])
+
+
+def test_greedy_incremental_equals_as_written(golden, sd_t, img):
+    """The incremental formulation (what the HIP path computes) reproduces the reference's tokens."""
+    vec, _ = golden
+    with torch.no_grad():
+        ids, lp, trace = O.greedy_incremental(sd_t, img, emulate_bf16=False, return_trace=True)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_b2_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_b2_logprobs'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.slow
+def test_greedy_untied_notebook_flow(golden, img):
+    """Notebook flow: tagemb=None, tie_weights=False (Loading Script.ipynb cell 10)."""
+    vec, _ = golden
+    sd = O.to_torch(W.make_state_dict(seed=0, tie_weights=False))
+    with torch.no_grad():
+        ids, lp = O.greedy_as_written(sd, img[:1], tagemb=None, reuse_encoder=True)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_untied_nocls_b1_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_untied_nocls_b1_logprobs'], rtol=1e-5, atol=1e-5)

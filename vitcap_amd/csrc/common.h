@@ -1,0 +1,65 @@
+// Shared device/host helpers for libvitcap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/vitcap_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;  // storage type
+
+#define WAVE 64
+
+void vitcap_set_error(const char* fmt, ...);
+
+#define VC_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      vitcap_set_error(__VA_ARGS__);          \
+      return VITCAP_EINVAL;                   \
+    }                                         \
+  } while (0)
+
+#define VC_LAUNCH_CHECK(name)                                                   \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      vitcap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return VITCAP_ELAUNCH;                                                    \
+    }                                                                           \
+  } while (0)
+
+// round-to-nearest-even fp32 -> bf16 (matches torch .to(bfloat16) for finite values and NaN->qNaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  // hipcc lowers the __bf16 casts to one v_cvt_pk_bf16_f32 (round-to-nearest-even)
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,230 @@
+// bf16 NT GEMM with fused epilogue for gfx950 (MI355X):  C = act(A . W^T + bias) (+ residual)
+//
+// Both operands are K-contiguous (A[M][K], W[N][K] = nn.Linear layout), which is exactly the MFMA
+// fragment layout (8 consecutive k per lane), so tiles go HBM -> LDS by `global_load_lds` (16 B per
+// lane, no VGPR round trip) and LDS -> VGPR by ds_read_b128.
+//
+// Tile: (32*WM) x (32*WN) x 64 per 256-thread workgroup (2x2 waves, each wave WM x WN MFMA tiles of
+// 16x16x32).  LDS rows are 128 B (one k-tile); 16-byte chunks are XOR-swizzled with (row & 7) so the
+// 16-lane ds_read_b128 groups hit 16 distinct slots.  global_load_lds writes lane-linear, hence the
+// swizzle is applied on the per-lane SOURCE address and again on the read (cdna guide rule 21).
+// Two LDS buffers; the next k-tile's loads are issued before the current tile's MFMAs and drained
+// once per k-tile (one barrier per tile).
+//
+// The accumulators are computed transposed (first MFMA operand = W fragment): each lane then holds
+// 4 consecutive n for one m, so bias/residual loads and the C store are 8/16-byte vectors.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  const float* bias;
+  const float* res;
+  void* C;
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int row_group, out_group_rows, out_row_off, res_periodic;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF_BYTES = A_BYTES + W_BYTES;   // buffer b: A tile at b*BUF_BYTES, W tile behind it
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware, bijective block remap: blocks that land on one XCD (id % 8) get a contiguous range of
+  // tiles, n fastest, so A row-panels are shared through that XCD's L2.
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // per-lane source rows for the staging loads (row index fixed over the k loop)
+  const int srow = lane >> 3;                        // 0..7 inside an 8-row glds piece
+  const int schunk = (lane & 7) ^ (srow & 7);        // swizzled 16-B chunk this lane fetches
+  const bf16_t* aptr[BM / 32];
+  const bf16_t* wptr[BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) {
+    int r = m0 + w * (BM / 4) + i * 8 + srow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    int r = n0 + w * (BN / 4) + i * 8 + srow;
+    r = r < p.N ? r : p.N - 1;
+    wptr[i] = p.W + (size_t)r * p.ldw + schunk * 8;
+  }
+
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i)
+      glds16(aptr[i] + k0, smem + buf * BUF_BYTES + (w * (BM / 4) + i * 8) * 128);
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i)
+      glds16(wptr[i] + k0, smem + buf * BUF_BYTES + A_BYTES + (w * (BN / 4) + i * 8) * 128);
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;       // row inside a 16-row fragment
+  const int fk = lane >> 4;         // which 8-wide k group inside a 32-wide MFMA k step
+  const int nk = p.K / BK;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) stage(buf ^ 1, (t + 1) * BK);
+    const char* la = smem + buf * BUF_BYTES + (wm * WM * 16 + frow) * 128;
+    const char* lw = smem + buf * BUF_BYTES + A_BYTES + (wn * WN * 16 + frow) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + fk) ^ (frow & 7)) * 16;
+      bf16x8 af[WM], wf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(la + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8*)(lw + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[m][n..n+3], m = frow, n = fk*4 within each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int m = m0 + wm * WM * 16 + i * 16 + frow;
+    if (m >= p.M) continue;
+    int orow = m, rrow = m;
+    if (p.row_group > 0) {
+      const int g = m / p.row_group, in = m - g * p.row_group;
+      orow = g * p.out_group_rows + p.out_row_off + in;
+      rrow = p.res_periodic ? in : orow;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const f32x4 b = *(const f32x4*)(p.bias + n);
+        v += b;
+      }
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (ACT == VITCAP_ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      if (HAS_RES) {
+        const f32x4 r = *(const f32x4*)(p.res + (size_t)rrow * p.ldr + n);
+        v += r;
+      }
+      if (OUT_F32) {
+        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
+      } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
+int launch(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt");
+  return VITCAP_OK;
+}
+
+template <int WM, int WN>
+int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+  const bool res = a.res != nullptr;
+#define CASE(ACT_, OUT_)                                                         \
+  if (act == ACT_ && out_f32 == OUT_)                                            \
+    return res ? launch<WM, WN, ACT_, OUT_, true>(a, s) : launch<WM, WN, ACT_, OUT_, false>(a, s);
+  CASE(VITCAP_ACT_NONE, 0)
+  CASE(VITCAP_ACT_NONE, 1)
+  CASE(VITCAP_ACT_GELU_ERF, 0)
+  CASE(VITCAP_ACT_GELU_ERF, 1)
+  CASE(VITCAP_ACT_TANH, 0)
+  CASE(VITCAP_ACT_TANH, 1)
+#undef CASE
+  vitcap_set_error("gemm: unsupported act %d / out %d", act, out_f32);
+  return VITCAP_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
+                                    void* C, const vitcap_gemm_desc* d, void* stream) {
+  VC_REQUIRE(A && W && C && d, "gemm: null pointer");
+  VC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+  VC_REQUIRE(d->K % 64 == 0, "gemm: K=%d must be a multiple of 64", d->K);
+  VC_REQUIRE(d->N % 4 == 0 && d->ldc % 4 == 0, "gemm: N=%d and ldc=%d must be multiples of 4", d->N, d->ldc);
+  VC_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0, "gemm: lda=%d ldw=%d must be multiples of 8", d->lda, d->ldw);
+  VC_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0,
+             "gemm: A/W/C must be 16-byte aligned");
+  VC_REQUIRE(!residual || (d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0), "gemm: residual misaligned");
+  VC_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "gemm: bias misaligned");
+  GemmArgs a;
+  a.A = (const bf16_t*)A;
+  a.W = (const bf16_t*)W;
+  a.bias = bias;
+  a.res = residual;
+  a.C = C;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = d->ldr;
+  a.row_group = d->row_group; a.out_group_rows = d->out_group_rows;
+  a.out_row_off = d->out_row_off; a.res_periodic = d->res_periodic;
+  a.tiles_m = a.tiles_n = 0;
+  hipStream_t s = (hipStream_t)stream;
+  // Small-M problems (decode steps, heads) use 64x64 tiles to put more workgroups on the chip.
+  if (d->M <= 256) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
+  return dispatch<4, 4>(a, d->act, d->out_dtype, s);
+}

@@ -1,0 +1,215 @@
+// LayerNorm / embedding+LayerNorm / small data movers (HBM-bound kernels, one wave per 768-wide row).
+//
+// D = 768 = 64 lanes x 12 elements: every lane owns three float4 (lane*4 + {0,256,512}) so each wave
+// instruction reads a contiguous 1 KiB.  Statistics are two-pass in registers (mean, then centred sum
+// of squares) in fp32, like ATen's CPU LayerNorm, then y = (x-mean)*rstd*gamma+beta.
+#include "common.h"
+
+namespace {
+
+constexpr int D768 = 768;
+
+__device__ __forceinline__ void ln_row(const f32x4 (&v)[3], const float* gamma, const float* beta, float eps,
+                                       int lane, bf16_t* yb, float* yf) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) * (1.0f / D768);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q += d * d;
+    }
+  const float var = wave_sum(q) * (1.0f / D768);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 g = *(const f32x4*)(gamma + c);
+    const f32x4 b = *(const f32x4*)(beta + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+    if (yf) *(f32x4*)(yf + c) = y;
+    if (yb) {
+      uint2 o;
+      o.x = pack2bf(y[0], y[1]);
+      o.y = pack2bf(y[2], y[3]);
+      *(uint2*)(yb + c) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+  ln_row(v, gamma, beta, eps, lane, yb ? yb + (size_t)row * D768 : nullptr, yf ? yf + (size_t)row * D768 : nullptr);
+}
+
+__device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
+  const uint2 u = *(const uint2*)p;
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+}
+
+// rows (b,0): word[ids[b][t-1]] + pos[t-1] + type[0];  rows (b,1): word[mask] + pos[t] + type[0]; then LN.
+__global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restrict__ ids, int max_len, int t,
+                                                         int mask_token, const bf16_t* __restrict__ word,
+                                                         const bf16_t* __restrict__ pos,
+                                                         const bf16_t* __restrict__ type,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row >> 1, which = row & 1;
+  const int64_t tok = which ? (int64_t)mask_token : ids[(size_t)b * max_len + (t - 1)];
+  const int p = which ? t : t - 1;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 a = ld_bf4(word + (size_t)tok * D768 + c);
+    const f32x4 q = ld_bf4(pos + (size_t)p * D768 + c);
+    const f32x4 ty = ld_bf4(type + c);
+    v[i] = (a + q) + ty;   // same association as `words + position + token_type` (modeling_bert.py:234)
+  }
+  ln_row(v, gamma, beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
+}
+
+// image [B,3,384,384] -> patches [B*576, 768], k = c*256 + kh*16 + kw.  One thread = 8 kw (16 B out).
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restrict__ image,
+                                                           bf16_t* __restrict__ out, int total_chunks) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total_chunks) return;
+  // chunk id -> (row = b*576 + ph*24 + pw, c, kh, half)
+  const int row = gid / 96, ck = gid - row * 96;      // 96 chunks of 8 per 768-wide row
+  const int c = ck >> 5, kh = (ck >> 1) & 15, half = ck & 1;
+  const int b = row / 576, pr = row - b * 576;
+  const int ph = pr / 24, pw = pr - ph * 24;
+  const size_t src = (((size_t)b * 3 + c) * 384 + (ph * 16 + kh)) * 384 + pw * 16 + half * 8;
+  uint4 o;
+  if (IN_BF16) {
+    o = *(const uint4*)((const bf16_t*)image + src);
+  } else {
+    const f32x4 lo = *(const f32x4*)((const float*)image + src);
+    const f32x4 hi = *(const f32x4*)((const float*)image + src + 4);
+    o.x = pack2bf(lo[0], lo[1]);
+    o.y = pack2bf(lo[2], lo[3]);
+    o.z = pack2bf(hi[0], hi[1]);
+    o.w = pack2bf(hi[2], hi[3]);
+  }
+  *(uint4*)(out + (size_t)row * 768 + ck * 8) = o;
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                                int rows_per_image) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < D768; c += blockDim.x) x[(size_t)b * rows_per_image * D768 + c] = cls[c] + pos[c];
+}
+
+// vis[b] = [tag_hidden[b,0], hidden[b,0..n_tok-1]]  (modeling_bert.py:1493), fp32 + bf16 copies
+__global__ __launch_bounds__(256) void assemble_visual_kernel(const float* __restrict__ hidden,
+                                                              const float* __restrict__ tag_hidden,
+                                                              float* __restrict__ vf, bf16_t* __restrict__ vb,
+                                                              int n_tok, size_t total4) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total4) return;
+  const size_t e = gid * 4;
+  const size_t row = e / D768;
+  const int c = (int)(e - row * D768);
+  const int S = n_tok + 1;
+  const size_t b = row / S;
+  const int r = (int)(row - b * S);
+  const float* src = r == 0 ? tag_hidden + (b * n_tok) * D768 + c : hidden + (b * n_tok + (r - 1)) * D768 + c;
+  const f32x4 v = *(const f32x4*)src;
+  *(f32x4*)(vf + e) = v;
+  uint2 o;
+  o.x = pack2bf(v[0], v[1]);
+  o.y = pack2bf(v[2], v[3]);
+  *(uint2*)(vb + e) = o;
+}
+
+__global__ void gather_rows_bf16_kernel(const float* __restrict__ x, int ldx_rows, bf16_t* __restrict__ out, int D) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(size_t)b * D + c] = f2bf(x[(size_t)b * ldx_rows * D + c]);
+}
+
+}  // namespace
+
+extern "C" int vitcap_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                                    void* y_bf16, float* y_f32, int M, int D, void* stream) {
+  VC_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "layernorm: null pointer");
+  VC_REQUIRE(D == D768, "layernorm: only D=768 is built (got %d)", D);
+  VC_REQUIRE(M > 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "layernorm: bad M/ldx/alignment");
+  hipLaunchKernelGGL(layernorm768_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     eps, (bf16_t*)y_bf16, y_f32, M);
+  VC_LAUNCH_CHECK("layernorm");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mask_token, const void* word_emb,
+                                 const void* pos_emb, const void* type_emb, const float* gamma, const float* beta,
+                                 float eps, float* x_f32, void* x_bf16, int B, void* stream) {
+  VC_REQUIRE(ids && word_emb && pos_emb && type_emb && gamma && beta && x_f32 && x_bf16, "embed_step: null pointer");
+  VC_REQUIRE(t >= 1 && t < max_len && B > 0, "embed_step: bad t=%d (max_len %d) or B=%d", t, max_len, B);
+  const int rows = 2 * B;
+  hipLaunchKernelGGL(embed_step_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, max_len, t,
+                     mask_token, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma,
+                     beta, eps, x_f32, (bf16_t*)x_bf16, rows);
+  VC_LAUNCH_CHECK("embed_step");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_patch_gather(const void* image, int image_is_bf16, void* patches_bf16, int B, void* stream) {
+  VC_REQUIRE(image && patches_bf16 && B > 0, "patch_gather: bad arguments");
+  const int total = B * 576 * 96;
+  if (image_is_bf16)
+    hipLaunchKernelGGL(patch_gather_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, image,
+                       (bf16_t*)patches_bf16, total);
+  else
+    hipLaunchKernelGGL(patch_gather_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, image,
+                       (bf16_t*)patches_bf16, total);
+  VC_LAUNCH_CHECK("patch_gather");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_cls_rows(const float* cls_token, const float* pos_embed, float* x, int B, int rows_per_image,
+                               void* stream) {
+  VC_REQUIRE(cls_token && pos_embed && x && B > 0, "cls_rows: bad arguments");
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cls_token, pos_embed, x,
+                     rows_per_image);
+  VC_LAUNCH_CHECK("cls_rows");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_assemble_visual(const float* hidden, const float* tag_hidden, float* vis_f32, void* vis_bf16,
+                                      int B, int n_tok, void* stream) {
+  VC_REQUIRE(hidden && tag_hidden && vis_f32 && vis_bf16 && B > 0 && n_tok > 0, "assemble_visual: bad arguments");
+  const size_t total4 = (size_t)B * (n_tok + 1) * D768 / 4;
+  hipLaunchKernelGGL(assemble_visual_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     hidden, tag_hidden, vis_f32, (bf16_t*)vis_bf16, n_tok, total4);
+  VC_LAUNCH_CHECK("assemble_visual");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_gather_rows_bf16(const float* x, int ldx_rows, void* out_bf16, int B, int D, void* stream) {
+  VC_REQUIRE(x && out_bf16 && B > 0 && D > 0, "gather_rows: bad arguments");
+  hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, ldx_rows,
+                     (bf16_t*)out_bf16, D);
+  VC_LAUNCH_CHECK("gather_rows");
+  return VITCAP_OK;
+}
