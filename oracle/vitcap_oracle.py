@@ -333,7 +333,7 @@ def _rw(sd, r):
         return sd
     out, seen = {}, {}
     for k, v in sd.items():
-        if v.dim() >= 2:
+        if v.dim() >= 2 and k.endswith('.weight'):
             if id(v) not in seen:
                 seen[id(v)] = r(v)
             out[k] = seen[id(v)]
@@ -376,15 +376,35 @@ def encoder_incremental(sdw, image, r):
     return x, tag
 
 
-def attn_rounded(qkv, S, r, n_q=None):
-    """softmax(QK^T/8)V over packed (B,S,2304) qkv; P rounded to bf16 for the PV product only."""
+C_LOG2 = float(torch.tensor(0.125, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
+
+
+def softmax_pv_rounded(s_raw, v, r):
+    """Device softmax.V: scores -> log2 domain (one fp32 multiply by fp32(0.125*log2 e)), row max rounded UP
+    to an integer so every online-softmax rescale is an exact power of two, P = exp2(t - m) in fp32, bf16(P)
+    for the product, row sum from the unrounded P.  Mathematically softmax(s/8) @ v (modeling_bert.py:320-336)."""
+    t = s_raw * C_LOG2
+    m = torch.ceil(t.max(dim=-1, keepdim=True).values)
+    e = torch.exp2(t - m)
+    return (r(e) @ v) / e.sum(dim=-1, keepdim=True)
+
+
+def attn_rounded(qkv, S, r):
+    """softmax(QK^T/8)V over packed (B,S,2304) qkv with the device's rounding points."""
     B = qkv.shape[0]
     q, k, v = qkv.view(B, S, 3, HEADS, HD).permute(2, 0, 3, 1, 4)
-    s = (q @ k.transpose(-1, -2)) * 0.125
-    m = s.max(dim=-1, keepdim=True).values
-    e = torch.exp(s - m)
-    o = (r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    o = softmax_pv_rounded(q @ k.transpose(-1, -2), v, r)
     return o.transpose(1, 2).reshape(B, S, HID)
+
+
+def tag_head_rounded(sdw, tag_hidden, r, topk=50):
+    """a6 with the device rounding points (engine.cpp encode tail)."""
+    p = 'module.bert.tag_logit.predictions'
+    pooled = r(torch.tanh(_lin(sdw, 'module.bert.pooler.dense', r(tag_hidden[:, 0]))))
+    h = _ln(sdw, p + '.transform.LayerNorm', gelu_erf(_lin(sdw, p + '.transform.dense', pooled)), 1e-12)
+    logit = F.linear(r(h), sdw[p + '.decoder.weight']) + sdw[p + '.bias']
+    prob, pred = torch.sigmoid(logit).topk(topk, dim=1, largest=True)
+    return logit, prob, pred, (prob >= 0.2).sum(dim=1)
 
 
 def _dec_w(sdw, i):
@@ -412,6 +432,7 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
     sdw = _rw(sd, r)
     B = image.shape[0]
     hidden, tag_hidden = encoder_incremental(sdw, image, r)
+    tags = tag_head_rounded(sdw, tag_hidden, r)
     vis = torch.cat([tag_hidden[:, :1], hidden], dim=1)                      # (B,578,768) fp32
     S = vis.shape[1]
     # ---- prefill: visual rows through the 4 decoder layers, keep per-layer K/V --------------
@@ -450,11 +471,9 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
             Vv = torch.cat([kv[i][1], tv[i][:, :t], qkv[:, 1:2, 1536:]], dim=1)
             Kh = K.view(B, -1, HEADS, HD).transpose(1, 2)
             Vh = Vv.view(B, -1, HEADS, HD).transpose(1, 2)
-            s = (q @ Kh.transpose(-1, -2)) * 0.125                           # (B,H,2,S+t+1)
+            s = q @ Kh.transpose(-1, -2)                                       # (B,H,2,S+t+1) raw dot products
             s[:, :, 0, -1] = float('-inf')                                   # row t-1 cannot see MASK row t
-            m = s.max(dim=-1, keepdim=True).values
-            ex = torch.exp(s - m)
-            ctx = (r(ex) @ Vh) / ex.sum(dim=-1, keepdim=True)
+            ctx = softmax_pv_rounded(s, Vh, r)
             ctx = ctx.transpose(1, 2).reshape(B, 2, HID)
             x = _post(sdw, p, ctx, x, r)
         hrow = x[:, 1]                                                       # MASK row
@@ -473,4 +492,6 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         unf = unf * add.ne(EOS).long()
     ids[:, -1].masked_fill_(unf.bool(), EOS)
     out = (ids.unsqueeze(1), (sum_lp / cnt).unsqueeze(1))
-    return out + (trace,) if return_trace else out
+    if return_trace:
+        return out + ({'steps': trace, 'hidden': hidden, 'tag_hidden': tag_hidden, 'tags': tags},)
+    return out

@@ -1,0 +1,257 @@
+"""Parity tests of every HIP kernel against the CPU oracle / plain fp32 torch, through the C ABI.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+
+Tolerances (stated per test): kernels take bf16 operands and accumulate in fp32; the reference value is
+computed in fp32 on the SAME bf16-rounded operands, so the only differences are fp32 summation order
+(~1e-6 relative) plus one bf16 rounding of the output where the kernel stores bf16 (2^-9 relative).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from vitcap_amd import ops as o
+    return o
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _close(got, want, rtol, atol, what=''):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), '%s: %d/%d elements off, max err %.3e (want max %.3e), first bad idx %s' % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(want.abs().max()),
+        bad.nonzero()[:4].tolist())
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 2304, 768), (1154, 768, 3072), (64, 768, 768),
+                                   (130, 3072, 768), (5, 128, 128)])
+def test_gemm_plain_f32_out(ops, M, N, K):
+    from vitcap_amd import _lib as L
+    a = _bf(_rand((M, K), 1)).cuda()
+    w = _bf(_rand((N, K), 2, 0.05)).cuda()
+    bias = _rand((N,), 3).cuda()
+    got = ops.gemm_bias_act(a, w, bias, act=L.ACT_NONE, out_dtype=torch.float32)
+    want = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    # fp32 accumulation of exact bf16 products: order-only differences
+    _close(got, want, 1e-4, 1e-4, 'gemm f32 %dx%dx%d' % (M, N, K))
+
+
+def test_gemm_transpose_detecting(ops):
+    """A = shifted identity, asymmetric W: catches a transposed/permuted C write (guide rule 16)."""
+    M = N = K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), (torch.arange(M) * 7 + 3) % K] = 1.0
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125.0
+    got = ops.gemm_bias_act(_bf(a).cuda(), _bf(w).cuda(), None, out_dtype=torch.float32)
+    want = _bf(a).float() @ _bf(w).float().t()
+    _close(got, want, 0, 1e-3, 'gemm permutation')
+
+
+@pytest.mark.parametrize('act', ['gelu', 'tanh'])
+def test_gemm_act_bf16_out(ops, act):
+    from vitcap_amd import _lib as L
+    M, N, K = 577, 3072, 768
+    a = _bf(_rand((M, K), 4)).cuda()
+    w = _bf(_rand((N, K), 5, 0.05)).cuda()
+    bias = _rand((N,), 6, 0.1).cuda()
+    got = ops.gemm_bias_act(a, w, bias, act=L.ACT_GELU_ERF if act == 'gelu' else L.ACT_TANH)
+    z = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    want = torch.nn.functional.gelu(z) if act == 'gelu' else torch.tanh(z)
+    assert got.dtype == torch.bfloat16
+    # one bf16 rounding of the output: 2^-8 relative, plus tiny absolute slack
+    _close(got, want, 2 ** -7, 2e-3, 'gemm ' + act)
+
+
+def test_gemm_residual_inplace(ops):
+    M, N, K = 1154, 768, 768
+    a = _bf(_rand((M, K), 7)).cuda()
+    w = _bf(_rand((N, K), 8, 0.05)).cuda()
+    bias = _rand((N,), 9, 0.1).cuda()
+    x = _rand((M, N), 10).cuda()
+    want = a.float().cpu() @ w.float().cpu().t() + bias.cpu() + x.cpu()
+    ops.gemm_bias_act(a, w, bias, residual=x, out=x)          # x <- x + a@w.T + b, in place as the engine does
+    _close(x, want, 1e-4, 1e-4, 'gemm residual in place')
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from vitcap_amd._lib import VitcapError
+    a = _bf(torch.zeros(8, 96)).cuda()
+    w = _bf(torch.zeros(16, 96)).cuda()
+    with pytest.raises(VitcapError):
+        ops.gemm_bias_act(a, w)                               # K % 64 != 0
+
+
+@pytest.mark.parametrize('eps', [1e-6, 1e-12])
+def test_layernorm(ops, eps):
+    M = 1157
+    x = (_rand((M, 768), 11, 3.0) + 0.5).cuda()
+    g = (1 + _rand((768,), 12, 0.2)).cuda()
+    b = _rand((768,), 13, 0.1).cuda()
+    yb, yf = ops.layernorm(x, g, b, eps, want_bf16=True, want_f32=True)
+    want = torch.nn.functional.layer_norm(x.cpu(), (768,), g.cpu(), b.cpu(), eps)
+    _close(yf, want, 1e-5, 1e-5, 'layernorm f32')
+    _close(yb, want, 2 ** -8, 1e-6, 'layernorm bf16')
+    assert torch.equal(yb.cpu(), yf.cpu().to(torch.bfloat16)), 'bf16 output must be RNE of the fp32 output'
+
+
+def test_patch_embed_matches_conv(ops, sd_t):
+    """patch gather + GEMM(+bias,+pos) + cls rows == PatchEmbed conv + cls + pos (a1)."""
+    from vitcap_amd import weights as W
+    from oracle import vitcap_oracle as O
+    B = 2
+    img = torch.from_numpy(W.gen_image_batch(B, 99))
+    p = 'image_encoder.module.'
+    r = O._R(True)
+    sdw = {k: (r(v) if k == p + 'patch_embed.proj.weight' else v) for k, v in sd_t.items() if k.startswith(p)}
+    want = O.patch_embed(sdw, r(img))
+    patches = ops.patch_gather(img.cuda())
+    x = torch.zeros((B * 577, 768), device='cuda')
+    from vitcap_amd._lib import lib, check
+    import ctypes as C
+    wq = _bf(sd_t[p + 'patch_embed.proj.weight'].reshape(768, 768)).cuda()
+    pos = sd_t[p + 'pos_embed'].reshape(577, 768).cuda().contiguous()
+    ops.gemm_bias_act(patches, wq, sd_t[p + 'patch_embed.proj.bias'].cuda(), residual=pos[1:], out=x,
+                      row_group=576, out_group_rows=577, out_row_off=1, res_periodic=1)
+    cls = sd_t[p + 'cls_token'].reshape(768).cuda().contiguous()
+    check(lib.vitcap_cls_rows(C.c_void_p(cls.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(x.data_ptr()), B, 577,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'cls_rows')
+    _close(x.view(B, 577, 768), want, 1e-4, 1e-4, 'patch embed')
+
+
+@pytest.mark.parametrize('B,S', [(1, 64), (2, 577), (1, 578), (3, 130)])
+def test_attn_dense(ops, B, S):
+    from oracle import vitcap_oracle as O
+    qkv = _bf(_rand((B, S, 2304), 20 + S, 2.0))
+    got = ops.attn_dense(qkv.reshape(B * S, 2304).cuda().contiguous(), B, S)
+    want_emu = O.attn_rounded(qkv.float(), S, O._R(True))               # device rounding points
+    q, k, v = qkv.float().view(B, S, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    want_ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B, S, 768)
+    # vs emulation: only summation order + 1 bf16 output rounding flip -> 1 bf16 ulp
+    _close(got.view(B, S, 768), want_emu, 2 ** -7, 2e-3, 'attn vs emulation')
+    # vs exact softmax in fp32: P rounded to bf16 inside (2^-9 relative per term, averaged)
+    _close(got.view(B, S, 768), want_ref, 2 ** -6, 4e-3, 'attn vs fp32 softmax')
+
+
+def test_attn_dense_spiked_scores(ops):
+    """Forces large running-max jumps between key tiles (guide rule 26: exercise the rescale path)."""
+    from oracle import vitcap_oracle as O
+    B, S = 1, 577
+    qkv = _bf(_rand((B, S, 2304), 77, 1.0))
+    qkv = qkv.float()
+    qkv[0, 5, :64] *= 6.0                    # query 5 head 0
+    qkv[0, 300, 768:768 + 64] = qkv[0, 5, :64] * 1.5     # key 300 aligned with it: score spike in tile 4
+    qkv[0, 570, 768:768 + 64] = qkv[0, 5, :64] * 3.0     # bigger spike in the last full tile
+    qkv = _bf(qkv)
+    got = ops.attn_dense(qkv.reshape(B * S, 2304).cuda().contiguous(), B, S)
+    want = O.attn_rounded(qkv.float(), S, O._R(True))
+    _close(got.view(B, S, 768), want, 2 ** -7, 2e-3, 'attn spiked')
+
+
+@pytest.mark.parametrize('t', [1, 2, 10, 19])
+def test_attn_decode_step(ops, t):
+    from oracle import vitcap_oracle as O
+    B, S = 3, 578
+    r = O._R(True)
+    vis = _bf(_rand((B, S, 2304), 30, 2.0))
+    step = _bf(_rand((B, 2, 2304), 31 + t, 2.0))
+    cache = _bf(_rand((B, 20, 2, 768), 32, 2.0))
+    cache_dev = cache.cuda().contiguous()
+    got = ops.attn_decode_step(step.reshape(B * 2, 2304).cuda().contiguous(), vis.reshape(B * S, 2304).cuda().contiguous(),
+                               cache_dev, B, S, t)
+    # reference: keys = visual | cached text 0..t-2 | this step's row 0 (pos t-1) | MASK row
+    K = torch.cat([vis[..., 768:1536].float(), cache[:, :t - 1, 0].float(), step[:, :, 768:1536].float()], 1)
+    V = torch.cat([vis[..., 1536:].float(), cache[:, :t - 1, 1].float(), step[:, :, 1536:].float()], 1)
+    q = step[..., :768].float().view(B, 2, 12, 64).transpose(1, 2)
+    Kh = K.view(B, -1, 12, 64).transpose(1, 2)
+    Vh = V.view(B, -1, 12, 64).transpose(1, 2)
+    s = q @ Kh.transpose(-1, -2)
+    s[:, :, 0, -1] = float('-inf')
+    want = O.softmax_pv_rounded(s, Vh, r).transpose(1, 2).reshape(B, 2, 768)
+    _close(got.view(B, 2, 768), want, 2 ** -7, 2e-3, 'attn decode t=%d' % t)
+    # cache row t-1 now holds this step's real-token K/V
+    c = cache_dev.cpu()
+    assert torch.equal(c[:, t - 1, 0], step[:, 0, 768:1536])
+    assert torch.equal(c[:, t - 1, 1], step[:, 0, 1536:])
+    if t >= 2:
+        assert torch.equal(c[:, :t - 1], cache[:, :t - 1])
+
+
+def test_embed_step(ops, sd_t):
+    from oracle import vitcap_oracle as O
+    e = 'module.bert.embeddings'
+    word = _bf(sd_t[e + '.word_embeddings.weight']).cuda()
+    pos = _bf(sd_t[e + '.position_embeddings.weight']).cuda()
+    typ = _bf(sd_t[e + '.token_type_embeddings.weight']).cuda()
+    g = sd_t[e + '.LayerNorm.weight'].cuda()
+    b = sd_t[e + '.LayerNorm.bias'].cuda()
+    B, t = 5, 7
+    ids = torch.randint(0, 30522, (B, 20), generator=torch.Generator().manual_seed(3))
+    xf, xb = ops.embed_step(ids.cuda(), t, word, pos, typ, g, b)
+    tok = torch.stack([ids[:, t - 1], torch.full((B,), 103)], 1)
+    x = (word.float().cpu()[tok] + pos.float().cpu()[torch.tensor([t - 1, t])] + typ.float().cpu()[0])
+    want = torch.nn.functional.layer_norm(x, (768,), g.cpu(), b.cpu(), 1e-12).reshape(B * 2, 768)
+    _close(xf, want, 1e-5, 1e-5, 'embed_step')
+    assert torch.equal(xb.cpu(), xf.cpu().to(torch.bfloat16))
+
+
+def test_greedy_step_bookkeeping(ops):
+    """argmax with lowest-index tie-break, log-softmax gather, EOS/pad bookkeeping (a12), bit-exact ids."""
+    B, V, ld = 6, 30522, 30592
+    g = torch.Generator().manual_seed(5)
+    st = ops.greedy_init(B)
+    ids_ref = torch.zeros(B, 20, dtype=torch.long)
+    ids_ref[:, 0] = 101
+    unf = torch.ones(B, dtype=torch.long)
+    lps, unfs = [], []
+    for t in range(1, 20):
+        logits = torch.randn(B, ld, generator=g)
+        logits[:, V:] = 1e9                        # padding columns must be ignored
+        logits[0, 777] = logits[0, 12345] = 50.0   # exact tie -> lowest index
+        if t == 4:
+            logits[1, 102] = 60.0                  # EOS for row 1
+        if t == 9:
+            logits[2, 102] = 60.0
+        ops.greedy_step(logits.cuda(), st, t)
+        row = logits[:, :V]
+        nxt = row.argmax(-1)
+        lp = torch.log_softmax(row, -1).gather(1, nxt[:, None])[:, 0]
+        lps.append(lp)
+        unfs.append(unf.clone())
+        add = nxt * unf
+        ids_ref[:, t] = add
+        unf = unf * (add != 102).long()
+    ids_ref[:, -1].masked_fill_(unf.bool(), 102)
+    lp_ref = (torch.stack(lps, 1) * torch.stack(unfs, 1).float()).sum(1) / torch.stack(unfs, 1).float().sum(1)
+    assert torch.equal(st['ids'].cpu(), ids_ref)
+    assert ids_ref[0, 1] == 777
+    _close(st['logprob'], lp_ref, 1e-5, 1e-5, 'greedy logprob')
+
+
+def test_sigmoid_topk(ops):
+    B, V, ld = 4, 30522, 30592
+    g = torch.Generator().manual_seed(8)
+    logits = torch.randn(B, ld, generator=g) * 2
+    logits[:, V:] = 100.0
+    ids, prob, ln = ops.sigmoid_topk(logits.cuda())
+    p, i = torch.sigmoid(logits[:, :V]).topk(50, dim=1)
+    assert torch.equal(ids.cpu(), i)
+    _close(prob, p, 1e-6, 1e-6, 'topk prob')
+    assert torch.equal(ln.cpu(), (p >= 0.2).sum(1))

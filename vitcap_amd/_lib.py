@@ -1,0 +1,105 @@
+"""ctypes binding of libvitcap_hip.so (the C ABI declared in include/vitcap_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C vitcap_amd/csrc``.  There is NO
+CPU fallback: if the shared object is missing or a symbol is absent, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvitcap_hip.so')
+
+VOCAB = 30522
+VOCAB_PAD = 30592
+HID = 768
+NVIS = 577
+MAXLEN = 20
+
+ACT_NONE, ACT_GELU_ERF, ACT_TANH = 0, 1, 2
+OUT_BF16, OUT_F32 = 0, 1
+
+vp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
+                                       'row_group', 'out_group_rows', 'out_row_off', 'res_periodic')]
+
+
+class VitBlockW(C.Structure):
+    _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
+                                  'n1_g', 'n1_b', 'n2_g', 'n2_b')]
+
+
+class BertLayerW(C.Structure):
+    _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'ao_w', 'ao_b', 'ao_g', 'ao_beta', 'i_w', 'i_b',
+                                  'o_w', 'o_b', 'o_g', 'o_beta')]
+
+
+class LmHeadW(C.Structure):
+    _fields_ = [(n, vp) for n in ('dense_w', 'dense_b', 'ln_g', 'ln_b', 'dec_w', 'dec_b')]
+
+
+class Weights(C.Structure):
+    _fields_ = [('patch_w', vp), ('patch_b', vp), ('cls_token', vp), ('pos_embed', vp),
+                ('blocks', VitBlockW * 12), ('tag_blocks', VitBlockW * 4),
+                ('pooler_w', vp), ('pooler_b', vp), ('tag_logit', LmHeadW),
+                ('word_emb', vp), ('pos_emb', vp), ('type_emb', vp), ('emb_ln_g', vp), ('emb_ln_b', vp),
+                ('dec', BertLayerW * 4), ('cls', LmHeadW)]
+
+
+_SIGS = {
+    'vitcap_last_error': (C.c_char_p, []),
+    'vitcap_version': (C.c_int, []),
+    'vitcap_gemm_bias_act': (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(GemmDesc), vp]),
+    'vitcap_layernorm_fwd': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, vp]),
+    'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,
+                                    C.c_int, vp]),
+    'vitcap_greedy_init': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_greedy_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, vp]),
+    'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
+    'vitcap_assemble_visual': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_gather_rows_bf16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    'vitcap_engine_create': (C.c_int, [C.POINTER(vp)]),
+    'vitcap_engine_destroy': (None, [vp]),
+    'vitcap_engine_bind_weights': (C.c_int, [vp, C.POINTER(Weights)]),
+    'vitcap_engine_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'vitcap_engine_greedy': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp]),
+    'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int]),
+    'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
+    'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class VitcapError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libvitcap_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C vitcap_amd/csrc`. There is no CPU fallback for the product path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise VitcapError('%s failed (%d): %s' % (what or 'vitcap call', rc, lib.vitcap_last_error().decode()))

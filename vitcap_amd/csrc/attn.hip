@@ -1,0 +1,345 @@
+// Attention kernels for gfx950.
+//
+// (1) attn_dense: unmasked multi-head self-attention over packed qkv (encoder blocks S=577, decoder
+//     visual prefill S=578), flash style, MFMA 32x32x16 bf16.
+//     Workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 query rows.
+//     Per 64-key tile:  S^T = K . Q^T   (A operand = K rows from LDS, B operand = Q^T held in VGPRs)
+//       -> every lane holds, for ONE query (lane & 31), 32 of the tile's 64 scores: softmax state
+//          (running max, sum, the O^T accumulator columns) is lane-local, the two half-waves only
+//          exchange their row max (one shuffle per tile).
+//     O^T += V^T . P^T          (A operand = V^T from LDS, B operand = P^T straight from the score
+//          registers: the MFMA C-layout of S^T *is* the B-operand layout of the next MFMA once the
+//          keys of each 16-key block are stored in the order [0-3, 8-11, 4-7, 12-15] in V^T).
+//     V is transposed on its way into LDS (4 keys x 4 d per thread, ds_write_b64).
+//     Softmax runs in the log2 domain with the running max rounded UP to an integer: every rescale
+//     factor is an exact power of two, so bf16(P) does not depend on the tile order (this is what
+//     makes the bf16 path reproducible by the CPU oracle's rounding emulation).
+// (2) attn_decode_step: 2 query rows per sequence against the cached visual K/V (read in place from
+//     the prefill's packed qkv buffer) plus the text K/V cache; HBM-bound, 8 lanes per key row.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim
+constexpr int NH = 12;          // heads
+constexpr int QKV_LD = 2304;    // packed row: [q | k | v] x [head][64]
+constexpr int KT = 64;          // keys per tile
+constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (conflict-free ds_read_b128)
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                         int S, float c_log2) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int qi = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
+
+  // Q^T fragments: lane holds Q[q0+qi][ds*16 + half*8 .. +7]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + qi;
+    qr = qr < S ? qr : S - 1;
+    const bf16_t* qp = base + (size_t)qr * QKV_LD + half * 8;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
+  }
+
+  // staging maps
+  const int k_key = tid >> 2, k_d = (tid & 3) * 16;             // K: 2 x 16 B per thread
+  const int v_kg = tid & 15, v_dg = tid >> 4;                   // V: 4 keys x 4 d per thread
+  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);  // permuted key slot
+
+  // prefetch registers (named scalars: arrays captured by a lambda were sent to scratch by hipcc)
+  uint4 kreg0, kreg1;
+  uint2 vreg0, vreg1, vreg2, vreg3;
+#define LOAD_TILE(kv0_)                                                                         \
+  do {                                                                                          \
+    int kr_ = (kv0_) + k_key;                                                                   \
+    kr_ = kr_ < S ? kr_ : S - 1;                                                                \
+    const bf16_t* kp_ = base + (size_t)kr_ * QKV_LD + 768 + k_d;                                \
+    kreg0 = *(const uint4*)kp_;                                                                 \
+    kreg1 = *(const uint4*)(kp_ + 8);                                                           \
+    int v0_ = (kv0_) + v_kg * 4;                                                                \
+    const int r0_ = v0_ < S ? v0_ : S - 1, r1_ = v0_ + 1 < S ? v0_ + 1 : S - 1;                 \
+    const int r2_ = v0_ + 2 < S ? v0_ + 2 : S - 1, r3_ = v0_ + 3 < S ? v0_ + 3 : S - 1;         \
+    vreg0 = *(const uint2*)(base + (size_t)r0_ * QKV_LD + 1536 + v_dg * 4);                     \
+    vreg1 = *(const uint2*)(base + (size_t)r1_ * QKV_LD + 1536 + v_dg * 4);                     \
+    vreg2 = *(const uint2*)(base + (size_t)r2_ * QKV_LD + 1536 + v_dg * 4);                     \
+    vreg3 = *(const uint2*)(base + (size_t)r3_ * QKV_LD + 1536 + v_dg * 4);                     \
+  } while (0)
+  // K rows as they are; V transposed 4x4 per thread: vregJ = V[key J][d0..d0+3] -> rows d0+dd hold keys 0..3
+#define STORE_TILE(buf_)                                                                        \
+  do {                                                                                          \
+    char* kl_ = smem + (buf_) * (2 * KT * LDS_ROW);                                             \
+    char* vl_ = kl_ + KT * LDS_ROW;                                                             \
+    *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2) = kreg0;                                         \
+    *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2 + 16) = kreg1;                                    \
+    uint2 t0_, t1_, t2_, t3_;                                                                   \
+    t0_.x = (vreg0.x & 0xffffu) | (vreg1.x << 16);                                              \
+    t0_.y = (vreg2.x & 0xffffu) | (vreg3.x << 16);                                              \
+    t1_.x = (vreg0.x >> 16) | (vreg1.x & 0xffff0000u);                                          \
+    t1_.y = (vreg2.x >> 16) | (vreg3.x & 0xffff0000u);                                          \
+    t2_.x = (vreg0.y & 0xffffu) | (vreg1.y << 16);                                              \
+    t2_.y = (vreg2.y & 0xffffu) | (vreg3.y << 16);                                              \
+    t3_.x = (vreg0.y >> 16) | (vreg1.y & 0xffff0000u);                                          \
+    t3_.y = (vreg2.y >> 16) | (vreg3.y & 0xffff0000u);                                          \
+    char* vp_ = vl_ + (v_dg * 4) * LDS_ROW + v_pos * 2;                                         \
+    *(uint2*)(vp_) = t0_;                                                                       \
+    *(uint2*)(vp_ + LDS_ROW) = t1_;                                                             \
+    *(uint2*)(vp_ + 2 * LDS_ROW) = t2_;                                                         \
+    *(uint2*)(vp_ + 3 * LDS_ROW) = t3_;                                                         \
+  } while (0)
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+  float m_i = -1e30f;   // running max, log2 domain, integer valued once set
+  float l_i = 0.f;      // this half-wave's partial row sum
+
+  const int ntiles = (S + KT - 1) / KT;
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const int kv0 = t * KT;
+    if (t + 1 < ntiles) LOAD_TILE(kv0 + KT);
+    const char* kl = smem + buf * (2 * KT * LDS_ROW);
+    const char* vl = kl + KT * LDS_ROW;
+
+    // ---- S^T = K . Q^T : two 32-key tiles
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const bf16x8 kf = *(const bf16x8*)(kl + (kt * 32 + qi) * LDS_ROW + (ds * 16 + half * 8) * 2);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], st[kt], 0, 0, 0);
+      }
+    }
+    // ---- scale to log2 domain, mask the tail, running max
+    float mx = -1e30f;
+    const bool tail = kv0 + KT > S;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = st[kt][r] * c_log2;
+        if (tail) {
+          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          v = key < S ? v : -INFINITY;
+        }
+        st[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, ceilf(mx));
+    const float alpha = fast_exp2(m_i - m_new);   // exact power of two (or 0 on the first tile)
+    m_i = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(st[kt][r] - m_new);
+        st[kt][r] = pv;
+        psum += pv;
+      }
+    l_i = l_i * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+
+    // ---- O^T += V^T . P^T over the four 16-key blocks
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int kt = kb >> 1, ks = kb & 1;
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 vf = *(const bf16x8*)(vl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+
+#undef LOAD_TILE
+#undef STORE_TILE
+  // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]
+  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + qi;
+  if (q < S) {
+    bf16_t* op = out + ((size_t)b * S + q) * 768 + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 o;
+        o.x = pack2bf(ot[dt][g * 4 + 0] * inv, ot[dt][g * 4 + 1] * inv);
+        o.y = pack2bf(ot[dt][g * 4 + 2] * inv, ot[dt][g * 4 + 3] * inv);
+        *(uint2*)(op + dt * 32 + g * 8) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode step.  One workgroup (256 threads) per (sequence, head).  Keys: S_vis visual rows (packed
+// qkv buffer of the prefill), text rows 0..t-2 from the cache, text row t-1 (this step's row 0) and,
+// for query row 1 only, this step's row 1 ([MASK]).  8 lanes share one key row (16 B each).
+// Two passes over the scores: they are staged in LDS (<= 640 keys x 2 rows fp32) so the softmax uses
+// the exact row max like the oracle.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXKEYS = 640;
+
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv_step,
+                                                          const bf16_t* __restrict__ vis_qkv,
+                                                          bf16_t* __restrict__ text_kv, bf16_t* __restrict__ out,
+                                                          int S_vis, int t, int max_len, int seq_per_image,
+                                                          float c_log2) {
+  __shared__ float sc[2][MAXKEYS];
+  __shared__ float red[2][4];
+  __shared__ float oacc[4][2][HD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int img = b / seq_per_image;
+  const int sub = lane & 7;          // which 8-wide d slice
+  const int kslot = tid >> 3;        // 0..31: key slot within a 32-key sweep
+  const int nkeys = S_vis + t + 1;   // visual | text 0..t-1 | mask row
+
+  const bf16_t* q0p = qkv_step + ((size_t)b * 2) * QKV_LD + h * HD + sub * 8;
+  const bf16_t* q1p = q0p + QKV_LD;
+  float q0[8], q1[8];
+  {
+    const bf16x8 a = *(const bf16x8*)q0p;
+    const bf16x8 c = *(const bf16x8*)q1p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q0[j] = (float)a[j]; q1[j] = (float)c[j]; }
+  }
+  bf16_t* tkv = text_kv + (size_t)b * max_len * 2 * 768;
+  // publish this step's real-token K/V (row 0) into the cache at position t-1
+  if (tid < 16) {
+    const int which = tid >> 3;   // 0 = K, 1 = V
+    const uint4 v = *(const uint4*)(qkv_step + ((size_t)b * 2) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8);
+    *(uint4*)(tkv + ((size_t)(t - 1) * 2 + which) * 768 + h * HD + sub * 8) = v;
+  }
+  auto key_ptr = [&](int k, int which) -> const bf16_t* {   // which: 0 K, 1 V
+    if (k < S_vis) return vis_qkv + ((size_t)img * S_vis + k) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
+    const int tp = k - S_vis;
+    if (tp < t - 1) return tkv + ((size_t)tp * 2 + which) * 768 + h * HD + sub * 8;
+    return qkv_step + ((size_t)b * 2 + (tp - (t - 1))) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
+  };
+
+  // ---- pass 1: scores
+  float mx0 = -1e30f, mx1 = -1e30f;
+  for (int k = kslot; k < nkeys; k += 32) {
+    const bf16x8 kv = *(const bf16x8*)key_ptr(k, 0);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float kf = (float)kv[j];
+      d0 += q0[j] * kf;
+      d1 += q1[j] * kf;
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      d0 += __shfl_xor(d0, o, 64);
+      d1 += __shfl_xor(d1, o, 64);
+    }
+    d0 *= c_log2;
+    d1 *= c_log2;
+    if (k == nkeys - 1) d0 = -INFINITY;   // row 0 (position t-1) cannot see the [MASK] row
+    if (sub == 0) { sc[0][k] = d0; sc[1][k] = d1; }
+    mx0 = fmaxf(mx0, d0);
+    mx1 = fmaxf(mx1, d1);
+  }
+  mx0 = wave_max(mx0);
+  mx1 = wave_max(mx1);
+  if (lane == 0) { red[0][w] = mx0; red[1][w] = mx1; }
+  __syncthreads();
+  const float m0 = ceilf(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+  const float m1 = ceilf(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+
+  // ---- pass 2: P.V   (P rounded to bf16 for the product, row sum from the unrounded fp32 P)
+  float o0[8], o1[8], l0 = 0.f, l1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { o0[j] = 0.f; o1[j] = 0.f; }
+  for (int k = kslot; k < nkeys; k += 32) {
+    const bf16x8 vv = *(const bf16x8*)key_ptr(k, 1);
+    const float p0 = fast_exp2(sc[0][k] - m0), p1 = fast_exp2(sc[1][k] - m1);
+    l0 += p0;
+    l1 += p1;
+    const float p0b = (float)(__bf16)p0, p1b = (float)(__bf16)p1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float vf = (float)vv[j];
+      o0[j] += p0b * vf;
+      o1[j] += p1b * vf;
+    }
+  }
+  // reduce over the 8 key slots of the wave (lanes with equal `sub`), then over waves through LDS
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    l0 += __shfl_xor(l0, o, 64);
+    l1 += __shfl_xor(l1, o, 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j] += __shfl_xor(o0[j], o, 64);
+      o1[j] += __shfl_xor(o1[j], o, 64);
+    }
+  }
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      oacc[w][0][lane * 8 + j] = o0[j];
+      oacc[w][1][lane * 8 + j] = o1[j];
+    }
+  }
+  if (lane == 0) { red[0][w] = l0; red[1][w] = l1; }
+  __syncthreads();
+  if (tid < 128) {
+    const int r = tid >> 6, d = tid & 63;
+    const float l = (red[r][0] + red[r][1]) + (red[r][2] + red[r][3]);
+    const float o = (oacc[0][r][d] + oacc[1][r][d]) + (oacc[2][r][d] + oacc[3][r][d]);
+    out[((size_t)b * 2 + r) * 768 + h * HD + d] = f2bf(o / l);
+  }
+}
+
+}  // namespace
+
+extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream) {
+  VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");
+  VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid((S + 127) / 128, NH, B);
+  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, S,
+                     c);
+  VC_LAUNCH_CHECK("attn_dense");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B,
+                                       int S_vis, int t, int max_len, int seq_per_image, float scale, void* stream) {
+  VC_REQUIRE(qkv_step && vis_qkv && text_kv && out && B > 0, "attn_decode: bad arguments");
+  VC_REQUIRE(t >= 1 && t < max_len && S_vis + t + 1 <= MAXKEYS, "attn_decode: t=%d S_vis=%d out of range", t, S_vis);
+  VC_REQUIRE(seq_per_image >= 1 && B % seq_per_image == 0, "attn_decode: bad seq_per_image");
+  const float c = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(NH, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_step,
+                     (const bf16_t*)vis_qkv, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len, seq_per_image, c);
+  VC_LAUNCH_CHECK("attn_decode");
+  return VITCAP_OK;
+}

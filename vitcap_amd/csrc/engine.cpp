@@ -1,0 +1,322 @@
+// Engine: enqueues the whole greedy-captioning forward of ViTCAP on one HIP stream.
+//
+//   encode  : patch embed -> 8 shared ViT blocks -> fork -> 4 caption blocks + 4 tag blocks   (a1-a5)
+//             tag head (pooler, transform, 30522-way classifier, sigmoid top-50)                (a6)
+//   prefill : [tag CLS | 577 visual] rows through the 4 post-LN decoder layers ONCE; the per-layer packed
+//             qkv buffers stay resident as the visual K/V cache                                  (a8/a9)
+//   decode  : 19 steps x (2 query rows per sequence through 4 layers against the caches, LM head on the
+//             [MASK] row, device-side greedy bookkeeping) -- no host synchronisation             (a9-a12)
+//
+// The reference recomputes encode+prefill at every step (modeling_utils.py:798-867 with past=None,
+// SURVEY.md headline 4); the result is the same because visual rows never attend text rows under the
+// seq2seq mask (..._bertemb.py:57-85) and text rows attend only earlier text rows (dataset.py:377-390).
+// The 50 tag slots of the text segment are attended by nothing and their outputs are discarded
+// (SURVEY.md headline 5), so they are not materialised; the tag head itself is still computed and exposed.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/vitcap_hip.h"
+
+void vitcap_set_error(const char* fmt, ...);
+
+namespace {
+
+constexpr int D = VITCAP_HID;
+constexpr int NV = VITCAP_NVIS;        // 577
+constexpr int SV = VITCAP_NVIS + 1;    // 578 decoder visual rows (tag CLS first)
+constexpr int L = VITCAP_MAXLEN;       // 20
+constexpr int VP = VITCAP_VOCAB_PAD;
+constexpr int TOPK = 50;
+constexpr int BOS = 101, EOS = 102, PAD = 0, MASK = 103;
+
+struct Layout {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+  size_t patches, x, xt, h, qkv, mlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
+  size_t xs_f, xs_b, sqkv, sctx, stmp, sa_f, sa_b, smlp, tcache;
+  size_t hd_f, hd_b, logits;
+  size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
+  size_t ids, unf, sum_lp, cnt, margins, logprob;
+  explicit Layout(int B) {
+    const size_t b = (size_t)B;
+    patches = take(b * 576 * D * 2);
+    x = take(b * NV * D * 4);
+    xt = take(b * NV * D * 4);
+    h = take(b * SV * D * 2);
+    qkv = take(b * NV * 3 * D * 2);
+    mlp = take(b * SV * 4 * D * 2);
+    vis_f = take(b * SV * D * 4);
+    vis_b = take(b * SV * D * 2);
+    for (int l = 0; l < 4; ++l) dqkv[l] = take(b * SV * 3 * D * 2);
+    da_f = take(b * SV * D * 4);
+    da_b = take(b * SV * D * 2);
+    dtmp = take(b * SV * D * 4);
+    xs_f = take(b * 2 * D * 4);
+    xs_b = take(b * 2 * D * 2);
+    sqkv = take(b * 2 * 3 * D * 2);
+    sctx = take(b * 2 * D * 2);
+    stmp = take(b * 2 * D * 4);
+    sa_f = take(b * 2 * D * 4);
+    sa_b = take(b * 2 * D * 2);
+    smlp = take(b * 2 * 4 * D * 2);
+    tcache = take(4 * b * L * 2 * D * 2);
+    hd_f = take(b * D * 4);
+    hd_b = take(b * D * 2);
+    logits = take(b * VP * 4);
+    pool_in = take(b * D * 2);
+    pooled = take(b * D * 2);
+    tg_f = take(b * D * 4);
+    tg_b = take(b * D * 2);
+    tag_logits = take(b * VP * 4);
+    tag_ids = take(b * TOPK * 8);
+    tag_prob = take(b * TOPK * 4);
+    tag_len = take(b * 8);
+    ids = take(b * L * 8);
+    unf = take(b * 4);
+    sum_lp = take(b * 4);
+    cnt = take(b * 4);
+    margins = take(b * L * 4);
+    logprob = take(b * 4);
+  }
+};
+
+int gemm(const void* A, int lda, const void* W, const float* bias, const float* res, int ldr, void* C, int ldc, int M,
+         int N, int K, int act, int out, void* s) {
+  vitcap_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K;
+  d.lda = lda; d.ldw = K; d.ldc = ldc; d.ldr = ldr;
+  d.act = act; d.out_dtype = out;
+  return vitcap_gemm_bias_act(A, W, bias, res, C, &d, s);
+}
+
+#define CK(call)             \
+  do {                       \
+    int rc_ = (call);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+}  // namespace
+
+struct vitcap_engine {
+  vitcap_weights w;
+  bool bound = false;
+};
+
+extern "C" int vitcap_engine_create(vitcap_engine** out) {
+  if (!out) return VITCAP_EINVAL;
+  *out = new (std::nothrow) vitcap_engine();
+  return *out ? VITCAP_OK : VITCAP_EINVAL;
+}
+extern "C" void vitcap_engine_destroy(vitcap_engine* e) { delete e; }
+
+extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w) {
+  if (!e || !w) { vitcap_set_error("bind_weights: null"); return VITCAP_EINVAL; }
+  const void* const* p = (const void* const*)w;
+  for (size_t i = 0; i < sizeof(vitcap_weights) / sizeof(void*); ++i)
+    if (!p[i]) { vitcap_set_error("bind_weights: pointer #%zu of vitcap_weights is NULL", i); return VITCAP_EINVAL; }
+  e->w = *w;
+  e->bound = true;
+  return VITCAP_OK;
+}
+
+extern "C" size_t vitcap_engine_workspace_bytes(int B) { return B > 0 ? Layout(B).off : 0; }
+
+static int check(vitcap_engine* e, int B, void* ws, size_t ws_bytes) {
+  if (!e || !e->bound) { vitcap_set_error("engine: weights not bound"); return VITCAP_ESTATE; }
+  if (B <= 0 || !ws) { vitcap_set_error("engine: bad batch/workspace"); return VITCAP_EINVAL; }
+  if (((uintptr_t)ws & 255) != 0) { vitcap_set_error("engine: workspace must be 256-byte aligned"); return VITCAP_EINVAL; }
+  if (ws_bytes < Layout(B).off) {
+    vitcap_set_error("engine: workspace %zu < required %zu bytes", ws_bytes, Layout(B).off);
+    return VITCAP_EWORKSPACE;
+  }
+  return VITCAP_OK;
+}
+
+static int vit_block(const vitcap_vit_block_w& w, float* x, char* ws, const Layout& lo, int B, void* s) {
+  const int M = B * NV;
+  void* h = ws + lo.h;
+  void* qkv = ws + lo.qkv;
+  void* mlp = ws + lo.mlp;
+  CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  CK(gemm(h, D, w.qkv_w, w.qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+  CK(vitcap_attn_dense_fwd(qkv, h, B, NV, 0.125f, s));
+  CK(gemm(h, D, w.proj_w, w.proj_b, x, D, x, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  CK(vitcap_layernorm_fwd(x, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, M, D, s));
+  CK(gemm(h, D, w.fc1_w, w.fc1_b, nullptr, 0, mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
+  CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
+                                    size_t workspace_bytes, void* s) {
+  CK(check(e, B, workspace, workspace_bytes));
+  if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
+  const Layout lo(B);
+  char* ws = (char*)workspace;
+  const vitcap_weights& w = e->w;
+  float* x = (float*)(ws + lo.x);
+  float* xt = (float*)(ws + lo.xt);
+  // a1: patch embed as GEMM (+bias +pos_embed[1+p]) into rows b*577+1+p; cls rows separately
+  CK(vitcap_patch_gather(image, image_is_bf16, ws + lo.patches, B, s));
+  {
+    vitcap_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = B * 576; d.N = D; d.K = D;
+    d.lda = D; d.ldw = D; d.ldc = D; d.ldr = D;
+    d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
+    d.row_group = 576; d.out_group_rows = NV; d.out_row_off = 1; d.res_periodic = 1;
+    CK(vitcap_gemm_bias_act(ws + lo.patches, w.patch_w, w.patch_b, w.pos_embed + D, x, &d, s));
+  }
+  CK(vitcap_cls_rows(w.cls_token, w.pos_embed, x, B, NV, s));
+  // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork
+  for (int i = 0; i < 12; ++i) {
+    if (i == 8) {
+      if (hipMemcpyAsync(xt, x, (size_t)B * NV * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
+        vitcap_set_error("encode: fork copy failed");
+        return VITCAP_ELAUNCH;
+      }
+    }
+    CK(vit_block(w.blocks[i], x, ws, lo, B, s));
+  }
+  for (int i = 0; i < 4; ++i) CK(vit_block(w.tag_blocks[i], xt, ws, lo, B, s));
+  // a6: tag head on the tag branch CLS row
+  CK(vitcap_gather_rows_bf16(xt, NV, ws + lo.pool_in, B, D, s));
+  CK(gemm(ws + lo.pool_in, D, w.pooler_w, w.pooler_b, nullptr, 0, ws + lo.pooled, D, B, D, D, VITCAP_ACT_TANH,
+          VITCAP_OUT_BF16, s));
+  CK(gemm(ws + lo.pooled, D, w.tag_logit.dense_w, w.tag_logit.dense_b, nullptr, 0, ws + lo.tg_f, D, B, D, D,
+          VITCAP_ACT_GELU_ERF, VITCAP_OUT_F32, s));
+  CK(vitcap_layernorm_fwd((const float*)(ws + lo.tg_f), D, w.tag_logit.ln_g, w.tag_logit.ln_b, 1e-12f, ws + lo.tg_b,
+                          nullptr, B, D, s));
+  CK(gemm(ws + lo.tg_b, D, w.tag_logit.dec_w, w.tag_logit.dec_b, nullptr, 0, ws + lo.tag_logits, VP, B, VP, D,
+          VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  CK(vitcap_sigmoid_topk((const float*)(ws + lo.tag_logits), VP, VITCAP_VOCAB, TOPK, 0.2f, (int64_t*)(ws + lo.tag_ids),
+                         (float*)(ws + lo.tag_prob), (int64_t*)(ws + lo.tag_len), B, s));
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* s) {
+  CK(check(e, B, workspace, workspace_bytes));
+  const Layout lo(B);
+  char* ws = (char*)workspace;
+  const vitcap_weights& w = e->w;
+  const int M = B * SV;
+  float* vis_f = (float*)(ws + lo.vis_f);
+  void* vis_b = ws + lo.vis_b;
+  CK(vitcap_assemble_visual((const float*)(ws + lo.x), (const float*)(ws + lo.xt), vis_f, vis_b, B, NV, s));
+  for (int l = 0; l < 4; ++l) {
+    const vitcap_bert_layer_w& lw = w.dec[l];
+    void* dq = ws + lo.dqkv[l];
+    CK(gemm(vis_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, dq, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+    if (l == 3) break;   // the last layer's visual-row outputs feed nothing: only its K/V are needed
+    CK(vitcap_attn_dense_fwd(dq, ws + lo.h, B, SV, 0.125f, s));
+    CK(gemm(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, D, ws + lo.dtmp, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+    CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,
+                            (float*)(ws + lo.da_f), M, D, s));
+    CK(gemm(ws + lo.da_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF,
+            VITCAP_OUT_BF16, s));
+    CK(gemm(ws + lo.mlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.da_f), D, ws + lo.dtmp, D, M, D, 4 * D,
+            VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+    CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.o_g, lw.o_beta, 1e-12f, vis_b, vis_f, M, D, s));
+  }
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                                    float* out_logprobs, void* s) {
+  CK(check(e, B, workspace, workspace_bytes));
+  if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
+  const Layout lo(B);
+  char* ws = (char*)workspace;
+  const vitcap_weights& w = e->w;
+  int64_t* ids = (int64_t*)(ws + lo.ids);
+  int32_t* unf = (int32_t*)(ws + lo.unf);
+  float* sum_lp = (float*)(ws + lo.sum_lp);
+  float* cnt = (float*)(ws + lo.cnt);
+  float* xs_f = (float*)(ws + lo.xs_f);
+  char* xs_b = ws + lo.xs_b;
+  const int R = 2 * B;
+  CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, B, L, BOS, PAD, s));
+  for (int t = 1; t < L; ++t) {
+    CK(vitcap_embed_step(ids, L, t, MASK, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
+                         B, s));
+    for (int l = 0; l < 4; ++l) {
+      const vitcap_bert_layer_w& lw = w.dec[l];
+      char* tc = ws + lo.tcache + (size_t)l * B * L * 2 * D * 2;
+      CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE,
+              VITCAP_OUT_BF16, s));
+      CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, B, SV, t, L, 1, 0.125f, s));
+      CK(gemm(ws + lo.sctx, D, lw.ao_w, lw.ao_b, xs_f, D, ws + lo.stmp, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+      CK(vitcap_layernorm_fwd((const float*)(ws + lo.stmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.sa_b,
+                              (float*)(ws + lo.sa_f), R, D, s));
+      CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
+              VITCAP_OUT_BF16, s));
+      CK(gemm(ws + lo.smlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.sa_f), D, ws + lo.stmp, D, R, D, 4 * D,
+              VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+      CK(vitcap_layernorm_fwd((const float*)(ws + lo.stmp), D, lw.o_g, lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
+    }
+    // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
+    CK(gemm(xs_b + D * 2, 2 * D, w.cls.dense_w, w.cls.dense_b, nullptr, 0, ws + lo.hd_f, D, B, D, D, VITCAP_ACT_GELU_ERF,
+            VITCAP_OUT_F32, s));
+    CK(vitcap_layernorm_fwd((const float*)(ws + lo.hd_f), D, w.cls.ln_g, w.cls.ln_b, 1e-12f, ws + lo.hd_b, nullptr, B, D,
+                            s));
+    CK(gemm(ws + lo.hd_b, D, w.cls.dec_w, w.cls.dec_b, nullptr, 0, ws + lo.logits, VP, B, VP, D, VITCAP_ACT_NONE,
+            VITCAP_OUT_F32, s));
+    CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
+                          (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, s));
+  }
+  if (hipMemcpyAsync(out_ids, ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
+      hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
+          hipSuccess) {
+    vitcap_set_error("decode: output copy failed");
+    return VITCAP_ELAUNCH;
+  }
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
+                                    size_t workspace_bytes, int64_t* out_ids, float* out_logprobs,
+                                    float* tag_logits_out, int64_t* tag_topk_out, void* s) {
+  CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
+  CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
+  CK(vitcap_engine_decode(e, B, workspace, workspace_bytes, out_ids, out_logprobs, s));
+  const Layout lo(B);
+  char* ws = (char*)workspace;
+  if (tag_logits_out) {
+    if (hipMemcpy2DAsync(tag_logits_out, (size_t)VITCAP_VOCAB * 4, ws + lo.tag_logits, (size_t)VP * 4,
+                         (size_t)VITCAP_VOCAB * 4, B, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
+      vitcap_set_error("greedy: tag logits copy failed");
+      return VITCAP_ELAUNCH;
+    }
+  }
+  if (tag_topk_out) {
+    if (hipMemcpyAsync(tag_topk_out, ws + lo.tag_ids, (size_t)B * TOPK * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
+        hipSuccess) {
+      vitcap_set_error("greedy: tag topk copy failed");
+      return VITCAP_ELAUNCH;
+    }
+  }
+  return VITCAP_OK;
+}
+
+extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B) {
+  if (!e || !name || !workspace || B <= 0) return nullptr;
+  const Layout lo(B);
+  char* ws = (char*)workspace;
+  if (!strcmp(name, "hidden")) return ws + lo.x;
+  if (!strcmp(name, "tag_hidden")) return ws + lo.xt;
+  if (!strcmp(name, "vis")) return ws + lo.vis_f;
+  if (!strcmp(name, "logits_last")) return ws + lo.logits;
+  if (!strcmp(name, "margins")) return ws + lo.margins;
+  if (!strcmp(name, "tag_logits")) return ws + lo.tag_logits;
+  if (!strcmp(name, "tag_prob")) return ws + lo.tag_prob;
+  if (!strcmp(name, "tag_len")) return ws + lo.tag_len;
+  if (!strcmp(name, "ids")) return ws + lo.ids;
+  return nullptr;
+}

@@ -171,7 +171,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   GemmArgs p = a;

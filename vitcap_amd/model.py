@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's model surface for the captioning hot path.
+
+``ImageCaptioning`` here plays the role of the reference's
+``src/pipelines/tagger_caption_uni_pipeline_expanding_bertemb.py:23-189 ImageCaptioning`` wrapping
+``src/layers/bert/modeling_bert.py:695 ViTCAP`` and the ``InputAsDict``-wrapped timm ViT patch embedder:
+
+* same ``state_dict()`` key names and shapes, so a reference checkpoint loads as is;
+* same call contract: ``forward(data: dict)`` -> at test time ``(ids int64 (B,1,20), logprobs fp32 (B,1))``.
+
+All arithmetic runs in the hand-written HIP kernels of libvitcap_hip.so through one C-ABI engine call
+per batch; PyTorch only owns the memory.  There is no CPU/eager fallback.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import weights as W
+from ._lib import lib, check
+
+
+class _Node(nn.Module):
+    """Anonymous container: the parameter tree only has to reproduce the reference's key names."""
+
+
+def _build_tree(root, spec, tie_weights):
+    params = {}
+    for key, (shape, _kind) in spec.items():
+        parts = key.split('.')
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        if tie_weights and key == W.TIED_DST:
+            prm = params[W.TIED_SRC]           # same Parameter object, as _tie_or_clone_weights does
+        else:
+            prm = nn.Parameter(torch.zeros(shape, dtype=torch.float32), requires_grad=False)
+        mod.register_parameter(parts[-1], prm)
+        params[key] = prm
+    return params
+
+
+class ImageCaptioning(nn.Module):
+    """ViT-B/16-384 + tag head + 4-layer BERT caption decoder, greedy decode on MI355X."""
+
+    def __init__(self, tie_weights=True, tagemb='cls', test_extra_input=None, cfg=None):
+        super().__init__()
+        self.tie_weights = tie_weights
+        self.tagemb = tagemb
+        self.cfg = cfg
+        # decode kwargs the reference passes at test time (..._bertemb.py:588-608)
+        self.test_extra_input = dict(is_decode=True, do_sample=False, bos_token_id=101, pad_token_id=0,
+                                     eos_token_ids=[102], mask_token_id=103, add_od_labels=True,
+                                     od_labels_start_posid=20, max_length=20, num_beams=1, temperature=1,
+                                     top_k=0, top_p=1, repetition_penalty=1, length_penalty=1,
+                                     num_return_sequences=1, num_keep_best=1)
+        if test_extra_input:
+            self.test_extra_input.update(test_extra_input)
+        self._params = _build_tree(self, W.state_dict_spec(), tie_weights)
+        self._engine = None
+        self._packed = None
+        self._ws = None
+        self.last_tags = None
+
+    # ---------------------------------------------------------------- weights
+    def load_recipe(self, seed=0):
+        sd = W.make_state_dict(seed=seed, tie_weights=self.tie_weights)
+        with torch.no_grad():
+            for k, v in sd.items():
+                self._params[k].copy_(torch.from_numpy(v))
+        self._packed = None
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        res = super().load_state_dict(state_dict, strict=strict)
+        self._packed = None
+        return res
+
+    def _t(self, key):
+        return self._params[key].detach()
+
+    def pack(self, device='cuda'):
+        """Re-lay the checkpoint tensors for the kernels (bf16 matrices, fused decoder QKV, padded vocab)."""
+        dev = torch.device(device)
+        keep = []
+
+        def bf(t):
+            o = t.to(device=dev, dtype=torch.float32).to(torch.bfloat16).contiguous()
+            keep.append(o)
+            return o
+
+        def f32(t):
+            o = t.to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(o)
+            return o
+
+        def ptr(t):
+            return C.c_void_p(t.data_ptr())
+
+        def pad_vocab(t):
+            o = torch.zeros((L.VOCAB_PAD,) + tuple(t.shape[1:]), dtype=torch.float32)
+            o[:t.shape[0]] = t
+            return o
+
+        w = L.Weights()
+        ie = 'image_encoder.module.'
+        w.patch_w = ptr(bf(self._t(ie + 'patch_embed.proj.weight').reshape(768, 768)))
+        w.patch_b = ptr(f32(self._t(ie + 'patch_embed.proj.bias')))
+        w.cls_token = ptr(f32(self._t(ie + 'cls_token').reshape(768)))
+        w.pos_embed = ptr(f32(self._t(ie + 'pos_embed').reshape(577, 768)))
+
+        def vit_block(dst, p):
+            dst.qkv_w = ptr(bf(self._t(p + '.attn.qkv.weight')))
+            dst.qkv_b = ptr(f32(self._t(p + '.attn.qkv.bias')))
+            dst.proj_w = ptr(bf(self._t(p + '.attn.proj.weight')))
+            dst.proj_b = ptr(f32(self._t(p + '.attn.proj.bias')))
+            dst.fc1_w = ptr(bf(self._t(p + '.mlp.fc1.weight')))
+            dst.fc1_b = ptr(f32(self._t(p + '.mlp.fc1.bias')))
+            dst.fc2_w = ptr(bf(self._t(p + '.mlp.fc2.weight')))
+            dst.fc2_b = ptr(f32(self._t(p + '.mlp.fc2.bias')))
+            dst.n1_g = ptr(f32(self._t(p + '.norm1.weight')))
+            dst.n1_b = ptr(f32(self._t(p + '.norm1.bias')))
+            dst.n2_g = ptr(f32(self._t(p + '.norm2.weight')))
+            dst.n2_b = ptr(f32(self._t(p + '.norm2.bias')))
+
+        for i in range(12):
+            vit_block(w.blocks[i], 'module.bert.encoder.blocks.%d' % i)
+        for i in range(4):
+            vit_block(w.tag_blocks[i], 'module.bert.encoder.tag_blocks.%d' % i)
+        w.pooler_w = ptr(bf(self._t('module.bert.pooler.dense.weight')))
+        w.pooler_b = ptr(f32(self._t('module.bert.pooler.dense.bias')))
+
+        def lm_head(dst, p, dec_w_packed=None):
+            dst.dense_w = ptr(bf(self._t(p + '.predictions.transform.dense.weight')))
+            dst.dense_b = ptr(f32(self._t(p + '.predictions.transform.dense.bias')))
+            dst.ln_g = ptr(f32(self._t(p + '.predictions.transform.LayerNorm.weight')))
+            dst.ln_b = ptr(f32(self._t(p + '.predictions.transform.LayerNorm.bias')))
+            dw = dec_w_packed if dec_w_packed is not None else bf(pad_vocab(self._t(p + '.predictions.decoder.weight')))
+            dst.dec_w = ptr(dw)
+            dst.dec_b = ptr(f32(pad_vocab(self._t(p + '.predictions.bias'))))
+            return dw
+
+        lm_head(w.tag_logit, 'module.bert.tag_logit')
+        e = 'module.bert.embeddings'
+        word = bf(pad_vocab(self._t(e + '.word_embeddings.weight')))
+        w.word_emb = ptr(word)
+        w.pos_emb = ptr(bf(self._t(e + '.position_embeddings.weight')))
+        w.type_emb = ptr(bf(self._t(e + '.token_type_embeddings.weight')))
+        w.emb_ln_g = ptr(f32(self._t(e + '.LayerNorm.weight')))
+        w.emb_ln_b = ptr(f32(self._t(e + '.LayerNorm.bias')))
+        for i in range(4):
+            p = 'module.bert.decoder.layer.%d' % i
+            d = w.dec[i]
+            d.qkv_w = ptr(bf(torch.cat([self._t('%s.attention.self.%s.weight' % (p, n))
+                                        for n in ('query', 'key', 'value')], 0)))
+            d.qkv_b = ptr(f32(torch.cat([self._t('%s.attention.self.%s.bias' % (p, n))
+                                         for n in ('query', 'key', 'value')], 0)))
+            d.ao_w = ptr(bf(self._t(p + '.attention.output.dense.weight')))
+            d.ao_b = ptr(f32(self._t(p + '.attention.output.dense.bias')))
+            d.ao_g = ptr(f32(self._t(p + '.attention.output.LayerNorm.weight')))
+            d.ao_beta = ptr(f32(self._t(p + '.attention.output.LayerNorm.bias')))
+            d.i_w = ptr(bf(self._t(p + '.intermediate.dense.weight')))
+            d.i_b = ptr(f32(self._t(p + '.intermediate.dense.bias')))
+            d.o_w = ptr(bf(self._t(p + '.output.dense.weight')))
+            d.o_b = ptr(f32(self._t(p + '.output.dense.bias')))
+            d.o_g = ptr(f32(self._t(p + '.output.LayerNorm.weight')))
+            d.o_beta = ptr(f32(self._t(p + '.output.LayerNorm.bias')))
+        tied = self._params[W.TIED_DST] is self._params[W.TIED_SRC]
+        lm_head(w.cls, 'module.cls', dec_w_packed=word if tied else None)
+
+        if self._engine is None:
+            h = C.c_void_p()
+            check(lib.vitcap_engine_create(C.byref(h)), 'engine_create')
+            self._engine = h
+        check(lib.vitcap_engine_bind_weights(self._engine, C.byref(w)), 'bind_weights')
+        self._packed = (w, keep, dev)
+        return self
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                lib.vitcap_engine_destroy(self._engine)
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- forward
+    def _workspace(self, B, dev):
+        need = lib.vitcap_engine_workspace_bytes(B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws, need
+
+    def generate(self, image, want_tags=False):
+        """image: (B,3,384,384) fp32 or bf16 on the GPU, normalised with mean=.5/std=.5."""
+        if self._packed is None:
+            self.pack(image.device)
+        dev = self._packed[2]
+        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
+        assert image.dtype in (torch.float32, torch.bfloat16)
+        B = image.shape[0]
+        ws, need = self._workspace(B, dev)
+        ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
+        lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        tag_logits = torch.empty((B, L.VOCAB), dtype=torch.float32, device=dev) if want_tags else None
+        tag_topk = torch.empty((B, 50), dtype=torch.int64, device=dev) if want_tags else None
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vitcap_engine_greedy(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16),
+                                       B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
+                                       C.c_void_p(lp.data_ptr()),
+                                       C.c_void_p(tag_logits.data_ptr()) if want_tags else None,
+                                       C.c_void_p(tag_topk.data_ptr()) if want_tags else None, s), 'engine_greedy')
+        if want_tags:
+            self.last_tags = (tag_logits, tag_topk)
+        return ids, lp
+
+    def tap(self, name, B, shape, dtype=torch.float32):
+        """Copy of an engine workspace buffer after the last generate() (parity taps)."""
+        ws, _ = self._workspace(B, self._packed[2])
+        p = lib.vitcap_engine_tap(self._engine, name.encode(), C.c_void_p(ws.data_ptr()), B)
+        if not p:
+            raise KeyError(name)
+        off = p - ws.data_ptr()
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return ws[off:off + n].view(dtype).view(shape).clone()
+
+    def forward(self, data):
+        """Test-time contract of the reference wrapper (..._bertemb.py:87-184)."""
+        if self.training:
+            raise NotImplementedError('the HIP training step is not built yet; call .eval() for captioning')
+        data = dict(data.items())
+        data.pop('key', None)
+        te = self.test_extra_input
+        if te.get('num_beams', 1) != 1 or te.get('do_sample', False):
+            raise NotImplementedError('only greedy decoding (num_beams=1, do_sample=False) is built on the HIP path')
+        if te.get('max_length', 20) != L.MAXLEN:
+            raise NotImplementedError('max_length is fixed to 20 in this build')
+        return self.generate(data['image'])

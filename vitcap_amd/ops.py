@@ -1,0 +1,122 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/vitcap_hip.h).
+
+PyTorch is plumbing only: it owns device memory and the HIP stream; every computation is done by the
+hand-written kernels in libvitcap_hip.so.  All functions enqueue on ``torch.cuda.current_stream()``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_bf16(t):
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), 'expect contiguous cuda bf16 tensor'
+
+
+def _dev_f32(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'expect contiguous cuda fp32 tensor'
+
+
+def gemm_bias_act(a, w, bias=None, residual=None, act=L.ACT_NONE, out_dtype=torch.bfloat16, out=None,
+                  row_group=0, out_group_rows=0, out_row_off=0, res_periodic=0, out_rows=None):
+    """C = act(A @ W.T + bias) (+ residual).  a [M,K] bf16, w [N,K] bf16 (nn.Linear layout)."""
+    _dev_bf16(a)
+    _dev_bf16(w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((out_rows or M, N), device=a.device, dtype=out_dtype)
+    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+                   ldr=residual.stride(0) if residual is not None else 0, act=act,
+                   out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16,
+                   row_group=row_group, out_group_rows=out_group_rows, out_row_off=out_row_off,
+                   res_periodic=res_periodic)
+    check(lib.vitcap_gemm_bias_act(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), 'gemm')
+    return out
+
+
+def layernorm(x, gamma, beta, eps, want_bf16=True, want_f32=False):
+    _dev_f32(x)
+    M, D = x.shape
+    yb = torch.empty((M, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    yf = torch.empty((M, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    check(lib.vitcap_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), eps, _p(yb), _p(yf), M, D, _stream()),
+          'layernorm')
+    return yb, yf
+
+
+def patch_gather(image):
+    assert image.is_cuda and image.is_contiguous() and image.shape[1:] == (3, 384, 384)
+    B = image.shape[0]
+    out = torch.empty((B * 576, 768), device=image.device, dtype=torch.bfloat16)
+    check(lib.vitcap_patch_gather(_p(image), int(image.dtype == torch.bfloat16), _p(out), B, _stream()), 'patch_gather')
+    return out
+
+
+def attn_dense(qkv, B, S, scale=0.125):
+    _dev_bf16(qkv)
+    assert qkv.shape == (B * S, 2304)
+    out = torch.empty((B * S, 768), device=qkv.device, dtype=torch.bfloat16)
+    check(lib.vitcap_attn_dense_fwd(_p(qkv), _p(out), B, S, scale, _stream()), 'attn_dense')
+    return out
+
+
+def attn_decode_step(qkv_step, vis_qkv, text_kv, B, S_vis, t, max_len=20, seq_per_image=1, scale=0.125):
+    _dev_bf16(qkv_step)
+    _dev_bf16(vis_qkv)
+    _dev_bf16(text_kv)
+    out = torch.empty((B * 2, 768), device=qkv_step.device, dtype=torch.bfloat16)
+    check(lib.vitcap_attn_decode_step(_p(qkv_step), _p(vis_qkv), _p(text_kv), _p(out), B, S_vis, t, max_len,
+                                      seq_per_image, scale, _stream()), 'attn_decode')
+    return out
+
+
+def embed_step(ids, t, word, pos, typ, gamma, beta, eps=1e-12, mask_token=103):
+    B, max_len = ids.shape
+    xf = torch.empty((2 * B, 768), device=ids.device, dtype=torch.float32)
+    xb = torch.empty((2 * B, 768), device=ids.device, dtype=torch.bfloat16)
+    check(lib.vitcap_embed_step(_p(ids), max_len, t, mask_token, _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), eps,
+                                _p(xf), _p(xb), B, _stream()), 'embed_step')
+    return xf, xb
+
+
+def greedy_init(B, max_len=20, device='cuda', bos=101, pad=0):
+    st = dict(ids=torch.empty((B, max_len), device=device, dtype=torch.int64),
+              unf=torch.empty((B,), device=device, dtype=torch.int32),
+              sum_lp=torch.empty((B,), device=device, dtype=torch.float32),
+              cnt=torch.empty((B,), device=device, dtype=torch.float32),
+              logprob=torch.zeros((B,), device=device, dtype=torch.float32),
+              margin=torch.zeros((B, max_len), device=device, dtype=torch.float32))
+    check(lib.vitcap_greedy_init(_p(st['ids']), _p(st['unf']), _p(st['sum_lp']), _p(st['cnt']), B, max_len, bos, pad,
+                                 _stream()), 'greedy_init')
+    return st
+
+
+def greedy_step(logits, st, t, V=L.VOCAB, eos=102, pad=0):
+    _dev_f32(logits)
+    B, max_len = st['ids'].shape
+    check(lib.vitcap_greedy_step(_p(logits), logits.stride(0), V, _p(st['ids']), _p(st['unf']), _p(st['sum_lp']),
+                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), B, t, max_len, eos, pad,
+                                 _stream()), 'greedy_step')
+
+
+def sigmoid_topk(logits, k=50, thresh=0.2, V=None):
+    _dev_f32(logits)
+    B = logits.shape[0]
+    V = V or logits.shape[1]
+    ids = torch.empty((B, k), device=logits.device, dtype=torch.int64)
+    prob = torch.empty((B, k), device=logits.device, dtype=torch.float32)
+    ln = torch.empty((B,), device=logits.device, dtype=torch.int64)
+    check(lib.vitcap_sigmoid_topk(_p(logits), logits.stride(0), V, k, thresh, _p(ids), _p(prob), _p(ln), B, _stream()),
+          'sigmoid_topk')
+    return ids, prob, ln
