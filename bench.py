@@ -1,0 +1,190 @@
+"""bench.py -- images/sec, end-to-end greedy 20-token caption, ViT-B/16-384 (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the captioning hot path (patch embed -> 16 ViT blocks -> tag head -> decoder
+prefill -> 19 incremental decode steps with device-side greedy bookkeeping) over one batch of 64 synthetic
+384x384 images per GPU, already resident in HBM as bf16 (BASELINE.json configs[1]).  Inference shards by
+image with no data-path collective ("replicas only"): every rank runs its own batch;
+torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- for the dominant kernel (the 128x128x64 bf16 MFMA GEMM): algorithmic FLOPs of its launches
+                  / their summed duration, measured live with hipEvents recorded on the launch stream around
+                  every such launch inside the timed region (vitcap_engine_timing_*).
+  cpu_baseline -- the CPU oracle's restatement of the reference algorithm AS WRITTEN (full re-encode per
+                  step, fp32 eager torch) timed on this host: a bounded sample of 1 image.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+VARIANT_NAMES = {0: 'gemm_nt<128x128,bias,bf16>', 1: 'gemm_nt<128x128,bias+res,bf16>',
+                 2: 'gemm_nt<128x128,bias,f32>', 3: 'gemm_nt<128x128,bias+residual,f32>',
+                 4: 'gemm_nt<128x128,bias+gelu,bf16>', 6: 'gemm_nt<128x128,bias+gelu,f32>'}
+
+
+def cpu_baseline(max_seconds=40.0):
+    """Reference algorithm as written (19 full re-encodes) on the host cores; bounded sample."""
+    from oracle import vitcap_oracle as O       # checker / baseline only
+    from vitcap_amd import weights as W
+    sd = O.to_torch(W.make_state_dict(0, True))
+    img = torch.from_numpy(W.gen_image_batch(1, 1234))
+    cores = torch.get_num_threads()
+    times = []
+    t_all = time.time()
+    with torch.no_grad():
+        for i in range(2):
+            t0 = time.time()
+            O.greedy_as_written(sd, img)
+            times.append(time.time() - t0)
+            if time.time() - t_all > max_seconds:
+                break
+    best = min(times)
+    return {'value': 1.0 / best, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 image (BASELINE configs[0]): greedy 20-token caption, reference algorithm as written '
+                      '(ViT re-run at each of 19 steps), fp32 eager torch, best of %d runs, %.2f s/image'
+                      % (len(times), best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=0, help='replay the step from a captured hipGraph (1) or launch eagerly (0)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node == --gpus'
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from vitcap_amd import weights as W
+    from vitcap_amd._lib import lib, check
+    from vitcap_amd.model import ImageCaptioning
+
+    B = args.batch
+    model = ImageCaptioning().load_recipe(0).eval()
+    model.pack('cuda:%d' % local)
+    img = torch.from_numpy(W.gen_image_batch(B, 1234 + rank)).cuda().to(torch.bfloat16).contiguous()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream()
+    ids = lp = None
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(max(args.warmup, 1)):
+            ids, lp = model.generate(img)
+        stream.synchronize()
+        if args.graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                ids, lp = model.generate(img)
+            graph.replay()
+            stream.synchronize()
+
+        # ---- timed region: exactly K steps -------------------------------------------------------
+        use_events = graph is None
+        if use_events:
+            check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                ids, lp = model.generate(img)
+        stream.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---- live per-launch timing of the dominant kernel.  Under graph replay the events are recorded in a
+        # second, eager pass of the same K steps (events cannot be queried across replays of one graph node).
+        if not use_events:
+            check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
+            for _ in range(args.steps):
+                model.generate(img)
+            stream.synchronize()
+        ms = (C.c_double * 12)()
+        fl = (C.c_double * 12)()
+        ln = (C.c_int * 12)()
+        check(lib.vitcap_engine_timing_end(model._engine, ms, fl, ln), 'timing_end')
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_images = B * world * args.steps
+    value = total_images / elapsed
+    tot_ms = sum(ms)
+    tot_fl = sum(fl)
+    dom = max(range(12), key=lambda i: ms[i])
+    gemm_all = (tot_fl / (tot_ms * 1e-3)) / 1e12 if tot_ms > 0 else 0.0
+    dom_tf = (fl[dom] / (ms[dom] * 1e-3)) / 1e12 if ms[dom] > 0 else 0.0
+    out = {
+        'metric': 'images/sec end-to-end greedy caption (20 tok), ViT-B/16-384',
+        'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: ViT-B/16-384 greedy decode (20 tok), batch %d bf16 per GPU, '
+                               'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM' % B,
+                   'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy', 'max_length': 20,
+                   'parallelism': 'replicas x%d (no data-path collective)' % world,
+                   'launch': 'hipGraph replay' if graph is not None else 'eager'},
+        'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),
+        'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),
+        'roofline': {
+            'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),
+            'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+            'launches': int(ln[dom]), 'avg_launch_ms': round(ms[dom] / max(1, ln[dom]), 4),
+            'avg_launch_gflop': round(fl[dom] / max(1, ln[dom]) / 1e9, 3),
+            'all_large_gemm_tflops': round(gemm_all, 2),
+            'large_gemm_share_of_step_time': round(tot_ms / args.steps / (elapsed / args.steps * 1e3), 4),
+            'per_variant': {VARIANT_NAMES.get(i, str(i)): {'launches': int(ln[i]), 'ms': round(ms[i], 3),
+                                                            'tflops': round(fl[i] / (ms[i] * 1e-3) / 1e12, 2)}
+                            for i in range(12) if ln[i] > 0},
+        },
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

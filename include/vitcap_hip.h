@@ -232,6 +232,12 @@ int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t works
 int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes,
                          int64_t* out_ids, float* out_logprobs, void* stream);
 
+/* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
+ * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
+ * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */
+int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches);
+int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, int* launches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+"""CPU-side checks: the C-ABI library loads, exports every symbol include/vitcap_hip.h declares, rejects bad
+arguments without touching a GPU, and the host-side mirror keeps the reference's checkpoint layout."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(REPO, 'vitcap_amd', 'libvitcap_hip.so')):
+        g.build()
+    from vitcap_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(L):
+    hdr = open(os.path.join(REPO, 'include', 'vitcap_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(vitcap_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 20
+    raw = C.CDLL(L.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(raw, n), 'declared in include/vitcap_hip.h but not exported: ' + n
+    assert names == set(L.EXPORTS), names ^ set(L.EXPORTS)
+
+
+def test_argument_validation_without_gpu(L):
+    d = L.GemmDesc(M=8, N=16, K=96, lda=96, ldw=96, ldc=16)
+    rc = L.lib.vitcap_gemm_bias_act(None, None, None, None, None, C.byref(d), None)
+    assert rc == -1 and b'null' in L.lib.vitcap_last_error()
+    buf = (C.c_char * 4096)()
+    a = C.c_void_p((C.addressof(buf) + 255) & ~255)
+    rc = L.lib.vitcap_gemm_bias_act(a, a, None, None, a, C.byref(d), None)
+    assert rc == -1 and b'multiple of 64' in L.lib.vitcap_last_error()
+    assert L.lib.vitcap_layernorm_fwd(a, 768, a, a, 1e-6, a, None, 4, 512, None) == -1      # D != 768
+    assert L.lib.vitcap_attn_decode_step(a, a, a, a, 2, 578, 20, 20, 1, 0.125, None) == -1  # t out of range
+    assert L.lib.vitcap_sigmoid_topk(a, 30592, 30522, 65, 0.2, a, a, a, 1, None) == -1      # k > 64
+
+
+def test_engine_lifecycle_and_workspace(L):
+    h = C.c_void_p()
+    assert L.lib.vitcap_engine_create(C.byref(h)) == 0 and h.value
+    w1, w64 = L.lib.vitcap_engine_workspace_bytes(1), L.lib.vitcap_engine_workspace_bytes(64)
+    assert 0 < w1 < w64 < 64 * w1 * 1.01 and w64 % 256 == 0
+    assert L.lib.vitcap_engine_workspace_bytes(0) == 0
+    # using the engine before binding weights is an error, not a crash
+    buf = (C.c_char * 1024)()
+    a = C.c_void_p((C.addressof(buf) + 255) & ~255)
+    assert L.lib.vitcap_engine_prefill(h, 1, a, 512, None) == -4
+    w = L.Weights()
+    assert L.lib.vitcap_engine_bind_weights(h, C.byref(w)) == -1 and b'NULL' in L.lib.vitcap_last_error()
+    L.lib.vitcap_engine_destroy(h)
+
+
+def test_struct_sizes_match_header(L):
+    # every field is one pointer: 12/12/6 per block struct, total as laid out in vitcap_hip.h
+    assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
+    assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6) * 8
+    assert C.sizeof(L.GemmDesc) == 13 * 4
+
+
+def test_model_surface(L, sd_np):
+    from vitcap_amd.model import ImageCaptioning
+    m = ImageCaptioning(tie_weights=True).load_recipe(0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(sd_np.keys()) and len(sd) == 288
+    assert sd['module.bert.decoder.layer.3.attention.self.query.weight'].shape == (768, 768)
+    assert sd['image_encoder.module.patch_embed.proj.weight'].shape == (768, 3, 16, 16)
+    assert torch.equal(sd['module.bert.encoder.blocks.0.attn.qkv.weight'],
+                       torch.from_numpy(sd_np['module.bert.encoder.blocks.0.attn.qkv.weight']))
+    m2 = ImageCaptioning(tie_weights=False)
+    m2.load_state_dict(sd)                     # a tied checkpoint loads into an untied model and vice versa
+    assert m2.state_dict()['module.cls.predictions.decoder.weight'].data_ptr() != \
+        m2.state_dict()['module.bert.embeddings.word_embeddings.weight'].data_ptr()
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
+    m.eval()
+    m.test_extra_input['num_beams'] = 5
+    with pytest.raises(NotImplementedError):
+        m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
+
+
+def test_recipe_is_reproducible():
+    from vitcap_amd import weights as W
+    a = W.gen_tensor('module.cls.predictions.bias', (30522,), 'bias', 0)
+    b = W.gen_tensor('module.cls.predictions.bias', (30522,), 'bias', 0)
+    assert (a == b).all() and W.tensor_digest(a) == W.tensor_digest(b)
+    assert abs(float(a.std()) - 0.02) < 1e-3 and abs(float(a.mean())) < 1e-3
+    img4, img2 = W.gen_image_batch(4, 7), W.gen_image_batch(2, 7)
+    assert (img4[:2] == img2).all() and img4.min() >= -1 and img4.max() < 1

@@ -250,7 +250,7 @@ def test_sigmoid_topk(ops):
     g = torch.Generator().manual_seed(8)
     logits = torch.randn(B, ld, generator=g) * 2
     logits[:, V:] = 100.0
-    ids, prob, ln = ops.sigmoid_topk(logits.cuda())
+    ids, prob, ln = ops.sigmoid_topk(logits.cuda(), V=V)
     p, i = torch.sigmoid(logits[:, :V]).topk(50, dim=1)
     assert torch.equal(ids.cpu(), i)
     _close(prob, p, 1e-6, 1e-6, 'topk prob')

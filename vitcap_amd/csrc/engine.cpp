@@ -21,6 +21,25 @@
 
 void vitcap_set_error(const char* fmt, ...);
 
+#include <vector>
+
+// Optional per-launch timing of the large-tile GEMM launches (bench.py's live roofline measurement):
+// hipEvents are recorded on the SAME stream right before/after each launch; the pool is grown outside
+// the timed region by vitcap_engine_timing_begin().
+struct GemmTiming {
+  hipEvent_t start, stop;
+  int variant;      // act*4 + out_f32*2 + has_res
+  double flops;
+};
+
+struct vitcap_engine {
+  vitcap_weights w;
+  bool bound = false;
+  bool timing = false;
+  std::vector<GemmTiming> pool;
+  size_t used = 0;
+};
+
 namespace {
 
 constexpr int D = VITCAP_HID;
@@ -86,6 +105,23 @@ struct Layout {
   }
 };
 
+thread_local vitcap_engine* g_cur = nullptr;   // engine whose launches are being enqueued (timing hook)
+
+int gemm_desc(const void* A, const void* W, const float* bias, const float* res, void* C, const vitcap_gemm_desc& d,
+              void* s) {
+  vitcap_engine* e = g_cur;
+  const bool timed = e && e->timing && d.M > 256 && e->used < e->pool.size();
+  GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
+  if (t) {
+    t->variant = d.act * 4 + d.out_dtype * 2 + (res ? 1 : 0);
+    t->flops = 2.0 * d.M * d.N * d.K;
+    (void)hipEventRecord(t->start, (hipStream_t)s);
+  }
+  const int rc = vitcap_gemm_bias_act(A, W, bias, res, C, &d, s);
+  if (t) (void)hipEventRecord(t->stop, (hipStream_t)s);
+  return rc;
+}
+
 int gemm(const void* A, int lda, const void* W, const float* bias, const float* res, int ldr, void* C, int ldc, int M,
          int N, int K, int act, int out, void* s) {
   vitcap_gemm_desc d;
@@ -93,7 +129,7 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
   d.M = M; d.N = N; d.K = K;
   d.lda = lda; d.ldw = K; d.ldc = ldc; d.ldr = ldr;
   d.act = act; d.out_dtype = out;
-  return vitcap_gemm_bias_act(A, W, bias, res, C, &d, s);
+  return gemm_desc(A, W, bias, res, C, d, s);
 }
 
 #define CK(call)             \
@@ -104,17 +140,58 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
 
 }  // namespace
 
-struct vitcap_engine {
-  vitcap_weights w;
-  bool bound = false;
-};
 
 extern "C" int vitcap_engine_create(vitcap_engine** out) {
   if (!out) return VITCAP_EINVAL;
   *out = new (std::nothrow) vitcap_engine();
   return *out ? VITCAP_OK : VITCAP_EINVAL;
 }
-extern "C" void vitcap_engine_destroy(vitcap_engine* e) { delete e; }
+extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
+  if (!e) return;
+  for (auto& t : e->pool) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  delete e;
+}
+
+extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
+  if (!e || max_launches < 0) return VITCAP_EINVAL;
+  while ((int)e->pool.size() < max_launches) {
+    GemmTiming t;
+    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
+      vitcap_set_error("timing_begin: hipEventCreate failed");
+      return VITCAP_ELAUNCH;
+    }
+    t.variant = 0;
+    t.flops = 0;
+    e->pool.push_back(t);
+  }
+  e->used = 0;
+  e->timing = max_launches > 0;
+  return VITCAP_OK;
+}
+
+// Sums per GEMM epilogue variant (index = act*4 + out_f32*2 + has_res, 12 slots): milliseconds, flops, launches.
+// Synchronises on the recorded events; call after the timed region.
+extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* flops, int* launches) {
+  if (!e || !ms || !flops || !launches) return VITCAP_EINVAL;
+  for (int i = 0; i < 12; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (size_t i = 0; i < e->used; ++i) {
+    GemmTiming& t = e->pool[i];
+    float el = 0.f;
+    if (hipEventSynchronize(t.stop) != hipSuccess || hipEventElapsedTime(&el, t.start, t.stop) != hipSuccess) {
+      vitcap_set_error("timing_end: event query failed");
+      return VITCAP_ELAUNCH;
+    }
+    ms[t.variant] += el;
+    flops[t.variant] += t.flops;
+    launches[t.variant] += 1;
+  }
+  e->timing = false;
+  e->used = 0;
+  return VITCAP_OK;
+}
 
 extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w) {
   if (!e || !w) { vitcap_set_error("bind_weights: null"); return VITCAP_EINVAL; }
@@ -157,6 +234,7 @@ static int vit_block(const vitcap_vit_block_w& w, float* x, char* ws, const Layo
 extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
                                     size_t workspace_bytes, void* s) {
   CK(check(e, B, workspace, workspace_bytes));
+  g_cur = e;
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
   const Layout lo(B);
   char* ws = (char*)workspace;
@@ -172,7 +250,7 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
     d.lda = D; d.ldw = D; d.ldc = D; d.ldr = D;
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
     d.row_group = 576; d.out_group_rows = NV; d.out_row_off = 1; d.res_periodic = 1;
-    CK(vitcap_gemm_bias_act(ws + lo.patches, w.patch_w, w.patch_b, w.pos_embed + D, x, &d, s));
+    CK(gemm_desc(ws + lo.patches, w.patch_w, w.patch_b, w.pos_embed + D, x, d, s));
   }
   CK(vitcap_cls_rows(w.cls_token, w.pos_embed, x, B, NV, s));
   // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork
@@ -203,6 +281,7 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
 
 extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* s) {
   CK(check(e, B, workspace, workspace_bytes));
+  g_cur = e;
   const Layout lo(B);
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;
@@ -231,6 +310,7 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, s
 extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                                     float* out_logprobs, void* s) {
   CK(check(e, B, workspace, workspace_bytes));
+  g_cur = e;
   if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
   const Layout lo(B);
   char* ws = (char*)workspace;
