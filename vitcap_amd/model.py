@@ -86,6 +86,8 @@ class ImageCaptioning(nn.Module):
     def pack(self, device='cuda'):
         """Re-lay the checkpoint tensors for the kernels (bf16 matrices, fused decoder QKV, padded vocab)."""
         dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
         keep = []
 
         def bf(t):
