@@ -67,6 +67,9 @@ typedef struct {
   int act;
   int out_dtype;
   int row_group, out_group_rows, out_row_off, res_periodic;
+  int tile_hint; /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x128 three-stage, 4 = skinny (tuning/tests) */
+  int split_k;   /* > 1: C is fp32 [split_k][M][ldc] partial slabs (no bias/act/residual applied); the consumer
+                    (vitcap_sum_layernorm) reduces them.  K must be a multiple of 128*split_k. */
 } vitcap_gemm_desc;
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
@@ -80,6 +83,15 @@ int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const 
  *   x: fp32 [M, ldx]; y_bf16 and/or y_f32 may be NULL (at least one non-NULL), both [M,768] dense.
  * ---------------------------------------------------------------------------------------------- */
 int vitcap_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                         void* y_bf16, float* y_f32, int M, int D, void* stream);
+
+/* Fused split-K reduction + bias + residual (+ GELU) + LayerNorm for the decode-step GEMMs:
+ *   v[row] = sum_s partials[s][row] + bias (+ residual[row]);  if act_before_ln: v = gelu_erf(v);
+ *   y = LayerNorm(v)   -- BertSelfOutput / BertOutput (modeling_bert.py:353-357, 415-419) and
+ *   BertPredictionHeadTransform (modeling_bert.py:540-544) with the dense layer computed by split-K.
+ *   partials fp32 [S][M][768] (slab_stride elements apart); residual fp32 [M, ldr] or NULL. */
+int vitcap_sum_layernorm(const float* partials, int S, size_t slab_stride, const float* bias, const float* residual,
+                         int ldr, int act_before_ln, const float* gamma, const float* beta, float eps,
                          void* y_bf16, float* y_f32, int M, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -91,6 +91,39 @@ def test_gemm_residual_inplace(ops):
     _close(x, want, 1e-4, 1e-4, 'gemm residual in place')
 
 
+@pytest.mark.parametrize('M,N,K,split', [(128, 768, 768, 6), (128, 768, 3072, 12), (64, 768, 768, 6), (128, 2304, 768, 1),
+                                          (64, 30592, 768, 1), (100, 3072, 768, 1), (256, 768, 3072, 4)])
+def test_gemm_skinny_splitk(ops, M, N, K, split):
+    """Register-fed skinny kernel (decode-step GEMMs); with split-K the partial slabs must sum to the product."""
+    a = _bf(_rand((M, K), 40)).cuda()
+    w = _bf(_rand((N, K), 41, 0.05)).cuda()
+    bias = _rand((N,), 42).cuda()
+    want = a.float().cpu() @ w.float().cpu().t()
+    if split > 1:
+        parts = ops.gemm_bias_act(a, w, None, split_k=split)
+        assert parts.shape == (split, M, N)
+        _close(parts.sum(0), want, 1e-4, 1e-4, 'split-K partial sum')
+    else:
+        got = ops.gemm_bias_act(a, w, bias, out_dtype=torch.float32, tile_hint=4)
+        _close(got, want + bias.cpu(), 1e-4, 1e-4, 'skinny')
+
+
+@pytest.mark.parametrize('act', [False, True])
+def test_sum_layernorm(ops, act):
+    S, M = 6, 130
+    parts = _rand((S, M, 768), 43).cuda()
+    bias = _rand((768,), 44, 0.1).cuda()
+    res = None if act else _rand((M, 768), 45).cuda()
+    g = (1 + _rand((768,), 46, 0.2)).cuda()
+    b = _rand((768,), 47, 0.1).cuda()
+    yb, yf = ops.sum_layernorm(parts, bias, res, g, b, 1e-12, act_before_ln=act)
+    v = parts.cpu().sum(0) + bias.cpu()
+    v = torch.nn.functional.gelu(v) if act else v + res.cpu()
+    want = torch.nn.functional.layer_norm(v, (768,), g.cpu(), b.cpu(), 1e-12)
+    _close(yf, want, 2e-5, 2e-5, 'sum_layernorm')
+    assert torch.equal(yb.cpu(), yf.cpu().to(torch.bfloat16))
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from vitcap_amd._lib import VitcapError
     a = _bf(torch.zeros(8, 96)).cuda()

@@ -23,7 +23,7 @@ vp = C.c_void_p
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
-                                       'row_group', 'out_group_rows', 'out_row_off', 'res_periodic')]
+                                       'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')]
 
 
 class VitBlockW(C.Structure):
@@ -53,6 +53,8 @@ _SIGS = {
     'vitcap_version': (C.c_int, []),
     'vitcap_gemm_bias_act': (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(GemmDesc), vp]),
     'vitcap_layernorm_fwd': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_sum_layernorm': (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp,
+                                       C.c_int, C.c_int, vp]),
     'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),

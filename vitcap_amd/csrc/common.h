@@ -51,7 +51,20 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form) = 0.5 x (1 + erf(x/sqrt2)).  Branch-free: erfc(|z|) by Abramowitz-Stegun 7.1.26
+// (|abs error| <= 1.5e-7, one rcp + one exp2 + 6 FMA) and 1+erf(z) = 2 - erfc(z) (z >= 0) or erfc(-z) (z < 0), so there
+// is no cancellation on the negative tail.  ocml's erff is piecewise (divergent) and ~2.5x the instructions.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfc_abs = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(|z|)
+  const float one_plus_erf = x >= 0.f ? 2.0f - erfc_abs : erfc_abs;
+  return 0.5f * x * one_plus_erf;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -49,6 +49,7 @@ constexpr int L = VITCAP_MAXLEN;       // 20
 constexpr int VP = VITCAP_VOCAB_PAD;
 constexpr int TOPK = 50;
 constexpr int BOS = 101, EOS = 102, PAD = 0, MASK = 103;
+constexpr int SPLIT_AO = 6, SPLIT_FC2 = 12, SPLIT_MAX = 12;   // split-K of the K=768 / K=3072 decode GEMMs with N=768
 
 struct Layout {
   size_t off = 0;
@@ -58,7 +59,7 @@ struct Layout {
     return o;
   }
   size_t patches, x, xt, h, qkv, mlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
-  size_t xs_f, xs_b, sqkv, sctx, stmp, sa_f, sa_b, smlp, tcache;
+  size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache;
   size_t hd_f, hd_b, logits;
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
   size_t ids, unf, sum_lp, cnt, margins, logprob;
@@ -80,7 +81,7 @@ struct Layout {
     xs_b = take(b * 2 * D * 2);
     sqkv = take(b * 2 * 3 * D * 2);
     sctx = take(b * 2 * D * 2);
-    stmp = take(b * 2 * D * 4);
+    spart = take((size_t)SPLIT_MAX * b * 2 * D * 4);   // split-K partial slabs of the decode-step GEMMs
     sa_f = take(b * 2 * D * 4);
     sa_b = take(b * 2 * D * 2);
     smlp = take(b * 2 * 4 * D * 2);
@@ -130,6 +131,16 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
   d.lda = lda; d.ldw = K; d.ldc = ldc; d.ldr = ldr;
   d.act = act; d.out_dtype = out;
   return gemm_desc(A, W, bias, res, C, d, s);
+}
+
+int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int N, int K, int split, void* s) {
+  vitcap_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K;
+  d.lda = lda; d.ldw = K; d.ldc = N;
+  d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
+  d.split_k = split;
+  return gemm_desc(A, W, nullptr, nullptr, partials, d, s);
 }
 
 #define CK(call)             \
@@ -332,20 +343,25 @@ extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, si
       CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE,
               VITCAP_OUT_BF16, s));
       CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, B, SV, t, L, 1, 0.125f, s));
-      CK(gemm(ws + lo.sctx, D, lw.ao_w, lw.ao_b, xs_f, D, ws + lo.stmp, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
-      CK(vitcap_layernorm_fwd((const float*)(ws + lo.stmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.sa_b,
-                              (float*)(ws + lo.sa_f), R, D, s));
+      // attention.output.dense and output.dense: split-K partial slabs, reduced inside the fused
+      // bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
+      float* part = (float*)(ws + lo.spart);
+      CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
+      CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
+                              ws + lo.sa_b, (float*)(ws + lo.sa_f), R, D, s));
       CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
               VITCAP_OUT_BF16, s));
-      CK(gemm(ws + lo.smlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.sa_f), D, ws + lo.stmp, D, R, D, 4 * D,
-              VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
-      CK(vitcap_layernorm_fwd((const float*)(ws + lo.stmp), D, lw.o_g, lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
+      CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
+      CK(vitcap_sum_layernorm(part, SPLIT_FC2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
+                              lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
     }
     // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
-    CK(gemm(xs_b + D * 2, 2 * D, w.cls.dense_w, w.cls.dense_b, nullptr, 0, ws + lo.hd_f, D, B, D, D, VITCAP_ACT_GELU_ERF,
-            VITCAP_OUT_F32, s));
-    CK(vitcap_layernorm_fwd((const float*)(ws + lo.hd_f), D, w.cls.ln_g, w.cls.ln_b, 1e-12f, ws + lo.hd_b, nullptr, B, D,
-                            s));
+    {
+      float* part = (float*)(ws + lo.spart);
+      CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, B, D, D, SPLIT_AO, s));
+      CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)B * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b,
+                              1e-12f, ws + lo.hd_b, nullptr, B, D, s));
+    }
     CK(gemm(ws + lo.hd_b, D, w.cls.dec_w, w.cls.dec_b, nullptr, 0, ws + lo.logits, VP, B, VP, D, VITCAP_ACT_NONE,
             VITCAP_OUT_F32, s));
     CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,

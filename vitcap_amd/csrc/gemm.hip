@@ -164,6 +164,309 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Large-M kernel: 256 x 128 x 64 tile, 8 waves (4 along M x 2 along N, 64x64 per wave), THREE LDS
+// stages (3 x 48 KiB): the loads of k-tile t+2 are issued while tile t is multiplied, and tile t is
+// awaited with a COUNTED `s_waitcnt vmcnt(6)` (this wave's 6 newer LDS-DMA pieces stay in flight)
+// followed by a raw s_barrier -- no vmcnt(0) drain in the main loop (cdna guide T3/T4).
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 128, BK = 64, WM = 4, WN = 4;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (srow & 7);
+  const bf16_t* aptr[4];
+  const bf16_t* wptr[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + w * 32 + i * 8 + srow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = n0 + w * 16 + i * 8 + srow;
+    r = r < p.N ? r : p.N - 1;
+    wptr[i] = p.W + (size_t)r * p.ldw + schunk * 8;
+  }
+#define STAGE(buf_, k0_)                                                                     \
+  do {                                                                                       \
+    char* sb_ = smem + (buf_) * BUF_BYTES;                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        glds16(aptr[i] + (k0_), sb_ + (w * 32 + i * 8) * 128);                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+        glds16(wptr[i] + (k0_), sb_ + A_BYTES + (w * 16 + i * 8) * 128);                     \
+  } while (0)
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int nk = p.K / BK;
+
+  STAGE(0, 0);
+  if (nk > 1) STAGE(1, BK);
+
+  int buf = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) {
+      const int nb = buf >= 1 ? buf - 1 : 2;   // (buf + 2) % 3
+      STAGE(nb, (t + 2) * BK);
+    }
+    const char* la = smem + buf * BUF_BYTES + (wm * 64 + frow) * 128;
+    const char* lw = smem + buf * BUF_BYTES + A_BYTES + (wn * 64 + frow) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + fk) ^ (frow & 7)) * 16;
+      bf16x8 af[WM], wf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(la + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8*)(lw + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+#undef STAGE
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+    int orow = m, rrow = m;
+    if (p.row_group > 0) {
+      const int g = m / p.row_group, in = m - g * p.row_group;
+      orow = g * p.out_group_rows + p.out_row_off + in;
+      rrow = p.res_periodic ? in : orow;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fk * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (ACT == VITCAP_ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + n);
+      if (OUT_F32) {
+        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
+      } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int ACT, int OUT_F32, bool HAS_RES>
+int launch_big(const GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 3 * (256 + 128) * 64 * 2;
+  auto kern = gemm_nt_big_kernel<ACT, OUT_F32, HAS_RES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + 255) / 256;
+  p.tiles_n = (a.N + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt_big");
+  return VITCAP_OK;
+}
+
+int dispatch_big(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+  const bool res = a.res != nullptr;
+#define CASE(ACT_, OUT_)                                                  \
+  if (act == ACT_ && out_f32 == OUT_)                                     \
+    return res ? launch_big<ACT_, OUT_, true>(a, s) : launch_big<ACT_, OUT_, false>(a, s);
+  CASE(VITCAP_ACT_NONE, 0)
+  CASE(VITCAP_ACT_NONE, 1)
+  CASE(VITCAP_ACT_GELU_ERF, 0)
+  CASE(VITCAP_ACT_GELU_ERF, 1)
+#undef CASE
+  vitcap_set_error("gemm(big): unsupported act %d / out %d", act, out_f32);
+  return VITCAP_EINVAL;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Skinny kernel for the decode-step GEMMs (M = 2B or B rows: 64..256).  These are weight-streaming,
+// latency-bound problems: the whole weight matrix is read once and there is almost no reuse, so LDS
+// staging buys nothing (cdna guide "GEMV / M <= 16 decode weights ... load straight to VGPRs, deep
+// unroll, late vmcnt").  Each wave owns a 32x32 output patch and loads its MFMA fragments directly
+// from global memory (16 B per lane, the fragment layout IS the memory layout for K-contiguous
+// operands); two register sets of 4 k-steps (128 k) each keep 16 loads in flight while the other set
+// is multiplied.  Parallelism comes from narrow 32-column tiles and split-K: with split_k > 1 the
+// kernel writes fp32 partial slabs P[kz][M][N] and the consumer (vitcap_sum_layernorm) reduces them.
+// ------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+  GemmArgs g;
+  int split_k;     // >= 1
+  int kc;          // k range per split (multiple of 128)
+  size_t slab;     // elements between partial slabs
+};
+
+template <int WAVES_M, int ACT, int OUT_F32, bool HAS_RES, bool PARTIAL>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs q) {
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int BM = 32 * WAVES_M, BN = 32 * WAVES_N;
+  const GemmArgs& p = q.g;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w / WAVES_N, wn = w % WAVES_N;
+  const int n0 = blockIdx.x * BN + wn * 32;
+  const int m0 = blockIdx.y * BM + wm * 32;
+  const int kz = blockIdx.z;
+  const int kbeg = kz * q.kc;
+  const int frow = lane & 15, fk = lane >> 4;
+
+  const bf16_t* ap[2];
+  const bf16_t* wp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = m0 + i * 16 + frow;
+    r = r < p.M ? r : p.M - 1;
+    ap[i] = p.A + (size_t)r * p.lda + kbeg + fk * 8;
+    int c = n0 + i * 16 + frow;
+    c = c < p.N ? c : p.N - 1;
+    wp[i] = p.W + (size_t)c * p.ldw + kbeg + fk * 8;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 a0[4][2], w0[4][2], a1[4][2], w1[4][2];
+#define LOADSET(A_, W_, k0_)                                                   \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                         \
+      A_[s_][i_] = *(const bf16x8*)(ap[i_] + (k0_) + s_ * 32);                 \
+      W_[s_][i_] = *(const bf16x8*)(wp[i_] + (k0_) + s_ * 32);                 \
+    }                                                                          \
+  }
+#define MMASET(A_, W_)                                                                          \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                          \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_[s_][j_], A_[s_][i_], acc[i_][j_], 0, 0, 0);
+
+  const int nch = q.kc / 128;
+  LOADSET(a0, w0, 0);
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) { LOADSET(a1, w1, (c + 1) * 128); }
+    MMASET(a0, w0);
+    if (c + 1 < nch) {
+      if (c + 2 < nch) { LOADSET(a0, w0, (c + 2) * 128); }
+      MMASET(a1, w1);
+    }
+  }
+#undef LOADSET
+#undef MMASET
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + j * 16 + fk * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (PARTIAL) {
+        *(f32x4*)((float*)p.C + (size_t)kz * q.slab + (size_t)m * p.ldc + n) = v;
+        continue;
+      }
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (ACT == VITCAP_ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)m * p.ldr + n);
+      if (OUT_F32) {
+        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+      } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int WAVES_M>
+int launch_skinny(const GemmArgs& a, int act, int out_f32, int split_k, hipStream_t s) {
+  constexpr int BM = 32 * WAVES_M, BN = 32 * (4 / WAVES_M);
+  SkinnyArgs q;
+  q.g = a;
+  q.split_k = split_k;
+  q.kc = a.K / split_k;
+  q.slab = (size_t)a.M * a.ldc;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, split_k);
+  const bool res = a.res != nullptr;
+#define SK(ACT_, OUT_, RES_, PART_)                                                                       \
+  hipLaunchKernelGGL((gemm_skinny_kernel<WAVES_M, ACT_, OUT_, RES_, PART_>), grid, dim3(256), 0, s, q)
+  if (split_k > 1) SK(0, 1, false, true);
+  else if (act == VITCAP_ACT_NONE && !out_f32 && !res) SK(0, 0, false, false);
+  else if (act == VITCAP_ACT_NONE && out_f32 && !res) SK(0, 1, false, false);
+  else if (act == VITCAP_ACT_NONE && out_f32 && res) SK(0, 1, true, false);
+  else if (act == VITCAP_ACT_NONE && !out_f32 && res) SK(0, 0, true, false);
+  else if (act == VITCAP_ACT_GELU_ERF && !out_f32 && !res) SK(1, 0, false, false);
+  else if (act == VITCAP_ACT_GELU_ERF && out_f32 && !res) SK(1, 1, false, false);
+  else if (act == VITCAP_ACT_TANH && !out_f32 && !res) SK(2, 0, false, false);
+  else if (act == VITCAP_ACT_TANH && out_f32 && !res) SK(2, 1, false, false);
+  else {
+    vitcap_set_error("gemm(skinny): unsupported epilogue act=%d out=%d res=%d", act, out_f32, (int)res);
+    return VITCAP_EINVAL;
+  }
+#undef SK
+  VC_LAUNCH_CHECK("gemm_skinny");
+  return VITCAP_OK;
+}
+
 template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
 int launch(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -224,7 +527,21 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   a.out_row_off = d->out_row_off; a.res_periodic = d->res_periodic;
   a.tiles_m = a.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  // Small-M problems (decode steps, heads) use 64x64 tiles to put more workgroups on the chip.
-  if (d->M <= 256) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
-  return dispatch<4, 4>(a, d->act, d->out_dtype, s);
+  // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K)
+  const int hint = d->tile_hint;
+  const int split_k = d->split_k > 1 ? d->split_k : 1;
+  const bool plain_rows = d->row_group == 0;
+  if (split_k > 1) {
+    VC_REQUIRE(d->K % (128 * split_k) == 0, "gemm: K=%d not divisible into %d splits of multiples of 128", d->K, split_k);
+    VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && plain_rows, "gemm: split-K writes fp32 partial slabs only");
+  }
+  if (split_k > 1 || hint == 4 || (hint == 0 && d->M <= 256 && d->K % 128 == 0 && plain_rows)) {
+    VC_REQUIRE(d->K % 128 == 0 && plain_rows, "gemm(skinny): needs K %% 128 == 0 and no row remap");
+    return d->M <= 64 ? launch_skinny<2>(a, d->act, d->out_dtype, split_k, s)
+                      : launch_skinny<4>(a, d->act, d->out_dtype, split_k, s);
+  }
+  if (hint == 1 || (hint == 0 && d->M <= 256)) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
+  if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
+    return dispatch<4, 4>(a, d->act, d->out_dtype, s);
+  return dispatch_big(a, d->act, d->out_dtype, s);
 }

@@ -57,6 +57,33 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restri
   ln_row(v, gamma, beta, eps, lane, yb ? yb + (size_t)row * D768 : nullptr, yf ? yf + (size_t)row * D768 : nullptr);
 }
 
+// split-K consumer: v = sum_s P[s][row] + bias (+ residual) (-> gelu) -> LayerNorm
+__global__ __launch_bounds__(256) void sum_layernorm768_kernel(const float* __restrict__ part, int S, size_t slab,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int ldr, int act,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    f32x4 a = *(const f32x4*)(part + (size_t)row * D768 + c);
+    for (int s = 1; s < S; ++s) a += *(const f32x4*)(part + (size_t)s * slab + (size_t)row * D768 + c);
+    a += *(const f32x4*)(bias + c);
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = gelu_erf(a[e]);
+    }
+    if (res) a += *(const f32x4*)(res + (size_t)row * ldr + c);
+    v[i] = a;
+  }
+  ln_row(v, gamma, beta, eps, lane, yb ? yb + (size_t)row * D768 : nullptr, yf ? yf + (size_t)row * D768 : nullptr);
+}
+
 __device__ __forceinline__ f32x4 ld_bf4(const bf16_t* p) {
   const uint2 u = *(const uint2*)p;
   return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
@@ -158,6 +185,19 @@ extern "C" int vitcap_layernorm_fwd(const float* x, int ldx, const float* gamma,
   hipLaunchKernelGGL(layernorm768_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
                      eps, (bf16_t*)y_bf16, y_f32, M);
   VC_LAUNCH_CHECK("layernorm");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_sum_layernorm(const float* partials, int S, size_t slab_stride, const float* bias,
+                                    const float* residual, int ldr, int act_before_ln, const float* gamma,
+                                    const float* beta, float eps, void* y_bf16, float* y_f32, int M, int D,
+                                    void* stream) {
+  VC_REQUIRE(partials && bias && gamma && beta && (y_bf16 || y_f32), "sum_layernorm: null pointer");
+  VC_REQUIRE(D == D768 && S >= 1 && M > 0, "sum_layernorm: only D=768, S>=1 (got D=%d S=%d)", D, S);
+  VC_REQUIRE(!(act_before_ln && residual), "sum_layernorm: activation and residual are mutually exclusive");
+  hipLaunchKernelGGL(sum_layernorm768_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, S,
+                     slab_stride, bias, residual, ldr, act_before_ln, gamma, beta, eps, (bf16_t*)y_bf16, y_f32, M);
+  VC_LAUNCH_CHECK("sum_layernorm");
   return VITCAP_OK;
 }
 

@@ -28,19 +28,20 @@ def _dev_f32(t):
 
 
 def gemm_bias_act(a, w, bias=None, residual=None, act=L.ACT_NONE, out_dtype=torch.bfloat16, out=None,
-                  row_group=0, out_group_rows=0, out_row_off=0, res_periodic=0, out_rows=None):
+                  row_group=0, out_group_rows=0, out_row_off=0, res_periodic=0, out_rows=None, tile_hint=0, split_k=0):
     """C = act(A @ W.T + bias) (+ residual).  a [M,K] bf16, w [N,K] bf16 (nn.Linear layout)."""
     _dev_bf16(a)
     _dev_bf16(w)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        out = torch.empty((out_rows or M, N), device=a.device, dtype=out_dtype)
-    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+        shape = (split_k, M, N) if split_k > 1 else (out_rows or M, N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if split_k > 1 else out_dtype)
+    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(-2),
                    ldr=residual.stride(0) if residual is not None else 0, act=act,
                    out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16,
                    row_group=row_group, out_group_rows=out_group_rows, out_row_off=out_row_off,
-                   res_periodic=res_periodic)
+                   res_periodic=res_periodic, tile_hint=tile_hint, split_k=split_k)
     check(lib.vitcap_gemm_bias_act(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), 'gemm')
     return out
 
@@ -52,6 +53,18 @@ def layernorm(x, gamma, beta, eps, want_bf16=True, want_f32=False):
     yf = torch.empty((M, D), device=x.device, dtype=torch.float32) if want_f32 else None
     check(lib.vitcap_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), eps, _p(yb), _p(yf), M, D, _stream()),
           'layernorm')
+    return yb, yf
+
+
+def sum_layernorm(partials, bias, residual, gamma, beta, eps, act_before_ln=False, want_bf16=True, want_f32=True):
+    """LayerNorm(sum_s partials[s] + bias (+ residual)) -- consumer of a split-K GEMM."""
+    _dev_f32(partials)
+    S, M, D = partials.shape
+    yb = torch.empty((M, D), device=partials.device, dtype=torch.bfloat16) if want_bf16 else None
+    yf = torch.empty((M, D), device=partials.device, dtype=torch.float32) if want_f32 else None
+    check(lib.vitcap_sum_layernorm(_p(partials), S, partials.stride(0), _p(bias), _p(residual),
+                                   residual.stride(0) if residual is not None else 0, int(act_before_ln), _p(gamma),
+                                   _p(beta), eps, _p(yb), _p(yf), M, D, _stream()), 'sum_layernorm')
     return yb, yf
 
 
