@@ -243,28 +243,39 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     return qkv_step + ((size_t)b * 2 + (tp - (t - 1))) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
   };
 
-  // ---- pass 1: scores
+  // ---- pass 1: scores.  Four keys per thread per sweep (4 x 16 B loads in flight; the kernel is HBM-latency bound)
   float mx0 = -1e30f, mx1 = -1e30f;
-  for (int k = kslot; k < nkeys; k += 32) {
-    const bf16x8 kv = *(const bf16x8*)key_ptr(k, 0);
-    float d0 = 0.f, d1 = 0.f;
+  for (int kb = kslot; kb < nkeys; kb += 128) {
+    bf16x8 kv[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float kf = (float)kv[j];
-      d0 += q0[j] * kf;
-      d1 += q1[j] * kf;
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + u * 32;
+      kv[u] = *(const bf16x8*)key_ptr(k < nkeys ? k : nkeys - 1, 0);
     }
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      d0 += __shfl_xor(d0, o, 64);
-      d1 += __shfl_xor(d1, o, 64);
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + u * 32;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float kf = (float)kv[u][j];
+        d0 += q0[j] * kf;
+        d1 += q1[j] * kf;
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) {
+        d0 += __shfl_xor(d0, o, 64);
+        d1 += __shfl_xor(d1, o, 64);
+      }
+      d0 *= c_log2;
+      d1 *= c_log2;
+      if (k == nkeys - 1) d0 = -INFINITY;   // row 0 (position t-1) cannot see the [MASK] row
+      if (k < nkeys) {
+        if (sub == 0) { sc[0][k] = d0; sc[1][k] = d1; }
+        mx0 = fmaxf(mx0, d0);
+        mx1 = fmaxf(mx1, d1);
+      }
     }
-    d0 *= c_log2;
-    d1 *= c_log2;
-    if (k == nkeys - 1) d0 = -INFINITY;   // row 0 (position t-1) cannot see the [MASK] row
-    if (sub == 0) { sc[0][k] = d0; sc[1][k] = d1; }
-    mx0 = fmaxf(mx0, d0);
-    mx1 = fmaxf(mx1, d1);
   }
   mx0 = wave_max(mx0);
   mx1 = wave_max(mx1);
@@ -277,17 +288,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   float o0[8], o1[8], l0 = 0.f, l1 = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { o0[j] = 0.f; o1[j] = 0.f; }
-  for (int k = kslot; k < nkeys; k += 32) {
-    const bf16x8 vv = *(const bf16x8*)key_ptr(k, 1);
-    const float p0 = fast_exp2(sc[0][k] - m0), p1 = fast_exp2(sc[1][k] - m1);
-    l0 += p0;
-    l1 += p1;
-    const float p0b = (float)(__bf16)p0, p1b = (float)(__bf16)p1;
+  for (int kb = kslot; kb < nkeys; kb += 128) {
+    bf16x8 vv[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float vf = (float)vv[j];
-      o0[j] += p0b * vf;
-      o1[j] += p1b * vf;
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + u * 32;
+      vv[u] = *(const bf16x8*)key_ptr(k < nkeys ? k : nkeys - 1, 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + u * 32;
+      if (k < nkeys) {
+        const float p0 = fast_exp2(sc[0][k] - m0), p1 = fast_exp2(sc[1][k] - m1);
+        l0 += p0;
+        l1 += p1;
+        const float p0b = (float)(__bf16)p0, p1b = (float)(__bf16)p1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float vf = (float)vv[u][j];
+          o0[j] += p0b * vf;
+          o1[j] += p1b * vf;
+        }
+      }
     }
   }
   // reduce over the 8 key slots of the wave (lanes with equal `sub`), then over waves through LDS

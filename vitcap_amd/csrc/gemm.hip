@@ -535,7 +535,9 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
     VC_REQUIRE(d->K % (128 * split_k) == 0, "gemm: K=%d not divisible into %d splits of multiples of 128", d->K, split_k);
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && plain_rows, "gemm: split-K writes fp32 partial slabs only");
   }
-  if (split_k > 1 || hint == 4 || (hint == 0 && d->M <= 256 && d->K % 128 == 0 && plain_rows)) {
+  // measured at B=64 (tools/decode_bench.py): without split-K the LDS-staged 64x64 kernel is ~2x faster than the
+  // register-fed one (7.4 vs 14.6 us for 128x2304x768), so the skinny kernel is used for split-K only.
+  if (split_k > 1 || hint == 4) {
     VC_REQUIRE(d->K % 128 == 0 && plain_rows, "gemm(skinny): needs K %% 128 == 0 and no row remap");
     return d->M <= 64 ? launch_skinny<2>(a, d->act, d->out_dtype, split_k, s)
                       : launch_skinny<4>(a, d->act, d->out_dtype, split_k, s);

@@ -57,29 +57,43 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restri
   ln_row(v, gamma, beta, eps, lane, yb ? yb + (size_t)row * D768 : nullptr, yf ? yf + (size_t)row * D768 : nullptr);
 }
 
-// split-K consumer: v = sum_s P[s][row] + bias (+ residual) (-> gelu) -> LayerNorm
-__global__ __launch_bounds__(256) void sum_layernorm768_kernel(const float* __restrict__ part, int S, size_t slab,
-                                                               const float* __restrict__ bias,
-                                                               const float* __restrict__ res, int ldr, int act,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float eps,
-                                                               bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+// split-K consumer: v = sum_s P[s][row] + bias (+ residual) (-> gelu) -> LayerNorm.
+// One 64-thread workgroup per row (M is 64..256 here: many small workgroups beat 4 rows per workgroup), slab loads
+// unrolled four deep so 12 float4 loads are in flight per lane.
+__global__ __launch_bounds__(64) void sum_layernorm768_kernel(const float* __restrict__ part, int S, size_t slab,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ res, int ldr, int act,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  const float* p0 = part + (size_t)row * D768 + lane * 4;
   f32x4 v[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int c = i * 256 + lane * 4;
-    f32x4 a = *(const f32x4*)(part + (size_t)row * D768 + c);
-    for (int s = 1; s < S; ++s) a += *(const f32x4*)(part + (size_t)s * slab + (size_t)row * D768 + c);
-    a += *(const f32x4*)(bias + c);
-    if (act) {
+  for (int i = 0; i < 3; ++i) v[i] = *(const f32x4*)(bias + i * 256 + lane * 4);
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    f32x4 t[4][3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = gelu_erf(a[e]);
-    }
-    if (res) a += *(const f32x4*)(res + (size_t)row * ldr + c);
-    v[i] = a;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[u][i] = *(const f32x4*)(p0 + (size_t)(s + u) * slab + i * 256);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += (t[0][i] + t[1][i]) + (t[2][i] + t[3][i]);
+  }
+  for (; s < S; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += *(const f32x4*)(p0 + (size_t)s * slab + i * 256);
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = gelu_erf(v[i][e]);
+  }
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += *(const f32x4*)(res + (size_t)row * ldr + i * 256 + lane * 4);
   }
   ln_row(v, gamma, beta, eps, lane, yb ? yb + (size_t)row * D768 : nullptr, yf ? yf + (size_t)row * D768 : nullptr);
 }
@@ -195,7 +209,7 @@ extern "C" int vitcap_sum_layernorm(const float* partials, int S, size_t slab_st
   VC_REQUIRE(partials && bias && gamma && beta && (y_bf16 || y_f32), "sum_layernorm: null pointer");
   VC_REQUIRE(D == D768 && S >= 1 && M > 0, "sum_layernorm: only D=768, S>=1 (got D=%d S=%d)", D, S);
   VC_REQUIRE(!(act_before_ln && residual), "sum_layernorm: activation and residual are mutually exclusive");
-  hipLaunchKernelGGL(sum_layernorm768_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, S,
+  hipLaunchKernelGGL(sum_layernorm768_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, partials, S,
                      slab_stride, bias, residual, ldr, act_before_ln, gamma, beta, eps, (bf16_t*)y_bf16, y_f32, M);
   VC_LAUNCH_CHECK("sum_layernorm");
   return VITCAP_OK;
