@@ -11,7 +11,7 @@ image with no data-path collective ("replicas only"): ever
 torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- for the dominant kernel (the 128x128x64 bf16 MFMA GEMM): algorithmic FLOPs of its launches
+  roofline     -- for the dominant kernel (the 256x256x64 bf16 MFMA GEMM): algorithmic FLOPs of its launches
                   / their summed duration, measured live with hipEvents recorded on the launch stream around
                   every such launch inside the timed region (vitcap_engine_timing_*).
   cpu_baseline -- the CPU oracle's restatement of the reference algorithm AS WRITTEN (full re-encode per
@@ -31,9 +31,9 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-VARIANT_NAMES = {0: 'gemm_nt<128x128,bias,bf16>', 1: 'gemm_nt<128x128,bias+res,bf16>',
-                 2: 'gemm_nt<128x128,bias,f32>', 3: 'gemm_nt<128x128,bias+residual,f32>',
-                 4: 'gemm_nt<128x128,bias+gelu,bf16>', 6: 'gemm_nt<128x128,bias+gelu,f32>'}
+VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
+                 2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
+                 4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}
 
 
 def cpu_baseline(max_seconds=40.0):

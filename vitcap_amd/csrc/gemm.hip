@@ -328,6 +328,233 @@ int dispatch_big(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 kernel, 8 waves, two LDS buffers of 64 KiB, role-alternating schedule.
+//
+// Waves 0-3 (group A) and 4-7 (group B) sit pairwise on the four SIMDs.  Every k-tile is processed in four
+// phases, one per 64x32 quadrant of the wave's 128x64 output; a phase is a LOAD segment (ds_read the
+// quadrant's fragments, issue LDS-DMA for the next k-tile) followed by a COMPUTE segment (16 MFMAs under
+// s_setprio 1), each closed by s_barrier.  Group B runs one barrier behind group A, so on every SIMD one
+// wave is in its compute segment while its partner is in its load segment: the matrix pipe is fed by one
+// wave while the other hides LDS/DMA latency (cdna guide T3/T4/T5, MI355X_MICROARCH "two waves per SIMD").
+//   LDS reads complete (lgkmcnt(0)) before the barrier that ends a load segment;
+//   the next k-tile's DMA is awaited (vmcnt(0)) right before the barrier after which group A reads it.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, BUF_BYTES = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w >> 2;            // 0 = group A, 1 = group B
+  const int wm = w >> 2, wn = w & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (srow & 7);
+  const bf16_t* aptr[4];
+  const bf16_t* wptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + w * 32 + i * 8 + srow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + schunk * 8;
+    int c = n0 + w * 32 + i * 8 + srow;
+    c = c < p.N ? c : p.N - 1;
+    wptr[i] = p.W + (size_t)c * p.ldw + schunk * 8;
+  }
+#define STAGE_A(buf_, k0_)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+      glds16(aptr[i] + (k0_), smem + (buf_) * BUF_BYTES + (w * 32 + i * 8) * 128)
+#define STAGE_W(buf_, k0_)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+      glds16(wptr[i] + (k0_), smem + (buf_) * BUF_BYTES + A_BYTES + (w * 32 + i * 8) * 128)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int coff0 = ((0 * 4 + fk) ^ (frow & 7)) * 16;
+  const int coff1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
+  const int a_base = (wm * 128 + frow) * 128;
+  const int b_base = A_BYTES + (wn * 64 + frow) * 128;
+  const int nk = p.K / BK;
+
+  bf16x8 afr[4][2];      // current m-half: 4 m-tiles x 2 k-steps
+  bf16x8 bfr[2][2][2];   // both n-halves: [nh][n-tile][k-step]
+
+#define LOAD_A(buf_, mh_)                                                                        \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                             \
+    const char* ra_ = smem + (buf_) * BUF_BYTES + a_base + ((mh_) * 4 + mt) * 16 * 128;          \
+    afr[mt][0] = *(const bf16x8*)(ra_ + coff0);                                                  \
+    afr[mt][1] = *(const bf16x8*)(ra_ + coff1);                                                  \
+  }
+#define LOAD_B(buf_, nh_)                                                                        \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                             \
+    const char* rb_ = smem + (buf_) * BUF_BYTES + b_base + ((nh_) * 2 + nt) * 16 * 128;          \
+    bfr[nh_][nt][0] = *(const bf16x8*)(rb_ + coff0);                                             \
+    bfr[nh_][nt][1] = *(const bf16x8*)(rb_ + coff1);                                             \
+  }
+#define END_LOAD()                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+  __builtin_amdgcn_sched_barrier(0);                        \
+  __builtin_amdgcn_s_barrier()
+#define COMPUTE(mh_, nh_)                                                                               \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+      _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
+        acc[(mh_) * 4 + mt][(nh_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+            bfr[nh_][nt][ks], afr[mt][ks], acc[(mh_) * 4 + mt][(nh_) * 2 + nt], 0, 0, 0);               \
+  __builtin_amdgcn_s_setprio(0)
+
+  // DMA schedule: the 8 LDS-DMA pieces of k-tile t+1 are spread two per load segment over L3(t-1), L0(t), L1(t),
+  // L2(t).  Buffer (t+1)&1 is free from L3(t-1) on (its last reader was L2(t-1)); the pieces must have landed
+  // before the barrier after which group A starts L0(t+1): that wait is vmcnt(2) -- the two pieces of tile t+2
+  // issued in L3(t) may stay in flight -- or vmcnt(0) when nothing newer was issued.
+#define STAGE2(base_, row0_, p0_, buf_, k0_)                                                            \
+  _Pragma("unroll") for (int i = (p0_); i < (p0_) + 2; ++i)                                             \
+      glds16((base_)[i] + (k0_), smem + (buf_) * BUF_BYTES + (row0_) + (w * 32 + i * 8) * 128)
+
+  // prologue: k-tile 0 into buffer 0, first two pieces of k-tile 1 into buffer 1
+  STAGE_A(0, 0);
+  STAGE_W(0, 0);
+  if (nk > 1) {
+    STAGE2(aptr, 0, 0, 1, BK);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // group B runs one barrier behind
+
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < nk;
+    const bool more2 = t + 2 < nk;
+    // ---- phase 0: quadrant (m-half 0, n-half 0)
+    LOAD_A(buf, 0);
+    LOAD_B(buf, 0);
+    if (more) { STAGE2(aptr, 0, 2, buf ^ 1, (t + 1) * BK); }
+    END_LOAD();
+    COMPUTE(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: (m-half 0, n-half 1)
+    LOAD_B(buf, 1);
+    if (more) { STAGE2(wptr, A_BYTES, 0, buf ^ 1, (t + 1) * BK); }
+    END_LOAD();
+    COMPUTE(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: (m-half 1, n-half 1)
+    LOAD_A(buf, 1);
+    if (more) { STAGE2(wptr, A_BYTES, 2, buf ^ 1, (t + 1) * BK); }
+    END_LOAD();
+    COMPUTE(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: (m-half 1, n-half 0); no LDS reads; first two pieces of k-tile t+2 (its buffer, `buf`, was last
+    // read in L2 above by both groups before the barrier that precedes this segment for either group)
+    if (more2) { STAGE2(aptr, 0, 0, buf, (t + 2) * BK); }
+    if (grp == 1) {
+      if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    COMPUTE(1, 0);
+    if (grp == 0) {
+      if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // match group B's extra barrier
+#undef STAGE_A
+#undef STAGE_W
+#undef STAGE2
+#undef LOAD_A
+#undef LOAD_B
+#undef END_LOAD
+#undef COMPUTE
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + frow;
+    if (m >= p.M) continue;
+    int orow = m, rrow = m;
+    if (p.row_group > 0) {
+      const int g = m / p.row_group, in = m - g * p.row_group;
+      orow = g * p.out_group_rows + p.out_row_off + in;
+      rrow = p.res_periodic ? in : orow;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fk * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + n);
+      if (OUT_F32) {
+        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
+      } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int ACT, int OUT_F32, bool HAS_RES>
+int launch_256(const GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 2 * 2 * 256 * 64 * 2;
+  auto kern = gemm_nt_256_kernel<ACT, OUT_F32, HAS_RES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + 255) / 256;
+  p.tiles_n = (a.N + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt_256");
+  return VITCAP_OK;
+}
+
+int dispatch_256(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+  const bool res = a.res != nullptr;
+#define CASE(ACT_, OUT_)                                                  \
+  if (act == ACT_ && out_f32 == OUT_)                                     \
+    return res ? launch_256<ACT_, OUT_, true>(a, s) : launch_256<ACT_, OUT_, false>(a, s);
+  CASE(VITCAP_ACT_NONE, 0)
+  CASE(VITCAP_ACT_NONE, 1)
+  CASE(VITCAP_ACT_GELU_ERF, 0)
+  CASE(VITCAP_ACT_GELU_ERF, 1)
+#undef CASE
+  vitcap_set_error("gemm(256): unsupported act %d / out %d", act, out_f32);
+  return VITCAP_EINVAL;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny kernel for the decode-step GEMMs (M = 2B or B rows: 64..256).  These are weight-streaming,
 // latency-bound problems: the whole weight matrix is read once and there is almost no reuse, so LDS
@@ -527,7 +754,8 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   a.out_row_off = d->out_row_off; a.res_periodic = d->res_periodic;
   a.tiles_m = a.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K)
+  // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K),
+  //            5 = 256x256 role-alternating (the auto choice for M >= 2048)
   const int hint = d->tile_hint;
   const int split_k = d->split_k > 1 ? d->split_k : 1;
   const bool plain_rows = d->row_group == 0;
@@ -545,5 +773,6 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   if (hint == 1 || (hint == 0 && d->M <= 256)) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
-  return dispatch_big(a, d->act, d->out_dtype, s);
+  if (hint == 3) return dispatch_big(a, d->act, d->out_dtype, s);
+  return dispatch_256(a, d->act, d->out_dtype, s);
 }
