@@ -341,10 +341,12 @@ int dispatch_big(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 //   LDS reads complete (lgkmcnt(0)) before the barrier that ends a load segment;
 //   the next k-tile's DMA is awaited (vmcnt(0)) right before the barrier after which group A reads it.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int OUT_F32, bool HAS_RES>
+template <int ACT, int OUT_F32, bool HAS_RES, int PH>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, BUF_BYTES = 2 * A_BYTES;
+  constexpr int ABL = PH >> 4;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
+  constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier()
 #define COMPUTE(mh_, nh_)                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                        \
+  if (!NO_MFMA)                                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
       _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
@@ -432,10 +435,43 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   _Pragma("unroll") for (int i = (p0_); i < (p0_) + 2; ++i)                                             \
       glds16((base_)[i] + (k0_), smem + (buf_) * BUF_BYTES + (row0_) + (w * 32 + i * 8) * 128)
 
+  if constexpr ((PH & 15) == 2) {
+    // Two phases per k-tile (32 MFMAs per compute segment): the load segment of phase 0 reads A(m-half 0) and both
+    // n-halves and issues all 8 DMA pieces of the next k-tile; phase 1 reads A(m-half 1).
+    STAGE_A(0, 0);
+    STAGE_W(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      const bool more = t + 1 < nk;
+      LOAD_A(buf, 0);
+      LOAD_B(buf, 0);
+      LOAD_B(buf, 1);
+      if (more) {
+        STAGE_A(buf ^ 1, (t + 1) * BK);
+        STAGE_W(buf ^ 1, (t + 1) * BK);
+      }
+      END_LOAD();
+      COMPUTE(0, 0);
+      COMPUTE(0, 1);
+      __builtin_amdgcn_s_barrier();
+      LOAD_A(buf, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      COMPUTE(1, 1);
+      COMPUTE(1, 0);
+      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   // prologue: k-tile 0 into buffer 0, first two pieces of k-tile 1 into buffer 1
   STAGE_A(0, 0);
   STAGE_W(0, 0);
-  if (nk > 1) {
+  if (nk > 1 && !NO_DMA) {
     STAGE2(aptr, 0, 0, 1, BK);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   } else {
@@ -446,23 +482,23 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    const bool more = t + 1 < nk;
-    const bool more2 = t + 2 < nk;
+    const bool more = !NO_DMA && t + 1 < nk;
+    const bool more2 = !NO_DMA && t + 2 < nk;
+    const bool rd = !NO_LDS || t == 0;
     // ---- phase 0: quadrant (m-half 0, n-half 0)
-    LOAD_A(buf, 0);
-    LOAD_B(buf, 0);
+    if (rd) { LOAD_A(buf, 0); LOAD_B(buf, 0); }
     if (more) { STAGE2(aptr, 0, 2, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(0, 0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: (m-half 0, n-half 1)
-    LOAD_B(buf, 1);
+    if (rd) { LOAD_B(buf, 1); }
     if (more) { STAGE2(wptr, A_BYTES, 0, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(0, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: (m-half 1, n-half 1)
-    LOAD_A(buf, 1);
+    if (rd) { LOAD_A(buf, 1); }
     if (more) { STAGE2(wptr, A_BYTES, 2, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(1, 1);
@@ -482,6 +518,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_s_barrier();
   }
+  }
   if (grp == 0) __builtin_amdgcn_s_barrier();   // match group B's extra barrier
 #undef STAGE_A
 #undef STAGE_W
@@ -491,43 +528,58 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #undef END_LOAD
 #undef COMPUTE
 
+  // ---- epilogue through LDS: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. 32-byte (bf16)
+  // pieces of 16 different rows per store instruction; measured, that caps the output stream at ~2.2 TB/s and costs
+  // 75 us per 36928x2304 GEMM.  Each wave therefore parks its accumulators (fp32) in a private 64x64 LDS patch
+  // (two halves of its 128 rows), reads them back row-major and issues full-line stores: 16 lanes cover one
+  // 64-column row segment (256 B fp32 / 128 B bf16), bias / GELU / residual are applied in this coalesced pass.
+  constexpr int EP_ROWB = 272;                       // 64 fp32 + 16 B pad: conflict-free ds_write_b128
+  char* ep = smem + w * (64 * EP_ROWB);
+  const int er = lane >> 4, ec = (lane & 15) * 4;    // read-back: row within a group of 4, first of 4 columns
+  const int ncol = n0 + wn * 64 + ec;
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + frow;
-    if (m >= p.M) continue;
-    int orow = m, rrow = m;
-    if (p.row_group > 0) {
-      const int g = m / p.row_group, in = m - g * p.row_group;
-      orow = g * p.out_group_rows + p.out_row_off + in;
-      rrow = p.res_periodic ? in : orow;
-    }
+  for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fk * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) v += *(const f32x4*)(p.bias + n);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * 4 + i][j];
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 4 + er;
+      f32x4 v = *(const f32x4*)(ep + rl * EP_ROWB + ec * 4);
+      const int m = m0 + wm * 128 + hm * 64 + rl;
+      if (m >= p.M || ncol >= p.N) continue;
+      int orow = m, rrow = m;
+      if (p.row_group > 0) {
+        const int g = m / p.row_group, in = m - g * p.row_group;
+        orow = g * p.out_group_rows + p.out_row_off + in;
+        rrow = p.res_periodic ? in : orow;
+      }
+      v += bias4;
       if (ACT == VITCAP_ACT_GELU_ERF) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
-      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + n);
+      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + ncol);
       if (OUT_F32) {
-        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
+        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
       } else {
         uint2 o;
         o.x = pack2bf(v[0], v[1]);
         o.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
+        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
       }
     }
   }
 }
 
-template <int ACT, int OUT_F32, bool HAS_RES>
+template <int ACT, int OUT_F32, bool HAS_RES, int PH>
 int launch_256(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = 2 * 2 * 256 * 64 * 2;
-  auto kern = gemm_nt_256_kernel<ACT, OUT_F32, HAS_RES>;
+  constexpr int smem = 8 * 64 * 272;   // max(2 x 64 KiB k-tile buffers, 8 x 17 KiB epilogue patches)
+  auto kern = gemm_nt_256_kernel<ACT, OUT_F32, HAS_RES, PH>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -541,11 +593,12 @@ int launch_256(const GemmArgs& a, hipStream_t s) {
   return VITCAP_OK;
 }
 
+template <int PH>
 int dispatch_256(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   const bool res = a.res != nullptr;
 #define CASE(ACT_, OUT_)                                                  \
   if (act == ACT_ && out_f32 == OUT_)                                     \
-    return res ? launch_256<ACT_, OUT_, true>(a, s) : launch_256<ACT_, OUT_, false>(a, s);
+    return res ? launch_256<ACT_, OUT_, true, PH>(a, s) : launch_256<ACT_, OUT_, false, PH>(a, s);
   CASE(VITCAP_ACT_NONE, 0)
   CASE(VITCAP_ACT_NONE, 1)
   CASE(VITCAP_ACT_GELU_ERF, 0)
@@ -774,5 +827,11 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
   if (hint == 3) return dispatch_big(a, d->act, d->out_dtype, s);
-  return dispatch_256(a, d->act, d->out_dtype, s);
+  if (hint == 6) return dispatch_256<2>(a, d->act, d->out_dtype, s);
+  if (hint == 7) return launch_256<0, 0, false, 4 + 16 * 1>(a, s);   // ablation: no DMA in the loop
+  if (hint == 8) return launch_256<0, 0, false, 4 + 16 * 2>(a, s);   // ablation: no ds_read in the loop
+  if (hint == 9) return launch_256<0, 0, false, 4 + 16 * 4>(a, s);   // ablation: no MFMA
+  if (hint == 10) return launch_256<0, 0, false, 4 + 16 * 3>(a, s);  // ablation: MFMA + barriers only
+  if (hint == 11) return launch_256<0, 0, false, 4 + 16 * 6>(a, s);  // ablation: DMA + barriers only
+  return dispatch_256<4>(a, d->act, d->out_dtype, s);
 }
