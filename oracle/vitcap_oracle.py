@@ -380,12 +380,14 @@ C_LOG2 = float(torch.tensor(0.125, dtype=torch.float32) * torch.tensor(1.4426950
 
 
 def softmax_pv_rounded(s_raw, v, r):
-    """Device softmax.V: scores -> log2 domain (one fp32 multiply by fp32(0.125*log2 e)), row max rounded UP
-    to an integer so every online-softmax rescale is an exact power of two, P = exp2(t - m) in fp32, bf16(P)
-    for the product, row sum from the unrounded P.  Mathematically softmax(s/8) @ v (modeling_bert.py:320-336)."""
-    t = s_raw * C_LOG2
-    m = torch.ceil(t.max(dim=-1, keepdim=True).values)
-    e = torch.exp2(t - m)
+    """Device softmax.V in the log2 domain: m = ceil(max(s) * c) with c = fp32(0.125*log2 e) (row max rounded UP to
+    an integer so every online-softmax rescale is an exact power of two), P = exp2(fma(s, c, -m)) -- the fused
+    multiply-add is reproduced exactly by doing it in float64 -- bf16(P) for the product, row sum from the unrounded
+    P.  Mathematically softmax(s/8) @ v (modeling_bert.py:320-336)."""
+    c32 = torch.tensor(C_LOG2, dtype=torch.float32)
+    m = torch.ceil(s_raw.max(dim=-1, keepdim=True).values * c32)
+    t = (s_raw.double() * float(C_LOG2) - m.double()).float()
+    e = torch.exp2(t)
     return (r(e) @ v) / e.sum(dim=-1, keepdim=True)
 
 

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const int qi = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + w * 32;
+  const bool active = q0 < S;        // waves past the last query row only help with staging
   const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
 
   // Q^T fragments: lane holds Q[q0+qi][ds*16 + half*8 .. +7]
@@ -51,24 +52,46 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const int k_key = tid >> 2, k_d = (tid & 3) * 16;             // K: 2 x 16 B per thread
   const int v_kg = tid & 15, v_dg = tid >> 4;                   // V: 4 keys x 4 d per thread
   const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);  // permuted key slot
+  const int nfull = S / KT;                                     // tiles with 64 valid keys
+  const int rem = S - nfull * KT;                               // 0..63 left-over keys
+  const bool tail_tile = rem > 8;                               // many left-overs: one masked MFMA tile
+  const int ntiles = nfull + (tail_tile ? 1 : 0);
 
-  // prefetch registers (named scalars: arrays captured by a lambda were sent to scratch by hipcc)
+  // per-thread source pointers of tile 0 (advanced by 64 rows per tile; clamped only for a masked tail tile)
+  const bf16_t* kp = base + (size_t)k_key * QKV_LD + 768 + k_d;
+  const bf16_t* vp0 = base + (size_t)(v_kg * 4) * QKV_LD + 1536 + v_dg * 4;
   uint4 kreg0, kreg1;
   uint2 vreg0, vreg1, vreg2, vreg3;
-#define LOAD_TILE(kv0_)                                                                         \
+#define LOAD_TILE_FAST(t_)                                                                      \
+  do {                                                                                          \
+    const bf16_t* kq_ = kp + (size_t)(t_) * KT * QKV_LD;                                        \
+    const bf16_t* vq_ = vp0 + (size_t)(t_) * KT * QKV_LD;                                       \
+    kreg0 = *(const uint4*)kq_;                                                                 \
+    kreg1 = *(const uint4*)(kq_ + 8);                                                           \
+    vreg0 = *(const uint2*)(vq_);                                                               \
+    vreg1 = *(const uint2*)(vq_ + QKV_LD);                                                      \
+    vreg2 = *(const uint2*)(vq_ + 2 * QKV_LD);                                                  \
+    vreg3 = *(const uint2*)(vq_ + 3 * QKV_LD);                                                  \
+  } while (0)
+#define LOAD_TILE_CLAMPED(kv0_)                                                                 \
   do {                                                                                          \
     int kr_ = (kv0_) + k_key;                                                                   \
     kr_ = kr_ < S ? kr_ : S - 1;                                                                \
-    const bf16_t* kp_ = base + (size_t)kr_ * QKV_LD + 768 + k_d;                                \
-    kreg0 = *(const uint4*)kp_;                                                                 \
-    kreg1 = *(const uint4*)(kp_ + 8);                                                           \
-    int v0_ = (kv0_) + v_kg * 4;                                                                \
+    const bf16_t* kq_ = base + (size_t)kr_ * QKV_LD + 768 + k_d;                                \
+    kreg0 = *(const uint4*)kq_;                                                                 \
+    kreg1 = *(const uint4*)(kq_ + 8);                                                           \
+    const int v0_ = (kv0_) + v_kg * 4;                                                          \
     const int r0_ = v0_ < S ? v0_ : S - 1, r1_ = v0_ + 1 < S ? v0_ + 1 : S - 1;                 \
     const int r2_ = v0_ + 2 < S ? v0_ + 2 : S - 1, r3_ = v0_ + 3 < S ? v0_ + 3 : S - 1;         \
     vreg0 = *(const uint2*)(base + (size_t)r0_ * QKV_LD + 1536 + v_dg * 4);                     \
     vreg1 = *(const uint2*)(base + (size_t)r1_ * QKV_LD + 1536 + v_dg * 4);                     \
     vreg2 = *(const uint2*)(base + (size_t)r2_ * QKV_LD + 1536 + v_dg * 4);                     \
     vreg3 = *(const uint2*)(base + (size_t)r3_ * QKV_LD + 1536 + v_dg * 4);                     \
+  } while (0)
+#define LOAD_TILE(t_)                                  \
+  do {                                                 \
+    if ((t_) < nfull) LOAD_TILE_FAST(t_);              \
+    else LOAD_TILE_CLAMPED((t_) * KT);                 \
   } while (0)
   // K rows as they are; V transposed 4x4 per thread: vregJ = V[key J][d0..d0+3] -> rows d0+dd hold keys 0..3
 #define STORE_TILE(buf_)                                                                        \
@@ -78,14 +101,14 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
     *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2) = kreg0;                                         \
     *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2 + 16) = kreg1;                                    \
     uint2 t0_, t1_, t2_, t3_;                                                                   \
-    t0_.x = (vreg0.x & 0xffffu) | (vreg1.x << 16);                                              \
-    t0_.y = (vreg2.x & 0xffffu) | (vreg3.x << 16);                                              \
-    t1_.x = (vreg0.x >> 16) | (vreg1.x & 0xffff0000u);                                          \
-    t1_.y = (vreg2.x >> 16) | (vreg3.x & 0xffff0000u);                                          \
-    t2_.x = (vreg0.y & 0xffffu) | (vreg1.y << 16);                                              \
-    t2_.y = (vreg2.y & 0xffffu) | (vreg3.y << 16);                                              \
-    t3_.x = (vreg0.y >> 16) | (vreg1.y & 0xffff0000u);                                          \
-    t3_.y = (vreg2.y >> 16) | (vreg3.y & 0xffff0000u);                                          \
+    t0_.x = __builtin_amdgcn_perm(vreg1.x, vreg0.x, 0x05040100);                                \
+    t0_.y = __builtin_amdgcn_perm(vreg3.x, vreg2.x, 0x05040100);                                \
+    t1_.x = __builtin_amdgcn_perm(vreg1.x, vreg0.x, 0x07060302);                                \
+    t1_.y = __builtin_amdgcn_perm(vreg3.x, vreg2.x, 0x07060302);                                \
+    t2_.x = __builtin_amdgcn_perm(vreg1.y, vreg0.y, 0x05040100);                                \
+    t2_.y = __builtin_amdgcn_perm(vreg3.y, vreg2.y, 0x05040100);                                \
+    t3_.x = __builtin_amdgcn_perm(vreg1.y, vreg0.y, 0x07060302);                                \
+    t3_.y = __builtin_amdgcn_perm(vreg3.y, vreg2.y, 0x07060302);                                \
     char* vp_ = vl_ + (v_dg * 4) * LDS_ROW + v_pos * 2;                                         \
     *(uint2*)(vp_) = t0_;                                                                       \
     *(uint2*)(vp_ + LDS_ROW) = t1_;                                                             \
@@ -94,90 +117,131 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   } while (0)
 
   f32x16 ot[2];
+  f32x16 zero16;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    ot[0][r] = 0.f;
+    ot[1][r] = 0.f;
+    zero16[r] = 0.f;
+  }
   float m_i = -1e30f;   // running max, log2 domain, integer valued once set
   float l_i = 0.f;      // this half-wave's partial row sum
 
-  const int ntiles = (S + KT - 1) / KT;
-  LOAD_TILE(0);
-  STORE_TILE(0);
+  if (ntiles > 0) {
+    LOAD_TILE(0);
+    STORE_TILE(0);
+  }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One key-tile step; MASKED_ is a literal so the left-over masking exists only in the peeled tail instance
+  // (inside the loop hipcc if-converted it into 97 extra VALU ops per tile).
+#define TILE_COMPUTE(buf_, t_, MASKED_)                                                                         \
+  do {                                                                                                          \
+    const char* kl = smem + (buf_) * (2 * KT * LDS_ROW);                                                        \
+    const char* vl = kl + KT * LDS_ROW;                                                                         \
+    f32x16 st[2];                                                                                               \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
+      const char* kr = kl + (kt * 32 + qi) * LDS_ROW + half * 16;                                               \
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr), qf[0], zero16, 0, 0, 0);           \
+      _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr + ds * 32), qf[ds], st[kt], 0, 0, 0); \
+    }                                                                                                           \
+    if (MASKED_) {                                                                                              \
+      const int kv0 = (t_) * KT;                                                                                \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                    \
+          st[kt][r] = key < S ? st[kt][r] : -INFINITY;                                                          \
+        }                                                                                                       \
+    }                                                                                                           \
+    /* running max on the raw scores (scale > 0), integer ceiling in the log2 domain */                         \
+    float mx0 = fmaxf(st[0][0], st[1][0]), mx1 = fmaxf(st[0][1], st[1][1]);                                     \
+    _Pragma("unroll") for (int r = 2; r < 16; r += 2) {                                                         \
+      mx0 = fmaxf(mx0, fmaxf(st[0][r], st[1][r]));                                                              \
+      mx1 = fmaxf(mx1, fmaxf(st[0][r + 1], st[1][r + 1]));                                                      \
+    }                                                                                                           \
+    float mx = fmaxf(mx0, mx1);                                                                                 \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                     \
+    const float m_new = fmaxf(m_i, ceilf(mx * c_log2));                                                         \
+    if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0) { /* rare after the first tiles: integer steps */       \
+      const float alpha = fast_exp2(m_i - m_new);         /* exact power of two (0 on the first tile) */        \
+      l_i *= alpha;                                                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
+        ot[0][r] *= alpha;                                                                                      \
+        ot[1][r] *= alpha;                                                                                      \
+      }                                                                                                         \
+      m_i = m_new;                                                                                              \
+    }                                                                                                           \
+    /* P = exp2(s*c - m) with one fma per score; row sum from the unrounded P */                                \
+    const float nm = -m_i;                                                                                      \
+    float ps0 = 0.f, ps1 = 0.f;                                                                                 \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                       \
+        const float p0 = fast_exp2(fmaf(st[kt][r], c_log2, nm));                                                \
+        const float p1 = fast_exp2(fmaf(st[kt][r + 1], c_log2, nm));                                            \
+        st[kt][r] = p0;                                                                                         \
+        st[kt][r + 1] = p1;                                                                                     \
+        ps0 += p0;                                                                                              \
+        ps1 += p1;                                                                                              \
+      }                                                                                                         \
+    l_i += ps0 + ps1;                                                                                           \
+    /* O^T += V^T . P^T over the four 16-key blocks */                                                          \
+    _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
+      const int kt = kb >> 1, ks = kb & 1;                                                                      \
+      bf16x8 pf;                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];                         \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
+        const bf16x8 vf = *(const bf16x8*)(vl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);           \
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);                              \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+  for (int t = 0; t < nfull; ++t) {
     const int buf = t & 1;
-    const int kv0 = t * KT;
-    if (t + 1 < ntiles) LOAD_TILE(kv0 + KT);
-    const char* kl = smem + buf * (2 * KT * LDS_ROW);
-    const char* vl = kl + KT * LDS_ROW;
-
-    // ---- S^T = K . Q^T : two 32-key tiles
-    f32x16 st[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const bf16x8 kf = *(const bf16x8*)(kl + (kt * 32 + qi) * LDS_ROW + (ds * 16 + half * 8) * 2);
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], st[kt], 0, 0, 0);
-      }
-    }
-    // ---- scale to log2 domain, mask the tail, running max
-    float mx = -1e30f;
-    const bool tail = kv0 + KT > S;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = st[kt][r] * c_log2;
-        if (tail) {
-          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          v = key < S ? v : -INFINITY;
-        }
-        st[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, ceilf(mx));
-    const float alpha = fast_exp2(m_i - m_new);   // exact power of two (or 0 on the first tile)
-    m_i = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(st[kt][r] - m_new);
-        st[kt][r] = pv;
-        psum += pv;
-      }
-    l_i = l_i * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
-
-    // ---- O^T += V^T . P^T over the four 16-key blocks
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int kt = kb >> 1, ks = kb & 1;
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 vf = *(const bf16x8*)(vl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);
-        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
-      }
-    }
+    if (t + 1 < ntiles) LOAD_TILE(t + 1);
+    if (active) TILE_COMPUTE(buf, t, false);
     if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
     __syncthreads();
   }
-
+  if (tail_tile && active) TILE_COMPUTE(nfull & 1, nfull, true);
+#undef TILE_COMPUTE
 #undef LOAD_TILE
+#undef LOAD_TILE_FAST
+#undef LOAD_TILE_CLAMPED
 #undef STORE_TILE
+
+  // ---- left-over keys (S = 577/578 leaves 1/2): one online-softmax step per key on the vector ALU.  The lane owns
+  // 32 of the 64 q dims (its partner lane^32 the rest) and 32 of the 64 output dims.
+  if (active && !tail_tile) {
+    for (int key = nfull * KT; key < S; ++key) {
+      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
+      float sp = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sp += (float)qf[ds][j] * (float)kv[j];
+      }
+      const float sc = sp + __shfl_xor(sp, 32, 64);
+      const float m_new = fmaxf(m_i, ceilf(sc * c_log2));
+      const float alpha = fast_exp2(m_i - m_new);
+      m_i = m_new;
+      const float pv = fast_exp2(fmaf(sc, c_log2, -m_new));
+      l_i = l_i * alpha + (half == 0 ? pv : 0.f);
+      const float pb = (float)(__bf16)pv;
+      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 vv = *(const bf16x4*)(vr + dt * 32 + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ot[dt][g * 4 + e] = fmaf(pb, (float)vv[e], ot[dt][g * 4 + e] * alpha);
+        }
+    }
+  }
+
   // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -267,8 +331,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         d0 += __shfl_xor(d0, o, 64);
         d1 += __shfl_xor(d1, o, 64);
       }
-      d0 *= c_log2;
-      d1 *= c_log2;
       if (k == nkeys - 1) d0 = -INFINITY;   // row 0 (position t-1) cannot see the [MASK] row
       if (k < nkeys) {
         if (sub == 0) { sc[0][k] = d0; sc[1][k] = d1; }
@@ -281,8 +343,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   mx1 = wave_max(mx1);
   if (lane == 0) { red[0][w] = mx0; red[1][w] = mx1; }
   __syncthreads();
-  const float m0 = ceilf(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
-  const float m1 = ceilf(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+  // scores are kept raw; P = exp2(fma(s, c, -m)) with m = ceil(max(s) * c), as in the dense kernel
+  const float m0 = ceilf(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])) * c_log2);
+  const float m1 = ceilf(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])) * c_log2);
 
   // ---- pass 2: P.V   (P rounded to bf16 for the product, row sum from the unrounded fp32 P)
   float o0[8], o1[8], l0 = 0.f, l1 = 0.f;
@@ -299,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     for (int u = 0; u < 4; ++u) {
       const int k = kb + u * 32;
       if (k < nkeys) {
-        const float p0 = fast_exp2(sc[0][k] - m0), p1 = fast_exp2(sc[1][k] - m1);
+        const float p0 = fast_exp2(fmaf(sc[0][k], c_log2, -m0)), p1 = fast_exp2(fmaf(sc[1][k], c_log2, -m1));
         l0 += p0;
         l1 += p1;
         const float p0b = (float)(__bf16)p0, p1b = (float)(__bf16)p1;
