@@ -66,18 +66,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='replay the step from a captured hipGraph (1) or launch eagerly (0)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from vitcap_amd import dist_util as D
+    rank, world, local = D.env_rank_world()
     assert world == args.gpus, 'launch with torchrun --nproc-per-node == --gpus'
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dist = D.init('nccl', torch.device('cuda', local)) if world > 1 else None
 
     from vitcap_amd import weights as W
     from vitcap_amd._lib import lib, check
@@ -86,7 +83,7 @@ def main():
     B = args.batch
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:%d' % local)
-    img = torch.from_numpy(W.gen_image_batch(B, 1234 + rank)).cuda().to(torch.bfloat16).contiguous()
+    img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
 
     def barrier():
         torch.cuda.synchronize()
@@ -97,6 +94,25 @@ def main():
     stream = torch.cuda.Stream()
     ids = lp = None
     graph = None
+    nstr = args.streams
+    side = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else []
+    chunks = list(img.chunk(nstr)) if nstr > 1 else [img]
+    chunks = [c.contiguous() for c in chunks]
+    if nstr > 1:
+        plain_generate = model.generate
+
+        def generate_split(_img):
+            """Sub-batches on separate streams: the tail of one sub-batch's kernels overlaps the other's work."""
+            cur = torch.cuda.current_stream()
+            outs = []
+            for i, (st_, ch) in enumerate(zip(side, chunks)):
+                st_.wait_stream(cur)
+                with torch.cuda.stream(st_):
+                    outs.append(plain_generate(ch, slot=i))
+            for st_ in side:
+                cur.wait_stream(st_)
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        model.generate = generate_split
     with torch.cuda.stream(stream):
         for _ in range(max(args.warmup, 1)):
             ids, lp = model.generate(img)
@@ -135,18 +151,14 @@ def main():
         ln = (C.c_int * 12)()
         check(lib.vitcap_engine_timing_end(model._engine, ms, fl, ln), 'timing_end')
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dist, device='cuda')
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    total_images = B * world * args.steps
-    value = total_images / elapsed
+    value = D.whole_job_rate(B, args.steps, world, elapsed)
     tot_ms = sum(ms)
     tot_fl = sum(fl)
     dom = max(range(12), key=lambda i: ms[i])
@@ -162,7 +174,7 @@ def main():
                                'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM' % B,
                    'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy', 'max_length': 20,
                    'parallelism': 'replicas x%d (no data-path collective)' % world,
-                   'launch': 'hipGraph replay' if graph is not None else 'eager'},
+                   'launch': 'hipGraph replay' if graph is not None else 'eager', 'streams_per_gpu': nstr},
         'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),
         'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),
         'roofline': {

@@ -63,7 +63,7 @@ class ImageCaptioning(nn.Module):
         self._params = _build_tree(self, W.state_dict_spec(), tie_weights)
         self._engine = None
         self._packed = None
-        self._ws = None
+        self._ws = {}
         self.last_tags = None
 
     # ---------------------------------------------------------------- weights
@@ -190,13 +190,16 @@ class ImageCaptioning(nn.Module):
             pass
 
     # ---------------------------------------------------------------- forward
-    def _workspace(self, B, dev):
+    def _workspace(self, B, dev, slot=0):
+        """One workspace per slot: concurrent generate() calls on different HIP streams use different slots."""
         need = lib.vitcap_engine_workspace_bytes(B)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        return self._ws, need
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[slot] = ws
+        return ws, need
 
-    def generate(self, image, want_tags=False):
+    def generate(self, image, want_tags=False, slot=0):
         """image: (B,3,384,384) fp32 or bf16 on the GPU, normalised with mean=.5/std=.5."""
         if self._packed is None:
             self.pack(image.device)
@@ -204,7 +207,7 @@ class ImageCaptioning(nn.Module):
         assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
         assert image.dtype in (torch.float32, torch.bfloat16)
         B = image.shape[0]
-        ws, need = self._workspace(B, dev)
+        ws, need = self._workspace(B, dev, slot)
         ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
         lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
         tag_logits = torch.empty((B, L.VOCAB), dtype=torch.float32, device=dev) if want_tags else None
