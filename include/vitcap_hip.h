@@ -162,6 +162,41 @@ int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_
 int vitcap_sigmoid_topk(const float* logits, int ldl, int V, int k, float thresh, int64_t* out_ids,
                         float* out_prob, int64_t* out_len, int B, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Beam search, device side (ViTCAP._generate_beam_search + BeamHypotheses, modeling_utils.py:888-1100, 1138-1180,
+ * with num_keep_best = 1, early_stopping = False):
+ *   vitcap_row_topk_lse   per row: logsumexp over V and the k = 2*beams largest logits (sorted, lowest index first
+ *                         on ties) -- the candidates `log_softmax(scores) + beam_scores` -> view(B, beams*V) ->
+ *                         topk(2*beams) can take from that row                       (modeling_utils.py:988-996)
+ *   vitcap_beam_step      per image: merge, sort, `is_done`, EOS / last-step candidates -> hypotheses, next beams,
+ *                         re-ordered + extended input_ids, parent indices            (modeling_utils.py:1003-1054)
+ *   vitcap_beam_reorder_cache   text K/V cache rows gathered by parent (the `past` re-ordering, 1056-1068)
+ *   vitcap_beam_finalize  best hypothesis + EOS, padded to max_len; logprob = sum_logprobs / len**lp (1076-1100)
+ * All state lives in caller-provided device arrays.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t* ids_in;    /* [B*beams][max_len] prefixes entering the step */
+  int64_t* ids_out;   /* [B*beams][max_len] prefixes leaving the step (caller swaps) */
+  float* beam_scores; /* [B*beams] */
+  int32_t* parent;    /* [B*beams] row each new beam was expanded from */
+  int32_t* done;      /* [B] */
+  int32_t* has_hyp;   /* [B] */
+  float* hyp_score;   /* [B] length-normalised score of the kept hypothesis */
+  int32_t* hyp_len;   /* [B] */
+  int64_t* hyp_tok;   /* [B][max_len] */
+} vitcap_beam_state;
+
+int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, float* out_val, int32_t* out_idx,
+                        float* out_lse, int rows, void* stream);
+int vitcap_beam_init(const vitcap_beam_state* s, int B, int beams, int max_len, int bos, int pad, void* stream);
+int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, const float* lse, const vitcap_beam_state* s,
+                     int B, int beams, int V, int t, int max_len, int eos, int pad, float length_penalty,
+                     void* stream);
+int vitcap_beam_reorder_cache(const void* src, void* dst, const int32_t* parent, int layers, int n_seq, int max_len,
+                              int t, void* stream);
+int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B, int max_len,
+                         int eos, int pad, void* stream);
+
 /* small data movers used by the engine and exposed for tests */
 int vitcap_assemble_visual(const float* hidden, const float* tag_hidden, float* vis_f32, void* vis_bf16,
                            int B, int n_tok, void* stream);  /* modeling_bert.py:1493 */
@@ -228,6 +263,12 @@ size_t vitcap_engine_workspace_bytes(int B);
 /* image: [B,3,384,384] fp32 or bf16, normalised as the reference's Normalize(.5,.5)
  * out_ids int64 [B,1,20]; out_logprobs fp32 [B,1]  (what ImageCaptioning.forward returns at test time).
  * Optional taps (may be NULL): tag_logits fp32 [B,30522], tag_topk int64 [B,50]. */
+/* Beam search variant (num_beams <= 8): same outputs; workspace from vitcap_engine_workspace_bytes_beam(B, beams). */
+size_t vitcap_engine_workspace_bytes_beam(int B, int beams);
+int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
+                       float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                       float* out_logprobs, void* stream);
+
 int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B,
                          void* workspace, size_t workspace_bytes,
                          int64_t* out_ids, float* out_logprobs,

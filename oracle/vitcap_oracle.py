@@ -497,3 +497,179 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
     if return_trace:
         return out + ({'steps': trace, 'hidden': hidden, 'tag_hidden': tag_hidden, 'tags': tags},)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# a13  beam search   (modeling_utils.py:888-1100, BeamHypotheses 1138-1180)
+# --------------------------------------------------------------------------------------------
+class BeamHypotheses:
+    """n-best list exactly as modeling_utils.py:1138-1180 (n_hyp = num_keep_best, max_length-1, length_penalty)."""
+
+    def __init__(self, n_hyp, max_length, length_penalty):
+        self.max_length = max_length - 1
+        self.length_penalty = length_penalty
+        self.n_hyp = n_hyp
+        self.hyp = []
+        self.worst_score = 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / len(hyp) ** self.length_penalty
+        if len(self.hyp) < self.n_hyp or score > self.worst_score:
+            self.hyp.append((score, hyp))
+            if len(self.hyp) > self.n_hyp:
+                ss = sorted([(sc, idx) for idx, (sc, _) in enumerate(self.hyp)])
+                del self.hyp[ss[0][1]]
+                self.worst_score = ss[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs):
+        if len(self.hyp) < self.n_hyp:
+            return False
+        return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
+
+
+def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1):
+    """The reference's beam driver around an abstract model: ``step_logits_fn(input_ids (B*beams, cur_len), beam_idx)``
+    returns the next-token logits (B*beams, V) for the current prefixes (``beam_idx`` = the re-ordering applied since
+    the previous call, None at the first).  Returns (decoded (B,keep,max_length), logprobs (B,keep))."""
+    K = num_beams
+    input_ids = torch.full((B * K, 1), BOS, dtype=torch.long)
+    hyps = [BeamHypotheses(num_keep_best, max_length, length_penalty) for _ in range(B)]
+    beam_scores = torch.zeros(B, K)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    done = [False] * B
+    cur_len = 1
+    beam_idx = None
+    while cur_len < max_length:
+        logits = step_logits_fn(input_ids, beam_idx)
+        scores = F.log_softmax(logits, dim=-1)
+        Vn = scores.shape[1]
+        _scores = (scores + beam_scores[:, None]).view(B, K * Vn)
+        next_scores, next_words = torch.topk(_scores, 2 * K, dim=1, largest=True, sorted=True)
+        nb = []
+        for b in range(B):
+            done[b] = done[b] or hyps[b].is_done(next_scores[b].max().item())
+            if done[b]:
+                nb.extend([(0, PAD, 0)] * K)
+                continue
+            sent = []
+            for idx, sc in zip(next_words[b], next_scores[b]):
+                beam_id = int(idx) // Vn
+                word_id = int(idx) % Vn
+                if word_id == EOS or cur_len + 1 == max_length:
+                    hyps[b].add(input_ids[b * K + beam_id, :cur_len].clone(), sc.item())
+                else:
+                    sent.append((sc, word_id, b * K + beam_id))
+                if len(sent) == K:
+                    break
+            if len(sent) == 0:
+                sent = [(0, PAD, 0)] * K
+            nb.extend(sent)
+        beam_scores = torch.tensor([float(x[0]) for x in nb])
+        beam_words = torch.tensor([int(x[1]) for x in nb], dtype=torch.long)
+        beam_idx = torch.tensor([int(x[2]) for x in nb], dtype=torch.long)
+        input_ids = torch.cat([input_ids[beam_idx, :], beam_words.unsqueeze(1)], dim=-1)
+        cur_len += 1
+        if all(done):
+            break
+    decoded = torch.full((B, num_keep_best, max_length), PAD, dtype=torch.long)
+    logprobs = torch.full((B, num_keep_best), -1e5)
+    for i, h in enumerate(hyps):
+        hs = torch.tensor([x[0] for x in h.hyp])
+        _, best = torch.topk(hs, min(num_keep_best, len(hs)), largest=True)
+        for bi, hi in enumerate(best):
+            conf, hyp = h.hyp[int(hi)]
+            logprobs[i, bi] = conf
+            decoded[i, bi, :len(hyp)] = hyp
+            decoded[i, bi, len(hyp)] = EOS
+    return decoded, logprobs
+
+
+def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN):
+    """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
+    B = image.shape[0]
+    K = num_beams
+    img_feats = patch_embed(sd, image)
+    enc1 = split_encoder(sd, img_feats)
+    input_ids0, am = test_text_inputs(B, max_length)
+    full_mask = construct_attn_mask(am, img_feats.shape[1])
+    rep = lambda x: x.unsqueeze(1).expand(x.shape[0], K, *x.shape[1:]).reshape(x.shape[0] * K, *x.shape[1:])
+    img_feats_k, full_mask_k = rep(img_feats), rep(full_mask)
+    enc_k = (rep(enc1[0]), rep(enc1[1]))
+    od = rep(input_ids0[:, max_length:])
+    pos_full = torch.cat([torch.arange(max_length), torch.arange(20, 20 + OD_LEN)])
+
+    def step(input_ids, beam_idx):
+        cur = input_ids.shape[1]
+        ids = torch.cat([input_ids, torch.full((B * K, 1), MASK, dtype=torch.long), od], dim=1)
+        curr = cur + 1
+        mask = _remove_rows_cols(full_mask_k, curr, max_length, curr, max_length)
+        pp = torch.cat([pos_full[:curr], pos_full[max_length:]]).unsqueeze(0).expand(B * K, -1)
+        tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
+        logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
+        return logits[:, cur, :]
+    return beam_bookkeeping(step, B, K, max_length)
+
+
+def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False):
+    """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
+    image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
+    r = _R(emulate_bf16)
+    sdw = _rw(sd, r)
+    B = image.shape[0]
+    K = num_beams
+    hidden, tag_hidden = encoder_incremental(sdw, image, r)
+    vis = torch.cat([tag_hidden[:, :1], hidden], dim=1)
+    S = vis.shape[1]
+    kv = []
+    x = vis
+    for i in range(4):
+        p, wqkv, bqkv = _dec_w(sdw, i)
+        qkv = r(F.linear(r(x), wqkv, bqkv))
+        kv.append((qkv[..., 768:1536].clone(), qkv[..., 1536:].clone()))
+        if i == 3:
+            break
+        x = _post(sdw, p, attn_rounded(qkv, S, r), x, r)
+    rep = lambda t: t.unsqueeze(1).expand(B, K, *t.shape[1:]).reshape(B * K, *t.shape[1:])
+    kvk = [(rep(k), rep(v)) for k, v in kv]
+    e = 'module.bert.embeddings'
+    N = B * K
+    tk = [torch.zeros(N, max_length, HID) for _ in range(4)]
+    tv = [torch.zeros(N, max_length, HID) for _ in range(4)]
+    trace = []
+
+    def step(input_ids, beam_idx):
+        t = input_ids.shape[1]
+        if beam_idx is not None:
+            for i in range(4):
+                tk[i][:] = tk[i][beam_idx]
+                tv[i][:] = tv[i][beam_idx]
+        tok = torch.stack([input_ids[:, t - 1], torch.full((N,), MASK, dtype=torch.long)], dim=1)
+        pos = torch.tensor([t - 1, t])
+        x = (sdw[e + '.word_embeddings.weight'][tok] + sdw[e + '.position_embeddings.weight'][pos]
+             + sdw[e + '.token_type_embeddings.weight'][0])
+        x = _ln(sdw, e + '.LayerNorm', x, 1e-12)
+        for i in range(4):
+            p, wqkv, bqkv = _dec_w(sdw, i)
+            qkv = r(F.linear(r(x), wqkv, bqkv))
+            q = qkv[..., :768].view(N, 2, HEADS, HD).transpose(1, 2)
+            tk[i][:, t - 1] = qkv[:, 0, 768:1536]
+            tv[i][:, t - 1] = qkv[:, 0, 1536:]
+            Kc = torch.cat([kvk[i][0], tk[i][:, :t], qkv[:, 1:2, 768:1536]], dim=1)
+            Vc = torch.cat([kvk[i][1], tv[i][:, :t], qkv[:, 1:2, 1536:]], dim=1)
+            Kh = Kc.view(N, -1, HEADS, HD).transpose(1, 2)
+            Vh = Vc.view(N, -1, HEADS, HD).transpose(1, 2)
+            sc = q @ Kh.transpose(-1, -2)
+            sc[:, :, 0, -1] = float('-inf')
+            ctx = softmax_pv_rounded(sc, Vh, r).transpose(1, 2).reshape(N, 2, HID)
+            x = _post(sdw, p, ctx, x, r)
+        c = 'module.cls.predictions'
+        h = _ln(sdw, c + '.transform.LayerNorm', gelu_erf(_lin(sdw, c + '.transform.dense', r(x[:, 1]))), 1e-12)
+        logits = F.linear(r(h), sdw[c + '.decoder.weight']) + sdw[c + '.bias']
+        if return_trace:
+            trace.append(logits.clone())
+        return logits
+    out = beam_bookkeeping(step, B, K, max_length)
+    return out + (trace,) if return_trace else out

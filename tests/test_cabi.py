@@ -82,7 +82,7 @@ def test_model_surface(L, sd_np):
     with pytest.raises(NotImplementedError):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    m.test_extra_input['num_beams'] = 5
+    m.test_extra_input['do_sample'] = True
     with pytest.raises(NotImplementedError):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
 

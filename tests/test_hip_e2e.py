@@ -136,3 +136,38 @@ def test_batch64_properties(model):
             k = row.index(102)
             assert all(v == 0 for v in row[k + 1:])
     assert torch.isfinite(lp1).all()
+
+
+@pytest.mark.parametrize('beams', [2, 5])
+def test_beam_search_vs_oracle(model, sd_t, golden, beams):
+    """a13: device beam search == the oracle's beam driver on the bf16-emulated incremental model."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    vec, _ = golden
+    B = 3
+    img = torch.from_numpy(W.gen_image_batch(B, 1234))
+    with torch.no_grad():
+        ids_o, lp_o = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True)
+    model.test_extra_input['num_beams'] = beams
+    try:
+        ids, lp = model({'image': img.cuda(), 'key': list(range(B))})
+    finally:
+        model.test_extra_input['num_beams'] = 1
+    torch.cuda.synchronize()
+    print('hip   ', ids.cpu()[:, 0].tolist(), lp.cpu().flatten().tolist())
+    print('oracle', ids_o[:, 0].tolist(), lp_o.flatten().tolist())
+    assert ids.shape == (B, 1, 20) and lp.shape == (B, 1)
+    same = (ids.cpu() == ids_o).all(-1).all(-1)
+    assert int(same.sum()) >= B - 1, 'more than one beam result differs from the oracle'
+    np.testing.assert_allclose(lp.cpu().numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=2e-3)
+    if beams == 2:
+        assert np.array_equal(ids.cpu().numpy()[:1], vec['beam2_b1_ids']), 'differs from the reference beam=2 golden'
+
+
+def test_beam1_equals_greedy_tokens(model):
+    """Beam search with one beam must pick the greedy tokens (scores are length-normalised differently)."""
+    from vitcap_amd import weights as W
+    img = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+    g_ids, _ = model.generate(img)
+    b_ids, _ = model.generate_beam(img, 1)
+    assert torch.equal(g_ids, b_ids)

@@ -124,3 +124,20 @@ def test_greedy_untied_notebook_flow(golden, img):
         ids, lp = O.greedy_as_written(sd, img[:1], tagemb=None, reuse_encoder=True)
     np.testing.assert_array_equal(ids.numpy(), vec['greedy_untied_nocls_b1_ids'])
     np.testing.assert_allclose(lp.numpy(), vec['greedy_untied_nocls_b1_logprobs'], rtol=1e-5, atol=1e-5)
+
+
+def test_beam2_as_written_matches_reference(golden, sd_t, img):
+    """a13: the beam driver + BeamHypotheses restatement against the reference's own beam=2 output."""
+    vec, _ = golden
+    with torch.no_grad():
+        ids, lp = O.beam_as_written(sd_t, img[:1], num_beams=2)
+    np.testing.assert_array_equal(ids.numpy(), vec['beam2_b1_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['beam2_b1_logprobs'], rtol=1e-5, atol=1e-5)
+
+
+def test_beam_incremental_equals_as_written(sd_t, img):
+    with torch.no_grad():
+        a = O.beam_as_written(sd_t, img[:1], num_beams=3)
+        b = O.beam_incremental(sd_t, img[:1], num_beams=3, emulate_bf16=False)
+    np.testing.assert_array_equal(a[0].numpy(), b[0].numpy())
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=1e-5, atol=1e-5)

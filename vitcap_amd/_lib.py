@@ -26,6 +26,11 @@ class GemmDesc(C.Structure):
                                        'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')]
 
 
+class BeamState(C.Structure):
+    _fields_ = [(n, vp) for n in ('ids_in', 'ids_out', 'beam_scores', 'parent', 'done', 'has_hyp', 'hyp_score',
+                                  'hyp_len', 'hyp_tok')]
+
+
 class VitBlockW(C.Structure):
     _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
                                   'n1_g', 'n1_b', 'n2_g', 'n2_b')]
@@ -66,12 +71,20 @@ _SIGS = {
     'vitcap_greedy_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
     'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
+    'vitcap_row_topk_lse': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
+    'vitcap_beam_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_beam_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, vp]),
+    'vitcap_beam_reorder_cache': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_beam_finalize': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_assemble_visual': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_gather_rows_bf16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     'vitcap_engine_create': (C.c_int, [C.POINTER(vp)]),
     'vitcap_engine_destroy': (None, [vp]),
     'vitcap_engine_bind_weights': (C.c_int, [vp, C.POINTER(Weights)]),
     'vitcap_engine_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'vitcap_engine_workspace_bytes_beam': (C.c_size_t, [C.c_int, C.c_int]),
+    'vitcap_engine_beam': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_greedy': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp]),
     'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int]),
     'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),

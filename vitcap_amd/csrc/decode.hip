@@ -157,6 +157,199 @@ __global__ __launch_bounds__(1024) void sigmoid_topk_kernel(const float* __restr
   if (tid == 0) out_len[b] = nlen;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Beam search (a13, modeling_utils.py:888-1100).  Per step:
+//   row_topk_lse_kernel : per sequence row, logsumexp over the vocabulary and its 2*beams largest logits
+//                         (the top 2*beams of a row are the only candidates that row can contribute, because
+//                         log_softmax + beam_score is a per-row constant shift);
+//   beam_step_kernel    : one thread per image merges beams x 2*beams candidates, sorts them by total score and
+//                         replays the reference's python candidate loop + BeamHypotheses (n_hyp = 1) on the device;
+//   beam_reorder_kernel : gathers the text K/V cache rows of the chosen parent beams.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void row_topk_lse_kernel(const float* __restrict__ logits, int ldl, int V, int k,
+                                                            float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                            float* __restrict__ out_lse) {
+  __shared__ ArgMax s_am[16];
+  __shared__ float s_sum[16];
+  __shared__ ArgMax s_best;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (size_t)b * ldl;
+  float pv[TK_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < TK_PER_THREAD; ++j) {
+    const int i = tid + j * 1024;
+    pv[j] = i < V ? row[i] : -INFINITY;
+  }
+  float rowmax = 0.f;
+  for (int r = 0; r < k; ++r) {
+    ArgMax best{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < TK_PER_THREAD; ++j) {
+      ArgMax c{pv[j], tid + j * 1024};
+      if (tid + j * 1024 < V) best = am_better(best, c);
+    }
+    best = wave_argmax(best);
+    if (lane == 0) s_am[w] = best;
+    __syncthreads();
+    if (tid == 0) {
+      ArgMax bb = s_am[0];
+      for (int q = 1; q < 16; ++q) bb = am_better(bb, s_am[q]);
+      s_best = bb;
+      out_val[(size_t)b * k + r] = bb.v;
+      out_idx[(size_t)b * k + r] = bb.i;
+    }
+    __syncthreads();
+    const ArgMax bb = s_best;
+    if (r == 0) {   // logsumexp with the row max, before anything is removed
+      rowmax = bb.v;
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < TK_PER_THREAD; ++j)
+        if (tid + j * 1024 < V) se += expf(pv[j] - rowmax);
+      se = wave_sum(se);
+      if (lane == 0) s_sum[w] = se;
+      __syncthreads();
+      if (tid == 0) {
+        float tot = 0.f;
+        for (int q = 0; q < 16; ++q) tot += s_sum[q];
+        out_lse[b] = rowmax + logf(tot);
+      }
+    }
+    if ((bb.i & 1023) == tid) {
+      const int jj = bb.i >> 10;
+#pragma unroll
+      for (int j = 0; j < TK_PER_THREAD; ++j)
+        if (j == jj) pv[j] = -INFINITY;
+    }
+  }
+}
+
+constexpr int MAXBEAM = 8;
+
+struct BeamState {
+  int64_t* ids_in;      // [B*K][max_len]
+  int64_t* ids_out;     // [B*K][max_len]
+  float* beam_scores;   // [B*K]
+  int* parent;          // [B*K]
+  int* done;            // [B]
+  int* has_hyp;         // [B]
+  float* hyp_score;     // [B]
+  int* hyp_len;         // [B]
+  int64_t* hyp_tok;     // [B][max_len]
+};
+
+__global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bos, int pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * K * max_len) {
+    st.ids_in[i] = (i % max_len == 0) ? bos : pad;
+    st.ids_out[i] = (i % max_len == 0) ? bos : pad;
+  }
+  if (i < B * K) {
+    st.beam_scores[i] = (i % K == 0) ? 0.f : -1e9f;
+    st.parent[i] = i;
+  }
+  if (i < B) {
+    st.done[i] = 0;
+    st.has_hyp[i] = 0;
+    st.hyp_score[i] = -1e30f;
+    st.hyp_len[i] = 0;
+  }
+  if (i < B * max_len) st.hyp_tok[i] = pad;
+}
+
+__global__ void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
+                                 const float* __restrict__ lse, BeamState st, int B, int K, int V, int t, int max_len,
+                                 int eos, int pad, float length_penalty) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int C = 2 * K;
+  float sc[MAXBEAM * 2 * MAXBEAM];
+  int fl[MAXBEAM * 2 * MAXBEAM];
+  const int n = K * C;
+  for (int k = 0; k < K; ++k) {
+    const int row = b * K + k;
+    const float shift = st.beam_scores[row] - lse[row];
+    for (int j = 0; j < C; ++j) {
+      sc[k * C + j] = cval[(size_t)row * C + j] + shift;       // log_softmax + beam score
+      fl[k * C + j] = k * V + cidx[(size_t)row * C + j];       // index into the (beams*V) view
+    }
+  }
+  // partial selection sort: the 2*beams best by (score desc, flat index asc)
+  for (int r = 0; r < C; ++r) {
+    int best = r;
+    for (int i = r + 1; i < n; ++i)
+      if (sc[i] > sc[best] || (sc[i] == sc[best] && fl[i] < fl[best])) best = i;
+    const float ts = sc[r]; sc[r] = sc[best]; sc[best] = ts;
+    const int tf = fl[r]; fl[r] = fl[best]; fl[best] = tf;
+  }
+  int done = st.done[b];
+  if (!done && st.has_hyp[b]) {
+    // BeamHypotheses.is_done with n_hyp = 1: worst_score is the kept hypothesis' score
+    if (st.hyp_score[b] >= sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
+  }
+  st.done[b] = done;
+  float nsc[MAXBEAM];
+  int nword[MAXBEAM], npar[MAXBEAM];
+  int cnt = 0;
+  if (!done) {
+    const bool last = (t + 1 == max_len);
+    for (int r = 0; r < C && cnt < K; ++r) {
+      const int beam = fl[r] / V, word = fl[r] - beam * V;
+      if (word == eos || last) {
+        const float hs = sc[r] / powf((float)t, length_penalty);     // len(hyp) == cur_len == t
+        if (!st.has_hyp[b] || hs > st.hyp_score[b]) {
+          st.has_hyp[b] = 1;
+          st.hyp_score[b] = hs;
+          st.hyp_len[b] = t;
+          const int64_t* src = st.ids_in + (size_t)(b * K + beam) * max_len;
+          for (int i = 0; i < t; ++i) st.hyp_tok[(size_t)b * max_len + i] = src[i];
+        }
+      } else {
+        nsc[cnt] = sc[r];
+        nword[cnt] = word;
+        npar[cnt] = b * K + beam;
+        ++cnt;
+      }
+    }
+  }
+  if (cnt < K) {   // finished image (or the last step): filler beams, ignored from here on
+    for (int i = 0; i < K; ++i) { nsc[i] = 0.f; nword[i] = pad; npar[i] = b * K; }
+  }
+  for (int i = 0; i < K; ++i) {
+    const int row = b * K + i;
+    const int64_t* src = st.ids_in + (size_t)npar[i] * max_len;
+    int64_t* dst = st.ids_out + (size_t)row * max_len;
+    for (int q = 0; q < t; ++q) dst[q] = src[q];
+    dst[t] = nword[i];
+    st.beam_scores[row] = nsc[i];
+    st.parent[row] = npar[i];
+  }
+}
+
+// dst[l][s][0..t) = src[l][parent[s]][0..t)   (rows of 2*768 bf16 = 3 KiB)
+__global__ __launch_bounds__(192) void beam_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                           const int* __restrict__ parent, int NS, int max_len, int t) {
+  const int s = blockIdx.x, l = blockIdx.y;
+  const size_t rowv = 2 * 768 * 2 / 16;   // 192 uint4 per position
+  const uint4* sp = src + ((size_t)l * NS + parent[s]) * max_len * rowv;
+  uint4* dp = dst + ((size_t)l * NS + s) * max_len * rowv;
+  for (int q = 0; q < t; ++q) dp[q * rowv + threadIdx.x] = sp[q * rowv + threadIdx.x];
+}
+
+__global__ void beam_finalize_kernel(BeamState st, int64_t* out_ids, float* out_lp, int B, int max_len, int eos, int pad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int L = st.hyp_len[b];
+  for (int i = 0; i < max_len; ++i) {
+    int64_t v = pad;
+    if (i < L) v = st.hyp_tok[(size_t)b * max_len + i];
+    else if (i == L) v = eos;
+    out_ids[(size_t)b * max_len + i] = v;
+  }
+  out_lp[b] = st.has_hyp[b] ? st.hyp_score[b] : -1e5f;
+}
+
 }  // namespace
 
 extern "C" int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_lp, float* cnt, int B, int max_len,
@@ -187,5 +380,62 @@ extern "C" int vitcap_sigmoid_topk(const float* logits, int ldl, int V, int k, f
   hipLaunchKernelGGL(sigmoid_topk_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, k, thresh,
                      out_ids, out_prob, out_len);
   VC_LAUNCH_CHECK("sigmoid_topk");
+  return VITCAP_OK;
+}
+
+
+extern "C" int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, float* out_val, int32_t* out_idx,
+                                   float* out_lse, int rows, void* stream) {
+  VC_REQUIRE(logits && out_val && out_idx && out_lse && rows > 0, "row_topk_lse: bad arguments");
+  VC_REQUIRE(k >= 1 && k <= 16 && V <= TK_PER_THREAD * 1024 && ldl >= V, "row_topk_lse: k=%d V=%d unsupported", k, V);
+  hipLaunchKernelGGL(row_topk_lse_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, k, out_val,
+                     out_idx, out_lse);
+  VC_LAUNCH_CHECK("row_topk_lse");
+  return VITCAP_OK;
+}
+
+static BeamState make_state(const vitcap_beam_state* s) {
+  BeamState st;
+  st.ids_in = s->ids_in; st.ids_out = s->ids_out; st.beam_scores = s->beam_scores; st.parent = s->parent;
+  st.done = s->done; st.has_hyp = s->has_hyp; st.hyp_score = s->hyp_score; st.hyp_len = s->hyp_len;
+  st.hyp_tok = s->hyp_tok;
+  return st;
+}
+
+extern "C" int vitcap_beam_init(const vitcap_beam_state* s, int B, int K, int max_len, int bos, int pad, void* stream) {
+  VC_REQUIRE(s && B > 0 && K >= 1 && K <= MAXBEAM && max_len > 1, "beam_init: bad arguments (beams <= %d)", MAXBEAM);
+  const int n = B * K * max_len;
+  hipLaunchKernelGGL(beam_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, make_state(s), B, K,
+                     max_len, bos, pad);
+  VC_LAUNCH_CHECK("beam_init");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, const float* lse,
+                                const vitcap_beam_state* s, int B, int K, int V, int t, int max_len, int eos, int pad,
+                                float length_penalty, void* stream) {
+  VC_REQUIRE(cand_val && cand_idx && lse && s && B > 0 && K >= 1 && K <= MAXBEAM, "beam_step: bad arguments");
+  VC_REQUIRE(t >= 1 && t < max_len, "beam_step: t=%d out of range", t);
+  hipLaunchKernelGGL(beam_step_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
+                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty);
+  VC_LAUNCH_CHECK("beam_step");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_beam_reorder_cache(const void* src, void* dst, const int32_t* parent, int layers, int NS,
+                                         int max_len, int t, void* stream) {
+  VC_REQUIRE(src && dst && parent && layers > 0 && NS > 0 && t >= 1 && t <= max_len, "beam_reorder: bad arguments");
+  hipLaunchKernelGGL(beam_reorder_kernel, dim3(NS, layers), dim3(192), 0, (hipStream_t)stream, (const uint4*)src,
+                     (uint4*)dst, parent, NS, max_len, t);
+  VC_LAUNCH_CHECK("beam_reorder");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B,
+                                    int max_len, int eos, int pad, void* stream) {
+  VC_REQUIRE(s && out_ids && out_logprobs && B > 0, "beam_finalize: bad arguments");
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, make_state(s),
+                     out_ids, out_logprobs, B, max_len, eos, pad);
+  VC_LAUNCH_CHECK("beam_finalize");
   return VITCAP_OK;
 }

@@ -58,13 +58,16 @@ struct Layout {
     off += (bytes + 255) & ~(size_t)255;
     return o;
   }
+  // image-sized buffers (B images) first, so their offsets do not depend on the number of decode sequences
   size_t patches, x, xt, h, qkv, mlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
-  size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache;
-  size_t hd_f, hd_b, logits;
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
-  size_t ids, unf, sum_lp, cnt, margins, logprob;
-  explicit Layout(int B) {
-    const size_t b = (size_t)B;
+  // sequence-sized buffers (NS = B for greedy, B*beams for beam search)
+  size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
+  size_t hd_f, hd_b, logits;
+  size_t ids, ids2, unf, sum_lp, cnt, margins, logprob;
+  size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok;
+  Layout(int B, int NS, bool beam) {
+    const size_t b = (size_t)B, n = (size_t)NS;
     patches = take(b * 576 * D * 2);
     x = take(b * NV * D * 4);
     xt = take(b * NV * D * 4);
@@ -77,18 +80,6 @@ struct Layout {
     da_f = take(b * SV * D * 4);
     da_b = take(b * SV * D * 2);
     dtmp = take(b * SV * D * 4);
-    xs_f = take(b * 2 * D * 4);
-    xs_b = take(b * 2 * D * 2);
-    sqkv = take(b * 2 * 3 * D * 2);
-    sctx = take(b * 2 * D * 2);
-    spart = take((size_t)SPLIT_MAX * b * 2 * D * 4);   // split-K partial slabs of the decode-step GEMMs
-    sa_f = take(b * 2 * D * 4);
-    sa_b = take(b * 2 * D * 2);
-    smlp = take(b * 2 * 4 * D * 2);
-    tcache = take(4 * b * L * 2 * D * 2);
-    hd_f = take(b * D * 4);
-    hd_b = take(b * D * 2);
-    logits = take(b * VP * 4);
     pool_in = take(b * D * 2);
     pooled = take(b * D * 2);
     tg_f = take(b * D * 4);
@@ -97,12 +88,38 @@ struct Layout {
     tag_ids = take(b * TOPK * 8);
     tag_prob = take(b * TOPK * 4);
     tag_len = take(b * 8);
-    ids = take(b * L * 8);
-    unf = take(b * 4);
-    sum_lp = take(b * 4);
-    cnt = take(b * 4);
-    margins = take(b * L * 4);
-    logprob = take(b * 4);
+    xs_f = take(n * 2 * D * 4);
+    xs_b = take(n * 2 * D * 2);
+    sqkv = take(n * 2 * 3 * D * 2);
+    sctx = take(n * 2 * D * 2);
+    spart = take((size_t)SPLIT_MAX * n * 2 * D * 4);   // split-K partial slabs of the decode-step GEMMs
+    sa_f = take(n * 2 * D * 4);
+    sa_b = take(n * 2 * D * 2);
+    smlp = take(n * 2 * 4 * D * 2);
+    tcache = take(4 * n * L * 2 * D * 2);
+    tcache2 = beam ? take(4 * n * L * 2 * D * 2) : 0;
+    hd_f = take(n * D * 4);
+    hd_b = take(n * D * 2);
+    logits = take(n * VP * 4);
+    ids = take(n * L * 8);
+    ids2 = beam ? take(n * L * 8) : 0;
+    unf = take(n * 4);
+    sum_lp = take(n * 4);
+    cnt = take(n * 4);
+    margins = take(n * L * 4);
+    logprob = take(n * 4);
+    if (beam) {
+      cand_val = take(n * 16 * 4);
+      cand_idx = take(n * 16 * 4);
+      lse = take(n * 4);
+      beam_scores = take(n * 4);
+      parent = take(n * 4);
+      done = take(b * 4);
+      has_hyp = take(b * 4);
+      hyp_score = take(b * 4);
+      hyp_len = take(b * 4);
+      hyp_tok = take(b * L * 8);
+    }
   }
 };
 
@@ -214,14 +231,18 @@ extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights
   return VITCAP_OK;
 }
 
-extern "C" size_t vitcap_engine_workspace_bytes(int B) { return B > 0 ? Layout(B).off : 0; }
+extern "C" size_t vitcap_engine_workspace_bytes(int B) { return B > 0 ? Layout(B, B, false).off : 0; }
+extern "C" size_t vitcap_engine_workspace_bytes_beam(int B, int beams) {
+  return (B > 0 && beams >= 1 && beams <= 8) ? Layout(B, B * beams, true).off : 0;
+}
 
-static int check(vitcap_engine* e, int B, void* ws, size_t ws_bytes) {
+static int check(vitcap_engine* e, int B, void* ws, size_t ws_bytes, size_t need = 0) {
   if (!e || !e->bound) { vitcap_set_error("engine: weights not bound"); return VITCAP_ESTATE; }
   if (B <= 0 || !ws) { vitcap_set_error("engine: bad batch/workspace"); return VITCAP_EINVAL; }
   if (((uintptr_t)ws & 255) != 0) { vitcap_set_error("engine: workspace must be 256-byte aligned"); return VITCAP_EINVAL; }
-  if (ws_bytes < Layout(B).off) {
-    vitcap_set_error("engine: workspace %zu < required %zu bytes", ws_bytes, Layout(B).off);
+  if (need == 0 && B > 0) need = Layout(B, B, false).off;
+  if (ws_bytes < need) {
+    vitcap_set_error("engine: workspace %zu < required %zu bytes", ws_bytes, need);
     return VITCAP_EWORKSPACE;
   }
   return VITCAP_OK;
@@ -247,7 +268,7 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
   CK(check(e, B, workspace, workspace_bytes));
   g_cur = e;
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
-  const Layout lo(B);
+  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;
   float* x = (float*)(ws + lo.x);
@@ -293,7 +314,7 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
 extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* s) {
   CK(check(e, B, workspace, workspace_bytes));
   g_cur = e;
-  const Layout lo(B);
+  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;
   const int M = B * SV;
@@ -318,52 +339,57 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, s
   return VITCAP_OK;
 }
 
+// One decode step for NS sequences (K sequences share one image's visual K/V): embeddings of (token t-1, [MASK]) ->
+// 4 decoder layers against the caches -> LM head on the [MASK] rows -> fp32 logits [NS, VOCAB_PAD].
+static int step_forward(const vitcap_weights& w, const Layout& lo, char* ws, int NS, int K, int t, const int64_t* ids,
+                        char* tcache, void* s) {
+  float* xs_f = (float*)(ws + lo.xs_f);
+  char* xs_b = ws + lo.xs_b;
+  const int R = 2 * NS;
+  CK(vitcap_embed_step(ids, L, t, MASK, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
+                       NS, s));
+  float* part = (float*)(ws + lo.spart);
+  for (int l = 0; l < 4; ++l) {
+    const vitcap_bert_layer_w& lw = w.dec[l];
+    char* tc = tcache + (size_t)l * NS * L * 2 * D * 2;
+    CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE,
+            VITCAP_OUT_BF16, s));
+    CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, NS, SV, t, L, K, 0.125f, s));
+    // attention.output.dense and output.dense: split-K partial slabs, reduced inside the fused
+    // bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
+    CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
+    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
+                            ws + lo.sa_b, (float*)(ws + lo.sa_f), R, D, s));
+    CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
+            VITCAP_OUT_BF16, s));
+    CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
+    CK(vitcap_sum_layernorm(part, SPLIT_FC2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
+                            lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
+  }
+  // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
+  CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, NS, D, D, SPLIT_AO, s));
+  CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
+                          ws + lo.hd_b, nullptr, NS, D, s));
+  CK(gemm(ws + lo.hd_b, D, w.cls.dec_w, w.cls.dec_b, nullptr, 0, ws + lo.logits, VP, NS, VP, D, VITCAP_ACT_NONE,
+          VITCAP_OUT_F32, s));
+  return VITCAP_OK;
+}
+
 extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                                     float* out_logprobs, void* s) {
   CK(check(e, B, workspace, workspace_bytes));
   g_cur = e;
   if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
-  const Layout lo(B);
+  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;
   int64_t* ids = (int64_t*)(ws + lo.ids);
   int32_t* unf = (int32_t*)(ws + lo.unf);
   float* sum_lp = (float*)(ws + lo.sum_lp);
   float* cnt = (float*)(ws + lo.cnt);
-  float* xs_f = (float*)(ws + lo.xs_f);
-  char* xs_b = ws + lo.xs_b;
-  const int R = 2 * B;
   CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, B, L, BOS, PAD, s));
   for (int t = 1; t < L; ++t) {
-    CK(vitcap_embed_step(ids, L, t, MASK, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
-                         B, s));
-    for (int l = 0; l < 4; ++l) {
-      const vitcap_bert_layer_w& lw = w.dec[l];
-      char* tc = ws + lo.tcache + (size_t)l * B * L * 2 * D * 2;
-      CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE,
-              VITCAP_OUT_BF16, s));
-      CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, B, SV, t, L, 1, 0.125f, s));
-      // attention.output.dense and output.dense: split-K partial slabs, reduced inside the fused
-      // bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
-      float* part = (float*)(ws + lo.spart);
-      CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
-      CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
-                              ws + lo.sa_b, (float*)(ws + lo.sa_f), R, D, s));
-      CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
-              VITCAP_OUT_BF16, s));
-      CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
-      CK(vitcap_sum_layernorm(part, SPLIT_FC2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
-                              lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
-    }
-    // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
-    {
-      float* part = (float*)(ws + lo.spart);
-      CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, B, D, D, SPLIT_AO, s));
-      CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)B * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b,
-                              1e-12f, ws + lo.hd_b, nullptr, B, D, s));
-    }
-    CK(gemm(ws + lo.hd_b, D, w.cls.dec_w, w.cls.dec_b, nullptr, 0, ws + lo.logits, VP, B, VP, D, VITCAP_ACT_NONE,
-            VITCAP_OUT_F32, s));
+    CK(step_forward(w, lo, ws, B, 1, t, ids, ws + lo.tcache, s));
     CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
                           (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, s));
   }
@@ -376,13 +402,57 @@ extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, si
   return VITCAP_OK;
 }
 
+// Beam search (a13): encoder + prefill once per image, B*beams sequences in the step loop, all bookkeeping on device.
+extern "C" int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
+                                  float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                                  float* out_logprobs, void* s) {
+  if (beams < 1 || beams > 8) { vitcap_set_error("beam: num_beams must be 1..8 (got %d)", beams); return VITCAP_EINVAL; }
+  const int NS = B * beams;
+  const Layout lo(B, NS, true);
+  CK(check(e, B, workspace, workspace_bytes, lo.off));
+  if (!out_ids || !out_logprobs) { vitcap_set_error("beam: null outputs"); return VITCAP_EINVAL; }
+  CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
+  CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
+  g_cur = e;
+  char* ws = (char*)workspace;
+  const vitcap_weights& w = e->w;
+  vitcap_beam_state st;
+  st.ids_in = (int64_t*)(ws + lo.ids);
+  st.ids_out = (int64_t*)(ws + lo.ids2);
+  st.beam_scores = (float*)(ws + lo.beam_scores);
+  st.parent = (int32_t*)(ws + lo.parent);
+  st.done = (int32_t*)(ws + lo.done);
+  st.has_hyp = (int32_t*)(ws + lo.has_hyp);
+  st.hyp_score = (float*)(ws + lo.hyp_score);
+  st.hyp_len = (int32_t*)(ws + lo.hyp_len);
+  st.hyp_tok = (int64_t*)(ws + lo.hyp_tok);
+  CK(vitcap_beam_init(&st, B, beams, L, BOS, PAD, s));
+  char* tc_cur = ws + lo.tcache;
+  char* tc_alt = ws + lo.tcache2;
+  const int C = 2 * beams;
+  for (int t = 1; t < L; ++t) {
+    CK(step_forward(w, lo, ws, NS, beams, t, st.ids_in, tc_cur, s));
+    CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),
+                           (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), NS, s));
+    CK(vitcap_beam_step((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
+                        (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, EOS, PAD, length_penalty, s));
+    if (t + 1 < L) {   // re-order the text K/V history (positions 0..t-1) by parent beam for the next step
+      CK(vitcap_beam_reorder_cache(tc_cur, tc_alt, st.parent, 4, NS, L, t, s));
+      char* tmp = tc_cur; tc_cur = tc_alt; tc_alt = tmp;
+    }
+    int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
+  }
+  CK(vitcap_beam_finalize(&st, out_ids, out_logprobs, B, L, EOS, PAD, s));
+  return VITCAP_OK;
+}
+
 extern "C" int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
                                     size_t workspace_bytes, int64_t* out_ids, float* out_logprobs,
                                     float* tag_logits_out, int64_t* tag_topk_out, void* s) {
   CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
   CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
   CK(vitcap_engine_decode(e, B, workspace, workspace_bytes, out_ids, out_logprobs, s));
-  const Layout lo(B);
+  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   if (tag_logits_out) {
     if (hipMemcpy2DAsync(tag_logits_out, (size_t)VITCAP_VOCAB * 4, ws + lo.tag_logits, (size_t)VP * 4,
@@ -403,7 +473,7 @@ extern "C" int vitcap_engine_greedy(vitcap_engine* e, const void* image, int ima
 
 extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B) {
   if (!e || !name || !workspace || B <= 0) return nullptr;
-  const Layout lo(B);
+  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   if (!strcmp(name, "hidden")) return ws + lo.x;
   if (!strcmp(name, "tag_hidden")) return ws + lo.xt;

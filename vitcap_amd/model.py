@@ -190,9 +190,9 @@ class ImageCaptioning(nn.Module):
             pass
 
     # ---------------------------------------------------------------- forward
-    def _workspace(self, B, dev, slot=0):
+    def _workspace(self, B, dev, slot=0, beams=0):
         """One workspace per slot: concurrent generate() calls on different HIP streams use different slots."""
-        need = lib.vitcap_engine_workspace_bytes(B)
+        need = lib.vitcap_engine_workspace_bytes_beam(B, beams) if beams else lib.vitcap_engine_workspace_bytes(B)
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -222,6 +222,22 @@ class ImageCaptioning(nn.Module):
             self.last_tags = (tag_logits, tag_topk)
         return ids, lp
 
+    def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0):
+        """Beam search (num_keep_best = 1) -> (ids (B,1,20), logprobs (B,1)) like ViTCAP._generate_beam_search."""
+        if self._packed is None:
+            self.pack(image.device)
+        dev = self._packed[2]
+        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
+        B = image.shape[0]
+        ws, need = self._workspace(B, dev, slot, beams=num_beams)
+        ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
+        lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vitcap_engine_beam(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B,
+                                     num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
+                                     C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()), s), 'engine_beam')
+        return ids, lp
+
     def tap(self, name, B, shape, dtype=torch.float32):
         """Copy of an engine workspace buffer after the last generate() (parity taps)."""
         ws, _ = self._workspace(B, self._packed[2])
@@ -239,8 +255,12 @@ class ImageCaptioning(nn.Module):
         data = dict(data.items())
         data.pop('key', None)
         te = self.test_extra_input
-        if te.get('num_beams', 1) != 1 or te.get('do_sample', False):
-            raise NotImplementedError('only greedy decoding (num_beams=1, do_sample=False) is built on the HIP path')
+        if te.get('do_sample', False):
+            raise NotImplementedError('sampled decoding (do_sample=True) is not built on the HIP path yet')
+        if te.get('num_keep_best', 1) != 1 or te.get('num_return_sequences', 1) != 1:
+            raise NotImplementedError('num_keep_best / num_return_sequences > 1 are not built')
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
+        if te.get('num_beams', 1) > 1:
+            return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)))
         return self.generate(data['image'])
