@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--beams', type=int, default=1, help='num_beams (1 = greedy, the headline metric; 5 = BASELINE configs[2])')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='replay the step from a captured hipGraph (1) or launch eagerly (0)')
     args = ap.parse_args()
@@ -84,6 +85,9 @@ def main():
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:%d' % local)
     img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
+    if args.beams > 1:
+        _greedy = model.generate
+        model.generate = lambda im, **kw: model.generate_beam(im, args.beams, slot=kw.get('slot', 0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,7 +176,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: ViT-B/16-384 greedy decode (20 tok), batch %d bf16 per GPU, '
                                'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM' % B,
-                   'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy', 'max_length': 20,
+                   'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy' if args.beams == 1 else 'beam%d' % args.beams, 'max_length': 20,
                    'parallelism': 'replicas x%d (no data-path collective)' % world,
                    'launch': 'hipGraph replay' if graph is not None else 'eager', 'streams_per_gpu': nstr},
         'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),

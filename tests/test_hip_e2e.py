@@ -171,3 +171,36 @@ def test_beam1_equals_greedy_tokens(model):
     g_ids, _ = model.generate(img)
     b_ids, _ = model.generate_beam(img, 1)
     assert torch.equal(g_ids, b_ids)
+
+
+def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch):
+    """run.py -c yaml flow: plugin-loaded pipeline, seeded weights saved as a reference-style checkpoint
+    (DDP 'module.' prefixes), suffix-matching load, captions written as the reference's predict TSV rows."""
+    import json
+    import yaml
+    import run
+    from vitcap_amd.model import ImageCaptioning
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
+    sd = ImageCaptioning().load_recipe(0).state_dict()
+    ck = tmp_path / 'base.pt'
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'iteration': 0}, ck)
+    cfg = {'type': 'pipeline_eval_multi',
+           'all_test_data': [{'test_data': 'synthetic', 'test_split': 'test'}],
+           'param': {'full_expid': 'E', 'max_iter': 10, 'basemodel': str(ck), 'text_encoder_type': str(enc),
+                     'tagemb': 'cls', 'test_batch_size': 2, 'synthetic_num_images': 3, 'force_predict': True,
+                     'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+    yf = tmp_path / 'exp.yaml'
+    yf.write_text(yaml.safe_dump(cfg))
+    kw = run.parse_general_args(['-c', str(yf)])
+    fn = kw.pop('type')
+    getattr(run, fn)(**kw)
+    out = str(ck) + '.synthetic.test.predict.tsv'
+    rows = [l.rstrip('\n').split('\t') for l in open(out)]
+    assert [r[0] for r in rows] == ['0_0', '0_1', '0_2']
+    cap = json.loads(rows[0][1])[0]
+    assert cap['caption'].startswith('w30341 w3203 w29703') and 0 < cap['conf'] < 1     # tokens of the golden caption

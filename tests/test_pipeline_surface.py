@@ -1,0 +1,68 @@
+"""Host-side drop-in surface: config/plugin semantics, checkpoint loader, detokenizer (CPU only)."""
+import base64
+import os
+
+import pytest
+import torch
+
+from vitcap_amd import config as Cfg
+from vitcap_amd.checkpoint import Checkpointer, align_state_dicts, load_state_dict_tolerant
+from vitcap_amd.tokenizer import CaptionDetokenizer
+
+
+def test_yaml_base_and_overrides(tmp_path):
+    (tmp_path / 'base.yaml').write_text('param:\n  a: 1\n  b: {c: 2, d: 3}\ntype: pipeline_eval_multi\n')
+    (tmp_path / 'exp.yaml').write_text('_base_: base.yaml\nparam:\n  b: {c: 20}\n  e: x\n')
+    kw = Cfg.parse_general_args(['-c', str(tmp_path / 'exp.yaml'), '-p', '{param$b$d: 30, type: pipeline_train_eval_multi}',
+                                 '-bp', base64.b64encode(b'all_test_data: [{test_data: T}]').decode()])
+    assert kw['param'] == {'a': 1, 'b': {'c': 20, 'd': 30}, 'e': 'x'}
+    assert kw['type'] == 'pipeline_train_eval_multi' and kw['all_test_data'] == [{'test_data': 'T'}]
+
+
+def test_config_returns_none_for_unknown_keys():
+    c = Cfg.Config({'num_beams': 1}, {'net': 'B'})
+    assert c.num_beams == 1 and c.net == 'B' and c.scst is None and c.get_dict() == {'num_beams': 1, 'net': 'B'}
+
+
+def test_plugin_loader_builds_our_pipeline():
+    pip = Cfg.execute_func({'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline',
+                            'param': {'full_expid': 'E', 'max_iter': 10, 'num_beams': 5}})
+    assert pip.full_expid == 'E' and pip.cfg.max_gen_length == 20 and pip.cfg.tie_weights is True
+    assert pip.get_checkpoint_file().endswith('output/E/snapshot/model_iter_0000010.pt')
+    assert 'beam5' in pip.get_predict_file('m.pt')
+    with pytest.raises(NotImplementedError):
+        pip.ensure_train()
+
+
+def test_suffix_matching_loader(tmp_path):
+    from vitcap_amd.model import ImageCaptioning
+    m = ImageCaptioning().load_recipe(0)
+    sd = m.state_dict()
+    # a DDP-saved reference checkpoint: extra 'module.' prefix on every key, one tensor with a wrong shape
+    ck = {'module.' + k: v.clone() for k, v in sd.items()}
+    ck['module.module.cls.predictions.bias'] = torch.zeros(7)
+    f = tmp_path / 'model_iter_0000005.pt'
+    torch.save({'model': ck, 'iteration': 5, 'optimizer': {'state': {}}}, f)
+    m2 = ImageCaptioning()
+    extra = Checkpointer(m2, save_dir=str(tmp_path)).load(str(f), model_only=True, load_if_has=False)
+    assert extra == {}
+    sd2 = m2.state_dict()
+    k = 'module.bert.decoder.layer.2.output.dense.weight'
+    assert torch.equal(sd2[k], sd[k])
+    assert float(sd2['module.cls.predictions.bias'].abs().sum()) == 0.0          # mismatched shape skipped
+    assert align_state_dicts(['a.b.c.weight'], {'c.weight': 0, 'b.c.weight': 1}) == {'a.b.c.weight': 'b.c.weight'}
+    # save / last_checkpoint round trip
+    ckp = Checkpointer(m2, save_dir=str(tmp_path / 'snap'), save_to_disk=True)
+    out = ckp.save('model_iter_0000001', iteration=1)
+    assert ckp.has_checkpoint() and ckp.get_checkpoint_file() == out
+    good, bad, missing = load_state_dict_tolerant(ImageCaptioning(), torch.load(out, weights_only=False)['model'])
+    assert len(good) == 288 and not bad and not missing
+
+
+def test_detokenizer_matches_reference_rules():
+    toks = ['[PAD]', '[UNK]', '[CLS]', '[SEP]', '[MASK]', 'a', 'cat', 'walk', '##ing', 'on', 'beach', '.', "'", 's', 'do', 'not']
+    t = CaptionDetokenizer(tokens=toks)
+    ids = t.convert_tokens_to_ids(['[CLS]', 'a', 'cat', 'walk', '##ing', 'on', 'a', 'beach', '.', '[SEP]', '[PAD]', '[PAD]'])
+    assert t.decode(ids, skip_special_tokens=True) == 'a cat walking on a beach.'
+    assert t.decode(ids[:4]) == '[CLS] a cat walk'
+    assert t.decode(t.convert_tokens_to_ids(['cat', "'", 's', 'beach'])) == "cat's beach"

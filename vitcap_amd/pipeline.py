@@ -1,0 +1,209 @@
+"""Pipeline surface of the reference (run.py -> param.pipeline_type -> CaptionUniPipeline) for the captioning hot path.
+
+Mirrors ``src/pipelines/uni_pipeline.py`` (UniPipeline.ensure_train / ensure_predict / ensure_evaluate / monitor_train
+/ is_train_finished / full_expid, lines 342-378, 673-697, 884-911, 1021-1038) and
+``src/pipelines/tagger_caption_uni_pipeline_expanding_bertemb.py`` (CaptionUniPipeline defaults 195-228,
+get_raw_model 566-618, predict_output_to_tsv_row 620-630) for what the hot path needs:
+
+* same YAML keys and defaults, ``Config`` semantics (unknown key -> None);
+* ``ensure_predict``: builds the HIP ``ImageCaptioning`` model, loads ``basemodel`` / the latest snapshot with the
+  reference's suffix-matching loader, captions the test split, writes ``<model>.…predict.tsv`` rows
+  ``key \\t json([{"caption": str, "conf": exp(logprob)}])`` per rank and merges them on rank 0;
+* the input side (TSV + JPEG decode) is not built: batches come from
+  ``data: synthetic`` (seeded uniform(-1,1) images) or from an iterable passed as ``test_batches``;
+* ``ensure_train`` raises until the HIP training step exists (round 2+); ``ensure_evaluate`` needs the external
+  coco-caption tools the reference does not vendor either and is a logged no-op without them.
+"""
+import copy
+import json
+import logging
+import os
+import os.path as op
+
+import torch
+
+from . import dist_util as D
+from .checkpoint import Checkpointer
+from .config import Config
+
+_UNI_DEFAULT = {   # the subset of UniPipeline._default (uni_pipeline.py:93-148) the hot path reads
+    'dist_backend': 'nccl', 'effective_batch_size': 256, 'test_batch_size': 48, 'max_iter': 10, 'log_step': 100,
+    'base_lr': 1e-4, 'weight_decay': 0.05, 'snapshot_steps': 5000, 'test_crop_size': 384, 'train_crop_size': 384,
+    'force_train': False, 'force_predict': False, 'ignore_predict': False, 'use_amp': False, 'random_seed': 88,
+    'expid_prefix': 'Jacob', 'num_workers': 8,
+}
+_CAPTION_DEFAULT = {   # CaptionUniPipeline._default.update (..._bertemb.py:195-228)
+    'mask_type': 'seq2seq', 'max_seq_a_length': 40, 'max_seq_length': 70, 'add_od_labels': True, 'drop_out': 0.1,
+    'tie_weights': True, 'label_smoothing': 0.1, 'img_layer_norm_eps': 1e-5, 'max_img_seq_length': 50,
+    'max_gen_length': 20, 'max_masked_tokens': 3, 'num_beams': 1, 'mask_prob': 0.15, 'replace_by_mask_prob': 0.8,
+    'replace_by_rand_prob': 0.1, 'temperature': 1, 'top_k': 0, 'top_p': 1, 'gradient_clip': 1.,
+    'optimizer_type': 'MAdamW', 'bias_no_weight_decay': True, 'ln_no_weight_decay': True, 'scheduler_type': 'linear',
+    'pad_to_max': True, 'pert_img_prob': None,
+}
+
+
+class CaptionUniPipeline(object):
+    def __init__(self, **kwargs):
+        self._default = copy.deepcopy(_UNI_DEFAULT)
+        self._default.update(_CAPTION_DEFAULT)
+        self.cfg = Config(self._default, dict(kwargs))
+        self.rank, self.world, self.local_rank = D.env_rank_world()
+        self._tokenizer = None
+        self._initialized = False
+
+    # ------------------------------------------------------------------ naming (uni_pipeline.py:150-170)
+    @property
+    def full_expid(self):
+        return self.cfg.full_expid or '_'.join(str(x) for x in (self.cfg.expid_prefix, self.cfg.data, self.cfg.net,
+                                                                  self.cfg.expid) if x)
+
+    @property
+    def output_folder(self):
+        return op.join('output', self.full_expid)
+
+    def get_snapshot_dir(self):
+        return op.join(self.output_folder, 'snapshot')
+
+    def get_checkpoint_file(self, iteration=None):
+        it = self.cfg.max_iter if iteration is None else iteration
+        if isinstance(it, str):
+            raise ValueError("max_iter given in epochs ('%s') needs the training set; use an integer" % it)
+        return op.join(self.get_snapshot_dir(), 'model_iter_{:07d}.pt'.format(int(it)))
+
+    def is_train_finished(self):
+        f = self.get_checkpoint_file()
+        return op.isfile(f) or bool(self.cfg.basemodel and op.isfile(self.cfg.basemodel))
+
+    def get_predict_file(self, model_file):
+        cc = [model_file, self.cfg.test_data or 'synthetic', self.cfg.test_split or 'test']
+        if self.cfg.num_beams not in (None, 1):
+            cc.append('beam{}'.format(self.cfg.num_beams))
+        return '.'.join(cc) + '.predict.tsv'
+
+    # ------------------------------------------------------------------ process group (torch_common.py:125-142)
+    def _ensure_initialized(self):
+        if self._initialized:
+            return
+        if self.world > 1:
+            backend = self.cfg.dist_backend if torch.cuda.is_available() else 'gloo'
+            D.init(backend, torch.device('cuda', self.local_rank) if backend == 'nccl' else None)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
+        self._initialized = True
+
+    # ------------------------------------------------------------------ model / tokenizer
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from .tokenizer import CaptionDetokenizer
+            vf = op.join(self.cfg.text_encoder_type or '.', 'vocab.txt')
+            if not op.isfile(vf):
+                raise FileNotFoundError('BERT vocab not found at %s (text_encoder_type: %s)' % (vf, self.cfg.text_encoder_type))
+            self._tokenizer = CaptionDetokenizer(vf)
+        return self._tokenizer
+
+    def get_raw_model(self, is_train):
+        if is_train:
+            raise NotImplementedError('the HIP training step is not built yet (round 2+)')
+        from .model import ImageCaptioning
+        extra = {'max_length': self.cfg.max_gen_length, 'num_beams': self.cfg.num_beams,
+                 'temperature': self.cfg.temperature, 'top_k': self.cfg.top_k, 'top_p': self.cfg.top_p,
+                 'add_od_labels': self.cfg.add_od_labels, 'od_labels_start_posid': self.cfg.max_seq_a_length}
+        return ImageCaptioning(tie_weights=bool(self.cfg.tie_weights), tagemb=self.cfg.tagemb or 'bert',
+                               test_extra_input=extra, cfg=self.cfg).eval()
+
+    def load_test_model(self, model, model_file):
+        if model_file and op.isfile(model_file):
+            Checkpointer(model=model, save_dir=self.get_snapshot_dir()).load(model_file, model_only=True,
+                                                                              load_if_has=False)
+        elif self.cfg.init_recipe_seed is not None:
+            model.load_recipe(int(self.cfg.init_recipe_seed))     # synthetic runs: seeded random init
+        else:
+            raise FileNotFoundError('no model file: {}'.format(model_file))
+        return model
+
+    # ------------------------------------------------------------------ entry points used by run.py
+    def ensure_train(self):
+        self._ensure_initialized()
+        raise NotImplementedError('pipeline_train_eval_multi: the HIP cross-entropy training step is not built yet')
+
+    def iter_test_batches(self):
+        """Per-rank shard of the test set.  `data: synthetic` -> seeded images, keys '<rank>_<i>'."""
+        if self.cfg.test_batches is not None:
+            for i, b in enumerate(self.cfg.test_batches):
+                if i % self.world == self.rank:
+                    yield b
+            return
+        from . import weights as W
+        n = int(self.cfg.synthetic_num_images or 8)
+        bs = int(self.cfg.test_batch_size)
+        seed = D.shard_seed(int(self.cfg.synthetic_seed or 1234), self.rank)
+        per_rank = (n + self.world - 1) // self.world
+        done = 0
+        while done < per_rank:
+            b = min(bs, per_rank - done)
+            img = torch.from_numpy(W.gen_image_batch(done + b, seed)[done:])
+            yield {'image': img, 'key': ['%d_%d' % (self.rank, done + i) for i in range(b)]}
+            done += b
+
+    def predict_output_to_tsv_row(self, data, output):
+        all_caps, all_confs = output[0], torch.exp(output[1])
+        for key, caps, confs in zip(data['key'], all_caps, all_confs):
+            res = [{'caption': self.tokenizer.decode(c.tolist(), skip_special_tokens=True), 'conf': float(p)}
+                   for c, p in zip(caps, confs)]
+            yield key, json.dumps(res)
+
+    def predict(self, model_file, predict_result_file):
+        model = self.load_test_model(self.get_raw_model(is_train=False), model_file)
+        dev = torch.device('cuda', self.local_rank)
+        model.pack(dev)
+        sub = predict_result_file if self.world == 1 else '{}_{}_{}.tsv'.format(predict_result_file, self.rank, self.world)
+        os.makedirs(op.dirname(sub) or '.', exist_ok=True)
+        with open(sub, 'w') as fp, torch.no_grad():
+            for batch in self.iter_test_batches():
+                batch = dict(batch)
+                batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
+                out = model(batch)
+                out = (out[0].cpu(), out[1].cpu())
+                for key, js in self.predict_output_to_tsv_row(batch, out):
+                    fp.write('{}\t{}\n'.format(key, js))
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            if self.rank == 0:      # concatenate and de-duplicate by key (uni_pipeline.py:816-831)
+                seen = set()
+                with open(predict_result_file, 'w') as fo:
+                    for r in range(self.world):
+                        with open('{}_{}_{}.tsv'.format(predict_result_file, r, self.world)) as fi:
+                            for line in fi:
+                                k = line.split('\t', 1)[0]
+                                if k not in seen:
+                                    seen.add(k)
+                                    fo.write(line)
+            dist.barrier()
+        return predict_result_file
+
+    def ensure_predict(self, model_file=None):
+        if self.cfg.ignore_predict:
+            logging.info('ignore to predict as instructed')
+            return None
+        self._ensure_initialized()
+        if model_file is None:
+            model_file = self.cfg.basemodel if (self.cfg.basemodel and op.isfile(self.cfg.basemodel)) \
+                else self.get_checkpoint_file()
+        predict_result_file = self.get_predict_file(model_file)
+        if not op.isfile(model_file) and self.cfg.init_recipe_seed is None:
+            logging.info('ignore to run predict since %s does not exist', model_file)
+            return predict_result_file
+        if op.isfile(predict_result_file) and not self.cfg.force_predict:
+            logging.info('ignore to do prediction %s', predict_result_file)
+            return predict_result_file
+        return self.predict(model_file, predict_result_file)
+
+    def ensure_evaluate(self, predict_file=None):
+        logging.info('ensure_evaluate: COCO caption metrics need the external coco_caption/cider packages that the '
+                     'reference does not vendor either (README:24); skipped')
+        return None
+
+    def monitor_train(self):
+        return None
