@@ -13,6 +13,8 @@
 //
 // The accumulators are computed transposed (first MFMA operand = W fragment): each lane then holds
 // 4 consecutive n for one m, so bias/residual loads and the C store are 8/16-byte vectors.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -608,6 +610,257 @@ int dispatch_256(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   return VITCAP_EINVAL;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant of the 256x256x64 role-alternating kernel: one workgroup per CU walks the tile list.
+// Before a tile's epilogue the first k-tile of the NEXT tile is already being fetched by LDS-DMA into the free
+// k-tile buffer (the epilogue stages through the other one, 8 KiB per wave, XOR-swizzled instead of padded),
+// the output stores are not waited for, and there is no workgroup relaunch between tiles: the prologue latency
+// and most of the store drain disappear behind useful work.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, BUF_BYTES = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w >> 2;
+  const int wm = w >> 2, wn = w & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (srow & 7);
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int coff0 = ((0 * 4 + fk) ^ (frow & 7)) * 16;
+  const int coff1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
+  const int a_base = (wm * 128 + frow) * 128;
+  const int b_base = A_BYTES + (wn * 64 + frow) * 128;
+  const int nk = p.K / BK;
+
+  const bf16_t* aptr[4];
+  const bf16_t* wptr[4];
+#define TILE_COORDS(tile_, m0_, n0_)                                                         \
+  do {                                                                                       \
+    int bid_ = (tile_);                                                                      \
+    const int q_ = nwg >> 3, r_ = nwg & 7, xcd_ = bid_ & 7;                                  \
+    bid_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + (bid_ >> 3);   \
+    const int tm_ = bid_ / p.tiles_n;                                                        \
+    m0_ = tm_ * BM;                                                                          \
+    n0_ = (bid_ - tm_ * p.tiles_n) * BN;                                                     \
+  } while (0)
+#define TILE_PTRS(m0_, n0_)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+    int r_ = (m0_) + w * 32 + i * 8 + srow;                                                  \
+    r_ = r_ < p.M ? r_ : p.M - 1;                                                            \
+    aptr[i] = p.A + (size_t)r_ * p.lda + schunk * 8;                                         \
+    int c_ = (n0_) + w * 32 + i * 8 + srow;                                                  \
+    c_ = c_ < p.N ? c_ : p.N - 1;                                                            \
+    wptr[i] = p.W + (size_t)c_ * p.ldw + schunk * 8;                                         \
+  }
+#define STAGE_A(buf_, k0_)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+      glds16(aptr[i] + (k0_), smem + (buf_) * BUF_BYTES + (w * 32 + i * 8) * 128)
+#define STAGE_W(buf_, k0_)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+      glds16(wptr[i] + (k0_), smem + (buf_) * BUF_BYTES + A_BYTES + (w * 32 + i * 8) * 128)
+#define STAGE2(base_, row0_, p0_, buf_, k0_)                                                 \
+  _Pragma("unroll") for (int i = (p0_); i < (p0_) + 2; ++i)                                  \
+      glds16((base_)[i] + (k0_), smem + (buf_) * BUF_BYTES + (row0_) + (w * 32 + i * 8) * 128)
+
+  bf16x8 afr[4][2];
+  bf16x8 bfr[2][2][2];
+#define LOAD_A(buf_, mh_)                                                                        \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                             \
+    const char* ra_ = smem + (buf_) * BUF_BYTES + a_base + ((mh_) * 4 + mt) * 16 * 128;          \
+    afr[mt][0] = *(const bf16x8*)(ra_ + coff0);                                                  \
+    afr[mt][1] = *(const bf16x8*)(ra_ + coff1);                                                  \
+  }
+#define LOAD_B(buf_, nh_)                                                                        \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                             \
+    const char* rb_ = smem + (buf_) * BUF_BYTES + b_base + ((nh_) * 2 + nt) * 16 * 128;          \
+    bfr[nh_][nt][0] = *(const bf16x8*)(rb_ + coff0);                                             \
+    bfr[nh_][nt][1] = *(const bf16x8*)(rb_ + coff1);                                             \
+  }
+#define END_LOAD()                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+  __builtin_amdgcn_sched_barrier(0);                        \
+  __builtin_amdgcn_s_barrier()
+#define COMPUTE(mh_, nh_)                                                                               \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+      _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
+        acc[(mh_) * 4 + mt][(nh_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+            bfr[nh_][nt][ks], afr[mt][ks], acc[(mh_) * 4 + mt][(nh_) * 2 + nt], 0, 0, 0);               \
+  __builtin_amdgcn_s_setprio(0)
+
+  int pb = 0;                       // LDS buffer holding k-tile 0 of the current tile
+  int tile = blockIdx.x;
+  int m0, n0;
+  TILE_COORDS(tile, m0, n0);
+  TILE_PTRS(m0, n0);
+  STAGE_A(0, 0);
+  STAGE_W(0, 0);
+
+  for (; tile < nwg; tile += gridDim.x) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // every wave has left the previous epilogue (its staging patch lives in buffer pb^1) before anyone DMAs into it
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) {
+      STAGE2(aptr, 0, 0, pb ^ 1, BK);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // k-tile 0 (and the previous tile's stores) done
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk; ++t) {
+      const int buf = (pb + t) & 1;
+      const bool more = t + 1 < nk;
+      const bool more2 = t + 2 < nk;
+      LOAD_A(buf, 0);
+      LOAD_B(buf, 0);
+      if (more) { STAGE2(aptr, 0, 2, buf ^ 1, (t + 1) * BK); }
+      END_LOAD();
+      COMPUTE(0, 0);
+      __builtin_amdgcn_s_barrier();
+      LOAD_B(buf, 1);
+      if (more) { STAGE2(wptr, A_BYTES, 0, buf ^ 1, (t + 1) * BK); }
+      END_LOAD();
+      COMPUTE(0, 1);
+      __builtin_amdgcn_s_barrier();
+      LOAD_A(buf, 1);
+      if (more) { STAGE2(wptr, A_BYTES, 2, buf ^ 1, (t + 1) * BK); }
+      END_LOAD();
+      COMPUTE(1, 1);
+      __builtin_amdgcn_s_barrier();
+      if (more2) { STAGE2(aptr, 0, 0, buf, (t + 2) * BK); }
+      if (grp == 1) {
+        if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      COMPUTE(1, 0);
+      if (grp == 0) {
+        if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- prefetch k-tile 0 of the next tile into the buffer the last k-tile did NOT use
+    const int ep_buf = (pb + nk - 1) & 1;      // last k-tile's buffer: free now, used for epilogue staging
+    const int cm0 = m0, cn0 = n0;
+    pb = ep_buf ^ 1;
+    if (tile + (int)gridDim.x < nwg) {
+      TILE_COORDS(tile + (int)gridDim.x, m0, n0);
+      TILE_PTRS(m0, n0);
+      STAGE_A(pb, 0);
+      STAGE_W(pb, 0);
+    }
+
+    // ---- epilogue: 4 passes of 32 rows through this wave's 8 KiB patch (XOR-swizzled 16-byte chunks)
+    char* ep = smem + ep_buf * BUF_BYTES + w * 8192;
+    const int er = lane >> 4, ec = lane & 15;
+    const int ncol = cn0 + wn * 64 + ec * 4;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = i * 16 + frow;
+          *(f32x4*)(ep + row * 256 + (((j * 4 + fk) ^ (row & 15)) * 16)) = acc[g * 2 + i][j];
+        }
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int rl = it * 4 + er;
+        f32x4 v = *(const f32x4*)(ep + rl * 256 + ((ec ^ (rl & 15)) * 16));
+        const int m = cm0 + wm * 128 + g * 32 + rl;
+        if (m >= p.M || ncol >= p.N) continue;
+        int orow = m, rrow = m;
+        if (p.row_group > 0) {
+          const int gq = m / p.row_group, in = m - gq * p.row_group;
+          orow = gq * p.out_group_rows + p.out_row_off + in;
+          rrow = p.res_periodic ? in : orow;
+        }
+        v += bias4;
+        if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + ncol);
+        if (OUT_F32) {
+          *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+        } else {
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+        }
+      }
+    }
+  }
+#undef TILE_COORDS
+#undef TILE_PTRS
+#undef STAGE_A
+#undef STAGE_W
+#undef STAGE2
+#undef LOAD_A
+#undef LOAD_B
+#undef END_LOAD
+#undef COMPUTE
+}
+
+template <int ACT, int OUT_F32, bool HAS_RES>
+int launch_256p(const GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 2 * 2 * 256 * 64 * 2;
+  auto kern = gemm_nt_256p_kernel<ACT, OUT_F32, HAS_RES>;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + 255) / 256;
+  p.tiles_n = (a.N + 255) / 256;
+  const int nwg = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3(nwg < n_cu ? nwg : n_cu), dim3(512), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt_256p");
+  return VITCAP_OK;
+}
+
+int dispatch_256p(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+  const bool res = a.res != nullptr;
+#define CASE(ACT_, OUT_)                                                  \
+  if (act == ACT_ && out_f32 == OUT_)                                     \
+    return res ? launch_256p<ACT_, OUT_, true>(a, s) : launch_256p<ACT_, OUT_, false>(a, s);
+  CASE(VITCAP_ACT_NONE, 0)
+  CASE(VITCAP_ACT_NONE, 1)
+  CASE(VITCAP_ACT_GELU_ERF, 0)
+  CASE(VITCAP_ACT_GELU_ERF, 1)
+#undef CASE
+  vitcap_set_error("gemm(256p): unsupported act %d / out %d", act, out_f32);
+  return VITCAP_EINVAL;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny kernel for the decode-step GEMMs (M = 2B or B rows: 64..256).  These are weight-streaming,
 // latency-bound problems: the whole weight matrix is read once and there is almost no reuse, so LDS
@@ -827,11 +1080,16 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
   if (hint == 3) return dispatch_big(a, d->act, d->out_dtype, s);
+  if (hint == 12) return dispatch_256p(a, d->act, d->out_dtype, s);
   if (hint == 6) return dispatch_256<2>(a, d->act, d->out_dtype, s);
   if (hint == 7) return launch_256<0, 0, false, 4 + 16 * 1>(a, s);   // ablation: no DMA in the loop
   if (hint == 8) return launch_256<0, 0, false, 4 + 16 * 2>(a, s);   // ablation: no ds_read in the loop
   if (hint == 9) return launch_256<0, 0, false, 4 + 16 * 4>(a, s);   // ablation: no MFMA
   if (hint == 10) return launch_256<0, 0, false, 4 + 16 * 3>(a, s);  // ablation: MFMA + barriers only
   if (hint == 11) return launch_256<0, 0, false, 4 + 16 * 6>(a, s);  // ablation: DMA + barriers only
+  // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %)
+  // and loses with one (the residual loads queue behind the next tile's DMA), so it is used for the former only.
+  static const int use_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+  if (hint == 0 && use_persistent && !residual && d->row_group == 0) return dispatch_256p(a, d->act, d->out_dtype, s);
   return dispatch_256<4>(a, d->act, d->out_dtype, s);
 }
