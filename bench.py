@@ -29,8 +29,11 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r01_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4>', 0: 'void gemm_nt_256p_kernel<0, 0, false>',
+              4: 'void gemm_nt_256p_kernel<1, 0, false>'}
 VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
                  2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
                  4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}
@@ -168,6 +171,13 @@ def main():
     dom = max(range(12), key=lambda i: ms[i])
     gemm_all = (tot_fl / (tot_ms * 1e-3)) / 1e12 if tot_ms > 0 else 0.0
     dom_tf = (fl[dom] / (ms[dom] * 1e-3)) / 1e12 if ms[dom] > 0 else 0.0
+    traffic = None
+    try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh);
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), KiB -> bytes
+        with open(TRAFFIC_FILE) as f:
+            traffic = json.load(f)[PMC_KERNEL[dom]]['hbm_bytes_per_launch_corrected']
+    except Exception:
+        traffic = None
     out = {
         'metric': 'images/sec end-to-end greedy caption (20 tok), ViT-B/16-384',
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
@@ -184,7 +194,8 @@ def main():
         'roofline': {
             'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),
             'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+            'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'traffic_note': 'bytes/launch, rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_hbm_traffic_pmc.json' if traffic else None,
             'launches': int(ln[dom]), 'avg_launch_ms': round(ms[dom] / max(1, ln[dom]), 4),
             'avg_launch_gflop': round(fl[dom] / max(1, ln[dom]) / 1e9, 3),
             'all_large_gemm_tflops': round(gemm_all, 2),

@@ -29,12 +29,23 @@ constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (confli
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                         int S, float c_log2) {
+                                                         int S, int B, float c_log2) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  // XCD-aware work mapping (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the q-blocks of one
+  // (image, head) -- which share that head's K/V -- are made consecutive *within* an XCD and hit its L2 instead of
+  // fetching K/V once per XCD (measured: 3.7x algorithmic fetch with the naive 3-D grid).
+  const int nqb = (S + 127) / 128;
+  const int nwork = nqb * NH * B;
+  int wid = blockIdx.x;
+  {
+    const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
+    wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
+  }
+  const int qb = wid % nqb;
+  const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
+  const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;        // waves past the last query row only help with staging
   const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
 
@@ -410,9 +421,9 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
   const float c = scale * 1.4426950408889634f;
-  dim3 grid((S + 127) / 128, NH, B);
+  dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
   hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, S,
-                     c);
+                     B, c);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
