@@ -673,3 +673,136 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
         return logits
     out = beam_bookkeeping(step, B, K, max_length)
     return out + (trace,) if return_trace else out
+
+
+# --------------------------------------------------------------------------------------------
+# a14 / a15-T  cross-entropy training step   (modeling_bert.py:751-807, 661-690; loss.py:5-22;
+#              trainer.py:95-142; optimization.py:151-210; ..._bertemb.py:280-356)
+# --------------------------------------------------------------------------------------------
+def synthetic_train_inputs(B, seed=4321, max_seq_a=20, max_seq=70, n_mask=3):
+    """What CaptionTensorizer.tensorize_ab(is_train=True, text_b='') emits (dataset.py:206-417), on synthetic captions:
+    [CLS] w1..wn [SEP] PAD.., n in [8,18]; 3 caption positions replaced by [MASK] (masked_ids = the originals);
+    attention_mask = tril over the seq_a_len caption slots, zero elsewhere; label = multi-hot of 10 random ids."""
+    g = torch.Generator().manual_seed(seed)
+    input_ids = torch.zeros(B, max_seq, dtype=torch.long)
+    attention_mask = torch.zeros(B, max_seq, max_seq)
+    masked_pos = torch.zeros(B, max_seq, dtype=torch.int32)
+    masked_ids = torch.zeros(B, n_mask, dtype=torch.long)
+    label = torch.zeros(B, V)
+    for b in range(B):
+        n = int(torch.randint(8, 19, (1,), generator=g))
+        toks = torch.randint(1000, 30000, (n,), generator=g)
+        seq_a_len = n + 2
+        input_ids[b, 0] = BOS
+        input_ids[b, 1:n + 1] = toks
+        input_ids[b, n + 1] = EOS
+        pos = torch.randperm(n, generator=g)[:n_mask].sort().values + 1
+        masked_ids[b] = input_ids[b, pos]
+        input_ids[b, pos] = MASK
+        masked_pos[b, pos] = 1
+        attention_mask[b, :seq_a_len, :seq_a_len] = torch.tril(torch.ones(seq_a_len, seq_a_len))
+        label[b, torch.randint(1000, 30000, (10,), generator=g)] = 1
+    return {'input_ids': input_ids, 'attention_mask': attention_mask, 'masked_pos': masked_pos,
+            'masked_ids': masked_ids, 'label': label, 'token_type_ids': torch.zeros(B, max_seq, dtype=torch.long)}
+
+
+def label_smoothed_kl(logits, target, eps=0.1):
+    """BertCaptioningLoss (modeling_bert.py:661-690) without drop_worst."""
+    n_class = logits.size(1)
+    one_hot = torch.zeros_like(logits).scatter(1, target.view(-1, 1), 1)
+    one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)
+    log_prb = F.log_softmax(logits, dim=1)
+    return F.kl_div(log_prb, one_hot, reduction='none').sum(1).mean()
+
+
+def focal_neg_loss(pred, target, alpha=0.5, gamma=1.0):
+    """FocalLossWithLogitsNegLoss (loss.py:5-22), summed as in modeling_bert.py:789-791."""
+    sp = pred.sigmoid()
+    loss = (target == 1) * alpha * torch.pow(1. - sp, gamma) * F.logsigmoid(pred)
+    loss = loss + (target == 0) * (1 - alpha) * torch.pow(sp, gamma) * F.logsigmoid(-pred)
+    return (-loss).sum()
+
+
+def train_losses_as_written(sd, image, batch, tagemb='cls'):
+    """ImageCaptioning.forward(train) -> ViTCAP.encode_forward(is_training=True): the full 648-row joint sequence,
+    attention dropout off.  Returns (masked_loss, tag_loss, class_logits)."""
+    img_feats = patch_embed(sd, image)
+    full = construct_attn_mask(batch['attention_mask'], img_feats.shape[1])
+    seq, tag_logit = joint_forward(sd, batch['input_ids'], img_feats, full, None, batch['token_type_ids'], tagemb)
+    T = batch['masked_pos'].shape[-1]
+    rows = seq[:, :T][batch['masked_pos'] == 1]
+    class_logits = lm_head(sd, 'module.cls', rows)
+    tgt = batch['masked_ids'][batch['masked_ids'] != 0]
+    return label_smoothed_kl(class_logits.float(), tgt), focal_neg_loss(tag_logit, batch['label']), class_logits
+
+
+def param_groups(names, base_lr=1e-4, weight_decay=0.05, lr_multiplier=0.1):
+    """name -> (lr, weight_decay) or None when the optimizer never sees the parameter (..._bertemb.py:280-356):
+    ten sub-module groups; lr x multiplier for tag_blocks, blocks[:-4], pooler, tag_logit; no decay for names
+    containing 'bias' or 'LayerNorm.weight'; `module.cls.*` is not in any group (decoder.weight only via its tie)."""
+    out = {}
+    for n in names:
+        if n.startswith('module.cls.'):
+            out[n] = None
+            continue
+        low = False
+        if n.startswith('module.bert.encoder.tag_blocks.') or n.startswith('module.bert.pooler.') \
+                or n.startswith('module.bert.tag_logit.'):
+            low = True
+        if n.startswith('module.bert.encoder.blocks.'):
+            low = int(n.split('.')[4]) < 8
+        wd = weight_decay
+        if 'bias' in n or 'LayerNorm.weight' in n:
+            wd = 0.0
+        out[n] = (base_lr * (lr_multiplier if low else 1.0), wd)
+    return out
+
+
+def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
+    """solver.AdamW.step for one tensor (optimization.py:187-208): decay applied AFTER the Adam update."""
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    p.addcdiv_(m, denom, value=-step_size)
+    if wd > 0.0:
+        p.add_(p, alpha=-lr * wd)
+
+
+def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, clip=1.0, state=None):
+    """One do_train_dict iteration (trainer.py:95-142) on a dict of leaf tensors: forward, backward, global-norm clip over
+    ALL parameters, AdamW over the optimizer's groups, linear LR decay.  Returns dict(loss, tag_loss, grad_norm, grads)."""
+    leaves = {}
+    seen = {}
+    for k, t in sd.items():
+        if id(t) not in seen:
+            seen[id(t)] = t.detach().clone().requires_grad_(True)
+        leaves[k] = seen[id(t)]
+    loss, tag_loss, _ = train_losses_as_written(leaves, image, batch)
+    loss.backward()
+    uniq = {}
+    for k, t in leaves.items():
+        uniq.setdefault(id(t), (k, t))
+    grads = {k: t.grad for k, t in uniq.values() if t.grad is not None}
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+    coef = clip / (total + 1e-6)
+    if coef < 1:
+        for g in grads.values():
+            g.mul_(coef)
+    pg = param_groups(leaves.keys(), base_lr)
+    lr_scale = 1.0 if state is None else state.get('lr_scale', 1.0)
+    state = state if state is not None else {'m': {}, 'v': {}}
+    new = {}
+    with torch.no_grad():
+        for k, t in uniq.values():
+            if t.grad is None or pg[k] is None:
+                continue
+            m = state['m'].setdefault(k, torch.zeros_like(t))
+            v = state['v'].setdefault(k, torch.zeros_like(t))
+            lr, wd = pg[k]
+            adamw_step(t, t.grad, m, v, step, lr * lr_scale, wd)
+    for k, t in leaves.items():
+        new[k] = t.detach()
+    state['lr_scale'] = max(0.0, float(max_iter - step) / float(max(1.0, max_iter)))     # WarmupLinearSchedule, warmup 0
+    return {'loss': float(loss), 'tag_loss': float(tag_loss), 'grad_norm': total, 'grads': grads, 'params': new,
+            'state': state}
