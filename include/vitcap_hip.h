@@ -114,6 +114,14 @@ int vitcap_cls_rows(const float* cls_token, const float* pos_embed, float* x, in
  * ---------------------------------------------------------------------------------------------- */
 int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream);
 
+/* Training forms of the dense attention (ViT blocks and the visual rows of the decoder in
+ * ViTCAP.encode_forward(is_training=True), modeling_bert.py:751-807): the forward additionally stores the log2-domain
+ * logsumexp lse[B][12][S]; the backward returns dqkv (bf16, packed like qkv) from dout, recomputing the probabilities.
+ * `dsum` is scratch fp32 [B][12][S]; `extra_dkv` (optional, bf16 [B*S][2][768]) is added to dK/dV. */
+int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, float scale, void* stream);
+int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                          const void* extra_dkv, void* dqkv, int B, int S, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Incremental decoder attention for one greedy step t (1..19), 2 query rows per sequence:
  *   row 0 = last real token (position t-1), row 1 = [MASK] (position t).

@@ -288,3 +288,30 @@ def test_sigmoid_topk(ops):
     assert torch.equal(ids.cpu(), i)
     _close(prob, p, 1e-6, 1e-6, 'topk prob')
     assert torch.equal(ln.cpu(), (p >= 0.2).sum(1))
+
+
+@pytest.mark.parametrize('B,S', [(1, 64), (2, 577), (1, 578), (2, 130)])
+def test_attn_dense_backward(ops, B, S):
+    """dq/dk/dv of softmax(qk^T/8)v vs torch autograd (fp32) on the same bf16 inputs.  P and dS are rounded to bf16
+    inside the kernels: tolerance 3e-2 of the tensor's max magnitude."""
+    qkv = _bf(_rand((B, S, 2304), 50 + S, 1.5))
+    dout = _bf(_rand((B, S, 768), 51 + S, 1.0))
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = x.view(B, S, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    o_ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B, S, 768)
+    o_ref.backward(dout.float())
+    want = x.grad
+    qd = qkv.reshape(B * S, 2304).cuda().contiguous()
+    out, lse = ops.attn_dense_train(qd, B, S)
+    _close(out.view(B, S, 768), o_ref.detach(), 2 ** -6, 4e-3, 'attn fwd(train)')
+    s = (q @ k.transpose(-1, -2) * 0.125).detach()
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634
+    _close(lse, lse_ref, 1e-4, 1e-3, 'lse2')
+    dqkv = ops.attn_dense_bwd(qd, out, dout.reshape(B * S, 768).cuda().contiguous(), lse, B, S).view(B, S, 2304).float().cpu()
+    for name, lo in (('dq', 0), ('dk', 768), ('dv', 1536)):
+        g, w_ = dqkv[..., lo:lo + 768], want[..., lo:lo + 768]
+        tol = 3e-2 * float(w_.abs().max())
+        err = float((g - w_).abs().max())
+        rel = float((g - w_).norm() / w_.norm())
+        print(name, 'max err %.3e (max %.3e) rel L2 %.3e' % (err, float(w_.abs().max()), rel))
+        assert err <= tol and rel < 2e-2, name

@@ -29,7 +29,7 @@ constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (confli
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                         int S, int B, float c_log2) {
+                                                         float* __restrict__ lse, int S, int B, float c_log2) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + qi;
+  if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)
   if (q < S) {
     bf16_t* op = out + ((size_t)b * S + q) * 768 + h * HD + 4 * half;
 #pragma unroll
@@ -422,9 +423,20 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
-  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, S,
-                     B, c);
+  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
+                     (float*)nullptr, S, B, c);
   VC_LAUNCH_CHECK("attn_dense");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, float scale,
+                                           void* stream) {
+  VC_REQUIRE(qkv && out && lse && B > 0 && S > 0, "attn_dense_train: bad arguments");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid(((S + 127) / 128) * NH * B);
+  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S,
+                     B, c);
+  VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }
 

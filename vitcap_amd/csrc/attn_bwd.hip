@@ -1,0 +1,474 @@
+// Backward of the dense (unmasked) multi-head attention over packed qkv, gfx950.
+//
+// Given dO and the forward's log2-domain logsumexp L[q] (P[q][k] = exp2(c*s[q][k] - L[q]) is the NORMALISED
+// probability), with D[q] = sum_d dO[q][d]*O[q][d]:
+//     dV[k] = sum_q P[q][k] dO[q]          dP[q][k] = dO[q] . V[k]         dS = P o (dP - D[q])
+//     dQ[q] = scale * sum_k dS[q][k] K[k]   dK[k] = scale * sum_q dS[q][k] Q[q]
+// Two kernels, both built like the forward (32x32x16 MFMA, transposed score tiles so per-row quantities are
+// lane-local, the MFMA C layout reused as the next B operand, no atomics):
+//   attn_bwd_dq_kernel  : a wave owns 32 queries and sweeps 64-key tiles:  S^T = K Q^T, dP^T = V dO^T,
+//                         dQ^T += K^T dS^T.  Also writes D[q] for the second kernel.
+//   attn_bwd_dkv_kernel : a wave owns 32 keys and sweeps 64-query tiles:   S = Q K^T, dP = dO V^T,
+//                         dV^T += dO^T P, dK^T += Q^T dS.
+// P and dS are rounded to bf16 for the MFMAs (fp32 accumulation), like the forward's P.
+// Left-over rows (S = 577/578 leaves 1/2) are handled on the vector ALU.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int NH = 12;
+constexpr int QKV_LD = 2304;
+constexpr int KT = 64;
+constexpr int LDS_ROW = 144;       // 64 bf16 + 16 B pad
+constexpr int TILE_B = KT * LDS_ROW;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// staging helpers --------------------------------------------------------------------------------
+// row-major tile: thread (tid>>2) = row, (tid&3)*16 = first of 16 columns (two 16-byte pieces)
+#define ROW_LOAD(r0_, r1_, src_, row_, ld_, col0_)                                   \
+  do {                                                                               \
+    const bf16_t* p_ = (src_) + (size_t)(row_) * (ld_) + (col0_) + (tid & 3) * 16;   \
+    r0_ = *(const uint4*)p_;                                                         \
+    r1_ = *(const uint4*)(p_ + 8);                                                   \
+  } while (0)
+#define ROW_STORE(lds_, r0_, r1_)                                                    \
+  do {                                                                               \
+    char* q_ = (lds_) + (tid >> 2) * LDS_ROW + (tid & 3) * 32;                       \
+    *(uint4*)q_ = r0_;                                                               \
+    *(uint4*)(q_ + 16) = r1_;                                                        \
+  } while (0)
+// transposed tile [64 d][64 slots]: thread loads 4 rows x 4 d (8 bytes each) and writes 4 x 8 bytes; the 4 rows
+// of each group of 16 are stored in the order 0-3,8-11,4-7,12-15 so a lane's 8 consecutive slots match the MFMA
+// C layout of the score tile (see attn.hip)
+#define TR_LOAD(v0_, v1_, v2_, v3_, src_, row0_, ld_, col0_, nrows_)                 \
+  do {                                                                               \
+    const int t0_ = (row0_) + v_kg * 4;                                              \
+    const int a0_ = t0_ < (nrows_) ? t0_ : (nrows_) - 1, a1_ = t0_ + 1 < (nrows_) ? t0_ + 1 : (nrows_) - 1; \
+    const int a2_ = t0_ + 2 < (nrows_) ? t0_ + 2 : (nrows_) - 1, a3_ = t0_ + 3 < (nrows_) ? t0_ + 3 : (nrows_) - 1; \
+    v0_ = *(const uint2*)((src_) + (size_t)a0_ * (ld_) + (col0_) + v_dg * 4);        \
+    v1_ = *(const uint2*)((src_) + (size_t)a1_ * (ld_) + (col0_) + v_dg * 4);        \
+    v2_ = *(const uint2*)((src_) + (size_t)a2_ * (ld_) + (col0_) + v_dg * 4);        \
+    v3_ = *(const uint2*)((src_) + (size_t)a3_ * (ld_) + (col0_) + v_dg * 4);        \
+  } while (0)
+#define TR_STORE(lds_, v0_, v1_, v2_, v3_)                                           \
+  do {                                                                               \
+    uint2 t0_, t1_, t2_, t3_;                                                        \
+    t0_.x = __builtin_amdgcn_perm(v1_.x, v0_.x, 0x05040100);                         \
+    t0_.y = __builtin_amdgcn_perm(v3_.x, v2_.x, 0x05040100);                         \
+    t1_.x = __builtin_amdgcn_perm(v1_.x, v0_.x, 0x07060302);                         \
+    t1_.y = __builtin_amdgcn_perm(v3_.x, v2_.x, 0x07060302);                         \
+    t2_.x = __builtin_amdgcn_perm(v1_.y, v0_.y, 0x05040100);                         \
+    t2_.y = __builtin_amdgcn_perm(v3_.y, v2_.y, 0x05040100);                         \
+    t3_.x = __builtin_amdgcn_perm(v1_.y, v0_.y, 0x07060302);                         \
+    t3_.y = __builtin_amdgcn_perm(v3_.y, v2_.y, 0x07060302);                         \
+    char* vp_ = (lds_) + (v_dg * 4) * LDS_ROW + v_pos * 2;                           \
+    *(uint2*)(vp_) = t0_;                                                            \
+    *(uint2*)(vp_ + LDS_ROW) = t1_;                                                  \
+    *(uint2*)(vp_ + 2 * LDS_ROW) = t2_;                                              \
+    *(uint2*)(vp_ + 3 * LDS_ROW) = t3_;                                              \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// dQ kernel.  grid = q-blocks(128 rows) x heads x B (1-D, XCD-aware like the forward).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
+                                                          float c_log2, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int qi = lane & 31, half = lane >> 5;
+  const int nqb = (S + 127) / 128;
+  const int nwork = nqb * NH * B;
+  int wid = blockIdx.x;
+  {
+    const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
+    wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
+  }
+  const int qb = wid % nqb;
+  const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
+  const int q0 = qb * 128 + w * 32;
+  const bool active = q0 < S;
+  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
+  const int qr = (q0 + qi) < S ? (q0 + qi) : S - 1;
+
+  // B-operand fragments held for the whole kernel: Q^T and dO^T (lane: row q, dims ds*16 + half*8 ..)
+  bf16x8 qf[4], dof[4];
+  float dpart = 0.f;
+  {
+    const bf16_t* qp = base + (size_t)qr * QKV_LD + half * 8;
+    const bf16_t* dp = dout + ((size_t)b * S + qr) * 768 + h * HD + half * 8;
+    const bf16_t* op = o + ((size_t)b * S + qr) * 768 + h * HD + half * 8;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      qf[ds] = *(const bf16x8*)(qp + ds * 16);
+      dof[ds] = *(const bf16x8*)(dp + ds * 16);
+      const bf16x8 of = *(const bf16x8*)(op + ds * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += (float)dof[ds][j] * (float)of[j];
+    }
+  }
+  const float Dq = dpart + __shfl_xor(dpart, 32, 64);          // D[q] = dO[q] . O[q]
+  const float Lq = lse[((size_t)b * NH + h) * S + qr];
+  if (active && half == 0 && q0 + qi < S) dsum[((size_t)b * NH + h) * S + q0 + qi] = Dq;
+
+  const int v_kg = tid & 15, v_dg = tid >> 4;
+  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
+  const int nfull = S / KT, rem = S - nfull * KT;
+  const bool tail_tile = rem > 8;
+  const int ntiles = nfull + (tail_tile ? 1 : 0);
+
+  uint4 k0, k1, v0, v1;
+  uint2 t0, t1, t2, t3;
+#define LOAD_TILE(t_)                                                                \
+  do {                                                                               \
+    int kr_ = (t_) * KT + (tid >> 2);                                                \
+    kr_ = kr_ < S ? kr_ : S - 1;                                                     \
+    ROW_LOAD(k0, k1, base, kr_, QKV_LD, 768);                                        \
+    ROW_LOAD(v0, v1, base, kr_, QKV_LD, 1536);                                       \
+    TR_LOAD(t0, t1, t2, t3, base, (t_) * KT, QKV_LD, 768, S);                        \
+  } while (0)
+#define STORE_TILE(buf_)                                                             \
+  do {                                                                               \
+    char* l_ = smem + (buf_) * 3 * TILE_B;                                           \
+    ROW_STORE(l_, k0, k1);                                                           \
+    ROW_STORE(l_ + TILE_B, v0, v1);                                                  \
+    TR_STORE(l_ + 2 * TILE_B, t0, t1, t2, t3);                                       \
+  } while (0)
+
+  f32x16 dqt[2], zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dqt[0][r] = 0.f;
+    dqt[1][r] = 0.f;
+    zero16[r] = 0.f;
+  }
+  if (ntiles > 0) {
+    LOAD_TILE(0);
+    STORE_TILE(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) LOAD_TILE(t + 1);
+    if (active) {
+      const char* kl = smem + buf * 3 * TILE_B;
+      const char* vl = kl + TILE_B;
+      const char* ktl = kl + 2 * TILE_B;
+      f32x16 st[2], dpt[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const char* kr = kl + (kt * 32 + qi) * LDS_ROW + half * 16;
+        const char* vr = vl + (kt * 32 + qi) * LDS_ROW + half * 16;
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr), qf[0], zero16, 0, 0, 0);
+        dpt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vr), dof[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int ds = 1; ds < 4; ++ds) {
+          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr + ds * 32), qf[ds], st[kt], 0, 0, 0);
+          dpt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vr + ds * 32), dof[ds], dpt[kt], 0, 0, 0);
+        }
+      }
+      const bool masked = t >= nfull;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(fmaf(st[kt][r], c_log2, -Lq));
+          if (masked) {
+            const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            p = key < S ? p : 0.f;
+          }
+          st[kt][r] = p * (dpt[kt][r] - Dq);        // dS^T
+        }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int kt = kb >> 1, ks = kb & 1;
+        bf16x8 sf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sf[j] = (__bf16)st[kt][ks * 8 + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 kf = *(const bf16x8*)(ktl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);
+          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dqt[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+  // left-over keys on the vector ALU
+  if (active && !tail_tile) {
+    for (int key = nfull * KT; key < S; ++key) {
+      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
+      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + half * 8;
+      float sp = 0.f, dp = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
+        const bf16x8 vv = *(const bf16x8*)(vr + ds * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sp += (float)qf[ds][j] * (float)kv[j];
+          dp += (float)dof[ds][j] * (float)vv[j];
+        }
+      }
+      sp += __shfl_xor(sp, 32, 64);
+      dp += __shfl_xor(dp, 32, 64);
+      const float p = fast_exp2(fmaf(sp, c_log2, -Lq));
+      const float dsb = (float)(__bf16)(p * (dp - Dq));
+      const bf16_t* ko = base + (size_t)key * QKV_LD + 768 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 kk = *(const bf16x4*)(ko + dt * 32 + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dqt[dt][g * 4 + e] = fmaf(dsb, (float)kk[e], dqt[dt][g * 4 + e]);
+        }
+    }
+  }
+  const int q = q0 + qi;
+  if (q < S) {
+    bf16_t* op = dqkv + ((size_t)b * S + q) * QKV_LD + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ov;
+        ov.x = pack2bf(dqt[dt][g * 4 + 0] * scale, dqt[dt][g * 4 + 1] * scale);
+        ov.y = pack2bf(dqt[dt][g * 4 + 2] * scale, dqt[dt][g * 4 + 3] * scale);
+        *(uint2*)(op + dt * 32 + g * 8) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK/dV kernel.  A wave owns 32 keys; grid = key-blocks(128 rows) x heads x B.
+// `extra` (optional, bf16 [B*S][2][768]) is added to the results: contributions of other queries
+// (the caption rows of the decoder) to these keys' K/V gradients.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
+                                                           int B, float c_log2, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ki = lane & 31, half = lane >> 5;
+  const int nkb = (S + 127) / 128;
+  const int nwork = nkb * NH * B;
+  int wid = blockIdx.x;
+  {
+    const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
+    wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
+  }
+  const int kb_ = wid % nkb;
+  const int h = (wid / nkb) % NH, b = wid / (nkb * NH);
+  const int key0 = kb_ * 128 + w * 32;
+  const bool active = key0 < S;
+  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
+  const bf16_t* dob = dout + (size_t)b * S * 768 + h * HD;
+  const float* Lb = lse + ((size_t)b * NH + h) * S;
+  const float* Db = dsum + ((size_t)b * NH + h) * S;
+  const int kr = (key0 + ki) < S ? (key0 + ki) : S - 1;
+
+  bf16x8 kf[4], vf[4];     // B operands: K^T and V^T columns of this lane's key
+  {
+    const bf16_t* kp = base + (size_t)kr * QKV_LD + 768 + half * 8;
+    const bf16_t* vp = base + (size_t)kr * QKV_LD + 1536 + half * 8;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      kf[ds] = *(const bf16x8*)(kp + ds * 16);
+      vf[ds] = *(const bf16x8*)(vp + ds * 16);
+    }
+  }
+  const int v_kg = tid & 15, v_dg = tid >> 4;
+  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
+  const int nfull = S / KT, rem = S - nfull * KT;
+  const bool tail_tile = rem > 8;
+  const int ntiles = nfull + (tail_tile ? 1 : 0);
+  constexpr int BUF = 4 * TILE_B + 512;
+
+  uint4 q0r, q1r, d0r, d1r;
+  uint2 a0, a1, a2, a3, c0, c1, c2, c3;
+  float lreg = 0.f;
+#define LOAD_TILE(t_)                                                                \
+  do {                                                                               \
+    int qr_ = (t_) * KT + (tid >> 2);                                                \
+    qr_ = qr_ < S ? qr_ : S - 1;                                                     \
+    ROW_LOAD(q0r, q1r, base, qr_, QKV_LD, 0);                                        \
+    ROW_LOAD(d0r, d1r, dob, qr_, 768, 0);                                            \
+    TR_LOAD(a0, a1, a2, a3, base, (t_) * KT, QKV_LD, 0, S);                          \
+    TR_LOAD(c0, c1, c2, c3, dob, (t_) * KT, 768, 0, S);                              \
+    if (tid < 128) {                                                                 \
+      int i_ = (t_) * KT + (tid & 63);                                               \
+      i_ = i_ < S ? i_ : S - 1;                                                      \
+      lreg = tid < 64 ? Lb[i_] : Db[i_];                                             \
+    }                                                                                \
+  } while (0)
+#define STORE_TILE(buf_)                                                             \
+  do {                                                                               \
+    char* l_ = smem + (buf_) * BUF;                                                  \
+    ROW_STORE(l_, q0r, q1r);                                                         \
+    ROW_STORE(l_ + TILE_B, d0r, d1r);                                                \
+    TR_STORE(l_ + 2 * TILE_B, a0, a1, a2, a3);                                       \
+    TR_STORE(l_ + 3 * TILE_B, c0, c1, c2, c3);                                       \
+    if (tid < 128) ((float*)(l_ + 4 * TILE_B))[tid] = lreg;                          \
+  } while (0)
+
+  f32x16 dvt[2], dkt[2], zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dvt[0][r] = 0.f; dvt[1][r] = 0.f; dkt[0][r] = 0.f; dkt[1][r] = 0.f; zero16[r] = 0.f;
+  }
+  if (ntiles > 0) {
+    LOAD_TILE(0);
+    STORE_TILE(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) LOAD_TILE(t + 1);
+    if (active) {
+      const char* ql = smem + buf * BUF;
+      const char* dl = ql + TILE_B;
+      const char* qtl = ql + 2 * TILE_B;
+      const char* dtl = ql + 3 * TILE_B;
+      const float* Ll = (const float*)(ql + 4 * TILE_B);
+      const float* Dl = Ll + 64;
+      f32x16 st[2], dpt[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const char* qr = ql + (qt * 32 + ki) * LDS_ROW + half * 16;
+        const char* dr = dl + (qt * 32 + ki) * LDS_ROW + half * 16;
+        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr), kf[0], zero16, 0, 0, 0);
+        dpt[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr), vf[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int ds = 1; ds < 4; ++ds) {
+          st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr + ds * 32), kf[ds], st[qt], 0, 0, 0);
+          dpt[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr + ds * 32), vf[ds], dpt[qt], 0, 0, 0);
+        }
+      }
+      // lane holds, for its key, queries q = qt*32 + 8g + 4*half + e  (r = 4g + e)
+      const bool masked = t >= nfull;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 L4 = *(const f32x4*)(Ll + qt * 32 + g * 8 + 4 * half);
+          const f32x4 D4 = *(const f32x4*)(Dl + qt * 32 + g * 8 + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g * 4 + e;
+            float p = fast_exp2(fmaf(st[qt][r], c_log2, -L4[e]));
+            if (masked) p = (t * KT + qt * 32 + g * 8 + 4 * half + e) < S ? p : 0.f;
+            st[qt][r] = p;                               // P[q][key]
+            dpt[qt][r] = p * (dpt[qt][r] - D4[e]);       // dS[q][key]
+          }
+        }
+#pragma unroll
+      for (int qb4 = 0; qb4 < 4; ++qb4) {
+        const int qt = qb4 >> 1, ks = qb4 & 1;
+        bf16x8 pf, sf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pf[j] = (__bf16)st[qt][ks * 8 + j];
+          sf[j] = (__bf16)dpt[qt][ks * 8 + j];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 dof = *(const bf16x8*)(dtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
+          const bf16x8 qtf = *(const bf16x8*)(qtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dkt[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+  // left-over queries on the vector ALU
+  if (active && !tail_tile) {
+    for (int q = nfull * KT; q < S; ++q) {
+      const bf16_t* qr = base + (size_t)q * QKV_LD + half * 8;
+      const bf16_t* dr = dob + (size_t)q * 768 + half * 8;
+      float sp = 0.f, dp = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const bf16x8 qv = *(const bf16x8*)(qr + ds * 16);
+        const bf16x8 dv = *(const bf16x8*)(dr + ds * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sp += (float)qv[j] * (float)kf[ds][j];
+          dp += (float)dv[j] * (float)vf[ds][j];
+        }
+      }
+      sp += __shfl_xor(sp, 32, 64);
+      dp += __shfl_xor(dp, 32, 64);
+      const float p = fast_exp2(fmaf(sp, c_log2, -Lb[q]));
+      const float pb = (float)(__bf16)p;
+      const float dsb = (float)(__bf16)(p * (dp - Db[q]));
+      const bf16_t* qo = base + (size_t)q * QKV_LD + 4 * half;
+      const bf16_t* dd = dob + (size_t)q * 768 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 qq = *(const bf16x4*)(qo + dt * 32 + g * 8);
+          const bf16x4 dq = *(const bf16x4*)(dd + dt * 32 + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dvt[dt][g * 4 + e] = fmaf(pb, (float)dq[e], dvt[dt][g * 4 + e]);
+            dkt[dt][g * 4 + e] = fmaf(dsb, (float)qq[e], dkt[dt][g * 4 + e]);
+          }
+        }
+    }
+  }
+  const int key = key0 + ki;
+  if (key < S) {
+    bf16_t* ok = dqkv + ((size_t)b * S + key) * QKV_LD + 768 + h * HD + 4 * half;
+    bf16_t* ov = ok + 768;
+    const bf16_t* ex = extra ? extra + ((size_t)b * S + key) * 1536 + h * HD + 4 * half : nullptr;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kx[4] = {0.f, 0.f, 0.f, 0.f}, vx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ex) {
+          const bf16x4 ek = *(const bf16x4*)(ex + dt * 32 + g * 8);
+          const bf16x4 ev = *(const bf16x4*)(ex + 768 + dt * 32 + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { kx[e] = (float)ek[e]; vx[e] = (float)ev[e]; }
+        }
+        uint2 o1, o2;
+        o1.x = pack2bf(dkt[dt][g * 4 + 0] * scale + kx[0], dkt[dt][g * 4 + 1] * scale + kx[1]);
+        o1.y = pack2bf(dkt[dt][g * 4 + 2] * scale + kx[2], dkt[dt][g * 4 + 3] * scale + kx[3]);
+        o2.x = pack2bf(dvt[dt][g * 4 + 0] + vx[0], dvt[dt][g * 4 + 1] + vx[1]);
+        o2.y = pack2bf(dvt[dt][g * 4 + 2] + vx[2], dvt[dt][g * 4 + 3] + vx[3]);
+        *(uint2*)(ok + dt * 32 + g * 8) = o1;
+        *(uint2*)(ov + dt * 32 + g * 8) = o2;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                                     const void* extra_dkv, void* dqkv, int B, int S, float scale, void* stream) {
+  VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0, "attn_dense_bwd: bad arguments");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid(((S + 127) / 128) * NH * B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
+                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, c, scale);
+  VC_LAUNCH_CHECK("attn_bwd_dq");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
+                     (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B, c,
+                     scale);
+  VC_LAUNCH_CHECK("attn_bwd_dkv");
+  return VITCAP_OK;
+}

@@ -84,6 +84,24 @@ def attn_dense(qkv, B, S, scale=0.125):
     return out
 
 
+def attn_dense_train(qkv, B, S, scale=0.125):
+    """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd"""
+    _dev_bf16(qkv)
+    out = torch.empty((B * S, 768), device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty((B, 12, S), device=qkv.device, dtype=torch.float32)
+    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, scale, _stream()), 'attn_dense_train')
+    return out, lse
+
+
+def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None):
+    _dev_bf16(qkv); _dev_bf16(out); _dev_bf16(dout); _dev_f32(lse)
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, scale,
+                                    _stream()), 'attn_dense_bwd')
+    return dqkv
+
+
 def attn_decode_step(qkv_step, vis_qkv, text_kv, B, S_vis, t, max_len=20, seq_per_image=1, scale=0.125):
     _dev_bf16(qkv_step)
     _dev_bf16(vis_qkv)
