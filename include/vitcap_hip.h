@@ -118,9 +118,10 @@ int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale,
  * ViTCAP.encode_forward(is_training=True), modeling_bert.py:751-807): the forward additionally stores the log2-domain
  * logsumexp lse[B][12][S]; the backward returns dqkv (bf16, packed like qkv) from dout, recomputing the probabilities.
  * `dsum` is scratch fp32 [B][12][S]; `extra_dkv` (optional, bf16 [B*S][2][768]) is added to dK/dV. */
-int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, float scale, void* stream);
+int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float scale,
+                                void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
 int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
-                          const void* extra_dkv, void* dqkv, int B, int S, float scale, void* stream);
+                          const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Incremental decoder attention for one greedy step t (1..19), 2 query rows per sequence:
@@ -292,6 +293,49 @@ int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16,
 int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
 int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes,
                          int64_t* out_ids, float* out_logprobs, void* stream);
+
+/* ================================================================================================
+ * Cross-entropy TRAINING step (ViTCAP.encode_forward(is_training=True) + backward + optimizer:
+ * modeling_bert.py:751-807, 661-690; loss.py:5-22; trainer.py:95-142; optimization.py:151-210).
+ * Backward GEMMs reuse vitcap_gemm_*: dX = dY . W is the NT kernel on a transposed weight copy, dW = dY^T . X is the
+ * NT kernel on transposed activations with split-K into fp32 slabs.
+ * ============================================================================================== */
+/* GEMM with training extras: `aux` (bf16 [M][ldaux]) multiplies the result by gelu'(aux) (backward of nn.GELU /
+ * `_gelu_python`); `zout` (bf16 [M][ldz]) receives the pre-activation (bias added) for the backward.  With
+ * d->split_k > 1 and M > 256 (weight gradients) K is split raggedly and C is fp32 [split_k][M][ldc]. */
+int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                   const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz, void* stream);
+/* XT[c][r] = X[r][c] (bf16), r padded with zeros up to ldt (multiple of 64); colsum[c] += sum_r X[r][c] (bias grads) */
+int vitcap_transpose_colsum(const void* x, int ldx, void* xt, int ldt, float* colsum, int R, int C, void* stream);
+/* LayerNorm backward (nn.LayerNorm): dx = LNbwd(dy; x, gamma) + dres;  dgamma/dbeta accumulated with atomics */
+int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32, const float* gamma, float eps,
+                         const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, int M, int D,
+                         void* stream);
+int vitcap_reduce_slabs(const float* slabs, size_t slab_stride, int S, float* out, size_t n, int accumulate, void* stream);
+int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream);
+/* BertEmbeddings backward: scatter-add into word / position / token-type gradient tables (modeling_bert.py:230-234) */
+int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
+                     int rows, void* stream);
+/* BertCaptioningLoss (label-smoothed KL, mean over rows; modeling_bert.py:661-690): loss_sum += loss; dlogits (bf16,
+ * [rows][ldd], columns >= V zeroed) = d loss / d logits */
+int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target, float eps, int rows, float* loss_sum,
+                      void* dlogits_bf16, int ldd, void* stream);
+/* FocalLossWithLogitsNegLoss(alpha, gamma=1).sum()  (loss.py:5-22, modeling_bert.py:789-791) */
+int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const float* label, float alpha, float* out, int B,
+                          void* stream);
+int vitcap_sumsq(const float* g, size_t n, float* out, void* stream);
+/* clip_grad_norm_(max_norm=clip) + solver.AdamW.step over a flat parameter buffer in 1024-element chunks; chunk_lr = 0
+ * marks chunks the optimizer does not own (trainer.py:124-142, optimization.py:187-208, ..._bertemb.py:306-356) */
+int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float* chunk_lr, const float* chunk_wd,
+                       const float* gsumsq, float clip, float lr_scale, int step, float b1, float b2, float eps,
+                       size_t nchunks, void* stream);
+/* fp32 master W[N][K] -> bf16 W and bf16 W^T[K][N] (the operands of the forward and the dgrad GEMMs) */
+int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, void* stream);
+/* caption rows of the decoder under teacher forcing: [S_vis visual | T caption] rows per image, caption row r attends
+ * all visual rows and caption rows <= r */
+int vitcap_attn_text_fwd(const void* qkv, void* out, int B, int S_vis, int T, int ld_rows, float scale, void* stream);
+int vitcap_attn_text_bwd(const void* qkv, const void* dout, void* dqkv, void* extra_dkv, int B, int S_vis, int T,
+                         int ld_rows, float scale, void* stream);
 
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);

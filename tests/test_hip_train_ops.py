@@ -1,0 +1,186 @@
+"""Parity of the training-step kernels (backward GEMM forms, LayerNorm backward, caption-row attention, losses,
+AdamW) against fp32 torch (autograd) on the same bf16-rounded inputs.  GPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available()
+    from vitcap_amd import ops as o
+    return o
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _rel(got, want):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+def test_transpose_colsum(ops):
+    R, Cc = 1154, 2304
+    x = _bf(_rand((R, Cc), 1))
+    cs = torch.zeros(Cc, device='cuda')
+    xt = ops.transpose_colsum(x.cuda(), cs)
+    assert xt.shape == (Cc, 1216)
+    assert torch.equal(xt[:, :R].cpu(), x.t().contiguous()) and float(xt[:, R:].abs().sum()) == 0.0
+    np.testing.assert_allclose(cs.cpu().numpy(), x.float().sum(0).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_weight_grad_splitk_and_dgrad(ops):
+    """dW = dY^T X via transposes + ragged split-K slabs; dX = dY W via the transposed weight; gelu' epilogue."""
+    M, N, K = 1154, 768, 3072            # y = x W^T, W [N][K]
+    x = _bf(_rand((M, K), 2)); w = _bf(_rand((N, K), 3, 0.05)); dy = _bf(_rand((M, N), 4))
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    dyT = ops.transpose_colsum(dyd)                    # [N][Mp]
+    xT = ops.transpose_colsum(xd)                      # [K][Mp]
+    slabs = ops.gemm_ex(dyT, xT, split_k=5)            # [5][N][K] fp32
+    dw = torch.zeros(N, K, device='cuda')
+    ops.reduce_slabs(slabs, dw)
+    want_dw = dy.float().t() @ x.float()
+    assert _rel(dw, want_dw) < 1e-5
+    ops.reduce_slabs(slabs, dw, accumulate=True)
+    assert _rel(dw, 2 * want_dw) < 1e-5
+    # dgrad with the gelu' epilogue: dz = (dy @ W) * gelu'(z)
+    from vitcap_amd._lib import lib, check
+    wt = torch.empty(K, N, device='cuda', dtype=torch.bfloat16)
+    wb = torch.empty(N, K, device='cuda', dtype=torch.bfloat16)
+    wf = w.float().cuda().contiguous()
+    check(lib.vitcap_cast_transpose(C.c_void_p(wf.data_ptr()), C.c_void_p(wb.data_ptr()), C.c_void_p(wt.data_ptr()), N, K,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'cast_transpose')
+    assert torch.equal(wb.cpu(), w) and torch.equal(wt.cpu(), w.t().contiguous())
+    z = _bf(_rand((M, K), 5, 2.0))
+    dz = ops.gemm_ex(dyd, wt, aux=z.cuda())            # [M][K] bf16
+    zz = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zz).backward(torch.ones_like(zz))
+    want = (dy.float() @ w.float()) * zz.grad
+    assert _rel(dz, want) < 4e-3
+    # forward with pre-activation output
+    zout = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    bias = _rand((N,), 6).cuda()
+    g = ops.gemm_ex(xd, wd, bias=bias, act=1, zout=zout)
+    pre = x.float() @ w.float().t() + bias.cpu()
+    assert _rel(zout, pre) < 4e-3 and _rel(g, torch.nn.functional.gelu(pre)) < 4e-3
+
+
+@pytest.mark.parametrize('dy_f32', [False, True])
+def test_layernorm_backward(ops, dy_f32):
+    M = 1157
+    x = (_rand((M, 768), 7, 2.0) + 0.3)
+    gam = 1 + _rand((768,), 8, 0.2)
+    dy = _rand((M, 768), 9)
+    dy = dy if dy_f32 else _bf(dy)
+    dres = _rand((M, 768), 10)
+    xx = x.clone().requires_grad_(True)
+    gg = gam.clone().requires_grad_(True)
+    bb = torch.zeros(768, requires_grad=True)
+    torch.nn.functional.layer_norm(xx, (768,), gg, bb, 1e-6).backward(dy.float())
+    dgam = torch.zeros(768, device='cuda'); dbet = torch.zeros(768, device='cuda')
+    dxf, dxb = ops.layernorm_bwd(x.cuda(), dy.cuda(), gam.cuda(), 1e-6, dgam, dbet, dres=dres.cuda())
+    assert _rel(dxf, xx.grad + dres) < 1e-5
+    assert torch.equal(dxb.cpu(), dxf.cpu().to(torch.bfloat16))
+    assert _rel(dgam, gg.grad) < 1e-4 and _rel(dbet, bb.grad) < 1e-4
+
+
+def test_attn_text_forward_backward(ops):
+    """20 caption rows vs 578 visual + causal caption keys, and the dense visual-visual backward with the caption
+    rows' contribution added: together they must equal autograd through the masked joint attention."""
+    B, SV, T = 2, 578, 20
+    Lr = SV + T
+    qkv = _bf(_rand((B, Lr, 2304), 11, 1.5))
+    dout = _bf(_rand((B, Lr, 768), 12))
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = x.view(B, Lr, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    mask = torch.zeros(Lr, Lr)
+    mask[:, :SV] = 1
+    mask[SV:, SV:] = torch.tril(torch.ones(T, T))
+    s = q @ k.transpose(-1, -2) * 0.125 + (1 - mask) * -10000.0
+    o_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Lr, 768)
+    o_ref.backward(dout.float())
+    want = x.grad
+    qd = qkv.reshape(B * Lr, 2304).cuda().contiguous()
+    dod = dout.reshape(B * Lr, 768).cuda().contiguous()
+    out, lse = ops.attn_dense_train(qd, B, SV, ld_rows=Lr)
+    ops.attn_text_fwd(qd, out, B, SV, T, Lr)
+    assert _rel(out.view(B, Lr, 768), o_ref) < 6e-3
+    dqkv = torch.zeros_like(qd)
+    extra = torch.zeros(B * Lr, 2, 768, device='cuda', dtype=torch.bfloat16)
+    ops.attn_text_bwd(qd, dod, dqkv, extra, B, SV, T, Lr)
+    ops.attn_dense_bwd(qd, out, dod, lse, B, SV, extra_dkv=extra, ld_rows=Lr, dqkv=dqkv)
+    got = dqkv.view(B, Lr, 2304).float().cpu()
+    for name, lo in (('dq', 0), ('dk', 768), ('dv', 1536)):
+        r = _rel(got[..., lo:lo + 768], want[..., lo:lo + 768])
+        print(name, 'rel L2 %.3e' % r)
+        assert r < 1e-2, name
+    assert _rel(got[:, SV:, :768], want[:, SV:, :768]) < 1e-2       # caption-row dq on its own
+
+
+def test_losses(ops, sd_t):
+    from oracle import vitcap_oracle as O
+    from vitcap_amd._lib import lib, check
+    n, V, ld = 5, 30522, 30592
+    logits = _rand((n, ld), 13, 3.0)
+    tgt = torch.tensor([5, 30521, 1234, 0, 777])
+    lg = logits[:, :V].clone().requires_grad_(True)
+    want = O.label_smoothed_kl(lg, tgt)
+    want.backward()
+    loss = torch.zeros(1, device='cuda')
+    dl = torch.empty(n, ld, device='cuda', dtype=torch.bfloat16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ld_, tg_ = logits.cuda(), tgt.cuda()
+    check(lib.vitcap_ls_kl_loss(C.c_void_p(ld_.data_ptr()), ld, V, C.c_void_p(tg_.data_ptr()), 0.1, n,
+                                C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()), ld, s), 'ls_kl')
+    assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want)) + 1e-5
+    assert _rel(dl[:, :V], lg.grad) < 4e-3 and float(dl[:, V:].float().abs().sum()) == 0.0
+    B = 3
+    tl = _rand((B, ld), 14, 4.0)
+    label = torch.zeros(B, V)
+    label[torch.arange(B).repeat_interleave(10), torch.randint(0, V, (B * 10,), generator=torch.Generator().manual_seed(1))] = 1
+    out = torch.zeros(1, device='cuda')
+    tl_, lb_ = tl.cuda(), label.cuda()
+    check(lib.vitcap_focal_loss_sum(C.c_void_p(tl_.data_ptr()), ld, V, C.c_void_p(lb_.data_ptr()), 0.5,
+                                    C.c_void_p(out.data_ptr()), B, s), 'focal')
+    wantf = float(O.focal_neg_loss(tl[:, :V], label))
+    assert abs(float(out) - wantf) < 2e-4 * abs(wantf)
+
+
+def test_adamw_clip_matches_oracle(ops):
+    from oracle import vitcap_oracle as O
+    from vitcap_amd._lib import lib, check
+    n = 4096
+    p = _rand((n,), 15); g = _rand((n,), 16, 3.0)
+    lr = torch.tensor([1e-4, 1e-5, 0.0, 1e-4]); wd = torch.tensor([0.05, 0.0, 0.05, 0.0])
+    P, G = p.cuda(), g.cuda()
+    Mm, Vv = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    ss = torch.zeros(1, device='cuda')
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pref, mref, vref = p.clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        ss.zero_()
+        check(lib.vitcap_sumsq(C.c_void_p(G.data_ptr()), n, C.c_void_p(ss.data_ptr()), s), 'sumsq')
+        check(lib.vitcap_adamw_multi(C.c_void_p(P.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(Mm.data_ptr()),
+                                     C.c_void_p(Vv.data_ptr()), C.c_void_p(lr.cuda().data_ptr()), C.c_void_p(wd.cuda().data_ptr()),
+                                     C.c_void_p(ss.data_ptr()), 1.0, 1.0, step, 0.9, 0.999, 1e-8, n // 1024, s), 'adamw')
+        coef = min(1.0, 1.0 / (float(g.norm()) + 1e-6))
+        for c in range(4):
+            sl = slice(c * 1024, (c + 1) * 1024)
+            if float(lr[c]) == 0.0:
+                continue
+            O.adamw_step(pref[sl], g[sl] * coef, mref[sl], vref[sl], step, float(lr[c]), float(wd[c]))
+    assert abs(float(ss.sqrt()) - float(g.norm())) < 1e-3
+    np.testing.assert_allclose(P.cpu().numpy(), pref.numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(P.cpu()[2048:3072], p[2048:3072])          # lr 0 chunk untouched

@@ -60,11 +60,25 @@ _SIGS = {
     'vitcap_layernorm_fwd': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_sum_layernorm': (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp,
                                        C.c_int, C.c_int, vp]),
+    'vitcap_gemm_ex': (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(GemmDesc), vp, C.c_int, vp, C.c_int, vp]),
+    'vitcap_transpose_colsum': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    'vitcap_layernorm_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_reduce_slabs': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp]),
+    'vitcap_cast_bf16': (C.c_int, [vp, vp, C.c_size_t, vp]),
+    'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
+    'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, C.c_int, vp]),
+    'vitcap_focal_loss_sum': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp]),
+    'vitcap_sumsq': (C.c_int, [vp, C.c_size_t, vp, vp]),
+    'vitcap_adamw_multi': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_size_t, vp]),
+    'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_attn_text_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    'vitcap_attn_text_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
-    'vitcap_attn_dense_fwd_train': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
-    'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    'vitcap_attn_dense_fwd_train': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, vp]),
     'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,

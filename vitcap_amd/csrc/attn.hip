@@ -29,7 +29,7 @@ constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (confli
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                         float* __restrict__ lse, int S, int B, float c_log2) {
+                                                         float* __restrict__ lse, int S, int B, int ld_rows, float c_log2) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;        // waves past the last query row only help with staging
-  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
+  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;   // ld_rows >= S rows per image in the buffers
 
   // Q^T fragments: lane holds Q[q0+qi][ds*16 + half*8 .. +7]
   bf16x8 qf[4];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const int q = q0 + qi;
   if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)
   if (q < S) {
-    bf16_t* op = out + ((size_t)b * S + q) * 768 + h * HD + 4 * half;
+    bf16_t* op = out + ((size_t)b * ld_rows + q) * 768 + h * HD + 4 * half;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -424,18 +424,18 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
   hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, c);
+                     (float*)nullptr, S, B, S, c);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, float scale,
-                                           void* stream) {
-  VC_REQUIRE(qkv && out && lse && B > 0 && S > 0, "attn_dense_train: bad arguments");
+extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
+                                           float scale, void* stream) {
+  VC_REQUIRE(qkv && out && lse && B > 0 && S > 0 && ld_rows >= S, "attn_dense_train: bad arguments");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
   hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S,
-                     B, c);
+                     B, ld_rows, c);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }

@@ -76,7 +76,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
-                                                          float c_log2, float scale) {
+                                                          int ld_rows, float c_log2, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;
-  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
+  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
   const int qr = (q0 + qi) < S ? (q0 + qi) : S - 1;
 
   // B-operand fragments held for the whole kernel: Q^T and dO^T (lane: row q, dims ds*16 + half*8 ..)
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   float dpart = 0.f;
   {
     const bf16_t* qp = base + (size_t)qr * QKV_LD + half * 8;
-    const bf16_t* dp = dout + ((size_t)b * S + qr) * 768 + h * HD + half * 8;
-    const bf16_t* op = o + ((size_t)b * S + qr) * 768 + h * HD + half * 8;
+    const bf16_t* dp = dout + ((size_t)b * ld_rows + qr) * 768 + h * HD + half * 8;
+    const bf16_t* op = o + ((size_t)b * ld_rows + qr) * 768 + h * HD + half * 8;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
       qf[ds] = *(const bf16x8*)(qp + ds * 16);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   }
   const int q = q0 + qi;
   if (q < S) {
-    bf16_t* op = dqkv + ((size_t)b * S + q) * QKV_LD + h * HD + 4 * half;
+    bf16_t* op = dqkv + ((size_t)b * ld_rows + q) * QKV_LD + h * HD + 4 * half;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
-                                                           int B, float c_log2, float scale) {
+                                                           int B, int ld_rows, float c_log2, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int h = (wid / nkb) % NH, b = wid / (nkb * NH);
   const int key0 = kb_ * 128 + w * 32;
   const bool active = key0 < S;
-  const bf16_t* base = qkv + (size_t)b * S * QKV_LD + h * HD;
-  const bf16_t* dob = dout + (size_t)b * S * 768 + h * HD;
+  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
+  const bf16_t* dob = dout + (size_t)b * ld_rows * 768 + h * HD;
   const float* Lb = lse + ((size_t)b * NH + h) * S;
   const float* Db = dsum + ((size_t)b * NH + h) * S;
   const int kr = (key0 + ki) < S ? (key0 + ki) : S - 1;
@@ -431,9 +431,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   }
   const int key = key0 + ki;
   if (key < S) {
-    bf16_t* ok = dqkv + ((size_t)b * S + key) * QKV_LD + 768 + h * HD + 4 * half;
+    bf16_t* ok = dqkv + ((size_t)b * ld_rows + key) * QKV_LD + 768 + h * HD + 4 * half;
     bf16_t* ov = ok + 768;
-    const bf16_t* ex = extra ? extra + ((size_t)b * S + key) * 1536 + h * HD + 4 * half : nullptr;
+    const bf16_t* ex = extra ? extra + ((size_t)b * ld_rows + key) * 1536 + h * HD + 4 * half : nullptr;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -459,16 +459,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 }  // namespace
 
 extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
-                                     const void* extra_dkv, void* dqkv, int B, int S, float scale, void* stream) {
-  VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0, "attn_dense_bwd: bad arguments");
+                                     const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
+                                     void* stream) {
+  VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0 && ld_rows >= S, "attn_dense_bwd: bad arguments");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, c, scale);
+                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale);
   VC_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                     (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B, c,
-                     scale);
+                     (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,
+                     ld_rows, c, scale);
   VC_LAUNCH_CHECK("attn_bwd_dkv");
   return VITCAP_OK;
 }

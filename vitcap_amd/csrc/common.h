@@ -66,6 +66,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * one_plus_erf;
 }
 
+// d/dz of the erf GELU: 0.5 (1 + erf(z/sqrt2)) + z exp(-z^2/2)/sqrt(2 pi), same erfc approximation as gelu_erf
+__device__ __forceinline__ float gelu_grad(float z) {
+  const float az = fabsf(z) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);   // exp(-z^2/2)
+  const float erfc_abs = p * t * e;
+  const float one_plus_erf = z >= 0.f ? 2.0f - erfc_abs : erfc_abs;
+  return 0.5f * one_plus_erf + z * e * 0.3989422804014327f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -29,6 +29,14 @@ struct GemmArgs {
   int lda, ldw, ldc, ldr;
   int row_group, out_group_rows, out_row_off, res_periodic;
   int tiles_m, tiles_n;
+  // training extras
+  const bf16_t* aux;   // epilogue multiplies by gelu'(aux) (backward of the MLP activation); bf16 [M][ldaux]
+  int ldaux;
+  bf16_t* zout;        // pre-activation copy (bias added, before the activation) for the backward; bf16 [M][ldz]
+  int ldz;
+  int split_k;         // > 1: blockIdx.y = split, ragged k-tile ranges, fp32 partial slabs, no epilogue
+  int kt_per_split;
+  size_t slab;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
@@ -96,13 +104,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   const int fk = lane >> 4;         // which 8-wide k group inside a 32-wide MFMA k step
   const int nk = p.K / BK;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // split-K (weight gradients): this workgroup owns k-tiles [t0, t1)
+  int t0 = 0, t1 = nk;
+  if (p.split_k > 1) {
+    t0 = blockIdx.y * p.kt_per_split;
+    t1 = t0 + p.kt_per_split < nk ? t0 + p.kt_per_split : nk;
+  }
+  if (t0 < t1) {
+    stage(0, t0 * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
 
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) stage(buf ^ 1, (t + 1) * BK);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) stage(buf ^ 1, (t + 1) * BK);
     const char* la = smem + buf * BUF_BYTES + (wm * WM * 16 + frow) * 128;
     const char* lw = smem + buf * BUF_BYTES + A_BYTES + (wn * WN * 16 + frow) * 128;
 #pragma unroll
@@ -139,9 +155,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
+      if (p.split_k > 1) {
+        *(f32x4*)((float*)p.C + (size_t)blockIdx.y * p.slab + (size_t)orow * p.ldc + n) = v;
+        continue;
+      }
       if (p.bias) {
         const f32x4 b = *(const f32x4*)(p.bias + n);
         v += b;
+      }
+      if (p.zout) {
+        uint2 zo;
+        zo.x = pack2bf(v[0], v[1]);
+        zo.y = pack2bf(v[2], v[3]);
+        *(uint2*)(p.zout + (size_t)orow * p.ldz + n) = zo;
+      }
+      if (p.aux) {
+        const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
       }
       if (ACT == VITCAP_ACT_GELU_ERF) {
 #pragma unroll
@@ -561,6 +592,17 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
         rrow = p.res_periodic ? in : orow;
       }
       v += bias4;
+      if (p.zout) {
+        uint2 zo;
+        zo.x = pack2bf(v[0], v[1]);
+        zo.y = pack2bf(v[2], v[3]);
+        *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
+      }
+      if (p.aux) {
+        const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
+      }
       if (ACT == VITCAP_ACT_GELU_ERF) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -1013,7 +1055,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   GemmArgs p = a;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, a.split_k > 1 ? a.split_k : 1), dim3(256), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt");
   return VITCAP_OK;
 }
@@ -1037,8 +1079,18 @@ int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                              const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
+                              void* stream);
+
 extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                                     void* C, const vitcap_gemm_desc* d, void* stream) {
+  return vitcap_gemm_ex(A, W, bias, residual, C, d, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                              const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
+                              void* stream) {
   VC_REQUIRE(A && W && C && d, "gemm: null pointer");
   VC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
   VC_REQUIRE(d->K % 64 == 0, "gemm: K=%d must be a multiple of 64", d->K);
@@ -1059,12 +1111,25 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   a.row_group = d->row_group; a.out_group_rows = d->out_group_rows;
   a.out_row_off = d->out_row_off; a.res_periodic = d->res_periodic;
   a.tiles_m = a.tiles_n = 0;
+  a.aux = (const bf16_t*)aux_bf16; a.ldaux = ldaux;
+  a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
+  a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
+  VC_REQUIRE(!(aux_bf16 && d->act != VITCAP_ACT_NONE), "gemm: aux (gelu') epilogue needs act == none");
   hipStream_t s = (hipStream_t)stream;
   // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K),
   //            5 = 256x256 role-alternating (the auto choice for M >= 2048)
   const int hint = d->tile_hint;
   const int split_k = d->split_k > 1 ? d->split_k : 1;
   const bool plain_rows = d->row_group == 0;
+  if (split_k > 1 && d->M > 256) {
+    // weight-gradient shape: few output tiles, very long K -> 128x128 tiles with ragged split-K into fp32 slabs
+    VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && plain_rows && !aux_bf16 && !zout_bf16, "gemm: split-K writes fp32 partial slabs only");
+    const int nk = d->K / 64;
+    a.split_k = split_k;
+    a.kt_per_split = (nk + split_k - 1) / split_k;
+    a.slab = (size_t)d->M * d->ldc;
+    return dispatch<4, 4>(a, VITCAP_ACT_NONE, 1, s);
+  }
   if (split_k > 1) {
     VC_REQUIRE(d->K % (128 * split_k) == 0, "gemm: K=%d not divisible into %d splits of multiples of 128", d->K, split_k);
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && plain_rows, "gemm: split-K writes fp32 partial slabs only");
@@ -1090,6 +1155,7 @@ extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* b
   // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %)
   // and loses with one (the residual loads queue behind the next tile's DMA), so it is used for the former only.
   static const int use_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
-  if (hint == 0 && use_persistent && !residual && d->row_group == 0) return dispatch_256p(a, d->act, d->out_dtype, s);
+  if (hint == 0 && use_persistent && !residual && !aux_bf16 && !zout_bf16 && d->row_group == 0)
+    return dispatch_256p(a, d->act, d->out_dtype, s);
   return dispatch_256<4>(a, d->act, d->out_dtype, s);
 }

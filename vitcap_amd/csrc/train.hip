@@ -1,0 +1,445 @@
+// Training-step kernels other than GEMM/attention (gfx950): transposes for the weight-gradient GEMMs, LayerNorm
+// backward, split-K slab reduction, embedding backward, losses, global-norm clip + fused AdamW, weight re-packing.
+// All are HBM-bound streaming kernels (vectorised 8/16-byte accesses, one wave per 768-wide row where rows matter).
+#include "common.h"
+
+namespace {
+
+constexpr int D768 = 768;
+
+// ---------------------------------------------------------------------------------------------------------------
+// XT[c][r] = X[r][c] (bf16), rows padded with zeros to Rp (multiple of 64); optional column sums (bias gradients).
+// 64x64 tile per 256-thread workgroup through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ xt,
+                                                               int ldt, float* __restrict__ colsum, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;            // 512 pieces of 8 elements
+    const int r = e >> 3, cc = (e & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R) v = *(const uint4*)(x + (size_t)(r0 + r) * ldx + c0 + cc);
+    const bf16_t* pv = (const bf16_t*)&v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[r][cc + j] = pv[j];
+  }
+  __syncthreads();
+  if (colsum && tid < 64) {
+    float s = 0.f;
+    for (int r = 0; r < 64; ++r) s += bf2f(tile[r][tid]);
+    atomicAdd(colsum + c0 + tid, s);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;
+    const int c = e >> 3, rr = (e & 7) * 8;
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = tile[rr + j][c];
+    *(uint4*)(xt + (size_t)(c0 + c) * ldt + r0 + rr) = *(const uint4*)o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward over 768-wide rows.  x: the forward input (fp32, statistics recomputed), dy: bf16 or fp32 gradient
+// of the output; dres: optional fp32 gradient arriving through the residual path (added to the result).
+//   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) + dres ;  dgamma += sum dy*xhat ; dbeta += sum dy
+// ---------------------------------------------------------------------------------------------------------------
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dyv,
+                                                            const float* __restrict__ gamma, float eps,
+                                                            const float* __restrict__ dres, float* __restrict__ dxf,
+                                                            bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  f32x4 g[3], ag[3], ab[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = wave * rows_per_wave + rr;
+    if (row >= M) break;
+    f32x4 v[3], dy[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      v[i] = *(const f32x4*)(x + (size_t)row * ldx + c);
+      if (DY_F32) {
+        dy[i] = *(const f32x4*)((const float*)dyv + (size_t)row * D768 + c);
+      } else {
+        const uint2 u = *(const uint2*)((const bf16_t*)dyv + (size_t)row * D768 + c);
+        dy[i] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                      __uint_as_float(u.y & 0xffff0000u)};
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) * (1.0f / D768);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D768) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[i][e] - mean) * rstd;
+        const float gd = g[i][e] * dy[i][e];
+        s1 += gd;
+        s2 += gd * xh;
+        ag[i][e] += dy[i][e] * xh;
+        ab[i][e] += dy[i][e];
+        v[i][e] = xh;
+        dy[i][e] = gd;
+      }
+    s1 = wave_sum(s1) * (1.0f / D768);
+    s2 = wave_sum(s2) * (1.0f / D768);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (dy[i][e] - s1 - v[i][e] * s2);
+      if (dres) o += *(const f32x4*)(dres + (size_t)row * D768 + c);
+      if (dxf) *(f32x4*)(dxf + (size_t)row * D768 + c) = o;
+      if (dxb) {
+        uint2 u;
+        u.x = pack2bf(o[0], o[1]);
+        u.y = pack2bf(o[2], o[3]);
+        *(uint2*)(dxb + (size_t)row * D768 + c) = u;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(dgamma + i * 256 + lane * 4 + e, ag[i][e]);
+      atomicAdd(dbeta + i * 256 + lane * 4 + e, ab[i][e]);
+    }
+}
+
+// out[i] (+)= sum_s slab[s][i]   (split-K reduction of the weight-gradient GEMMs)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, size_t slab_stride, int S,
+                                                           float* __restrict__ out, size_t n4, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 a = accumulate ? *(const f32x4*)(out + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) a += *(const f32x4*)(slabs + (size_t)s * slab_stride + i * 4);
+  *(f32x4*)(out + i * 4) = a;
+}
+
+// fp32 [R][C] (+ optional bf16 copy)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = *(const f32x4*)(x + i * 4);
+  uint2 u;
+  u.x = pack2bf(v[0], v[1]);
+  u.y = pack2bf(v[2], v[3]);
+  *(uint2*)(y + i * 4) = u;
+}
+
+// embedding backward: gword[ids[row]] += d[row]; gpos[pos[row]] += d[row]; gtype[0] += d[row]
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ d, const int64_t* __restrict__ ids,
+                                                        int rows_per_seq, float* __restrict__ gword, float* __restrict__ gpos,
+                                                        float* __restrict__ gtype, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t tok = ids[row];
+  const int pos = row % rows_per_seq;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 v = *(const f32x4*)(d + (size_t)row * D768 + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(gword + (size_t)tok * D768 + c + e, v[e]);
+      atomicAdd(gpos + (size_t)pos * D768 + c + e, v[e]);
+      atomicAdd(gtype + c + e, v[e]);
+    }
+  }
+}
+
+// label-smoothed KL (BertCaptioningLoss, modeling_bert.py:661-690): per row loss and d(loss)/d(logits) * (1/n_rows)
+__global__ __launch_bounds__(1024) void ls_kl_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                     const int64_t* __restrict__ target, float eps, float inv_rows,
+                                                     float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits, int ldd) {
+  __shared__ float s_red[16];
+  __shared__ float s_val;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (size_t)b * ldl;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) s_red[w] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m = s_red[0];
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, s_red[k]);
+    s_val = m;
+  }
+  __syncthreads();
+  mx = s_val;
+  float se = 0.f, sl = 0.f;
+  for (int i = tid; i < V; i += 1024) {
+    se += expf(row[i] - mx);
+    sl += row[i];
+  }
+  se = wave_sum(se);
+  sl = wave_sum(sl);
+  __syncthreads();
+  if (lane == 0) s_red[w] = se;
+  __syncthreads();
+  float tot = 0.f;
+  for (int k = 0; k < 16; ++k) tot += s_red[k];
+  __syncthreads();
+  if (lane == 0) s_red[w] = sl;
+  __syncthreads();
+  float sumlogit = 0.f;
+  for (int k = 0; k < 16; ++k) sumlogit += s_red[k];
+  const float lse = mx + logf(tot);
+  const int tgt = (int)target[b];
+  const float q_on = 1.0f - eps, q_off = eps / (float)(V - 1);
+  if (tid == 0) {
+    // sum_v q_v (log q_v - logp_v),  logp_v = x_v - lse
+    const float ent = q_on * logf(q_on) + (eps > 0.f ? eps * logf(q_off) : 0.f);
+    const float cross = q_on * (row[tgt] - lse) + q_off * ((sumlogit - row[tgt]) - (float)(V - 1) * lse);
+    atomicAdd(loss_sum, (ent - cross) * inv_rows);
+  }
+  if (dlogits) {
+    bf16_t* drow = dlogits + (size_t)b * ldd;
+    for (int i = tid; i < ldd; i += 1024) {
+      float gv = 0.f;
+      if (i < V) gv = (expf(row[i] - lse) - (i == tgt ? q_on : q_off)) * inv_rows;
+      drow[i] = f2bf(gv);
+    }
+  }
+}
+
+// focal loss with logits (loss.py:5-22), alpha 0.5 gamma 1, summed
+__global__ __launch_bounds__(256) void focal_sum_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                        const float* __restrict__ label, float alpha, float* __restrict__ out,
+                                                        int B) {
+  __shared__ float s_red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc = 0.f;
+  const size_t total = (size_t)B * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i / V), v = (int)(i - (size_t)b * V);
+    const float x = logits[(size_t)b * ldl + v];
+    const float y = label[i];
+    const float sp = 1.0f / (1.0f + expf(-x));
+    // logsigmoid(x) = min(x,0) - log1p(exp(-|x|))
+    const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+    const float lsn = fminf(-x, 0.f) - log1pf(expf(-fabsf(x)));
+    float l = 0.f;
+    if (y == 1.0f) l += alpha * (1.0f - sp) * ls;
+    if (y == 0.0f) l += (1.0f - alpha) * sp * lsn;
+    acc -= l;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) s_red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+// sum of squares of a flat fp32 buffer -> out[0] (atomic)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ out) {
+  __shared__ float s_red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(g + i * 4);
+    acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) s_red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+// fused clip + AdamW over a flat parameter buffer laid out in 1024-element chunks; chunk_lr/chunk_wd give each chunk's
+// learning rate (0 = not owned by the optimizer) and weight decay.  Update order as solver.AdamW.step
+// (optimization.py:187-208): moments, p -= step_size * m / (sqrt(v) + eps), then p -= lr * wd * p.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, const float* __restrict__ chunk_lr,
+                                                    const float* __restrict__ chunk_wd, const float* __restrict__ gsumsq,
+                                                    float clip, float lr_scale, float bc1, float bc2_sqrt, float b1, float b2,
+                                                    float eps, size_t nchunks) {
+  const size_t chunk = blockIdx.x;
+  if (chunk >= nchunks) return;
+  const float lr = chunk_lr[chunk] * lr_scale;
+  if (chunk_lr[chunk] == 0.f) return;
+  const float wd = chunk_wd[chunk];
+  const float norm = sqrtf(gsumsq[0]);
+  float coef = clip / (norm + 1e-6f);
+  coef = coef < 1.0f ? coef : 1.0f;
+  const float step_size = lr * bc2_sqrt / bc1;
+  const size_t i = chunk * 1024 + threadIdx.x * 4;
+  f32x4 pv = *(const f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ge = gv[e] * coef;
+    mv[e] = mv[e] * b1 + (1.0f - b1) * ge;
+    vv[e] = vv[e] * b2 + (1.0f - b2) * ge * ge;
+    float pe = pv[e] - step_size * (mv[e] / (sqrtf(vv[e]) + eps));
+    if (wd > 0.f) pe -= lr * wd * pe;
+    pv[e] = pe;
+  }
+  *(f32x4*)(p + i) = pv;
+  *(f32x4*)(m + i) = mv;
+  *(f32x4*)(v + i) = vv;
+}
+
+// fp32 W[N][K] -> bf16 W[N][K] and bf16 WT[K][N] (both K and N multiples of 64)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb,
+                                                             bf16_t* __restrict__ wt, int N, int K) {
+  __shared__ bf16_t tile[64][66];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * 256;            // 1024 pieces of 4 elements
+    const int r = e >> 4, cc = (e & 15) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n0 + r < N) v = *(const f32x4*)(w + (size_t)(n0 + r) * K + k0 + cc);
+    uint2 u;
+    u.x = pack2bf(v[0], v[1]);
+    u.y = pack2bf(v[2], v[3]);
+    if (n0 + r < N && wb) *(uint2*)(wb + (size_t)(n0 + r) * K + k0 + cc) = u;
+    const bf16_t* pu = (const bf16_t*)&u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[r][cc + j] = pu[j];
+  }
+  __syncthreads();
+  if (!wt) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;
+    const int c = e >> 3, rr = (e & 7) * 8;
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = tile[rr + j][c];
+    if (n0 + rr + 7 < N) {
+      *(uint4*)(wt + (size_t)(k0 + c) * N + n0 + rr) = *(const uint4*)o;
+    } else {
+      for (int j = 0; j < 8; ++j)
+        if (n0 + rr + j < N) wt[(size_t)(k0 + c) * N + n0 + rr + j] = o[j];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vitcap_transpose_colsum(const void* x, int ldx, void* xt, int ldt, float* colsum, int R, int C, void* stream) {
+  VC_REQUIRE(x && xt && R > 0 && C > 0 && C % 64 == 0 && ldt % 64 == 0 && ldt >= R && ldx % 8 == 0,
+             "transpose: needs C %% 64 == 0, ldt %% 64 == 0 >= R (R=%d C=%d ldt=%d)", R, C, ldt);
+  dim3 grid(ldt / 64, C / 64);
+  hipLaunchKernelGGL(transpose_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)xt, ldt,
+                     colsum, R, C);
+  VC_LAUNCH_CHECK("transpose_colsum");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32, const float* gamma, float eps,
+                                    const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, int M,
+                                    int D, void* stream) {
+  VC_REQUIRE(x && dy && gamma && dgamma && dbeta && (dx_f32 || dx_bf16) && D == D768 && M > 0, "layernorm_bwd: bad arguments");
+  const int rpw = 16;
+  const int waves = (M + rpw - 1) / rpw;
+  dim3 grid((waves + 3) / 4);
+  if (dy_is_f32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres,
+                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres,
+                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);
+  VC_LAUNCH_CHECK("layernorm_bwd");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_reduce_slabs(const float* slabs, size_t slab_stride, int S, float* out, size_t n, int accumulate,
+                                   void* stream) {
+  VC_REQUIRE(slabs && out && S >= 1 && n % 4 == 0, "reduce_slabs: bad arguments");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs,
+                     slab_stride, S, out, n4, accumulate);
+  VC_LAUNCH_CHECK("reduce_slabs");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream) {
+  VC_REQUIRE(x && y && n % 4 == 0, "cast_bf16: bad arguments");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y,
+                     n4);
+  VC_LAUNCH_CHECK("cast_bf16");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
+                                int rows, void* stream) {
+  VC_REQUIRE(d && ids && gword && gpos && gtype && rows > 0, "embed_bwd: bad arguments");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, ids, rows_per_seq, gword,
+                     gpos, gtype, rows);
+  VC_LAUNCH_CHECK("embed_bwd");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target, float eps, int rows,
+                                 float* loss_sum, void* dlogits_bf16, int ldd, void* stream) {
+  VC_REQUIRE(logits && target && loss_sum && rows > 0 && V > 1, "ls_kl_loss: bad arguments");
+  hipLaunchKernelGGL(ls_kl_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, target, eps,
+                     1.0f / (float)rows, loss_sum, (bf16_t*)dlogits_bf16, ldd);
+  VC_LAUNCH_CHECK("ls_kl_loss");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const float* label, float alpha, float* out, int B,
+                                     void* stream) {
+  VC_REQUIRE(logits && label && out && B > 0, "focal_loss: bad arguments");
+  hipLaunchKernelGGL(focal_sum_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, label, alpha, out, B);
+  VC_LAUNCH_CHECK("focal_loss");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_sumsq(const float* g, size_t n, float* out, void* stream) {
+  VC_REQUIRE(g && out && n % 4 == 0, "sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, g, n / 4, out);
+  VC_LAUNCH_CHECK("sumsq");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float* chunk_lr, const float* chunk_wd,
+                                  const float* gsumsq, float clip, float lr_scale, int step, float b1, float b2, float eps,
+                                  size_t nchunks, void* stream) {
+  VC_REQUIRE(p && g && m && v && chunk_lr && chunk_wd && gsumsq && step >= 1 && nchunks > 0, "adamw: bad arguments");
+  const float bc1 = 1.0f - powf(b1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, chunk_lr, chunk_wd,
+                     gsumsq, clip, lr_scale, bc1, bc2s, b1, b2, eps, nchunks);
+  VC_LAUNCH_CHECK("adamw");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, void* stream) {
+  VC_REQUIRE(w && (w_bf16 || wt_bf16) && N > 0 && K > 0 && K % 64 == 0, "cast_transpose: K must be a multiple of 64");
+  dim3 grid((N + 63) / 64, K / 64);
+  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bf16, (bf16_t*)wt_bf16, N, K);
+  VC_LAUNCH_CHECK("cast_transpose");
+  return VITCAP_OK;
+}

@@ -84,21 +84,26 @@ def attn_dense(qkv, B, S, scale=0.125):
     return out
 
 
-def attn_dense_train(qkv, B, S, scale=0.125):
-    """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd"""
+def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None):
+    """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd; ld_rows = rows per image
+    in the buffers (>= S; only the first S rows of each image are attended / written)"""
     _dev_bf16(qkv)
-    out = torch.empty((B * S, 768), device=qkv.device, dtype=torch.bfloat16)
+    ld_rows = ld_rows or S
+    if out is None:
+        out = torch.empty((B * ld_rows, 768), device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty((B, 12, S), device=qkv.device, dtype=torch.float32)
-    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, scale, _stream()), 'attn_dense_train')
+    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, _stream()), 'attn_dense_train')
     return out, lse
 
 
-def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None):
+def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None, ld_rows=None, dqkv=None):
     _dev_bf16(qkv); _dev_bf16(out); _dev_bf16(dout); _dev_f32(lse)
-    dqkv = torch.empty_like(qkv)
+    ld_rows = ld_rows or S
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
-    check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, scale,
-                                    _stream()), 'attn_dense_bwd')
+    check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, ld_rows,
+                                    scale, _stream()), 'attn_dense_bwd')
     return dqkv
 
 
@@ -151,3 +156,67 @@ def sigmoid_topk(logits, k=50, thresh=0.2, V=None):
     check(lib.vitcap_sigmoid_topk(_p(logits), logits.stride(0), V, k, thresh, _p(ids), _p(prob), _p(ln), B, _stream()),
           'sigmoid_topk')
     return ids, prob, ln
+
+
+# ------------------------------------------------------------------------------------------------ training ops
+def gemm_ex(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_dtype=torch.bfloat16, aux=None, zout=None,
+            split_k=0, tile_hint=0):
+    """GEMM with the training extras of vitcap_gemm_ex (gelu' multiply, pre-activation output, ragged split-K slabs)."""
+    _dev_bf16(a)
+    _dev_bf16(w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        shape = (split_k, M, N) if split_k > 1 else (M, N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if split_k > 1 else out_dtype)
+    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(-2),
+                   ldr=residual.stride(0) if residual is not None else 0, act=act,
+                   out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16, tile_hint=tile_hint, split_k=split_k)
+    check(lib.vitcap_gemm_ex(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _p(aux),
+                             aux.stride(0) if aux is not None else 0, _p(zout), zout.stride(0) if zout is not None else 0,
+                             _stream()), 'gemm_ex')
+    return out
+
+
+def transpose_colsum(x, colsum=None, out=None):
+    """x bf16 [R][C] -> x^T bf16 [C][Rp] (Rp = R rounded up to 64, zero padded); colsum[c] += sum_r x[r][c]."""
+    _dev_bf16(x)
+    R, Cc = x.shape
+    Rp = (R + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((Cc, Rp), device=x.device, dtype=torch.bfloat16)
+    check(lib.vitcap_transpose_colsum(_p(x), x.stride(0), _p(out), out.stride(0), _p(colsum), R, Cc, _stream()), 'transpose')
+    return out
+
+
+def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dres=None, want_f32=True, want_bf16=True):
+    _dev_f32(x)
+    M, D = x.shape
+    dxf = torch.empty((M, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    dxb = torch.empty((M, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    check(lib.vitcap_layernorm_bwd(_p(x), x.stride(0), _p(dy), int(dy.dtype == torch.float32), _p(gamma), eps, _p(dres),
+                                   _p(dxf), _p(dxb), _p(dgamma), _p(dbeta), M, D, _stream()), 'layernorm_bwd')
+    return dxf, dxb
+
+
+def reduce_slabs(slabs, out, accumulate=False):
+    S = slabs.shape[0]
+    n = slabs[0].numel()
+    check(lib.vitcap_reduce_slabs(_p(slabs), slabs.stride(0), S, _p(out), n, int(accumulate), _stream()), 'reduce_slabs')
+    return out
+
+
+def cast_bf16(x):
+    _dev_f32(x)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib.vitcap_cast_bf16(_p(x), _p(y), x.numel(), _stream()), 'cast_bf16')
+    return y
+
+
+def attn_text_fwd(qkv, out, B, S_vis, T, ld_rows, scale=0.125):
+    check(lib.vitcap_attn_text_fwd(_p(qkv), _p(out), B, S_vis, T, ld_rows, scale, _stream()), 'attn_text_fwd')
+
+
+def attn_text_bwd(qkv, dout, dqkv, extra, B, S_vis, T, ld_rows, scale=0.125):
+    check(lib.vitcap_attn_text_bwd(_p(qkv), _p(dout), _p(dqkv), _p(extra), B, S_vis, T, ld_rows, scale, _stream()),
+          'attn_text_bwd')
