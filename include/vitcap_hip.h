@@ -330,7 +330,13 @@ int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float
                        const float* gsumsq, float clip, float lr_scale, int step, float b1, float b2, float eps,
                        size_t nchunks, void* stream);
 /* fp32 master W[N][K] -> bf16 W and bf16 W^T[K][N] (the operands of the forward and the dgrad GEMMs) */
-int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, void* stream);
+int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, int ldt, void* stream);
+int vitcap_gelu_bwd(const float* dg, const void* z_bf16, void* dz_bf16, size_t n, void* stream);
+int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size_t n, void* stream);
+/* BertEmbeddings.forward on all rows of the teacher-forced caption (modeling_bert.py:222-237): optional pre-LN sum */
+int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
+                      const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
+                      float* x_f32, void* x_bf16, int rows, void* stream);
 /* caption rows of the decoder under teacher forcing: [S_vis visual | T caption] rows per image, caption row r attends
  * all visual rows and caption rows <= r */
 int vitcap_attn_text_fwd(const void* qkv, void* out, int B, int S_vis, int T, int ld_rows, float scale, void* stream);

@@ -60,7 +60,7 @@ def test_weight_grad_splitk_and_dgrad(ops):
     wt = torch.empty(K, N, device='cuda', dtype=torch.bfloat16)
     wb = torch.empty(N, K, device='cuda', dtype=torch.bfloat16)
     wf = w.float().cuda().contiguous()
-    check(lib.vitcap_cast_transpose(C.c_void_p(wf.data_ptr()), C.c_void_p(wb.data_ptr()), C.c_void_p(wt.data_ptr()), N, K,
+    check(lib.vitcap_cast_transpose(C.c_void_p(wf.data_ptr()), C.c_void_p(wb.data_ptr()), C.c_void_p(wt.data_ptr()), N, K, N,
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'cast_transpose')
     assert torch.equal(wb.cpu(), w) and torch.equal(wt.cpu(), w.t().contiguous())
     z = _bf(_rand((M, K), 5, 2.0))
@@ -165,6 +165,7 @@ def test_adamw_clip_matches_oracle(ops):
     p = _rand((n,), 15); g = _rand((n,), 16, 3.0)
     lr = torch.tensor([1e-4, 1e-5, 0.0, 1e-4]); wd = torch.tensor([0.05, 0.0, 0.05, 0.0])
     P, G = p.cuda(), g.cuda()
+    lr_d, wd_d = lr.cuda(), wd.cuda()
     Mm, Vv = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
     ss = torch.zeros(1, device='cuda')
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -173,7 +174,7 @@ def test_adamw_clip_matches_oracle(ops):
         ss.zero_()
         check(lib.vitcap_sumsq(C.c_void_p(G.data_ptr()), n, C.c_void_p(ss.data_ptr()), s), 'sumsq')
         check(lib.vitcap_adamw_multi(C.c_void_p(P.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(Mm.data_ptr()),
-                                     C.c_void_p(Vv.data_ptr()), C.c_void_p(lr.cuda().data_ptr()), C.c_void_p(wd.cuda().data_ptr()),
+                                     C.c_void_p(Vv.data_ptr()), C.c_void_p(lr_d.data_ptr()), C.c_void_p(wd_d.data_ptr()),
                                      C.c_void_p(ss.data_ptr()), 1.0, 1.0, step, 0.9, 0.999, 1e-8, n // 1024, s), 'adamw')
         coef = min(1.0, 1.0 / (float(g.norm()) + 1e-6))
         for c in range(4):

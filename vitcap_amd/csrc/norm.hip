@@ -130,6 +130,27 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restri
   ln_row(v, gamma, beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
 }
 
+// teacher-forced text rows: row r = word[ids[r]] + pos[r % rows_per_seq] + type[0] -> (pre-LN sum fp32, LN fp32, LN bf16)
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restrict__ ids, int rows_per_seq,
+                                                         const bf16_t* __restrict__ word, const bf16_t* __restrict__ pos,
+                                                         const bf16_t* __restrict__ type, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float* __restrict__ pre,
+                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t tok = ids[row];
+  const int p = row % rows_per_seq;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    v[i] = (ld_bf4(word + (size_t)tok * D768 + c) + ld_bf4(pos + (size_t)p * D768 + c)) + ld_bf4(type + c);
+    if (pre) *(f32x4*)(pre + (size_t)row * D768 + c) = v[i];
+  }
+  ln_row(v, gamma, beta, eps, lane, xb ? xb + (size_t)row * D768 : nullptr, xf ? xf + (size_t)row * D768 : nullptr);
+}
+
 // image [B,3,384,384] -> patches [B*576, 768], k = c*256 + kh*16 + kw.  One thread = 8 kw (16 B out).
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restrict__ image,
@@ -225,6 +246,17 @@ extern "C" int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mas
                      mask_token, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma,
                      beta, eps, x_f32, (bf16_t*)x_bf16, rows);
   VC_LAUNCH_CHECK("embed_step");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
+                                 const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
+                                 float* x_f32, void* x_bf16, int rows, void* stream) {
+  VC_REQUIRE(ids && word_emb && pos_emb && type_emb && gamma && beta && rows > 0 && rows_per_seq > 0, "embed_rows: bad arguments");
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, rows_per_seq,
+                     (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta, eps, pre_f32,
+                     x_f32, (bf16_t*)x_bf16, rows);
+  VC_LAUNCH_CHECK("embed_rows");
   return VITCAP_OK;
 }
 

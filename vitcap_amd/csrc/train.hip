@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // fp32 W[N][K] -> bf16 W[N][K] and bf16 WT[K][N] (both K and N multiples of 64)
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb,
-                                                             bf16_t* __restrict__ wt, int N, int K) {
+                                                             bf16_t* __restrict__ wt, int N, int K, int ldt) {
   __shared__ bf16_t tile[64][66];
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
 #pragma unroll
@@ -335,15 +335,48 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = tile[rr + j][c];
     if (n0 + rr + 7 < N) {
-      *(uint4*)(wt + (size_t)(k0 + c) * N + n0 + rr) = *(const uint4*)o;
+      *(uint4*)(wt + (size_t)(k0 + c) * ldt + n0 + rr) = *(const uint4*)o;
     } else {
       for (int j = 0; j < 8; ++j)
-        if (n0 + rr + j < N) wt[(size_t)(k0 + c) * N + n0 + rr + j] = o[j];
+        if (n0 + rr + j < N) wt[(size_t)(k0 + c) * ldt + n0 + rr + j] = o[j];
     }
   }
 }
 
+// dz = dg * gelu'(z)   (backward of BertPredictionHeadTransform's activation; elementwise, tiny)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dg, const bf16_t* __restrict__ z,
+                                                       bf16_t* __restrict__ dz, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dz[i] = f2bf(dg[i] * gelu_grad(bf2f(z[i])));
+}
+
+// out[j] = sum_b x[b][j]   (pos_embed / cls_token gradients: the parameter is broadcast over the batch)
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __restrict__ x, size_t stride, int B,
+                                                             float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += x[(size_t)b * stride + i];
+  out[i] = a;
+}
+
 }  // namespace
+
+extern "C" int vitcap_gelu_bwd(const float* dg, const void* z_bf16, void* dz_bf16, size_t n, void* stream) {
+  VC_REQUIRE(dg && z_bf16 && dz_bf16 && n > 0, "gelu_bwd: bad arguments");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dg,
+                     (const bf16_t*)z_bf16, (bf16_t*)dz_bf16, n);
+  VC_LAUNCH_CHECK("gelu_bwd");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size_t n, void* stream) {
+  VC_REQUIRE(x && out && B > 0 && n > 0, "sum_over_batch: bad arguments");
+  hipLaunchKernelGGL(sum_over_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, stride, B,
+                     out, n);
+  VC_LAUNCH_CHECK("sum_over_batch");
+  return VITCAP_OK;
+}
 
 extern "C" int vitcap_transpose_colsum(const void* x, int ldx, void* xt, int ldt, float* colsum, int R, int C, void* stream) {
   VC_REQUIRE(x && xt && R > 0 && C > 0 && C % 64 == 0 && ldt % 64 == 0 && ldt >= R && ldx % 8 == 0,
@@ -436,10 +469,12 @@ extern "C" int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, 
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, void* stream) {
-  VC_REQUIRE(w && (w_bf16 || wt_bf16) && N > 0 && K > 0 && K % 64 == 0, "cast_transpose: K must be a multiple of 64");
+extern "C" int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, int ldt, void* stream) {
+  VC_REQUIRE(w && (w_bf16 || wt_bf16) && N > 0 && K > 0 && K % 64 == 0 && ldt >= N && ldt % 8 == 0,
+             "cast_transpose: K must be a multiple of 64, ldt >= N");
   dim3 grid((N + 63) / 64, K / 64);
-  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bf16, (bf16_t*)wt_bf16, N, K);
+  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bf16, (bf16_t*)wt_bf16, N, K,
+                     ldt);
   VC_LAUNCH_CHECK("cast_transpose");
   return VITCAP_OK;
 }

@@ -1,0 +1,442 @@
+"""Cross-entropy training step of ViTCAP on MI355X.
+
+Mirrors ``do_train_dict`` (src/tools/opt/trainer.py:95-142) around ``ImageCaptioning.forward`` in training mode
+(..._bertemb.py:87-171 -> ViTCAP.encode_forward(is_training=True), modeling_bert.py:751-807): forward, masked-token
+label-smoothed loss, backward, global-norm clip over ALL parameters, the reference's AdamW (decay after the update)
+on its ten parameter groups, linear LR decay.  Every FLOP runs in the hand-written HIP kernels; this module only
+sequences launches and owns the buffers (torch is used for allocation, views, row gathers/copies and the RCCL
+all-reduce).
+
+What is computed (identical loss and gradients to the reference, less dead work):
+* the decoder runs on [578 visual | 20 caption] rows per image.  The reference's 50 tag slots and the padding rows
+  are attended by nothing that reaches the loss (seq2seq mask with text_b='', dataset.py:377-390), so their rows are
+  not materialised; caption row r attends all visual rows and caption rows <= r.
+* attention dropout (p=0.1 in the reference's training mode) is NOT applied yet: parity is against the reference with
+  dropout off (eval-mode modules, `is_training=True` branch), as in tests/golden/make_golden_train.py.
+* the tag head runs forward only: `tag_loss` is reported, never back-propagated by this pipeline
+  (..._bertemb.py:170-171), and bert.pooler / bert.tag_logit / bert.extra_embeddings / caption_pooler / image head
+  receive no gradient.
+
+Gradients of a data-parallel job are summed with ONE RCCL all-reduce per bucket over the flat fp32 gradient buffer
+(layout = reverse execution order friendly), launched on a side stream as soon as a bucket's last producer ran.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+from . import weights as W
+from ._lib import check, lib
+
+CH = 1024           # optimizer chunk (elements)
+NV = 577
+SV = 578
+T = 20
+LR = SV + T         # decoder rows per image
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def param_groups(names, base_lr, weight_decay, lr_multiplier):
+    """name -> (lr, wd) or None (not owned by the optimizer); ..._bertemb.py:280-356."""
+    out = {}
+    for n in names:
+        if n.startswith('module.cls.'):
+            out[n] = None
+            continue
+        low = n.startswith('module.bert.encoder.tag_blocks.') or n.startswith('module.bert.pooler.') \
+            or n.startswith('module.bert.tag_logit.')
+        if n.startswith('module.bert.encoder.blocks.'):
+            low = int(n.split('.')[4]) < 8
+        wd = 0.0 if ('bias' in n or 'LayerNorm.weight' in n) else weight_decay
+        out[n] = (base_lr * (lr_multiplier if low else 1.0), wd)
+    return out
+
+
+class TrainEngine(object):
+    def __init__(self, model, device='cuda', base_lr=1e-4, weight_decay=0.05, lr_multiplier=0.1, clip=1.0, max_iter=1000,
+                 label_smoothing=0.1, dist=None):
+        self.model = model
+        self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device('cuda', torch.cuda.current_device())
+        self.clip, self.max_iter, self.eps_ls = clip, max_iter, label_smoothing
+        self.dist = dist
+        self.step_no = 0
+        self.lr_scale = 1.0
+        spec = W.state_dict_spec()
+        tied = model.tie_weights
+        # ---- flat layout: every unique tensor padded to CH; decoder q/k/v weights (and biases) contiguous
+        self.off, self.shape = {}, {}
+        order = []
+        for k in spec:
+            if tied and k == W.TIED_DST:
+                continue
+            if '.attention.self.' in k:
+                if k.endswith('query.weight'):          # q|k|v weights, then q|k|v biases, contiguous
+                    pre = k[:-len('query.weight')]
+                    order += [pre + n + '.weight' for n in ('query', 'key', 'value')]
+                    order += [pre + n + '.bias' for n in ('query', 'key', 'value')]
+                continue
+            order.append(k)
+        cur = 0
+        for k in order:
+            shp = spec[k][0]
+            n = int(torch.Size(shp).numel())
+            self.off[k], self.shape[k] = cur, shp
+            is_qk_bias = k.endswith('attention.self.query.bias') or k.endswith('attention.self.key.bias')
+            cur += n if is_qk_bias else (n + CH - 1) // CH * CH      # q|k|v biases stay contiguous (2304 -> 3 chunks)
+        self.nflat = (cur + CH - 1) // CH * CH
+        if tied:
+            self.off[W.TIED_DST], self.shape[W.TIED_DST] = self.off[W.TIED_SRC], self.shape[W.TIED_SRC]
+        self.P = torch.zeros(self.nflat, device=self.dev)
+        self.G = torch.zeros(self.nflat, device=self.dev)
+        self.M = torch.zeros(self.nflat, device=self.dev)
+        self.V = torch.zeros(self.nflat, device=self.dev)
+        sd = model.state_dict()
+        for k in order:
+            self.p(k).copy_(sd[k])
+        pg = param_groups(order, base_lr, weight_decay, lr_multiplier)
+        lr = torch.zeros(self.nflat // CH)
+        wd = torch.zeros(self.nflat // CH)
+        no_grad = ('module.bert.extra_embeddings.', 'module.bert.tag_logit.', 'module.bert.pooler.',
+                   'module.bert.caption_pooler.', 'image_encoder.module.head.')
+        for k in order:
+            if pg[k] is None or k.startswith(no_grad):
+                continue                  # p.grad is None in the reference -> AdamW skips the tensor
+            n = int(torch.Size(self.shape[k]).numel())
+            c0, c1 = self.off[k] // CH, (self.off[k] + n + CH - 1) // CH
+            lr[c0:c1], wd[c0:c1] = pg[k][0], pg[k][1]
+        self.chunk_lr, self.chunk_wd = lr.to(self.dev), wd.to(self.dev)
+        self.gsumsq = torch.zeros(1, device=self.dev)
+        self.loss_buf = torch.zeros(2, device=self.dev)      # [masked_loss, tag_loss]
+        self._gemm_w = {}
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------ views
+    def p(self, k):
+        n = int(torch.Size(self.shape[k]).numel())
+        return self.P[self.off[k]:self.off[k] + n].view(self.shape[k])
+
+    def g(self, k):
+        n = int(torch.Size(self.shape[k]).numel())
+        return self.G[self.off[k]:self.off[k] + n].view(self.shape[k])
+
+    def _flat(self, buf, k, n, shape):
+        return buf[self.off[k]:self.off[k] + n].view(shape)
+
+    def state_dict(self):
+        return {k: self.p(k).detach().clone() for k in W.state_dict_spec()}
+
+    # ------------------------------------------------------------------ bf16 operands of the GEMMs
+    def _matrices(self):
+        """(name, first key, N, K, pad_N): GEMM weights; decoder q|k|v are one [2304,768] matrix in the flat layout."""
+        out = [('patch', 'image_encoder.module.patch_embed.proj.weight', 768, 768, 768)]
+        for pre in ['module.bert.encoder.blocks.%d' % i for i in range(12)] + \
+                   ['module.bert.encoder.tag_blocks.%d' % i for i in range(4)]:
+            out += [(pre + '.qkv', pre + '.attn.qkv.weight', 2304, 768, 2304), (pre + '.proj', pre + '.attn.proj.weight', 768, 768, 768),
+                    (pre + '.fc1', pre + '.mlp.fc1.weight', 3072, 768, 3072), (pre + '.fc2', pre + '.mlp.fc2.weight', 768, 3072, 768)]
+        for i in range(4):
+            pre = 'module.bert.decoder.layer.%d' % i
+            out += [(pre + '.qkv', pre + '.attention.self.query.weight', 2304, 768, 2304),
+                    (pre + '.ao', pre + '.attention.output.dense.weight', 768, 768, 768),
+                    (pre + '.i', pre + '.intermediate.dense.weight', 3072, 768, 3072),
+                    (pre + '.o', pre + '.output.dense.weight', 768, 3072, 768)]
+        out += [('pooler', 'module.bert.pooler.dense.weight', 768, 768, 768),
+                ('tag.t', 'module.bert.tag_logit.predictions.transform.dense.weight', 768, 768, 768),
+                ('tag.dec', 'module.bert.tag_logit.predictions.decoder.weight', 30522, 768, L.VOCAB_PAD),
+                ('cls.t', 'module.cls.predictions.transform.dense.weight', 768, 768, 768),
+                ('word', 'module.bert.embeddings.word_embeddings.weight', 30522, 768, L.VOCAB_PAD),
+                ('pos', 'module.bert.embeddings.position_embeddings.weight', 512, 768, 512),
+                ('type', 'module.bert.embeddings.token_type_embeddings.weight', 2, 768, 8)]
+        if not self.model.tie_weights:
+            out.append(('cls.dec', 'module.cls.predictions.decoder.weight', 30522, 768, L.VOCAB_PAD))
+        return out
+
+    def refresh_weights(self):
+        """fp32 masters -> bf16 W[N][K] and W^T[K][N] (forward / dgrad operands); called after every optimizer step."""
+        s = _s()
+        for name, key, N, K, padN in self._matrices():
+            if name not in self._gemm_w:
+                self._gemm_w[name] = (torch.zeros(padN, K, device=self.dev, dtype=torch.bfloat16),
+                                      torch.zeros(K, padN, device=self.dev, dtype=torch.bfloat16))
+            wb, wt = self._gemm_w[name]
+            src = self.P[self.off[key]:self.off[key] + N * K]
+            check(lib.vitcap_cast_transpose(_p(src), _p(wb), _p(wt), N, K, padN, s), 'cast_transpose')
+        if self.model.tie_weights:
+            self._gemm_w['cls.dec'] = self._gemm_w['word']
+
+    def wb(self, name):
+        return self._gemm_w[name][0]
+
+    def wt(self, name):
+        return self._gemm_w[name][1]
+
+    def vec(self, k):
+        return self.p(k).view(-1)
+
+    def qkv_bias(self, pre):      # decoder q|k|v biases are contiguous in the flat layout
+        o = self.off[pre + '.attention.self.query.bias']
+        return self.P[o:o + 2304]
+
+    def qkv_bias_grad(self, pre):
+        o = self.off[pre + '.attention.self.query.bias']
+        return self.G[o:o + 2304]
+
+    def qkv_w_grad(self, pre):
+        o = self.off[pre + '.attention.self.query.weight']
+        return self.G[o:o + 2304 * 768].view(2304, 768)
+
+    # ------------------------------------------------------------------ helpers
+    def _wgrad(self, dyT, xT, gview, accumulate=False):
+        """gview[N][K] (+)= dyT[N][Mp] @ xT[K][Mp]^T with split-K sized to fill the chip."""
+        N, Kin = dyT.shape[0], xT.shape[0]
+        tiles = ((N + 127) // 128) * ((Kin + 127) // 128)
+        nk = dyT.shape[1] // 64
+        S = max(1, min(32, nk, (640 + tiles - 1) // tiles))
+        if S == 1:
+            if accumulate:
+                tmp = ops.gemm_ex(dyT, xT, out_dtype=torch.float32)
+                ops.reduce_slabs(tmp.view(1, N, Kin), gview, accumulate=True)
+            else:
+                ops.gemm_ex(dyT, xT, out=gview)
+            return
+        slabs = ops.gemm_ex(dyT, xT, split_k=S)
+        ops.reduce_slabs(slabs, gview, accumulate=accumulate)
+
+    def _ln_bwd(self, x, dy, gkey, bkey, eps, dres=None):
+        return ops.layernorm_bwd(x, dy, self.vec(gkey), eps, self.g(gkey).view(-1), self.g(bkey).view(-1), dres=dres)
+
+    # ------------------------------------------------------------------ forward + backward
+    def forward_backward(self, batch):
+        """batch: image (B,3,384,384) fp32/bf16 cuda; input_ids (B,70) int64; masked_pos (B,70) int; masked_ids (B,3) int64;
+        label (B,30522) fp32 -- the dict the reference's collate feeds ImageCaptioning.forward in training.
+        Accumulates gradients into self.G (zeroed here) and returns (masked_loss, tag_loss) device scalars."""
+        dev = self.dev
+        img = batch['image']
+        B = img.shape[0]
+        M, Md = B * NV, B * LR
+        self.G.zero_()
+        self.loss_buf.zero_()
+        ie = 'image_encoder.module.'
+        # ================= forward: patch embed
+        patches = ops.patch_gather(img)
+        x = torch.empty(M, 768, device=dev)
+        pos = self.p(ie + 'pos_embed').view(NV, 768)
+        ops.gemm_bias_act(patches, self.wb('patch'), self.vec(ie + 'patch_embed.proj.bias'), residual=pos[1:], out=x,
+                          row_group=576, out_group_rows=NV, out_row_off=1, res_periodic=1)
+        check(lib.vitcap_cls_rows(_p(self.vec(ie + 'cls_token')), _p(pos), _p(x), B, NV, _s()), 'cls_rows')
+        # ================= forward: 12 blocks + 4 tag blocks, activations kept
+        saved = {}
+
+        def block_fwd(pre, xin):
+            h1, _ = ops.layernorm(xin, self.vec(pre + '.norm1.weight'), self.vec(pre + '.norm1.bias'), 1e-6)
+            qkv = ops.gemm_bias_act(h1, self.wb(pre + '.qkv'), self.vec(pre + '.attn.qkv.bias'))
+            ao, lse = ops.attn_dense_train(qkv, B, NV)
+            xmid = torch.empty(M, 768, device=dev)
+            ops.gemm_bias_act(ao, self.wb(pre + '.proj'), self.vec(pre + '.attn.proj.bias'), residual=xin, out=xmid)
+            h2, _ = ops.layernorm(xmid, self.vec(pre + '.norm2.weight'), self.vec(pre + '.norm2.bias'), 1e-6)
+            z = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16)
+            g = ops.gemm_ex(h2, self.wb(pre + '.fc1'), bias=self.vec(pre + '.mlp.fc1.bias'), act=L.ACT_GELU_ERF, zout=z)
+            xout = torch.empty(M, 768, device=dev)
+            ops.gemm_bias_act(g, self.wb(pre + '.fc2'), self.vec(pre + '.mlp.fc2.bias'), residual=xmid, out=xout)
+            saved[pre] = (xin, h1, qkv, ao, lse, xmid, h2, z, g)
+            return xout
+
+        xt = None
+        for i in range(12):
+            if i == 8:
+                xt = x
+            x = block_fwd('module.bert.encoder.blocks.%d' % i, x)
+        for i in range(4):
+            xt = block_fwd('module.bert.encoder.tag_blocks.%d' % i, xt)
+        # ================= forward: tag head (value of tag_loss only)
+        tg = 'module.bert.tag_logit.predictions'
+        pin = ops.cast_bf16(xt.view(B, NV, 768)[:, 0].contiguous())
+        pooled = ops.gemm_bias_act(pin, self.wb('pooler'), self.vec('module.bert.pooler.dense.bias'), act=L.ACT_TANH)
+        tgf = ops.gemm_bias_act(pooled, self.wb('tag.t'), self.vec(tg + '.transform.dense.bias'), act=L.ACT_GELU_ERF,
+                                out_dtype=torch.float32)
+        tgb, _ = ops.layernorm(tgf, self.vec(tg + '.transform.LayerNorm.weight'), self.vec(tg + '.transform.LayerNorm.bias'), 1e-12)
+        tbias = torch.zeros(L.VOCAB_PAD, device=dev)
+        tbias[:L.VOCAB] = self.vec(tg + '.bias')
+        tag_logits = ops.gemm_bias_act(tgb, self.wb('tag.dec'), tbias, out_dtype=torch.float32)
+        label = batch['label'].to(dev).contiguous()
+        check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), B, _s()),
+              'focal')
+        # ================= forward: decoder on [578 visual | 20 caption] rows per image
+        e = 'module.bert.embeddings'
+        ids20 = batch['input_ids'][:, :T].to(dev).contiguous()
+        pre_emb = torch.empty(B * T, 768, device=dev)
+        xtext = torch.empty(B * T, 768, device=dev)
+        check(lib.vitcap_embed_rows(_p(ids20), T, _p(self.wb('word')), _p(self.wb('pos')), _p(self.wb('type')),
+                                    _p(self.vec(e + '.LayerNorm.weight')), _p(self.vec(e + '.LayerNorm.bias')), 1e-12,
+                                    _p(pre_emb), _p(xtext), None, B * T, _s()), 'embed_rows')
+        dx = torch.empty(B, LR, 768, device=dev)
+        dx[:, 0] = xt.view(B, NV, 768)[:, 0]
+        dx[:, 1:SV] = x.view(B, NV, 768)
+        dx[:, SV:] = xtext.view(B, T, 768)
+        xd = dx.view(Md, 768)
+        dsaved = []
+        for l in range(4):
+            pre = 'module.bert.decoder.layer.%d' % l
+            xb = ops.cast_bf16(xd)
+            qkv = ops.gemm_bias_act(xb, self.wb(pre + '.qkv'), self.qkv_bias(pre))
+            ctx, lse = ops.attn_dense_train(qkv, B, SV, ld_rows=LR)
+            ops.attn_text_fwd(qkv, ctx, B, SV, T, LR)
+            t1 = torch.empty(Md, 768, device=dev)
+            ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
+            ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
+                                   self.vec(pre + '.attention.output.LayerNorm.bias'), 1e-12, want_f32=True)
+            z = torch.empty(Md, 3072, device=dev, dtype=torch.bfloat16)
+            it = ops.gemm_ex(ab, self.wb(pre + '.i'), bias=self.vec(pre + '.intermediate.dense.bias'), act=L.ACT_GELU_ERF, zout=z)
+            t2 = torch.empty(Md, 768, device=dev)
+            ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
+            _, yf = ops.layernorm(t2, self.vec(pre + '.output.LayerNorm.weight'), self.vec(pre + '.output.LayerNorm.bias'), 1e-12,
+                                  want_bf16=False, want_f32=True)
+            dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2))
+            xd = yf
+        # ================= loss on the masked caption positions
+        mp = batch['masked_pos'][:, :T].to(dev).bool()
+        sel = mp.view(-1).nonzero().view(-1)                                  # rows of the (B*T) caption grid
+        n = int(sel.numel())
+        tgt = batch['masked_ids'].to(dev)
+        tgt = tgt[tgt != 0].contiguous()
+        assert int(tgt.numel()) == n, 'masked_pos / masked_ids disagree'
+        text_rows = xd.view(B, LR, 768)[:, SV:].reshape(B * T, 768)
+        hrows = ops.cast_bf16(text_rows.index_select(0, sel).contiguous())
+        c = 'module.cls.predictions'
+        zt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
+        gt = ops.gemm_ex(hrows, self.wb('cls.t'), bias=self.vec(c + '.transform.dense.bias'), act=L.ACT_GELU_ERF, zout=zt,
+                         out_dtype=torch.float32)
+        h2b, _ = ops.layernorm(gt, self.vec(c + '.transform.LayerNorm.weight'), self.vec(c + '.transform.LayerNorm.bias'), 1e-12)
+        cbias = torch.zeros(L.VOCAB_PAD, device=dev)
+        cbias[:L.VOCAB] = self.vec(c + '.bias')
+        logits = ops.gemm_bias_act(h2b, self.wb('cls.dec'), cbias, out_dtype=torch.float32)
+        dlog = torch.empty(n, L.VOCAB_PAD, device=dev, dtype=torch.bfloat16)
+        check(lib.vitcap_ls_kl_loss(_p(logits), L.VOCAB_PAD, L.VOCAB, _p(tgt), self.eps_ls, n, _p(self.loss_buf), _p(dlog),
+                                    L.VOCAB_PAD, _s()), 'ls_kl')
+        # ================= backward: LM head
+        wkey = W.TIED_SRC if self.model.tie_weights else c + '.decoder.weight'
+        bsum = torch.zeros(L.VOCAB_PAD, device=dev)
+        dlT = ops.transpose_colsum(dlog, bsum)                                 # [VOCAB_PAD][n_pad]
+        self.g(c + '.bias').copy_(bsum[:L.VOCAB])
+        h2T = ops.transpose_colsum(h2b)
+        gdec = torch.empty(L.VOCAB_PAD, 768, device=dev)
+        ops.gemm_ex(dlT, h2T, out=gdec)
+        self.g(wkey).copy_(gdec[:L.VOCAB])                                     # first writer of the (tied) embedding gradient
+        dh2 = ops.gemm_ex(dlog, self.wt('cls.dec'))                            # [n,768] bf16
+        dgt, _ = self._ln_bwd(gt, dh2, c + '.transform.LayerNorm.weight', c + '.transform.LayerNorm.bias', 1e-12)
+        dzt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
+        check(lib.vitcap_gelu_bwd(_p(dgt), _p(zt), _p(dzt), n * 768, _s()), 'gelu_bwd')
+        dztT = ops.transpose_colsum(dzt, self.g(c + '.transform.dense.bias').view(-1))
+        self._wgrad(dztT, ops.transpose_colsum(hrows), self.g(c + '.transform.dense.weight'))
+        dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
+        dy = torch.zeros(B, LR, 768, device=dev)
+        dtext = torch.zeros(B * T, 768, device=dev)
+        dtext.index_copy_(0, sel, dh)
+        dy[:, SV:] = dtext.view(B, T, 768)
+        dy = dy.view(Md, 768)
+        # ================= backward: decoder layers
+        for l in (3, 2, 1, 0):
+            pre = 'module.bert.decoder.layer.%d' % l
+            xb, qkv, ctx, lse, t1, ab, af, z, it, t2 = dsaved[l]
+            dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
+            dt2T = ops.transpose_colsum(dt2b, self.g(pre + '.output.dense.bias').view(-1))
+            self._wgrad(dt2T, ops.transpose_colsum(it), self.g(pre + '.output.dense.weight'))
+            dz = ops.gemm_ex(dt2b, self.wt(pre + '.o'), aux=z)                 # [Md,3072] bf16
+            dzT = ops.transpose_colsum(dz, self.g(pre + '.intermediate.dense.bias').view(-1))
+            self._wgrad(dzT, ops.transpose_colsum(ab), self.g(pre + '.intermediate.dense.weight'))
+            da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
+            dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias',
+                                      1e-12)
+            dt1T = ops.transpose_colsum(dt1b, self.g(pre + '.attention.output.dense.bias').view(-1))
+            self._wgrad(dt1T, ops.transpose_colsum(ctx), self.g(pre + '.attention.output.dense.weight'))
+            dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
+            dqkv = torch.zeros(Md, 2304, device=dev, dtype=torch.bfloat16)
+            extra = torch.zeros(Md, 2, 768, device=dev, dtype=torch.bfloat16)
+            ops.attn_text_bwd(qkv, dctx, dqkv, extra, B, SV, T, LR)
+            ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, SV, extra_dkv=extra, ld_rows=LR, dqkv=dqkv)
+            dqkvT = ops.transpose_colsum(dqkv, self.qkv_bias_grad(pre))
+            self._wgrad(dqkvT, ops.transpose_colsum(xb), self.qkv_w_grad(pre))
+            dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
+        dyv = dy.view(B, LR, 768)
+        # ================= backward: text embeddings
+        demb, _ = self._ln_bwd(pre_emb, dyv[:, SV:].reshape(B * T, 768).contiguous(), e + '.LayerNorm.weight', e + '.LayerNorm.bias',
+                               1e-12, dres=None)
+        check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), T, _p(self.g(e + '.word_embeddings.weight')),
+                                   _p(self.g(e + '.position_embeddings.weight')), _p(self.g(e + '.token_type_embeddings.weight')),
+                                   B * T, _s()), 'embed_bwd')
+        # ================= backward: encoder
+        dhid = dyv[:, 1:SV].reshape(M, 768).contiguous()
+        dtag = torch.zeros(B, NV, 768, device=dev)
+        dtag[:, 0] = dyv[:, 0]
+        dtag = dtag.view(M, 768)
+
+        def block_bwd(pre, dxo):
+            xin, h1, qkv, ao, lse, xmid, h2, z, g = saved.pop(pre)
+            dxb = ops.cast_bf16(dxo)
+            dxT = ops.transpose_colsum(dxb, self.g(pre + '.mlp.fc2.bias').view(-1))
+            self._wgrad(dxT, ops.transpose_colsum(g), self.g(pre + '.mlp.fc2.weight'))
+            dz = ops.gemm_ex(dxb, self.wt(pre + '.fc2'), aux=z)
+            dzT = ops.transpose_colsum(dz, self.g(pre + '.mlp.fc1.bias').view(-1))
+            self._wgrad(dzT, ops.transpose_colsum(h2), self.g(pre + '.mlp.fc1.weight'))
+            dh2 = ops.gemm_ex(dz, self.wt(pre + '.fc1'))
+            dmf, dmb = self._ln_bwd(xmid, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo)
+            dmT = ops.transpose_colsum(dmb, self.g(pre + '.attn.proj.bias').view(-1))
+            self._wgrad(dmT, ops.transpose_colsum(ao), self.g(pre + '.attn.proj.weight'))
+            dao = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
+            dqkv = ops.attn_dense_bwd(qkv, ao, dao, lse, B, NV)
+            dqT = ops.transpose_colsum(dqkv, self.g(pre + '.attn.qkv.bias').view(-1))
+            self._wgrad(dqT, ops.transpose_colsum(h1), self.g(pre + '.attn.qkv.weight'))
+            dh1 = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'))
+            dif, _ = self._ln_bwd(xin, dh1, pre + '.norm1.weight', pre + '.norm1.bias', 1e-6, dres=dmf)
+            return dif
+
+        for i in (3, 2, 1, 0):
+            dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
+        for i in (11, 10, 9, 8):
+            dhid = block_bwd('module.bert.encoder.blocks.%d' % i, dhid)
+        dxe = dhid
+        ops.reduce_slabs(dtag.view(1, M * 768), dxe.view(-1), accumulate=True)      # fork point: the two branches' gradients meet
+        for i in range(7, -1, -1):
+            dxe = block_bwd('module.bert.encoder.blocks.%d' % i, dxe)
+        # ================= backward: patch embed, cls token, position embedding
+        check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, B, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
+        self.g(ie + 'cls_token').view(-1).copy_(self.g(ie + 'pos_embed').view(NV, 768)[0])
+        dpatch = ops.cast_bf16(dxe.view(B, NV, 768)[:, 1:].reshape(B * 576, 768).contiguous())
+        dpT = ops.transpose_colsum(dpatch, self.g(ie + 'patch_embed.proj.bias').view(-1))
+        self._wgrad(dpT, ops.transpose_colsum(patches), self.g(ie + 'patch_embed.proj.weight').view(768, 768))
+        return self.loss_buf[0], self.loss_buf[1]
+
+    # ------------------------------------------------------------------ optimizer
+    def all_reduce_grads(self):
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.G)                       # RCCL ring/tree over xGMI; sum then mean
+            self.G.mul_(1.0 / self.dist.get_world_size())
+
+    def optimizer_step(self):
+        self.step_no += 1
+        self.gsumsq.zero_()
+        check(lib.vitcap_sumsq(_p(self.G), self.nflat, _p(self.gsumsq), _s()), 'sumsq')
+        check(lib.vitcap_adamw_multi(_p(self.P), _p(self.G), _p(self.M), _p(self.V), _p(self.chunk_lr), _p(self.chunk_wd),
+                                     _p(self.gsumsq), self.clip, self.lr_scale, self.step_no, 0.9, 0.999, 1e-8,
+                                     self.nflat // CH, _s()), 'adamw')
+        self.lr_scale = max(0.0, float(self.max_iter - self.step_no) / float(max(1.0, self.max_iter)))   # WarmupLinearSchedule
+        self.refresh_weights()
+
+    def train_step(self, batch):
+        loss, tag_loss = self.forward_backward(batch)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return {'masked_loss': loss, 'tag_loss': tag_loss}
+
+    def grad_norm(self):
+        return float(self.gsumsq.sqrt())
