@@ -62,7 +62,14 @@ def test_gradients_per_tensor(run):
 
 
 def test_parameter_update(run):
-    ref, out, _, params, sd = run
+    """Adam's first step is lr*sign(g) wherever |g| >> eps, so comparing updates computed from two slightly different
+    gradients is ill-conditioned (e.g. key biases have a mathematically zero gradient).  The update rule and the
+    parameter-group / flat-layout mapping are therefore checked on the SAME gradients: the oracle's AdamW applied to the
+    device gradients must reproduce the device parameters; parameters the reference never updates must not move."""
+    from oracle import vitcap_oracle as O
+    ref, out, grads, params, sd = run
+    pg = O.param_groups(sd.keys())
+    coef = min(1.0, 1.0 / (out['grad_norm'] + 1e-6))
     worst = []
     for k in sd:
         d_ref = ref['params'][k] - sd[k]
@@ -70,7 +77,13 @@ def test_parameter_update(run):
         if float(d_ref.abs().max()) == 0.0:
             assert float(d_hip.abs().max()) == 0.0, 'updated a parameter the reference never touches: ' + k
             continue
-        worst.append((float((d_hip - d_ref).norm() / d_ref.norm()), k))
+        assert float(d_hip.abs().max()) > 0.0, 'parameter not updated: ' + k
+        if k not in grads or pg[k] is None:
+            continue
+        exp = sd[k].clone()
+        m, v = torch.zeros_like(exp), torch.zeros_like(exp)
+        O.adamw_step(exp, grads[k] * coef, m, v, 1, pg[k][0], pg[k][1])
+        worst.append((float((params[k] - exp).abs().max()), k))
     worst.sort(reverse=True)
-    print(worst[:5])
-    assert worst[0][0] < 5e-2, worst[:5]
+    print(worst[:3])
+    assert worst[0][0] < 2e-6, worst[:5]
