@@ -62,6 +62,54 @@ def cpu_baseline(max_seconds=40.0):
                       % (len(times), best)}
 
 
+TRAIN_FLOP_PER_SAMPLE = 569.3e9     # fwd+bwd, SURVEY.md section 8d (algorithmic)
+
+
+def bench_train(args, rank, world, local, dist, D):
+    """Cross-entropy training step, data parallel: forward + backward + RCCL gradient all-reduce + clip + AdamW.
+    One step = one optimizer step on `batch` samples per GPU (weak scaling: global batch = batch x N)."""
+    from oracle import vitcap_oracle as O          # only for the synthetic batch layout (host side, not timed)
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    B = args.batch
+    model = ImageCaptioning().load_recipe(0)
+    eng = TrainEngine(model, 'cuda:%d' % local, max_iter=10 ** 6, dist=dist)
+    batch = O.synthetic_train_inputs(B, seed=D.shard_seed(4321, rank))
+    batch = {k: v.cuda() for k, v in batch.items()}
+    batch['image'] = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        out = eng.train_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.train_step(batch)
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dist, device='cuda')
+    if rank == 0:
+        value = D.whole_job_rate(B, args.steps, world, elapsed)
+        print(json.dumps({
+            'metric': 'images/sec cross-entropy training step, ViT-B/16-384 + 4-layer caption decoder',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[3]: cross-entropy training step, %d samples per GPU (global %d), '
+                                   'attention dropout off, fp32 master weights + AdamW, gradient all-reduce over RCCL' % (B, B * world),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
+            'end_to_end_tflops_algorithmic': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12, 2),
+            'end_to_end_frac_of_bf16_peak': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_TFLOPS, 4),
+            'masked_loss': float(out['masked_loss']), 'tag_loss': float(out['tag_loss'])}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -69,6 +117,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='caption', choices=['caption', 'train'],
+                    help="'caption' = the headline metric; 'train' = cross-entropy training step (BASELINE configs[3])")
     ap.add_argument('--beams', type=int, default=1, help='num_beams (1 = greedy, the headline metric; 5 = BASELINE configs[2])')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='replay the step from a captured hipGraph (1) or launch eagerly (0)')
@@ -85,6 +135,8 @@ def main():
     from vitcap_amd.model import ImageCaptioning
 
     B = args.batch
+    if args.mode == 'train':
+        return bench_train(args, rank, world, local, dist, D)
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:%d' % local)
     img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()

@@ -87,3 +87,28 @@ def test_parameter_update(run):
     worst.sort(reverse=True)
     print(worst[:3])
     assert worst[0][0] < 2e-6, worst[:5]
+
+
+def test_data_parallel_invariant_on_one_gpu():
+    """What DDP's gradient averaging relies on: mean of the per-shard gradients == gradient of the whole batch when
+    every shard holds the same number of masked tokens (3 per sample here).  Two shards of 2 vs one batch of 4."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    img = torch.from_numpy(W.gen_image_batch(4, 1234)).cuda()
+    batch = {k: v.cuda() for k, v in O.synthetic_train_inputs(4).items()}
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda')
+
+    def run(sl):
+        b = {k: v[sl].contiguous() for k, v in batch.items()}
+        b['image'] = img[sl].contiguous()
+        loss, _ = eng.forward_backward(b)
+        return float(loss), eng.G.clone()
+    l_all, g_all = run(slice(0, 4))
+    l0, g0 = run(slice(0, 2))
+    l1, g1 = run(slice(2, 4))
+    g_avg = (g0 + g1) / 2
+    rel = float((g_avg - g_all).norm() / g_all.norm())
+    print('loss full %.5f shards %.5f %.5f | grad rel diff %.3e' % (l_all, l0, l1, rel))
+    assert abs((l0 + l1) / 2 - l_all) < 1e-4 and rel < 2e-2
