@@ -68,14 +68,14 @@ TRAIN_FLOP_PER_SAMPLE = 569.3e9     # fwd+bwd, SURVEY.md section 8d (algorithmic
 def bench_train(args, rank, world, local, dist, D):
     """Cross-entropy training step, data parallel: forward + backward + RCCL gradient all-reduce + clip + AdamW.
     One step = one optimizer step on `batch` samples per GPU (weak scaling: global batch = batch x N)."""
-    from oracle import vitcap_oracle as O          # only for the synthetic batch layout (host side, not timed)
+    from vitcap_amd.synthetic import synthetic_train_inputs
     from vitcap_amd import weights as W
     from vitcap_amd.model import ImageCaptioning
     from vitcap_amd.train import TrainEngine
     B = args.batch
     model = ImageCaptioning().load_recipe(0)
     eng = TrainEngine(model, 'cuda:%d' % local, max_iter=10 ** 6, dist=dist)
-    batch = O.synthetic_train_inputs(B, seed=D.shard_seed(4321, rank))
+    batch = synthetic_train_inputs(B, seed=D.shard_seed(4321, rank))
     batch = {k: v.cuda() for k, v in batch.items()}
     batch['image'] = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
 

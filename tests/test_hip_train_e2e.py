@@ -112,3 +112,32 @@ def test_data_parallel_invariant_on_one_gpu():
     rel = float((g_avg - g_all).norm() / g_all.norm())
     print('loss full %.5f shards %.5f %.5f | grad rel diff %.3e' % (l_all, l0, l1, rel))
     assert abs((l0 + l1) / 2 - l_all) < 1e-4 and rel < 2e-2
+
+
+def test_pipeline_train_then_eval(tmp_path, monkeypatch):
+    """run.py `pipeline_train_eval_multi` on synthetic data: 2 optimizer steps, snapshot in the reference's format,
+    then the eval pipeline captions from that snapshot."""
+    import yaml
+    import run
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
+    cfg = {'type': 'pipeline_train_eval_multi',
+           'all_test_data': [{'test_data': 'synthetic', 'test_split': 'test'}],
+           'param': {'full_expid': 'T', 'max_iter': 2, 'effective_batch_size': 2, 'init_recipe_seed': 0, 'log_step': 1,
+                     'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'test_batch_size': 2,
+                     'synthetic_num_images': 2, 'force_train': True, 'force_predict': True,
+                     'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+    yf = tmp_path / 'exp.yaml'
+    yf.write_text(yaml.safe_dump(cfg))
+    kw = run.parse_general_args(['-c', str(yf)])
+    fn = kw.pop('type')
+    getattr(run, fn)(**kw)
+    snap = tmp_path / 'output' / 'T' / 'snapshot'
+    ck = torch.load(snap / 'model_iter_0000002.pt', weights_only=False)
+    assert ck['iteration'] == 2 and len(ck['model']) == 288
+    assert (snap / 'last_checkpoint').read_text().endswith('model_iter_0000002.pt')
+    assert list(snap.glob('*.predict.tsv')), 'eval after training wrote no predictions'

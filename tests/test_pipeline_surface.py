@@ -30,8 +30,6 @@ def test_plugin_loader_builds_our_pipeline():
     assert pip.full_expid == 'E' and pip.cfg.max_gen_length == 20 and pip.cfg.tie_weights is True
     assert pip.get_checkpoint_file().endswith('output/E/snapshot/model_iter_0000010.pt')
     assert 'beam5' in pip.get_predict_file('m.pt')
-    with pytest.raises(NotImplementedError):
-        pip.ensure_train()
 
 
 def test_suffix_matching_loader(tmp_path):

@@ -11,7 +11,8 @@ get_raw_model 566-618, predict_output_to_tsv_row 620-630) for what the hot path 
   ``key \\t json([{"caption": str, "conf": exp(logprob)}])`` per rank and merges them on rank 0;
 * the input side (TSV + JPEG decode) is not built: batches come from
   ``data: synthetic`` (seeded uniform(-1,1) images) or from an iterable passed as ``test_batches``;
-* ``ensure_train`` raises until the HIP training step exists (round 2+); ``ensure_evaluate`` needs the external
+* ``ensure_train`` runs the HIP training engine (vitcap_amd/train.py) on synthetic or caller-provided batches and
+  writes reference-format snapshots; ``ensure_evaluate`` needs the external
   coco-caption tools the reference does not vendor either and is a logged no-op without them.
 """
 import copy
@@ -40,6 +41,16 @@ _CAPTION_DEFAULT = {   # CaptionUniPipeline._default.update (..._bertemb.py:195-
     'optimizer_type': 'MAdamW', 'bias_no_weight_decay': True, 'ln_no_weight_decay': True, 'scheduler_type': 'linear',
     'pad_to_max': True, 'pert_img_prob': None,
 }
+
+
+class _EngineState(object):
+    """state_dict() view of the training engine for Checkpointer.save (same keys as the reference checkpoint)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def state_dict(self):
+        return {k: v.cpu() for k, v in self.eng.state_dict().items()}
 
 
 class CaptionUniPipeline(object):
@@ -123,9 +134,70 @@ class CaptionUniPipeline(object):
         return model
 
     # ------------------------------------------------------------------ entry points used by run.py
+    def iter_train_batches(self, per_gpu):
+        """`data: synthetic` -> endless seeded batches with the training collate's layout (per-rank seeds)."""
+        if self.cfg.train_batches is not None:
+            while True:
+                for b in self.cfg.train_batches:
+                    yield b
+        from . import weights as W
+        from .synthetic import synthetic_train_inputs
+        it = 0
+        while True:
+            seed = D.shard_seed(int(self.cfg.synthetic_seed or 1234), self.rank) + 1000 * it
+            batch = synthetic_train_inputs(per_gpu, seed=seed)
+            batch['image'] = torch.from_numpy(W.gen_image_batch(per_gpu, seed))
+            yield batch
+            it += 1
+
     def ensure_train(self):
+        """do_train_dict (trainer.py:33-213) on the HIP training engine: per-GPU batch = effective_batch_size // world,
+        AdamW on the reference's parameter groups, linear LR decay, snapshot every snapshot_steps and at max_iter."""
+        import time
         self._ensure_initialized()
-        raise NotImplementedError('pipeline_train_eval_multi: the HIP cross-entropy training step is not built yet')
+        last = self.get_checkpoint_file()
+        if op.isfile(last) and not self.cfg.force_train:
+            logging.info('skip to train')
+            return last
+        from .model import ImageCaptioning
+        from .train import TrainEngine
+        dev = torch.device('cuda', self.local_rank)
+        model = ImageCaptioning(tie_weights=bool(self.cfg.tie_weights), tagemb=self.cfg.tagemb or 'bert', cfg=self.cfg)
+        if self.cfg.basemodel and op.isfile(self.cfg.basemodel):
+            Checkpointer(model=model).load(self.cfg.basemodel, model_only=True, load_if_has=False)
+            sd = model.state_dict()                      # tag_blocks <- copy of blocks[-4:] (..._bertemb.py:265-267)
+            for i in range(4):
+                for k in [k for k in sd if k.startswith('module.bert.encoder.blocks.%d.' % (8 + i))]:
+                    sd[k.replace('blocks.%d.' % (8 + i), 'tag_blocks.%d.' % i)].copy_(sd[k])
+        elif self.cfg.init_recipe_seed is not None:
+            model.load_recipe(int(self.cfg.init_recipe_seed))
+        else:
+            raise FileNotFoundError('basemodel not found: {}'.format(self.cfg.basemodel))
+        max_iter = int(self.cfg.max_iter)
+        dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+        eng = TrainEngine(model, dev, base_lr=float(self.cfg.base_lr), weight_decay=float(self.cfg.weight_decay),
+                          lr_multiplier=float(self.cfg.lr_multiplier or 1.0), clip=float(self.cfg.gradient_clip),
+                          max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist)
+        per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
+        ckpt = Checkpointer(model=_EngineState(eng), save_dir=self.get_snapshot_dir(), save_to_disk=self.rank == 0)
+        t0, log_step = time.time(), int(self.cfg.log_step)
+        batches = self.iter_train_batches(per_gpu)
+        for it in range(1, max_iter + 1):
+            b = next(batches)
+            b = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+            out = eng.train_step(b)
+            if it % log_step == 0 or it == max_iter:
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                n = log_step if it % log_step == 0 else (it % log_step)
+                logging.info('iter %d  masked_loss %.4f  speed: %.1f images/sec', it, float(out['masked_loss']),
+                             self.world * n * per_gpu / dt)
+                t0 = time.time()
+            if it % int(self.cfg.snapshot_steps) == 0 or it == max_iter:
+                ckpt.save('model_iter_{:07d}'.format(it), iteration=it)
+        return self.get_checkpoint_file()
 
     def iter_test_batches(self):
         """Per-rank shard of the test set.  `data: synthetic` -> seeded images, keys '<rank>_<i>'."""
