@@ -339,23 +339,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const char* dtl = ql + 3 * TILE_B;
       const float* Ll = (const float*)(ql + 4 * TILE_B);
       const float* Dl = Ll + 64;
-      f32x16 st[2], dpt[2];
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const char* qr = ql + (qt * 32 + ki) * LDS_ROW + half * 16;
-        const char* dr = dl + (qt * 32 + ki) * LDS_ROW + half * 16;
-        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr), kf[0], zero16, 0, 0, 0);
-        dpt[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr), vf[0], zero16, 0, 0, 0);
-#pragma unroll
-        for (int ds = 1; ds < 4; ++ds) {
-          st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr + ds * 32), kf[ds], st[qt], 0, 0, 0);
-          dpt[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr + ds * 32), vf[ds], dpt[qt], 0, 0, 0);
-        }
-      }
-      // lane holds, for its key, queries q = qt*32 + 8g + 4*half + e  (r = 4g + e)
+      // one 32-query half-tile at a time (keeps the register footprint at 2 waves per SIMD)
       const bool masked = t >= nfull;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 st, dpt;
+        const char* qr = ql + (qt * 32 + ki) * LDS_ROW + half * 16;
+        const char* dr = dl + (qt * 32 + ki) * LDS_ROW + half * 16;
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr), kf[0], zero16, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr), vf[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int ds = 1; ds < 4; ++ds) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr + ds * 32), kf[ds], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr + ds * 32), vf[ds], dpt, 0, 0, 0);
+        }
+        // lane holds, for its key, queries q = qt*32 + 8g + 4*half + e  (r = 4g + e)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 L4 = *(const f32x4*)(Ll + qt * 32 + g * 8 + 4 * half);
@@ -363,27 +361,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = g * 4 + e;
-            float p = fast_exp2(fmaf(st[qt][r], c_log2, -L4[e]));
+            float p = fast_exp2(fmaf(st[r], c_log2, -L4[e]));
             if (masked) p = (t * KT + qt * 32 + g * 8 + 4 * half + e) < S ? p : 0.f;
-            st[qt][r] = p;                               // P[q][key]
-            dpt[qt][r] = p * (dpt[qt][r] - D4[e]);       // dS[q][key]
+            st[r] = p;                           // P[q][key]
+            dpt[r] = p * (dpt[r] - D4[e]);       // dS[q][key]
           }
         }
 #pragma unroll
-      for (int qb4 = 0; qb4 < 4; ++qb4) {
-        const int qt = qb4 >> 1, ks = qb4 & 1;
-        bf16x8 pf, sf;
+        for (int ks = 0; ks < 2; ++ks) {
+          const int qb4 = qt * 2 + ks;
+          bf16x8 pf, sf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pf[j] = (__bf16)st[qt][ks * 8 + j];
-          sf[j] = (__bf16)dpt[qt][ks * 8 + j];
-        }
+          for (int j = 0; j < 8; ++j) {
+            pf[j] = (__bf16)st[ks * 8 + j];
+            sf[j] = (__bf16)dpt[ks * 8 + j];
+          }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 dof = *(const bf16x8*)(dtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
-          const bf16x8 qtf = *(const bf16x8*)(qtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dkt[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 dof = *(const bf16x8*)(dtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
+            const bf16x8 qtf = *(const bf16x8*)(qtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
+            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dkt[dt], 0, 0, 0);
+          }
         }
       }
     }
