@@ -164,6 +164,25 @@ int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_
                        int max_len, int eos, int pad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sampling variant of the step above (do_sample=True, modeling_utils.py:839-846 + top_k_top_p_filtering
+ * 1103-1135): x = logits / temperature; top-k keeps x >= k-th largest (ties kept); top-p keeps a token iff the
+ * probability mass ranked strictly above it is <= top_p; tok ~ softmax(filtered x); lp = log_softmax(filtered x)[tok]
+ * (the reference scores the FILTERED distribution, 850-851).  The draw is argmax(x + Gumbel(seed, b, t, column)),
+ * a counter-based pure function of its coordinates (csrc/rng.h), so runs are reproducible and checkable on the CPU.
+ * Book-keeping identical to vitcap_greedy_step.  V <= 30720.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vitcap_sample_params {
+  int do_sample;       /* 0 = greedy */
+  float temperature;   /* > 0 */
+  int top_k;           /* 0 = off */
+  float top_p;         /* 1 = off */
+  uint32_t seed;
+} vitcap_sample_params;
+int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
+                       int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Tag head tail: prob = sigmoid(logit); top-k (largest, sorted, lowest index first on ties);
  *   topk_len = #(prob_topk >= thresh)        (modeling_bert.py:1428-1432)
  *   logits fp32 [B, ldl]; out_ids int64 [B,k]; out_prob fp32 [B,k]; out_len int64 [B].  k <= 64.
@@ -282,6 +301,10 @@ int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16,
                          void* workspace, size_t workspace_bytes,
                          int64_t* out_ids, float* out_logprobs,
                          float* tag_logits_out, int64_t* tag_topk_out, void* stream);
+/* Token choice of the decode loop: greedy (default) or sampled (a12 do_sample branch, modeling_utils.py:839-846;
+ * the pipeline passes do_sample / temperature / top_k / top_p through test_extra_input, ..._bertemb.py:590-606).
+ * Takes effect at the next vitcap_engine_decode / vitcap_engine_greedy. */
+int vitcap_engine_set_sampling(vitcap_engine* e, const vitcap_sample_params* sp);
 
 /* Debug/parity taps into the workspace after vitcap_engine_greedy (device pointers, valid until the next
  * call): name in {"img_feats","hidden","tag_hidden","vis","logits_last","margins"} */

@@ -27,6 +27,8 @@ Two formulations of the greedy decoder are provided:
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -423,7 +425,7 @@ def _post(sdw, p, ctx, x, r):
     return _ln(sdw, p + '.output.LayerNorm', _lin(sdw, p + '.output.dense', i) + a, 1e-12)
 
 
-def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False):
+def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, sampler=None):
     """Greedy caption via encoder-once + visual prefill + 2-row incremental steps.
 
     Equivalent to ``greedy_as_written`` under the shipped test mask: caption row i attends caption
@@ -482,11 +484,16 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         c = 'module.cls.predictions'
         h = _ln(sdw, c + '.transform.LayerNorm', gelu_erf(_lin(sdw, c + '.transform.dense', r(hrow))), 1e-12)
         logits = F.linear(r(h), sdw[c + '.decoder.weight']) + sdw[c + '.bias']
-        nxt = torch.argmax(logits, dim=-1)
-        lp = torch.gather(F.log_softmax(logits, dim=-1), -1, nxt.unsqueeze(-1)).squeeze(-1)
-        if return_trace:
-            top2 = logits.topk(2, dim=-1).values
-            trace.append({'logits_row': logits.clone(), 'margin': (top2[:, 0] - top2[:, 1]).clone()})
+        if sampler is not None:                                                # do_sample branch (a12)
+            nxt, lp, smargin = sampler(logits, t)
+            if return_trace:
+                trace.append({'logits_row': logits.clone(), 'margin': smargin})
+        else:
+            nxt = torch.argmax(logits, dim=-1)
+            lp = torch.gather(F.log_softmax(logits, dim=-1), -1, nxt.unsqueeze(-1)).squeeze(-1)
+            if return_trace:
+                top2 = logits.topk(2, dim=-1).values
+                trace.append({'logits_row': logits.clone(), 'margin': (top2[:, 0] - top2[:, 1]).clone()})
         sum_lp += lp * unf
         cnt += unf
         add = nxt * unf + PAD * (1 - unf)
@@ -498,6 +505,88 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         return out + ({'steps': trace, 'hidden': hidden, 'tag_hidden': tag_hidden, 'tags': tags},)
     return out
 
+
+
+# --------------------------------------------------------------------------------------------
+# a12  sampling branch   (modeling_utils.py:839-851, top_k_top_p_filtering 1103-1135)
+def top_k_top_p_filter(logits, top_k=0, top_p=1.0):
+    """Returns a copy of ``logits`` (B,V) with every filtered entry set to -inf.
+
+    top-k: everything strictly below the k-th largest value goes (ties with it stay).
+    top-p: rank descending, p = softmax over the row as it stands after top-k; entry of rank i goes iff the
+    cumulative probability of ranks 0..i-1 exceeds top_p (so the entry that crosses the threshold stays and rank 0
+    always stays)."""
+    x = logits.clone()
+    V = x.shape[-1]
+    if top_k > 0:
+        k = min(max(int(top_k), 1), V)
+        kth = torch.topk(x, k, dim=-1).values[..., -1:]
+        x = torch.where(x < kth, torch.full_like(x, float('-inf')), x)
+    if top_p < 1.0:
+        order = torch.argsort(x, dim=-1, descending=True)
+        ranked = torch.gather(x, -1, order)
+        cum = torch.cumsum(F.softmax(ranked, dim=-1), dim=-1)
+        before = torch.cat([torch.zeros_like(cum[..., :1]), cum[..., :-1]], dim=-1)   # mass of the better ranks
+        drop_ranked = before > top_p
+        drop_ranked[..., 0] = False
+        drop = torch.zeros_like(drop_ranked).scatter(-1, order, drop_ranked)
+        x = torch.where(drop, torch.full_like(x, float('-inf')), x)
+    return x
+
+
+def _lowbias32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def rng_mix(h, v):
+    """Counter hash of vitcap_amd/csrc/rng.h (vc_mix), vectorised over uint32 arrays."""
+    h = np.asarray(h, dtype=np.uint32)
+    v = np.asarray(v, dtype=np.uint32)
+    with np.errstate(over='ignore'):
+        return _lowbias32(h ^ (v + np.uint32(0x9e3779b9) + (h << np.uint32(6)) + (h >> np.uint32(2))))
+
+
+def rng_uniform(r):
+    return ((r >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+
+
+def gumbel_noise(seed, b, t, V):
+    h = rng_mix(rng_mix(np.uint32(seed & 0xffffffff), np.uint32(b)), np.uint32(t))
+    u = rng_uniform(rng_mix(h, np.arange(V, dtype=np.uint32)))
+    return -np.log(-np.log(u.astype(np.float32))).astype(np.float32)
+
+
+def make_sampler(temperature=1.0, top_k=0, top_p=1.0, seed=0):
+    """sampler(logits (B,V), t) -> (token (B,), logprob (B,), margin (B,)).
+
+    The reference draws with torch.multinomial(softmax(filtered)); its generator stream cannot be reproduced by
+    another implementation, so the draw is restated as the Gumbel-max form of the same distribution,
+    argmax(filtered + G), G = -log(-log(u)), u a counter-based uniform of (seed, b, t, column):
+    P[argmax = i] = softmax(filtered)_i exactly (tests/test_oracle_golden.py checks this against the softmax
+    frequencies).  The log-prob is taken on the filtered, temperature-scaled logits as modeling_utils.py:850-851."""
+    def sampler(logits, t):
+        x = logits / temperature if temperature != 1.0 else logits
+        x = top_k_top_p_filter(x, top_k, top_p)
+        B, V = x.shape
+        g = torch.from_numpy(np.stack([gumbel_noise(seed, b, t, V) for b in range(B)]))
+        sc = x + g
+        top2 = sc.topk(2, dim=-1)
+        tok = top2.indices[:, 0]
+        lp = torch.gather(F.log_softmax(x, dim=-1), -1, tok.unsqueeze(-1)).squeeze(-1)
+        return tok, lp, (top2.values[:, 0] - top2.values[:, 1])
+    return sampler
+
+
+def sample_incremental(sd, image, temperature=1.0, top_k=0, top_p=1.0, seed=0, emulate_bf16=False,
+                       return_trace=False):
+    return greedy_incremental(sd, image, emulate_bf16=emulate_bf16, return_trace=return_trace,
+                              sampler=make_sampler(temperature, top_k, top_p, seed))
 
 # --------------------------------------------------------------------------------------------
 # a13  beam search   (modeling_utils.py:888-1100, BeamHypotheses 1138-1180)

@@ -31,6 +31,11 @@ class BeamState(C.Structure):
                                   'hyp_len', 'hyp_tok')]
 
 
+class SampleParams(C.Structure):
+    _fields_ = [('do_sample', C.c_int), ('temperature', C.c_float), ('top_k', C.c_int), ('top_p', C.c_float),
+                ('seed', C.c_uint32)]
+
+
 class VitBlockW(C.Structure):
     _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
                                   'n1_g', 'n1_b', 'n2_g', 'n2_b')]
@@ -89,6 +94,9 @@ _SIGS = {
     'vitcap_greedy_init': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_greedy_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
+    'vitcap_sample_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, vp, vp]),
+    'vitcap_engine_set_sampling': (C.c_int, [vp, vp]),
     'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
     'vitcap_row_topk_lse': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_beam_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

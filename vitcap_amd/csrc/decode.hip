@@ -1,5 +1,6 @@
 // Greedy bookkeeping and tag top-k: row-wise scans over the 30522-wide vocabulary (HBM/L2-bound).
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -102,6 +103,189 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
     if (t == max_len - 1) {
       if (nu) outtok = eos;                          // modeling_utils.py:870-871
       logprob_out[b] = s / c;                        // modeling_utils.py:873-877
+    }
+    ids[(size_t)b * max_len + t] = outtok;
+    sum_lp[b] = s;
+    cnt[b] = c;
+    unf[b] = nu;
+  }
+}
+
+
+// ---- sampling step (do_sample): temperature, top-k / top-p filtering, one draw per sequence ----------------------
+// One 1024-thread workgroup per sequence; the whole 30522-wide row lives in registers (30 values per thread).
+constexpr int SM_NPT = 30;
+__device__ __forceinline__ uint32_t order_key(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // unsigned order == float order
+}
+
+// MSB-first radix selection over the order keys: returns the largest key `thr` such that the total weight of the
+// elements with key > thr is <= T while adding the elements equal to thr would exceed T -- i.e. "keep key >= thr".
+// With unit weights and T = k-1 this is the k-th largest value (top-k keeps ties, like `logits < kth` removes);
+// with weights = probability mass and T = top_p it is the nucleus boundary (an element is kept iff the mass ranked
+// strictly above it is <= top_p, modeling_utils.py:1119-1131).  Integer weights make the sums order-independent.
+#define SM_RADIX_SELECT(THR, WEIGHT_EXPR, T)                                                   \
+  {                                                                                            \
+    uint32_t prefix_ = 0, pmask_ = 0;                                                          \
+    unsigned long long acc_ = 0;                                                               \
+    for (int pass_ = 0; pass_ < 4; ++pass_) {                                                  \
+      const int shift_ = 24 - 8 * pass_;                                                       \
+      if (tid < 256) s_hist[tid] = 0;                                                          \
+      __syncthreads();                                                                         \
+      _Pragma("unroll") for (int j = 0; j < SM_NPT; ++j) {                                     \
+        if ((key[j] & pmask_) == prefix_ && key[j] != 0) {                                     \
+          const unsigned long long w_ = (WEIGHT_EXPR);                                         \
+          if (w_) atomicAdd(&s_hist[(key[j] >> shift_) & 255u], w_);                           \
+        }                                                                                      \
+      }                                                                                        \
+      __syncthreads();                                                                         \
+      if (tid == 0) {                                                                          \
+        unsigned long long a_ = acc_;                                                          \
+        int d_ = 255;                                                                          \
+        for (; d_ > 0; --d_) {                                                                 \
+          if (a_ + s_hist[d_] > (T)) break;                                                    \
+          a_ += s_hist[d_];                                                                    \
+        }                                                                                      \
+        s_sel = (uint32_t)d_;                                                                  \
+        s_acc = a_;                                                                            \
+      }                                                                                        \
+      __syncthreads();                                                                         \
+      prefix_ |= s_sel << shift_;                                                              \
+      pmask_ |= 255u << shift_;                                                                \
+      acc_ = s_acc;                                                                            \
+      __syncthreads();                                                                         \
+    }                                                                                          \
+    THR = prefix_;                                                                             \
+  }
+
+__global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                           int64_t* __restrict__ ids, int32_t* __restrict__ unf,
+                                                           float* __restrict__ sum_lp, float* __restrict__ cnt,
+                                                           float* __restrict__ logprob_out,
+                                                           float* __restrict__ margin_out, int t, int max_len, int eos,
+                                                           int pad, float temperature, int top_k, float top_p,
+                                                           uint32_t seed) {
+  __shared__ unsigned long long s_hist[256];
+  __shared__ unsigned long long s_acc;
+  __shared__ uint32_t s_sel;
+  __shared__ float s_f[16];
+  __shared__ float s_bcast;
+  __shared__ ArgMax s_am[16];
+  __shared__ float s_second[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (size_t)b * ldl;
+  float x[SM_NPT];
+  uint32_t key[SM_NPT];      // 0 = absent (column >= V)
+#pragma unroll
+  for (int j = 0; j < SM_NPT; ++j) {
+    const int i = tid + j * 1024;
+    float v = i < V ? row[i] : -INFINITY;
+    if (temperature != 1.0f) v = v / temperature;
+    x[j] = v;
+    key[j] = i < V ? order_key(v) : 0u;
+  }
+  // ---- top-k -------------------------------------------------------------------------------------------------
+  uint32_t thr = 1u;                                       // keep every present element
+  if (top_k > 0) {
+    const unsigned long long kk = (unsigned long long)(top_k < V ? top_k : V) - 1ull;
+    uint32_t tk;
+    SM_RADIX_SELECT(tk, 1ull, kk);
+    thr = tk > thr ? tk : thr;
+  }
+  // ---- softmax statistics of the surviving set ------------------------------------------------------------------
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < SM_NPT; ++j) if (key[j] >= thr) m = fmaxf(m, x[j]);
+  m = wave_max(m);
+  if (lane == 0) s_f[w] = m;
+  __syncthreads();
+  if (tid == 0) { float mm = s_f[0]; for (int k = 1; k < 16; ++k) mm = fmaxf(mm, s_f[k]); s_bcast = mm; }
+  __syncthreads();
+  m = s_bcast;
+  __syncthreads();
+  float z = 0.f;
+#pragma unroll
+  for (int j = 0; j < SM_NPT; ++j) if (key[j] >= thr) z += expf(x[j] - m);
+  z = wave_sum(z);
+  if (lane == 0) s_f[w] = z;
+  __syncthreads();
+  if (tid == 0) { float zz = 0.f; for (int k = 0; k < 16; ++k) zz += s_f[k]; s_bcast = zz; }
+  __syncthreads();
+  z = s_bcast;
+  __syncthreads();
+  // ---- top-p (nucleus) ---------------------------------------------------------------------------------------
+  if (top_p < 1.0f) {
+    const float scale = 1099511627776.0f / z;              // 2^40 / Z: probabilities as 40-bit fixed point
+    const unsigned long long P = (unsigned long long)((double)top_p * 1099511627776.0);
+    uint32_t tp;
+    const uint32_t thr_k = thr;
+    SM_RADIX_SELECT(tp, (key[j] >= thr_k ? (unsigned long long)(expf(x[j] - m) * scale) : 0ull), P);
+    if (tp > thr) {
+      thr = tp;
+      z = 0.f;                                             // renormalise over the nucleus
+#pragma unroll
+      for (int j = 0; j < SM_NPT; ++j) if (key[j] >= thr) z += expf(x[j] - m);
+      z = wave_sum(z);
+      if (lane == 0) s_f[w] = z;
+      __syncthreads();
+      if (tid == 0) { float zz = 0.f; for (int k = 0; k < 16; ++k) zz += s_f[k]; s_bcast = zz; }
+      __syncthreads();
+      z = s_bcast;
+    }
+  }
+  // ---- one draw: argmax(x + Gumbel noise) over the surviving set == multinomial(softmax(filtered)) ----------
+  const uint32_t hrow = vc_mix(vc_mix(seed, (uint32_t)b), (uint32_t)t);
+  ArgMax best{-INFINITY, 0x7fffffff};
+  float bx = 0.f, second = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < SM_NPT; ++j) {
+    const int i = tid + j * 1024;
+    if (key[j] >= thr) {
+      const float u = vc_uniform(vc_mix(hrow, (uint32_t)i));
+      const float sc = x[j] - logf(-logf(u));
+      if (sc > best.v || (sc == best.v && i < best.i)) {
+        second = fmaxf(second, best.v);
+        best.v = sc; best.i = i; bx = x[j];
+      } else {
+        second = fmaxf(second, sc);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax ob;
+    ob.v = __shfl_xor(best.v, o, 64);
+    ob.i = __shfl_xor(best.i, o, 64);
+    const float obx = __shfl_xor(bx, o, 64);
+    const float os = __shfl_xor(second, o, 64);
+    const ArgMax nb = am_better(best, ob);
+    second = fmaxf(fmaxf(second, os), (nb.i == best.i) ? ob.v : best.v);
+    bx = (nb.i == best.i) ? bx : obx;
+    best = nb;
+  }
+  if (lane == 0) { s_am[w] = best; s_second[w] = second; s_f[w] = bx; }
+  __syncthreads();
+  if (tid == 0) {
+    ArgMax bb = s_am[0];
+    float ss = s_second[0], xx = s_f[0];
+    for (int k = 1; k < 16; ++k) {
+      const ArgMax nb = am_better(bb, s_am[k]);
+      ss = fmaxf(fmaxf(ss, s_second[k]), (nb.i == bb.i) ? s_am[k].v : bb.v);
+      xx = (nb.i == bb.i) ? xx : s_f[k];
+      bb = nb;
+    }
+    if (margin_out) margin_out[(size_t)b * max_len + t] = bb.v - ss;
+    const float lp = xx - m - logf(z);                   // log_softmax of the FILTERED, temperature-scaled logits
+    const int u = unf[b];
+    const int add = u ? bb.i : pad;
+    float s = sum_lp[b] + lp * (float)u;
+    float c = cnt[b] + (float)u;
+    int nu = u * (add != eos ? 1 : 0);
+    int64_t outtok = add;
+    if (t == max_len - 1) {
+      if (nu) outtok = eos;
+      logprob_out[b] = s / c;
     }
     ids[(size_t)b * max_len + t] = outtok;
     sum_lp[b] = s;
@@ -437,5 +621,21 @@ extern "C" int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids
   hipLaunchKernelGGL(beam_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, make_state(s),
                      out_ids, out_logprobs, B, max_len, eos, pad);
   VC_LAUNCH_CHECK("beam_finalize");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
+                                  int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
+  VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out && sp, "sample_step: null pointer");
+  VC_REQUIRE(B > 0 && V > 0 && V <= SM_NPT * 1024 && ldl >= V && t >= 1 && t < max_len,
+             "sample_step: bad sizes (V=%d t=%d)", V, t);
+  VC_REQUIRE(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f,
+             "sample_step: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature, sp->top_k,
+             (double)sp->top_p);
+  hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
+                     sum_lp, cnt, logprob_out, margin_out, t, max_len, eos, pad, sp->temperature, sp->top_k, sp->top_p,
+                     sp->seed);
+  VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
 }

@@ -36,6 +36,7 @@ struct vitcap_engine {
   vitcap_weights w;
   bool bound = false;
   bool timing = false;
+  vitcap_sample_params sampling = {0, 1.0f, 0, 1.0f, 0u};
   std::vector<GemmTiming> pool;
   size_t used = 0;
 };
@@ -390,8 +391,12 @@ extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, si
   CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, B, L, BOS, PAD, s));
   for (int t = 1; t < L; ++t) {
     CK(step_forward(w, lo, ws, B, 1, t, ids, ws + lo.tcache, s));
-    CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                          (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, s));
+    if (e->sampling.do_sample)
+      CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, &e->sampling, s));
+    else
+      CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, s));
   }
   if (hipMemcpyAsync(out_ids, ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
       hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
@@ -443,6 +448,17 @@ extern "C" int vitcap_engine_beam(vitcap_engine* e, const void* image, int image
     int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
   }
   CK(vitcap_beam_finalize(&st, out_ids, out_logprobs, B, L, EOS, PAD, s));
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_set_sampling(vitcap_engine* e, const vitcap_sample_params* sp) {
+  if (!e || !sp) { vitcap_set_error("set_sampling: null pointer"); return VITCAP_EINVAL; }
+  if (sp->do_sample && !(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f)) {
+    vitcap_set_error("set_sampling: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature,
+                     sp->top_k, (double)sp->top_p);
+    return VITCAP_EINVAL;
+  }
+  e->sampling = *sp;
   return VITCAP_OK;
 }
 

@@ -199,6 +199,15 @@ class ImageCaptioning(nn.Module):
             self._ws[slot] = ws
         return ws, need
 
+    def set_sampling(self, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, seed=0):
+        """Token choice of generate(): greedy, or one draw from the temperature / top-k / top-p filtered distribution
+        (modeling_utils.py:839-846).  Draws are a pure function of (seed, sequence, step, token)."""
+        from ._lib import SampleParams
+        sp = SampleParams(int(bool(do_sample)), float(temperature), int(top_k), float(top_p), int(seed) & 0xffffffff)
+        if self._packed is None:
+            raise RuntimeError('pack() the model before set_sampling()')
+        check(lib.vitcap_engine_set_sampling(self._engine, C.byref(sp)), 'set_sampling')
+
     def generate(self, image, want_tags=False, slot=0):
         """image: (B,3,384,384) fp32 or bf16 on the GPU, normalised with mean=.5/std=.5."""
         if self._packed is None:
@@ -255,12 +264,21 @@ class ImageCaptioning(nn.Module):
         data = dict(data.items())
         data.pop('key', None)
         te = self.test_extra_input
-        if te.get('do_sample', False):
-            raise NotImplementedError('sampled decoding (do_sample=True) is not built on the HIP path yet')
         if te.get('num_keep_best', 1) != 1 or te.get('num_return_sequences', 1) != 1:
             raise NotImplementedError('num_keep_best / num_return_sequences > 1 are not built')
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
         if te.get('num_beams', 1) > 1:
             return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)))
+        if te.get('do_sample', False):
+            # every forward() call advances the stream of draws, like consecutive torch.multinomial calls would
+            self._sample_calls = getattr(self, '_sample_calls', 0) + 1
+            if self._packed is None:
+                self.pack(data['image'].device)
+            self.set_sampling(True, te.get('temperature', 1), te.get('top_k', 0), te.get('top_p', 1),
+                              int(te.get('seed', 0)) + 0x632be5ab * (self._sample_calls - 1))
+            try:
+                return self.generate(data['image'])
+            finally:
+                self.set_sampling(False)
         return self.generate(data['image'])

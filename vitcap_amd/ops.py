@@ -146,6 +146,17 @@ def greedy_step(logits, st, t, V=L.VOCAB, eos=102, pad=0):
                                  _stream()), 'greedy_step')
 
 
+def sample_step(logits, st, t, temperature=1.0, top_k=0, top_p=1.0, seed=0, V=L.VOCAB, eos=102, pad=0):
+    """do_sample variant of greedy_step (modeling_utils.py:839-851): same state dict, one draw per sequence."""
+    from ._lib import SampleParams
+    _dev_f32(logits)
+    B, max_len = st['ids'].shape
+    sp = SampleParams(1, float(temperature), int(top_k), float(top_p), int(seed) & 0xffffffff)
+    check(lib.vitcap_sample_step(_p(logits), logits.stride(0), V, _p(st['ids']), _p(st['unf']), _p(st['sum_lp']),
+                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), B, t, max_len, eos, pad,
+                                 C.byref(sp), _stream()), 'sample_step')
+
+
 def sigmoid_topk(logits, k=50, thresh=0.2, V=None):
     _dev_f32(logits)
     B = logits.shape[0]
