@@ -79,10 +79,10 @@ def test_model_surface(L, sd_np):
     assert m2.state_dict()['module.cls.predictions.decoder.weight'].data_ptr() != \
         m2.state_dict()['module.bert.embeddings.word_embeddings.weight'].data_ptr()
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    m.test_extra_input['do_sample'] = True
+    m.test_extra_input['num_keep_best'] = 3
     with pytest.raises(NotImplementedError):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
 

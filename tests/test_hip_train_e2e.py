@@ -89,6 +89,38 @@ def test_parameter_update(run):
     assert worst[0][0] < 2e-6, worst[:5]
 
 
+def test_training_mode_forward_is_the_trainer_contract():
+    """a16 train branch: do_train_dict's loop body (trainer.py:112-131) -- loss_dict = model(data);
+    losses = sum(loss_dict.values()); losses.backward(); step -- gives the same parameters as train_step."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    B = 2
+    batch = dict(O.synthetic_train_inputs(B))
+    batch['image'] = torch.from_numpy(W.gen_image_batch(B, 1234)).cuda()
+    m1 = ImageCaptioning().load_recipe(0)
+    e1 = TrainEngine(m1, 'cuda', max_iter=10)
+    want = e1.train_step(batch)
+    m2 = ImageCaptioning().load_recipe(0).train()
+    e2 = TrainEngine(m2, 'cuda', max_iter=10)
+    data = dict(batch)
+    data['key'] = [0, 1]
+    loss_dict = m2(data)
+    assert list(loss_dict) == ['masked_loss'] and loss_dict['masked_loss'].requires_grad
+    losses = sum(loss for loss in loss_dict.values())
+    losses.backward()
+    e2.optimizer_step()
+    torch.cuda.synchronize()
+    # float atomics in the loss / LayerNorm-gradient reductions make two runs differ in the last bits; Adam's first step
+    # is lr * g / (|g| + eps), so only the (mathematically zero) key-bias gradients can move by up to 2 lr
+    assert abs(float(losses) - float(want['masked_loss'])) < 1e-5
+    d = (e1.P - e2.P).abs()
+    assert float(d.max()) <= 2.1e-4 and float(d.mean()) < 1e-7, (float(d.max()), float(d.mean()))
+    with pytest.raises(RuntimeError):
+        losses.backward()
+
+
 def test_data_parallel_invariant_on_one_gpu():
     """What DDP's gradient averaging relies on: mean of the per-shard gradients == gradient of the whole batch when
     every shard holds the same number of masked tokens (3 per sample here).  Two shards of 2 vs one batch of 4."""

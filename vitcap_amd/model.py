@@ -259,10 +259,16 @@ class ImageCaptioning(nn.Module):
 
     def forward(self, data):
         """Test-time contract of the reference wrapper (..._bertemb.py:87-184)."""
-        if self.training:
-            raise NotImplementedError('the HIP training step is not built yet; call .eval() for captioning')
         data = dict(data.items())
         data.pop('key', None)
+        if self.training:
+            # a16 train branch (..._bertemb.py:93-171): returns {'masked_loss': loss}.  Forward and backward are one fused
+            # pass of the HIP training engine; loss.backward() (what do_train_dict calls, trainer.py:119) finalises the
+            # gradients already sitting in the engine's flat buffer, engine.optimizer_step() is clip + AdamW + schedule.
+            eng = getattr(self, 'train_engine', None)
+            if eng is None:
+                raise RuntimeError('training-mode forward needs a vitcap_amd.train.TrainEngine(model, ...) attached')
+            return eng.loss_dict(data)
         te = self.test_extra_input
         if te.get('num_keep_best', 1) != 1 or te.get('num_return_sequences', 1) != 1:
             raise NotImplementedError('num_keep_best / num_return_sequences > 1 are not built')
