@@ -119,9 +119,15 @@ int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale,
  * logsumexp lse[B][12][S]; the backward returns dqkv (bf16, packed like qkv) from dout, recomputing the probabilities.
  * `dsum` is scratch fp32 [B][12][S]; `extra_dkv` (optional, bf16 [B*S][2][768]) is added to dK/dV. */
 int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float scale,
-                                void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
+                                float p_drop, uint32_t drop_seed, void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
 int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
-                          const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, void* stream);
+                          const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, float p_drop,
+                          uint32_t drop_seed, void* stream);
+/* p_drop > 0 (decoder layers in training, attention_probs_dropout_prob of BertSelfAttention, modeling_bert.py:330-333):
+ * the probabilities entering P.V are dropped with probability p_drop and the survivors scaled by 1/(1-p_drop); the
+ * keep decision of (query row q, key row k) of image b, head h is the counter hash vc_drop_keep() of csrc/rng.h on
+ * stream (drop_seed, b, h) -- the same function in the forward, both backward kernels and the caption-row kernels, and
+ * restated on the CPU by oracle.dropout_keep().  drop_seed must differ per layer and per step.  p_drop = 0: no dropout. */
 
 /* ------------------------------------------------------------------------------------------------
  * Incremental decoder attention for one greedy step t (1..19), 2 query rows per sequence:
@@ -362,9 +368,10 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
                       float* x_f32, void* x_bf16, int rows, void* stream);
 /* caption rows of the decoder under teacher forcing: [S_vis visual | T caption] rows per image, caption row r attends
  * all visual rows and caption rows <= r */
-int vitcap_attn_text_fwd(const void* qkv, void* out, int B, int S_vis, int T, int ld_rows, float scale, void* stream);
+int vitcap_attn_text_fwd(const void* qkv, void* out, int B, int S_vis, int T, int ld_rows, float scale, float p_drop,
+                         uint32_t drop_seed, void* stream);
 int vitcap_attn_text_bwd(const void* qkv, const void* dout, void* dqkv, void* extra_dkv, int B, int S_vis, int T,
-                         int ld_rows, float scale, void* stream);
+                         int ld_rows, float scale, float p_drop, uint32_t drop_seed, void* stream);
 
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);

@@ -164,7 +164,9 @@ def encode_tag_to_embedding(sd, pred_topk, cls_emb_weight=None, caption_len=20):
 # --------------------------------------------------------------------------------------------
 # a9  post-LN BERT layer   (modeling_bert.py:275-437)
 # --------------------------------------------------------------------------------------------
-def bert_layer(sd, p, x, ext_mask):
+def bert_layer(sd, p, x, ext_mask, keep=None, p_drop=0.0):
+    """``keep`` (B,12,S,S) bool + ``p_drop``: the training-mode dropout on the attention probabilities
+    (modeling_bert.py:330-333) with the keep decisions made explicit."""
     B, S, _ = x.shape
 
     def heads(t):
@@ -174,7 +176,9 @@ def bert_layer(sd, p, x, ext_mask):
     v = heads(_lin(sd, p + '.attention.self.value', x))
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(HD)
     s = s + ext_mask
-    pr = torch.softmax(s, dim=-1)                                           # attention dropout: eval
+    pr = torch.softmax(s, dim=-1)
+    if keep is not None:
+        pr = pr * keep.to(pr.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p_drop)))
     ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).contiguous().view(B, S, HID)
     a = _ln(sd, p + '.attention.output.LayerNorm', _lin(sd, p + '.attention.output.dense', ctx) + x, 1e-12)
     i = gelu_erf(_lin(sd, p + '.intermediate.dense', a))
@@ -209,7 +213,7 @@ def construct_attn_mask(attention_mask, num_img_feats):
 # ViTSplitCLSEmbModel.forward as written   (modeling_bert.py:1408-1516)
 # --------------------------------------------------------------------------------------------
 def joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_type_ids,
-                  tagemb='cls', topk=50, enc=None):
+                  tagemb='cls', topk=50, enc=None, attn_keep=None, p_drop=0.0):
     """Returns (sequence_output (B,S,768), tag_logit (B,V)).  ``enc`` may carry a precomputed
     (hidden, tag_hidden) pair -- the encoder is a pure function of img_feats."""
     input_ids = input_ids.clone()
@@ -243,7 +247,8 @@ def joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_
     ext = (1.0 - am.unsqueeze(1)) * -10000.0                                 # :1498-1501
     x = torch.cat((emb, enc_out), 1)
     for i in range(4):
-        x = bert_layer(sd, 'module.bert.decoder.layer.%d' % i, x, ext)
+        x = bert_layer(sd, 'module.bert.decoder.layer.%d' % i, x, ext,
+                       None if attn_keep is None else attn_keep[i], p_drop)
     return x, logit
 
 
@@ -788,12 +793,47 @@ def focal_neg_loss(pred, target, alpha=0.5, gamma=1.0):
     return (-loss).sum()
 
 
-def train_losses_as_written(sd, image, batch, tagemb='cls'):
-    """ImageCaptioning.forward(train) -> ViTCAP.encode_forward(is_training=True): the full 648-row joint sequence,
-    attention dropout off.  Returns (masked_loss, tag_loss, class_logits)."""
+def dropout_keep(layer_seed, B, rows, p_drop):
+    """Keep decisions (B,12,rows,rows) bool of vitcap_amd/csrc/rng.h vc_drop_keep for one decoder layer, rows indexed in
+    the device's [578 visual | 20 caption] order."""
+    thr = np.uint32(int(float(np.float32(p_drop)) * 4294967296.0))
+    q = (np.arange(rows, dtype=np.uint32)[:, None] << np.uint32(10))
+    k = np.arange(rows, dtype=np.uint32)[None, :]
+    out = np.empty((B, HEADS, rows, rows), dtype=bool)
+    for b in range(B):
+        hb = rng_mix(np.uint32(layer_seed & 0xffffffff), np.uint32(b))
+        for h in range(HEADS):
+            stream = rng_mix(hb, np.uint32(h))
+            out[b, h] = _lowbias32(stream ^ q ^ k) >= thr
+    return out
+
+
+def dropout_keep_joint(layer_seed, B, p_drop, n_text=70, max_len=MAX_LEN, n_vis=578):
+    """The same decisions re-indexed to the reference's joint sequence [70 text | tag CLS | 577 visual]; the 50 tag /
+    padding slots (not materialised on the device, and not able to reach the loss) are always kept."""
+    S = n_text + n_vis
+    dev = np.full(S, -1, dtype=np.int64)
+    dev[:max_len] = n_vis + np.arange(max_len)
+    dev[n_text:] = np.arange(n_vis)
+    k598 = dropout_keep(layer_seed, B, n_vis + max_len, p_drop)
+    ok = dev >= 0
+    keep = np.ones((B, HEADS, S, S), dtype=bool)
+    idx = np.where(ok)[0]
+    keep[:, :, idx[:, None], idx[None, :]] = k598[:, :, dev[idx][:, None], dev[idx][None, :]]
+    return torch.from_numpy(keep)
+
+
+def train_losses_as_written(sd, image, batch, tagemb='cls', layer_seeds=None, p_drop=0.0):
+    """ImageCaptioning.forward(train) -> ViTCAP.encode_forward(is_training=True): the full 648-row joint sequence.
+    ``layer_seeds`` (4 ints) + ``p_drop`` switch the decoder's attention dropout on with the device's keep decisions;
+    None = dropout off.  Returns (masked_loss, tag_loss, class_logits)."""
     img_feats = patch_embed(sd, image)
     full = construct_attn_mask(batch['attention_mask'], img_feats.shape[1])
-    seq, tag_logit = joint_forward(sd, batch['input_ids'], img_feats, full, None, batch['token_type_ids'], tagemb)
+    keep = None
+    if layer_seeds is not None:
+        keep = [dropout_keep_joint(sv, image.shape[0], p_drop, n_text=batch['input_ids'].shape[1]) for sv in layer_seeds]
+    seq, tag_logit = joint_forward(sd, batch['input_ids'], img_feats, full, None, batch['token_type_ids'], tagemb,
+                                   attn_keep=keep, p_drop=p_drop)
     T = batch['masked_pos'].shape[-1]
     rows = seq[:, :T][batch['masked_pos'] == 1]
     class_logits = lm_head(sd, 'module.cls', rows)
@@ -834,7 +874,8 @@ def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
         p.add_(p, alpha=-lr * wd)
 
 
-def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, clip=1.0, state=None):
+def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, clip=1.0, state=None, layer_seeds=None,
+                          p_drop=0.0):
     """One do_train_dict iteration (trainer.py:95-142) on a dict of leaf tensors: forward, backward, global-norm clip over
     ALL parameters, AdamW over the optimizer's groups, linear LR decay.  Returns dict(loss, tag_loss, grad_norm, grads)."""
     leaves = {}
@@ -843,7 +884,7 @@ def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, c
         if id(t) not in seen:
             seen[id(t)] = t.detach().clone().requires_grad_(True)
         leaves[k] = seen[id(t)]
-    loss, tag_loss, _ = train_losses_as_written(leaves, image, batch)
+    loss, tag_loss, _ = train_losses_as_written(leaves, image, batch, layer_seeds=layer_seeds, p_drop=p_drop)
     loss.backward()
     uniq = {}
     for k, t in leaves.items():

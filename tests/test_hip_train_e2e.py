@@ -22,7 +22,7 @@ def run(sd_t):
     batch = O.synthetic_train_inputs(B)
     ref = O.train_step_as_written(sd_t, img, batch, step=1, max_iter=10)
     model = ImageCaptioning().load_recipe(0)
-    eng = TrainEngine(model, 'cuda', max_iter=10)
+    eng = TrainEngine(model, 'cuda', max_iter=10, attn_dropout=0.0)        # the goldens are defined with dropout off
     dbatch = dict(batch)
     dbatch['image'] = img.cuda()
     loss, tag_loss = eng.forward_backward(dbatch)
@@ -89,6 +89,41 @@ def test_parameter_update(run):
     assert worst[0][0] < 2e-6, worst[:5]
 
 
+def test_step_with_attention_dropout(sd_t):
+    """Training-mode semantics of the reference (decoder attention dropout p=0.1 active): with the device's keep
+    decisions replayed in the oracle, loss and gradients match like the dropout-off step; and the loss differs from
+    the dropout-off loss (the masks are really applied) while a second step draws new masks."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine, mix32
+    B = 2
+    img = torch.from_numpy(W.gen_image_batch(B, 1234))
+    batch = O.synthetic_train_inputs(B)
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.1, dropout_seed=77)
+    seeds = [mix32(mix32(eng.dropout_seed, 0), l) for l in range(4)]
+    ref = O.train_step_as_written(sd_t, img, batch, step=1, max_iter=10, layer_seeds=seeds, p_drop=0.1)
+    ref0 = O.train_step_as_written(sd_t, img, batch, step=1, max_iter=10)
+    dbatch = dict(batch)
+    dbatch['image'] = img.cuda()
+    loss, _ = eng.forward_backward(dbatch)
+    torch.cuda.synchronize()
+    print('loss hip %.5f oracle(dropout) %.5f oracle(no dropout) %.5f' % (float(loss), ref['loss'], ref0['loss']))
+    assert abs(float(loss) - ref['loss']) < 2e-3
+    assert abs(ref['loss'] - ref0['loss']) > 1e-2
+    coef = min(1.0, 1.0 / (ref['grad_norm'] + 1e-6))
+    bad = []
+    for k, g_ref in ref['grads'].items():
+        g_ref = g_ref / coef
+        rel = float((eng.g(k).cpu() - g_ref).norm() / (g_ref.norm() + 1e-20))
+        if rel > 4e-2 and float(g_ref.norm()) > 1e-6:
+            bad.append((rel, k))
+    assert not bad, sorted(bad, reverse=True)[:5]
+    eng.optimizer_step()
+    loss2, _ = eng.forward_backward(dbatch)
+    assert abs(float(loss2) - float(loss)) > 1e-4
+
+
 def test_training_mode_forward_is_the_trainer_contract():
     """a16 train branch: do_train_dict's loop body (trainer.py:112-131) -- loss_dict = model(data);
     losses = sum(loss_dict.values()); losses.backward(); step -- gives the same parameters as train_step."""
@@ -130,7 +165,7 @@ def test_data_parallel_invariant_on_one_gpu():
     from vitcap_amd.train import TrainEngine
     img = torch.from_numpy(W.gen_image_batch(4, 1234)).cuda()
     batch = {k: v.cuda() for k, v in O.synthetic_train_inputs(4).items()}
-    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda')
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', attn_dropout=0.0)   # masks are indexed by position in the batch
 
     def run(sl):
         b = {k: v[sl].contiguous() for k, v in batch.items()}

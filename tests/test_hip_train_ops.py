@@ -96,10 +96,14 @@ def test_layernorm_backward(ops, dy_f32):
     assert _rel(dgam, gg.grad) < 1e-4 and _rel(dbet, bb.grad) < 1e-4
 
 
-def test_attn_text_forward_backward(ops):
+@pytest.mark.parametrize('p_drop', [0.0, 0.1, 0.5])
+def test_attn_text_forward_backward(ops, p_drop):
     """20 caption rows vs 578 visual + causal caption keys, and the dense visual-visual backward with the caption
-    rows' contribution added: together they must equal autograd through the masked joint attention."""
+    rows' contribution added: together they must equal autograd through the masked joint attention -- with p_drop > 0,
+    through the SAME dropout mask (the counter-based keep decisions restated by oracle.dropout_keep)."""
+    from oracle import vitcap_oracle as O
     B, SV, T = 2, 578, 20
+    seed = 0x1234abcd
     Lr = SV + T
     qkv = _bf(_rand((B, Lr, 2304), 11, 1.5))
     dout = _bf(_rand((B, Lr, 768), 12))
@@ -109,18 +113,25 @@ def test_attn_text_forward_backward(ops):
     mask[:, :SV] = 1
     mask[SV:, SV:] = torch.tril(torch.ones(T, T))
     s = q @ k.transpose(-1, -2) * 0.125 + (1 - mask) * -10000.0
-    o_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Lr, 768)
+    pr = torch.softmax(s, -1)
+    if p_drop > 0:
+        keep = torch.from_numpy(O.dropout_keep(seed, B, Lr, p_drop))
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p_drop)) < 2e-3, frac
+        pr = pr * keep / (1 - p_drop)
+    o_ref = (pr @ v).transpose(1, 2).reshape(B, Lr, 768)
     o_ref.backward(dout.float())
     want = x.grad
     qd = qkv.reshape(B * Lr, 2304).cuda().contiguous()
     dod = dout.reshape(B * Lr, 768).cuda().contiguous()
-    out, lse = ops.attn_dense_train(qd, B, SV, ld_rows=Lr)
-    ops.attn_text_fwd(qd, out, B, SV, T, Lr)
+    dk = dict(p_drop=p_drop, drop_seed=seed)
+    out, lse = ops.attn_dense_train(qd, B, SV, ld_rows=Lr, **dk)
+    ops.attn_text_fwd(qd, out, B, SV, T, Lr, **dk)
     assert _rel(out.view(B, Lr, 768), o_ref) < 6e-3
     dqkv = torch.zeros_like(qd)
     extra = torch.zeros(B * Lr, 2, 768, device='cuda', dtype=torch.bfloat16)
-    ops.attn_text_bwd(qd, dod, dqkv, extra, B, SV, T, Lr)
-    ops.attn_dense_bwd(qd, out, dod, lse, B, SV, extra_dkv=extra, ld_rows=Lr, dqkv=dqkv)
+    ops.attn_text_bwd(qd, dod, dqkv, extra, B, SV, T, Lr, **dk)
+    ops.attn_dense_bwd(qd, out, dod, lse, B, SV, extra_dkv=extra, ld_rows=Lr, dqkv=dqkv, **dk)
     got = dqkv.view(B, Lr, 2304).float().cpu()
     for name, lo in (('dq', 0), ('dk', 768), ('dv', 1536)):
         r = _rel(got[..., lo:lo + 768], want[..., lo:lo + 768])

@@ -17,6 +17,7 @@
 // (2) attn_decode_step: 2 query rows per sequence against the cached visual K/V (read in place from
 //     the prefill's packed qkv buffer) plus the text K/V cache; HBM-bound, 8 lanes per key row.
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -28,8 +29,13 @@ constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (confli
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// DROP: attention dropout of the decoder in training -- the probabilities that feed P.V are zeroed where
+// vc_drop_keep() says so and the output is scaled by 1/(1-p); the softmax statistics (and lse) are those of the
+// undropped row.
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                         float* __restrict__ lse, int S, int B, int ld_rows, float c_log2) {
+                                                         float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
+                                                         uint32_t drop_seed, uint32_t drop_thr, float drop_scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -47,6 +53,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;        // waves past the last query row only help with staging
+  const uint32_t hq = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10) ^ (4u * half)) : 0u;
   const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;   // ld_rows >= S rows per image in the buffers
 
   // Q^T fragments: lane holds Q[q0+qi][ds*16 + half*8 .. +7]
@@ -196,6 +203,14 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
         ps1 += p1;                                                                                              \
       }                                                                                                         \
     l_i += ps0 + ps1;                                                                                           \
+    if (DROP) {                                                                                                 \
+      const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                           \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+          const uint32_t kbits = (uint32_t)(kt * 32 + (r & 3) + 8 * (r >> 2));                                  \
+          st[kt][r] = vc_lowbias32(hx ^ kbits) >= drop_thr ? st[kt][r] : 0.f;                                   \
+        }                                                                                                       \
+    }                                                                                                           \
     /* O^T += V^T . P^T over the four 16-key blocks */                                                          \
     _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
       const int kt = kb >> 1, ks = kb & 1;                                                                      \
@@ -240,7 +255,8 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
       m_i = m_new;
       const float pv = fast_exp2(fmaf(sc, c_log2, -m_new));
       l_i = l_i * alpha + (half == 0 ? pv : 0.f);
-      const float pb = (float)(__bf16)pv;
+      float pb = (float)(__bf16)pv;
+      if (DROP) pb = vc_lowbias32((hq ^ (4u * half)) ^ (uint32_t)key) >= drop_thr ? pb : 0.f;
       const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
 
   // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
-  const float inv = 1.0f / l_tot;
+  const float inv = DROP ? drop_scale / l_tot : 1.0f / l_tot;
   const int q = q0 + qi;
   if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)
   if (q < S) {
@@ -423,19 +439,25 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
-  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c);
+  hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
 
 extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
-                                           float scale, void* stream) {
+                                           float scale, float p_drop, uint32_t drop_seed, void* stream) {
   VC_REQUIRE(qkv && out && lse && B > 0 && S > 0 && ld_rows >= S, "attn_dense_train: bad arguments");
+  VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_train: p_drop %g / ld_rows %d out of range",
+             (double)p_drop, ld_rows);
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
-  hipLaunchKernelGGL(attn_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S,
-                     B, ld_rows, c);
+  if (p_drop > 0.f)
+    hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
+                       lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop));
+  else
+    hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }

@@ -13,6 +13,7 @@
 // P and dS are rounded to bf16 for the MFMAs (fp32 accumulation), like the forward's P.
 // Left-over rows (S = 577/578 leaves 1/2) are handled on the vector ALU.
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -73,10 +74,14 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ------------------------------------------------------------------------------------------------
 // dQ kernel.  grid = q-blocks(128 rows) x heads x B (1-D, XCD-aware like the forward).
 // ------------------------------------------------------------------------------------------------
+// DROP (both kernels): the forward multiplied P by keep/(1-p) before P.V, so dP = (dO.V) o keep/(1-p) and dV uses the
+// dropped P; D[q] = dO[q].O[q] is unchanged in form (O is the dropped output).
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
-                                                          int ld_rows, float c_log2, float scale) {
+                                                          int ld_rows, float c_log2, float scale, uint32_t drop_seed,
+                                                          uint32_t drop_thr, float drop_scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bool active = q0 < S;
   const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
   const int qr = (q0 + qi) < S ? (q0 + qi) : S - 1;
+  const uint32_t hq = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10)) : 0u;
 
   // B-operand fragments held for the whole kernel: Q^T and dO^T (lane: row q, dims ds*16 + half*8 ..)
   bf16x8 qf[4], dof[4];
@@ -180,7 +186,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             p = key < S ? p : 0.f;
           }
-          st[kt][r] = p * (dpt[kt][r] - Dq);        // dS^T
+          float dp = dpt[kt][r];
+          if (DROP) {
+            const uint32_t key = (uint32_t)(t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            dp = vc_lowbias32(hq ^ key) >= drop_thr ? dp * drop_scale : 0.f;
+          }
+          st[kt][r] = p * (dp - Dq);        // dS^T
         }
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       sp += __shfl_xor(sp, 32, 64);
       dp += __shfl_xor(dp, 32, 64);
       const float p = fast_exp2(fmaf(sp, c_log2, -Lq));
+      if (DROP) dp = vc_lowbias32(hq ^ (uint32_t)key) >= drop_thr ? dp * drop_scale : 0.f;
       const float dsb = (float)(__bf16)(p * (dp - Dq));
       const bf16_t* ko = base + (size_t)key * QKV_LD + 768 + 4 * half;
 #pragma unroll
@@ -251,10 +263,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // `extra` (optional, bf16 [B*S][2][768]) is added to the results: contributions of other queries
 // (the caption rows of the decoder) to these keys' K/V gradients.
 // ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
-                                                           int B, int ld_rows, float c_log2, float scale) {
+                                                           int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
+                                                           uint32_t drop_thr, float drop_scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const float* Lb = lse + ((size_t)b * NH + h) * S;
   const float* Db = dsum + ((size_t)b * NH + h) * S;
   const int kr = (key0 + ki) < S ? (key0 + ki) : S - 1;
+  const uint32_t hk = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ (uint32_t)(key0 + ki)) : 0u;
 
   bf16x8 kf[4], vf[4];     // B operands: K^T and V^T columns of this lane's key
   {
@@ -363,8 +378,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             const int r = g * 4 + e;
             float p = fast_exp2(fmaf(st[r], c_log2, -L4[e]));
             if (masked) p = (t * KT + qt * 32 + g * 8 + 4 * half + e) < S ? p : 0.f;
-            st[r] = p;                           // P[q][key]
-            dpt[r] = p * (dpt[r] - D4[e]);       // dS[q][key]
+            float dp = dpt[r], pd = p;
+            if (DROP) {
+              const uint32_t q = (uint32_t)(t * KT + qt * 32 + g * 8 + 4 * half + e);
+              const bool keep = vc_lowbias32(hk ^ (q << 10)) >= drop_thr;
+              dp = keep ? dp * drop_scale : 0.f;
+              pd = keep ? p : 0.f;
+            }
+            st[r] = pd;                          // (dropped) P[q][key]
+            dpt[r] = p * (dp - D4[e]);           // dS[q][key]
           }
         }
 #pragma unroll
@@ -410,7 +432,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       sp += __shfl_xor(sp, 32, 64);
       dp += __shfl_xor(dp, 32, 64);
       const float p = fast_exp2(fmaf(sp, c_log2, -Lb[q]));
-      const float pb = (float)(__bf16)p;
+      float pb = (float)(__bf16)p;
+      if (DROP) {
+        const bool keep = vc_lowbias32(hk ^ ((uint32_t)q << 10)) >= drop_thr;
+        dp = keep ? dp * drop_scale : 0.f;
+        pb = keep ? pb : 0.f;
+      }
       const float dsb = (float)(__bf16)(p * (dp - Db[q]));
       const bf16_t* qo = base + (size_t)q * QKV_LD + 4 * half;
       const bf16_t* dd = dob + (size_t)q * 768 + 4 * half;
@@ -447,8 +474,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         uint2 o1, o2;
         o1.x = pack2bf(dkt[dt][g * 4 + 0] * scale + kx[0], dkt[dt][g * 4 + 1] * scale + kx[1]);
         o1.y = pack2bf(dkt[dt][g * 4 + 2] * scale + kx[2], dkt[dt][g * 4 + 3] * scale + kx[3]);
-        o2.x = pack2bf(dvt[dt][g * 4 + 0] + vx[0], dvt[dt][g * 4 + 1] + vx[1]);
-        o2.y = pack2bf(dvt[dt][g * 4 + 2] + vx[2], dvt[dt][g * 4 + 3] + vx[3]);
+        const float vs = DROP ? drop_scale : 1.0f;
+        o2.x = pack2bf(dvt[dt][g * 4 + 0] * vs + vx[0], dvt[dt][g * 4 + 1] * vs + vx[1]);
+        o2.y = pack2bf(dvt[dt][g * 4 + 2] * vs + vx[2], dvt[dt][g * 4 + 3] * vs + vx[3]);
         *(uint2*)(ok + dt * 32 + g * 8) = o1;
         *(uint2*)(ov + dt * 32 + g * 8) = o2;
       }
@@ -459,16 +487,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                                      const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
-                                     void* stream) {
+                                     float p_drop, uint32_t drop_seed, void* stream) {
   VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0 && ld_rows >= S, "attn_dense_bwd: bad arguments");
+  VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_bwd: p_drop %g / ld_rows %d out of range",
+             (double)p_drop, ld_rows);
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale);
-  VC_LAUNCH_CHECK("attn_bwd_dq");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                     (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,
-                     ld_rows, c, scale);
-  VC_LAUNCH_CHECK("attn_bwd_dkv");
+  const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+  const float rs = 1.0f / (1.0f - p_drop);
+#define VC_BWD_LAUNCH(DROP_)                                                                                              \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
+                       drop_seed, thr, rs);                                                                               \
+    VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
+                       (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
+                       ld_rows, c, scale, drop_seed, thr, rs);                                                            \
+    VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
+  } while (0)
+  if (p_drop > 0.f) VC_BWD_LAUNCH(true);
+  else VC_BWD_LAUNCH(false);
+#undef VC_BWD_LAUNCH
   return VITCAP_OK;
 }

@@ -177,9 +177,20 @@ class CaptionUniPipeline(object):
         dist = None
         if self.world > 1:
             import torch.distributed as dist
+        # BertConfig.from_pretrained(text_encoder_type) carries attention_probs_dropout_prob (0.1 in the shipped config);
+        # only hidden_dropout_prob is overridden by cfg.drop_out (..._bertemb.py:535)
+        attn_drop = 0.1
+        cj = op.join(self.cfg.text_encoder_type or '.', 'config.json')
+        if op.isfile(cj):
+            import json
+            with open(cj) as fp:
+                attn_drop = float(json.load(fp).get('attention_probs_dropout_prob', attn_drop))
+        if self.cfg.attention_probs_dropout_prob is not None:
+            attn_drop = float(self.cfg.attention_probs_dropout_prob)
         eng = TrainEngine(model, dev, base_lr=float(self.cfg.base_lr), weight_decay=float(self.cfg.weight_decay),
                           lr_multiplier=float(self.cfg.lr_multiplier or 1.0), clip=float(self.cfg.gradient_clip),
-                          max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist)
+                          max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist,
+                          attn_dropout=attn_drop, dropout_seed=int(self.cfg.random_seed or 0))
         per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
         ckpt = Checkpointer(model=_EngineState(eng), save_dir=self.get_snapshot_dir(), save_to_disk=self.rank == 0)
         t0, log_step = time.time(), int(self.cfg.log_step)

@@ -11,8 +11,10 @@ What is computed (identical loss and gradients to the reference, less dead work)
 * the decoder runs on [578 visual | 20 caption] rows per image.  The reference's 50 tag slots and the padding rows
   are attended by nothing that reaches the loss (seq2seq mask with text_b='', dataset.py:377-390), so their rows are
   not materialised; caption row r attends all visual rows and caption rows <= r.
-* attention dropout (p=0.1 in the reference's training mode) is NOT applied yet: parity is against the reference with
-  dropout off (eval-mode modules, `is_training=True` branch), as in tests/golden/make_golden_train.py.
+* attention dropout of the decoder (attention_probs_dropout_prob = 0.1, active in the reference's training mode,
+  modeling_bert.py:330-333) is applied inside the attention kernels with a counter-based keep decision
+  (csrc/rng.h) that the forward and both backward passes recompute -- no mask is stored.  `attn_dropout=0` gives the
+  deterministic step the goldens of tests/golden/make_golden_train.py are defined on.
 * the tag head runs forward only: `tag_loss` is reported, never back-propagated by this pipeline
   (..._bertemb.py:170-171), and bert.pooler / bert.tag_logit / bert.extra_embeddings / caption_pooler / image head
   receive no gradient.
@@ -43,6 +45,21 @@ def _p(t):
 
 def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _lowbias32(x):
+    x &= 0xffffffff
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def mix32(h, v):
+    """vc_mix of csrc/rng.h on Python ints."""
+    return _lowbias32(h ^ ((v + 0x9e3779b9 + (h << 6) + (h >> 2)) & 0xffffffff))
 
 
 def param_groups(names, base_lr, weight_decay, lr_multiplier):
@@ -83,13 +100,16 @@ class _FusedLoss(torch.autograd.Function):
 
 class TrainEngine(object):
     def __init__(self, model, device='cuda', base_lr=1e-4, weight_decay=0.05, lr_multiplier=0.1, clip=1.0, max_iter=1000,
-                 label_smoothing=0.1, dist=None):
+                 label_smoothing=0.1, dist=None, attn_dropout=0.1, dropout_seed=0):
         self.model = model
         self.dev = torch.device(device)
         if self.dev.index is None:
             self.dev = torch.device('cuda', torch.cuda.current_device())
         self.clip, self.max_iter, self.eps_ls = clip, max_iter, label_smoothing
         self.dist = dist
+        self.attn_dropout = float(attn_dropout)
+        rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+        self.dropout_seed = mix32(int(dropout_seed) & 0xffffffff, rank)      # every rank drops differently
         self.step_no = 0
         self.lr_scale = 1.0
         spec = W.state_dict_spec()
@@ -312,12 +332,14 @@ class TrainEngine(object):
         dx[:, SV:] = xtext.view(B, T, 768)
         xd = dx.view(Md, 768)
         dsaved = []
+        pd = self.attn_dropout
+        dseed = [mix32(mix32(self.dropout_seed, self.step_no), l) for l in range(4)]      # per step, per layer
         for l in range(4):
             pre = 'module.bert.decoder.layer.%d' % l
             xb = ops.cast_bf16(xd)
             qkv = ops.gemm_bias_act(xb, self.wb(pre + '.qkv'), self.qkv_bias(pre))
-            ctx, lse = ops.attn_dense_train(qkv, B, SV, ld_rows=LR)
-            ops.attn_text_fwd(qkv, ctx, B, SV, T, LR)
+            ctx, lse = ops.attn_dense_train(qkv, B, SV, ld_rows=LR, p_drop=pd, drop_seed=dseed[l])
+            ops.attn_text_fwd(qkv, ctx, B, SV, T, LR, p_drop=pd, drop_seed=dseed[l])
             t1 = torch.empty(Md, 768, device=dev)
             ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
             ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
@@ -389,8 +411,9 @@ class TrainEngine(object):
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
             dqkv = torch.zeros(Md, 2304, device=dev, dtype=torch.bfloat16)
             extra = torch.zeros(Md, 2, 768, device=dev, dtype=torch.bfloat16)
-            ops.attn_text_bwd(qkv, dctx, dqkv, extra, B, SV, T, LR)
-            ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, SV, extra_dkv=extra, ld_rows=LR, dqkv=dqkv)
+            ops.attn_text_bwd(qkv, dctx, dqkv, extra, B, SV, T, LR, p_drop=pd, drop_seed=dseed[l])
+            ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, SV, extra_dkv=extra, ld_rows=LR, dqkv=dqkv, p_drop=pd,
+                               drop_seed=dseed[l])
             dqkvT = ops.transpose_colsum(dqkv, self.qkv_bias_grad(pre))
             self._wgrad(dqkvT, ops.transpose_colsum(xb), self.qkv_w_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
