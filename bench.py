@@ -100,7 +100,7 @@ def bench_train(args, rank, world, local, dist, D):
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[3]: cross-entropy training step, %d samples per GPU (global %d), '
-                                   'attention dropout off, fp32 master weights + AdamW, gradient all-reduce over RCCL' % (B, B * world),
+                                   'decoder attention dropout 0.1 on, fp32 master weights + AdamW, gradient all-reduce over RCCL' % (B, B * world),
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
             'end_to_end_tflops_algorithmic': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12, 2),
             'end_to_end_frac_of_bf16_peak': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_TFLOPS, 4),
