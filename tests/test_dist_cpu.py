@@ -47,3 +47,99 @@ def test_two_rank_timing_and_sharding():
     assert res[0][2] != res[1][2]                # different images per rank
     from vitcap_amd import dist_util as D
     assert D.whole_job_rate(64, 10, 2, 2.0) == 640.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training: the one exchange step of the path (gradient mean), bucketed behind the backward pass
+def test_grad_buckets_cover_exactly_the_tensors_that_get_gradients():
+    from vitcap_amd import weights as W
+    from vitcap_amd.train import CH, GRAD_STAGES, NO_GRAD_PREFIXES, flat_layout, grad_buckets, grad_stage
+    for tied in (True, False):
+        order, off, shape, nflat = flat_layout(tied)
+        assert len(set(order)) == len(order) and set(order) == set(W.state_dict_spec()) - ({W.TIED_DST} if tied else set())
+        buckets = grad_buckets(order, off, shape)
+        assert list(buckets) == GRAD_STAGES
+        covered = torch.zeros(nflat, dtype=torch.int8)
+        for st in GRAD_STAGES:
+            assert buckets[st], st
+            for a, b in buckets[st]:
+                assert 0 <= a < b <= nflat
+                covered[a:b] += 1
+        assert int(covered.max()) == 1, 'buckets overlap'
+        for k in order:
+            n = int(torch.Size(shape[k]).numel())
+            want = 0 if k.startswith(NO_GRAD_PREFIXES) else 1
+            assert int(covered[off[k]:off[k] + n].min()) == want and int(covered[off[k]:off[k] + n].max()) == want, k
+            assert off[k] % CH == 0 or '.attention.self.' in k
+        # a stage never finishes before one that owns a later layer of the same stack
+        assert grad_stage('module.bert.encoder.blocks.11.mlp.fc2.weight') == 'blk5'
+        assert grad_stage('module.bert.encoder.blocks.0.norm1.bias') == 'blk0'
+        assert grad_stage('module.bert.tag_logit.predictions.decoder.weight') is None
+        # optimizer chunks: every element of a tensor sees exactly that tensor's (lr, wd) of the reference's groups
+        from vitcap_amd.train import chunk_hparams, param_groups
+        pg = param_groups(order, 1e-4, 0.05, 0.1)
+        lr, wd = chunk_hparams(order, off, shape, nflat, pg)
+        for k in order:
+            n = int(torch.Size(shape[k]).numel())
+            c0, c1 = off[k] // CH, (off[k] + n + CH - 1) // CH
+            hp = (0.0, 0.0) if (pg[k] is None or k.startswith(NO_GRAD_PREFIXES)) else pg[k]
+            assert torch.all(lr[c0:c1] == torch.tensor(hp[0])) and torch.all(wd[c0:c1] == torch.tensor(hp[1])), k
+        sizes = [sum(b - a for a, b in buckets[st]) * 4 / 2 ** 20 for st in GRAD_STAGES]
+        assert max(sizes) < 128 and sum(s > 32 for s in sizes) >= 10      # MB: few large messages
+
+
+def _reduce_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from vitcap_amd import dist_util as D
+    dist = D.init('gloo')
+    n = 4096
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    buckets = {'last': [(3000, 4000)], 'mid': [(1024, 2048), (2100, 2900)], 'first': [(0, 1000)]}
+    red = D.BucketedAllReduce(flat, buckets, ['last', 'mid', 'first'], dist)
+    red.begin()
+    err = None
+    try:
+        red.stage_done('mid')                   # out of order: must be refused
+    except RuntimeError as e:
+        err = str(e)
+    red.stage_done('last')
+    red.stage_done('mid')
+    try:
+        red.finish()                            # a stage is still missing
+        missing_caught = False
+    except RuntimeError:
+        missing_caught = True
+    red.stage_done('first')
+    red.finish()
+    red.begin()                                 # second step on the same object
+    for st in ('last', 'mid', 'first'):
+        red.stage_done(st)
+    red.finish()
+    out.put((rank, mine, flat.clone(), err, missing_caught, red.launched_bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, m0, f0, e0, c0, nb), (_, m1, f1, e1, c1, _) = res
+    assert e0 and 'out of order' in e0 and e1 and c0 and c1
+    mean = (m0 + m1) / 2                        # after step 1 both hold the mean; step 2 averages two equal copies
+    inside = torch.zeros(4096, dtype=torch.bool)
+    for a, b in ((3000, 4000), (1024, 2048), (2100, 2900), (0, 1000)):
+        inside[a:b] = True
+    assert torch.allclose(f0[inside], mean[inside]) and torch.equal(f0[inside], f1[inside])
+    assert torch.equal(f0[~inside], m0[~inside]) and torch.equal(f1[~inside], m1[~inside])   # untouched outside buckets
+    assert nb == int(inside.sum()) * 4

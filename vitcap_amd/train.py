@@ -78,6 +78,97 @@ def param_groups(names, base_lr, weight_decay, lr_multiplier):
     return out
 
 
+def flat_layout(tied):
+    """Flat fp32 parameter / gradient layout: (order, offset, shape, total).  Every unique tensor is padded to CH
+    elements (optimizer chunks carry lr / weight decay); the decoder's q|k|v weights, then their biases, are contiguous
+    so one GEMM / one bias vector covers the three projections."""
+    spec = W.state_dict_spec()
+    off, shape, order = {}, {}, []
+    for k in spec:
+        if tied and k == W.TIED_DST:
+            continue
+        if '.attention.self.' in k:
+            if k.endswith('query.weight'):          # q|k|v weights, then q|k|v biases, contiguous
+                pre = k[:-len('query.weight')]
+                order += [pre + n + '.weight' for n in ('query', 'key', 'value')]
+                order += [pre + n + '.bias' for n in ('query', 'key', 'value')]
+            continue
+        order.append(k)
+    cur = 0
+    for k in order:
+        shp = spec[k][0]
+        n = int(torch.Size(shp).numel())
+        off[k], shape[k] = cur, shp
+        is_qk_bias = k.endswith('attention.self.query.bias') or k.endswith('attention.self.key.bias')
+        cur = cur + n if is_qk_bias else (cur + n + CH - 1) // CH * CH      # q|k|v biases stay contiguous (2304 -> 3 chunks)
+    nflat = (cur + CH - 1) // CH * CH
+    if tied:
+        off[W.TIED_DST], shape[W.TIED_DST] = off[W.TIED_SRC], shape[W.TIED_SRC]
+    return order, off, shape, nflat
+
+
+def chunk_hparams(order, off, shape, nflat, pg):
+    """Per-chunk (lr, weight decay) of the fused AdamW; lr 0 = the tensor is not stepped (no gradient in the reference, or
+    not owned by its optimizer).  A chunk never mixes tensors with different hyper-parameters."""
+    lr = torch.zeros(nflat // CH)
+    wd = torch.zeros(nflat // CH)
+    owner = {}
+    for k in order:
+        n = int(torch.Size(shape[k]).numel())
+        c0, c1 = off[k] // CH, (off[k] + n + CH - 1) // CH
+        hp = (0.0, 0.0) if (pg[k] is None or k.startswith(NO_GRAD_PREFIXES)) else (float(pg[k][0]), float(pg[k][1]))
+        for c in (c0, c1 - 1):
+            if owner.setdefault(c, hp) != hp:
+                raise AssertionError('optimizer chunk %d shared by tensors with different lr / weight decay (%s)' % (c, k))
+        lr[c0:c1], wd[c0:c1] = hp
+    return lr, wd
+
+
+NO_GRAD_PREFIXES = ('module.bert.extra_embeddings.', 'module.bert.tag_logit.', 'module.bert.pooler.',
+                    'module.bert.caption_pooler.', 'image_encoder.module.head.')
+
+
+def grad_stage(key):
+    """Backward stage after which the gradient of `key` is final, or None if it never receives one.  Stages complete in
+    the order of GRAD_STAGES; two consecutive layers share a stage so a bucket is ~57 MB (ring all-reduce over xGMI is
+    per-link bound: few large messages)."""
+    if key.startswith(NO_GRAD_PREFIXES):
+        return None
+    if key.startswith('module.cls.'):
+        return 'cls'
+    if key.startswith('module.bert.decoder.layer.'):
+        return 'dec%d' % (int(key.split('.')[4]) // 2)
+    if key.startswith('module.bert.embeddings.'):
+        return 'emb'
+    if key.startswith('module.bert.encoder.tag_blocks.'):
+        return 'tag%d' % (int(key.split('.')[4]) // 2)
+    if key.startswith('module.bert.encoder.blocks.'):
+        return 'blk%d' % (int(key.split('.')[4]) // 2)
+    if key.startswith('image_encoder.module.'):
+        return 'patch'
+    raise KeyError(key)
+
+
+GRAD_STAGES = ['cls', 'dec1', 'dec0', 'emb', 'tag1', 'tag0', 'blk5', 'blk4', 'blk3', 'blk2', 'blk1', 'blk0', 'patch']
+
+
+def grad_buckets(order, off, shape):
+    """stage -> list of (start, end) element ranges of the flat gradient (adjacent tensors of a stage merged)."""
+    out = {st: [] for st in GRAD_STAGES}
+    for k in order:
+        st = grad_stage(k)
+        if st is None:
+            continue
+        n = int(torch.Size(shape[k]).numel())
+        a, b = off[k], off[k] + n
+        runs = out[st]
+        if runs and a - runs[-1][1] < CH:       # only chunk padding in between
+            runs[-1] = (runs[-1][0], b)
+        else:
+            runs.append((a, b))
+    return out
+
+
 class _FusedLoss(torch.autograd.Function):
     """Loss tensor of a fused forward+backward: .backward() scales the gradients the engine already holds."""
     @staticmethod
@@ -112,31 +203,8 @@ class TrainEngine(object):
         self.dropout_seed = mix32(int(dropout_seed) & 0xffffffff, rank)      # every rank drops differently
         self.step_no = 0
         self.lr_scale = 1.0
-        spec = W.state_dict_spec()
         tied = model.tie_weights
-        # ---- flat layout: every unique tensor padded to CH; decoder q/k/v weights (and biases) contiguous
-        self.off, self.shape = {}, {}
-        order = []
-        for k in spec:
-            if tied and k == W.TIED_DST:
-                continue
-            if '.attention.self.' in k:
-                if k.endswith('query.weight'):          # q|k|v weights, then q|k|v biases, contiguous
-                    pre = k[:-len('query.weight')]
-                    order += [pre + n + '.weight' for n in ('query', 'key', 'value')]
-                    order += [pre + n + '.bias' for n in ('query', 'key', 'value')]
-                continue
-            order.append(k)
-        cur = 0
-        for k in order:
-            shp = spec[k][0]
-            n = int(torch.Size(shp).numel())
-            self.off[k], self.shape[k] = cur, shp
-            is_qk_bias = k.endswith('attention.self.query.bias') or k.endswith('attention.self.key.bias')
-            cur += n if is_qk_bias else (n + CH - 1) // CH * CH      # q|k|v biases stay contiguous (2304 -> 3 chunks)
-        self.nflat = (cur + CH - 1) // CH * CH
-        if tied:
-            self.off[W.TIED_DST], self.shape[W.TIED_DST] = self.off[W.TIED_SRC], self.shape[W.TIED_SRC]
+        order, self.off, self.shape, self.nflat = flat_layout(tied)
         self.P = torch.zeros(self.nflat, device=self.dev)
         self.G = torch.zeros(self.nflat, device=self.dev)
         self.M = torch.zeros(self.nflat, device=self.dev)
@@ -145,21 +213,14 @@ class TrainEngine(object):
         for k in order:
             self.p(k).copy_(sd[k])
         pg = param_groups(order, base_lr, weight_decay, lr_multiplier)
-        lr = torch.zeros(self.nflat // CH)
-        wd = torch.zeros(self.nflat // CH)
-        no_grad = ('module.bert.extra_embeddings.', 'module.bert.tag_logit.', 'module.bert.pooler.',
-                   'module.bert.caption_pooler.', 'image_encoder.module.head.')
-        for k in order:
-            if pg[k] is None or k.startswith(no_grad):
-                continue                  # p.grad is None in the reference -> AdamW skips the tensor
-            n = int(torch.Size(self.shape[k]).numel())
-            c0, c1 = self.off[k] // CH, (self.off[k] + n + CH - 1) // CH
-            lr[c0:c1], wd[c0:c1] = pg[k][0], pg[k][1]
+        lr, wd = chunk_hparams(order, self.off, self.shape, self.nflat, pg)
         self.chunk_lr, self.chunk_wd = lr.to(self.dev), wd.to(self.dev)
         self.gsumsq = torch.zeros(1, device=self.dev)
         self.loss_buf = torch.zeros(2, device=self.dev)      # [masked_loss, tag_loss]
         self._gemm_w = {}
         self.refresh_weights()
+        from .dist_util import BucketedAllReduce
+        self.reducer = BucketedAllReduce(self.G, grad_buckets(order, self.off, self.shape), GRAD_STAGES, dist)
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self._pending = False
         model.__dict__['train_engine'] = self          # ImageCaptioning.forward (training mode) routes here
@@ -272,6 +333,7 @@ class TrainEngine(object):
         B = img.shape[0]
         M, Md = B * NV, B * LR
         self.G.zero_()
+        self.reducer.begin()
         self.loss_buf.zero_()
         ie = 'image_encoder.module.'
         # ================= forward: patch embed
@@ -388,6 +450,7 @@ class TrainEngine(object):
         dztT = ops.transpose_colsum(dzt, self.g(c + '.transform.dense.bias').view(-1))
         self._wgrad(dztT, ops.transpose_colsum(hrows), self.g(c + '.transform.dense.weight'))
         dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
+        self.reducer.stage_done('cls')
         dy = torch.zeros(B, LR, 768, device=dev)
         dtext = torch.zeros(B * T, 768, device=dev)
         dtext.index_copy_(0, sel, dh)
@@ -417,6 +480,8 @@ class TrainEngine(object):
             dqkvT = ops.transpose_colsum(dqkv, self.qkv_bias_grad(pre))
             self._wgrad(dqkvT, ops.transpose_colsum(xb), self.qkv_w_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
+            if l % 2 == 0:
+                self.reducer.stage_done('dec%d' % (l // 2))
         dyv = dy.view(B, LR, 768)
         # ================= backward: text embeddings
         demb, _ = self._ln_bwd(pre_emb, dyv[:, SV:].reshape(B * T, 768).contiguous(), e + '.LayerNorm.weight', e + '.LayerNorm.bias',
@@ -424,6 +489,7 @@ class TrainEngine(object):
         check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), T, _p(self.g(e + '.word_embeddings.weight')),
                                    _p(self.g(e + '.position_embeddings.weight')), _p(self.g(e + '.token_type_embeddings.weight')),
                                    B * T, _s()), 'embed_bwd')
+        self.reducer.stage_done('emb')
         # ================= backward: encoder
         dhid = dyv[:, 1:SV].reshape(M, 768).contiguous()
         dtag = torch.zeros(B, NV, 768, device=dev)
@@ -452,25 +518,31 @@ class TrainEngine(object):
 
         for i in (3, 2, 1, 0):
             dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
+            if i % 2 == 0:
+                self.reducer.stage_done('tag%d' % (i // 2))
         for i in (11, 10, 9, 8):
             dhid = block_bwd('module.bert.encoder.blocks.%d' % i, dhid)
+            if i % 2 == 0:
+                self.reducer.stage_done('blk%d' % (i // 2))
         dxe = dhid
         ops.reduce_slabs(dtag.view(1, M * 768), dxe.view(-1), accumulate=True)      # fork point: the two branches' gradients meet
         for i in range(7, -1, -1):
             dxe = block_bwd('module.bert.encoder.blocks.%d' % i, dxe)
+            if i % 2 == 0:
+                self.reducer.stage_done('blk%d' % (i // 2))
         # ================= backward: patch embed, cls token, position embedding
         check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, B, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
         self.g(ie + 'cls_token').view(-1).copy_(self.g(ie + 'pos_embed').view(NV, 768)[0])
         dpatch = ops.cast_bf16(dxe.view(B, NV, 768)[:, 1:].reshape(B * 576, 768).contiguous())
         dpT = ops.transpose_colsum(dpatch, self.g(ie + 'patch_embed.proj.bias').view(-1))
         self._wgrad(dpT, ops.transpose_colsum(patches), self.g(ie + 'patch_embed.proj.weight').view(768, 768))
+        self.reducer.stage_done('patch')
         return self.loss_buf[0], self.loss_buf[1]
 
     # ------------------------------------------------------------------ optimizer
     def all_reduce_grads(self):
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            self.dist.all_reduce(self.G)                       # RCCL ring/tree over xGMI; sum then mean
-            self.G.mul_(1.0 / self.dist.get_world_size())
+        """Joins the bucketed all-reduces that forward_backward launched behind the backward pass (mean over ranks)."""
+        self.reducer.finish()
 
     def optimizer_step(self):
         self.step_no += 1
