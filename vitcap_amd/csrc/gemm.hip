@@ -572,6 +572,27 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   const int ncol = n0 + wn * 64 + ec;
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
+  // residual rows are requested one chunk (8 iterations = 32 rows) ahead of their use
+  const bool col_ok = ncol < p.N;
+  f32x4 rres[2][8];
+#define ROWS_OF(m_, orow_, rrow_)                                             \
+  int orow_ = (m_), rrow_ = (m_);                                             \
+  if (p.row_group > 0) {                                                      \
+    const int g_ = (m_) / p.row_group, in_ = (m_) - g_ * p.row_group;         \
+    orow_ = g_ * p.out_group_rows + p.out_row_off + in_;                      \
+    rrow_ = p.res_periodic ? in_ : orow_;                                     \
+  }
+#define ISSUE_RES(c_)                                                                                        \
+  if (HAS_RES) {                                                                                             \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                       \
+      const int m_ = m0 + wm * 128 + (c_) * 32 + it * 4 + er;                                                \
+      ROWS_OF(m_, o_, r_);                                                                                   \
+      (void)o_;                                                                                              \
+      rres[(c_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + ncol)        \
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};                                 \
+    }                                                                                                        \
+  }
+  ISSUE_RES(0);
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
@@ -579,45 +600,50 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * 4 + i][j];
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int rl = it * 4 + er;
-      f32x4 v = *(const f32x4*)(ep + rl * EP_ROWB + ec * 4);
-      const int m = m0 + wm * 128 + hm * 64 + rl;
-      if (m >= p.M || ncol >= p.N) continue;
-      int orow = m, rrow = m;
-      if (p.row_group > 0) {
-        const int g = m / p.row_group, in = m - g * p.row_group;
-        orow = g * p.out_group_rows + p.out_row_off + in;
-        rrow = p.res_periodic ? in : orow;
-      }
-      v += bias4;
-      if (p.zout) {
-        uint2 zo;
-        zo.x = pack2bf(v[0], v[1]);
-        zo.y = pack2bf(v[2], v[3]);
-        *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
-      }
-      if (p.aux) {
-        const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
-      }
-      if (ACT == VITCAP_ACT_GELU_ERF) {
+    for (int ch = 0; ch < 2; ++ch) {
+      const int c = hm * 2 + ch;
+      if (c + 1 < 4) { ISSUE_RES(c + 1); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-      }
-      if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + ncol);
-      if (OUT_F32) {
-        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
-      } else {
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+      for (int it = 0; it < 8; ++it) {
+        const int rl = ch * 32 + it * 4 + er;
+        f32x4 v = *(const f32x4*)(ep + rl * EP_ROWB + ec * 4);
+        const int m = m0 + wm * 128 + hm * 64 + rl;
+        const bool ok = m < p.M && col_ok;
+        ROWS_OF(m, orow, rrow);
+        (void)rrow;
+        v += bias4;
+        if (p.zout && ok) {
+          uint2 zo;
+          zo.x = pack2bf(v[0], v[1]);
+          zo.y = pack2bf(v[2], v[3]);
+          *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
+        }
+        if (p.aux && ok) {
+          const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
+        }
+        if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (HAS_RES) v += rres[c & 1][it];
+        if (ok) {
+          if (OUT_F32) {
+            *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+          } else {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+          }
+        }
       }
     }
   }
+#undef ISSUE_RES
+#undef ROWS_OF
 }
 
 template <int ACT, int OUT_F32, bool HAS_RES, int PH>
@@ -804,21 +830,34 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     const int ep_buf = (pb + nk - 1) & 1;      // last k-tile's buffer: free now, used for epilogue staging
     const int cm0 = m0, cn0 = n0;
     pb = ep_buf ^ 1;
+    // ---- epilogue: 4 passes of 32 rows through this wave's 8 KiB patch (XOR-swizzled 16-byte chunks).
+    // The residual rows of pass g+1 are requested before pass g is processed, so their HBM latency hides behind a
+    // whole pass instead of stalling every 4 rows (proj / fc2: the fp32 residual + fp32 output stream IS the cost).
+    char* ep = smem + ep_buf * BUF_BYTES + w * 8192;
+    const int er = lane >> 4, ec = lane & 15;
+    const int ncol = cn0 + wn * 64 + ec * 4;
+    const bool col_ok = ncol < p.N;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col_ok) bias4 = *(const f32x4*)(p.bias + ncol);
+    f32x4 rres[2][8];
+#define ISSUE_RES(g_)                                                                                     \
+  if (HAS_RES) {                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                    \
+      const int m_ = cm0 + wm * 128 + (g_) * 32 + it * 4 + er;                                            \
+      rres[(g_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)m_ * p.ldr + ncol)    \
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};                              \
+    }                                                                                                     \
+  }
+    ISSUE_RES(0);                      // ahead of the next tile's DMA in the memory pipeline
     if (tile + (int)gridDim.x < nwg) {
       TILE_COORDS(tile + (int)gridDim.x, m0, n0);
       TILE_PTRS(m0, n0);
       STAGE_A(pb, 0);
       STAGE_W(pb, 0);
     }
-
-    // ---- epilogue: 4 passes of 32 rows through this wave's 8 KiB patch (XOR-swizzled 16-byte chunks)
-    char* ep = smem + ep_buf * BUF_BYTES + w * 8192;
-    const int er = lane >> 4, ec = lane & 15;
-    const int ncol = cn0 + wn * 64 + ec * 4;
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) { ISSUE_RES(g + 1); }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -826,34 +865,30 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
           const int row = i * 16 + frow;
           *(f32x4*)(ep + row * 256 + (((j * 4 + fk) ^ (row & 15)) * 16)) = acc[g * 2 + i][j];
         }
-#pragma unroll 4
+#pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int rl = it * 4 + er;
         f32x4 v = *(const f32x4*)(ep + rl * 256 + ((ec ^ (rl & 15)) * 16));
         const int m = cm0 + wm * 128 + g * 32 + rl;
-        if (m >= p.M || ncol >= p.N) continue;
-        int orow = m, rrow = m;
-        if (p.row_group > 0) {
-          const int gq = m / p.row_group, in = m - gq * p.row_group;
-          orow = gq * p.out_group_rows + p.out_row_off + in;
-          rrow = p.res_periodic ? in : orow;
-        }
         v += bias4;
         if (ACT == VITCAP_ACT_GELU_ERF) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
-        if (HAS_RES) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldr + ncol);
-        if (OUT_F32) {
-          *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
-        } else {
-          uint2 o;
-          o.x = pack2bf(v[0], v[1]);
-          o.y = pack2bf(v[2], v[3]);
-          *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+        if (HAS_RES) v += rres[g & 1][it];
+        if (m < p.M && col_ok) {
+          if (OUT_F32) {
+            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + ncol) = v;
+          } else {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol) = o;
+          }
         }
       }
     }
+#undef ISSUE_RES
   }
 #undef TILE_COORDS
 #undef TILE_PTRS
@@ -1152,10 +1187,11 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   if (hint == 9) return launch_256<0, 0, false, 4 + 16 * 4>(a, s);   // ablation: no MFMA
   if (hint == 10) return launch_256<0, 0, false, 4 + 16 * 3>(a, s);  // ablation: MFMA + barriers only
   if (hint == 11) return launch_256<0, 0, false, 4 + 16 * 6>(a, s);  // ablation: DMA + barriers only
-  // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %)
-  // and loses with one (the residual loads queue behind the next tile's DMA), so it is used for the former only.
+  // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %);
+  // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
   static const int use_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
-  if (hint == 0 && use_persistent && !residual && !aux_bf16 && !zout_bf16 && d->row_group == 0)
+  // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
+  if (hint == 0 && use_persistent && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);
   return dispatch_256<4>(a, d->act, d->out_dtype, s);
 }
