@@ -119,14 +119,18 @@ int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale,
  * logsumexp lse[B][12][S]; the backward returns dqkv (bf16, packed like qkv) from dout, recomputing the probabilities.
  * `dsum` is scratch fp32 [B][12][S]; `extra_dkv` (optional, bf16 [B*S][2][768]) is added to dK/dV. */
 int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float scale,
-                                float p_drop, uint32_t drop_seed, void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
+                                float p_drop, uint32_t drop_seed, int causal_from, void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
 int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                           const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, float p_drop,
-                          uint32_t drop_seed, void* stream);
+                          uint32_t drop_seed, int causal_from, void* stream);
+/* causal_from > 0: the decoder's joint sequence under teacher forcing, rows [causal_from visual | S - causal_from caption]
+ * per image with the seq2seq mask of dataset.py:377-390 + ..._bertemb.py:57-85: a visual row attends visual rows only,
+ * caption row q attends every visual row and caption rows <= q.  All caption keys must fall in the last 64-key tile
+ * (578 = 9*64 + 2 for ViT-B/16-384).  causal_from = 0: unmasked (ViT blocks). */
 /* p_drop > 0 (decoder layers in training, attention_probs_dropout_prob of BertSelfAttention, modeling_bert.py:330-333):
  * the probabilities entering P.V are dropped with probability p_drop and the survivors scaled by 1/(1-p_drop); the
  * keep decision of (query row q, key row k) of image b, head h is the counter hash vc_drop_keep() of csrc/rng.h on
- * stream (drop_seed, b, h) -- the same function in the forward, both backward kernels and the caption-row kernels, and
+ * stream (drop_seed, b, h) -- the same function in the forward and both backward kernels, and
  * restated on the CPU by oracle.dropout_keep().  drop_seed must differ per layer and per step.  p_drop = 0: no dropout. */
 
 /* ------------------------------------------------------------------------------------------------
@@ -352,6 +356,8 @@ int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target
 /* FocalLossWithLogitsNegLoss(alpha, gamma=1).sum()  (loss.py:5-22, modeling_bert.py:789-791) */
 int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const float* label, float alpha, float* out, int B,
                           void* stream);
+/* out[0] = sum g[i]^2 (overwritten, not accumulated), fixed summation order: bit-reproducible, so that data-parallel ranks
+ * derive the same clip coefficient from the same all-reduced gradient (torch.nn.utils.clip_grad_norm_, trainer.py:124). */
 int vitcap_sumsq(const float* g, size_t n, float* out, void* stream);
 /* clip_grad_norm_(max_norm=clip) + solver.AdamW.step over a flat parameter buffer in 1024-element chunks; chunk_lr = 0
  * marks chunks the optimizer does not own (trainer.py:124-142, optimization.py:187-208, ..._bertemb.py:306-356) */
@@ -366,13 +372,6 @@ int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size
 int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
                       const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
                       float* x_f32, void* x_bf16, int rows, void* stream);
-/* caption rows of the decoder under teacher forcing: [S_vis visual | T caption] rows per image, caption row r attends
- * all visual rows and caption rows <= r */
-int vitcap_attn_text_fwd(const void* qkv, void* out, int B, int S_vis, int T, int ld_rows, float scale, float p_drop,
-                         uint32_t drop_seed, void* stream);
-int vitcap_attn_text_bwd(const void* qkv, const void* dout, void* dqkv, void* extra_dkv, int B, int S_vis, int T,
-                         int ld_rows, float scale, float p_drop, uint32_t drop_seed, void* stream);
-
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */

@@ -80,16 +80,13 @@ _SIGS = {
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_embed_rows': (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, vp]),
-    'vitcap_attn_text_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, vp]),
-    'vitcap_attn_text_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
-                                       C.c_uint32, vp]),
     'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'vitcap_attn_dense_fwd_train': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32,
-                                              vp]),
+                                              C.c_int, vp]),
     'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
-                                        C.c_uint32, vp]),
+                                        C.c_uint32, C.c_int, vp]),
     'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, vp]),
     'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
                                                           int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                          uint32_t drop_thr, float drop_scale) {
+                                                          uint32_t drop_thr, float drop_scale, int causal_from) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int v_kg = tid & 15, v_dg = tid >> 4;
   const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
   const int nfull = S / KT, rem = S - nfull * KT;
-  const bool tail_tile = rem > 8;
+  const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);   // caption keys (>= causal_from) live in the masked tail tile
   const int ntiles = nfull + (tail_tile ? 1 : 0);
 
   uint4 k0, k1, v0, v1;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
           float p = fast_exp2(fmaf(st[kt][r], c_log2, -Lq));
           if (masked) {
             const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            p = key < S ? p : 0.f;
+            p = (key < S && (causal_from <= 0 || key < causal_from || key <= q0 + qi)) ? p : 0.f;
           }
           float dp = dpt[kt][r];
           if (DROP) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
                                                            int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                           uint32_t drop_thr, float drop_scale) {
+                                                           uint32_t drop_thr, float drop_scale, int causal_from) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -303,8 +303,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int v_kg = tid & 15, v_dg = tid >> 4;
   const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
   const int nfull = S / KT, rem = S - nfull * KT;
-  const bool tail_tile = rem > 8;
+  const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);
   const int ntiles = nfull + (tail_tile ? 1 : 0);
+  // a caption key (>= causal_from) only hears from caption queries q >= key: waves that own such keys mask every tile
+  const bool wave_causal = causal_from > 0 && key0 + 31 >= causal_from;
   constexpr int BUF = 4 * TILE_B + 512;
 
   uint4 q0r, q1r, d0r, d1r;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const float* Ll = (const float*)(ql + 4 * TILE_B);
       const float* Dl = Ll + 64;
       // one 32-query half-tile at a time (keeps the register footprint at 2 waves per SIMD)
-      const bool masked = t >= nfull;
+      const bool masked = t >= nfull || wave_causal;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         f32x16 st, dpt;
@@ -377,7 +379,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
           for (int e = 0; e < 4; ++e) {
             const int r = g * 4 + e;
             float p = fast_exp2(fmaf(st[r], c_log2, -L4[e]));
-            if (masked) p = (t * KT + qt * 32 + g * 8 + 4 * half + e) < S ? p : 0.f;
+            if (masked) {
+              const int q = t * KT + qt * 32 + g * 8 + 4 * half + e;
+              p = (q < S && (causal_from <= 0 || key0 + ki < causal_from || q >= key0 + ki)) ? p : 0.f;
+            }
             float dp = dpt[r], pd = p;
             if (DROP) {
               const uint32_t q = (uint32_t)(t * KT + qt * 32 + g * 8 + 4 * half + e);
@@ -487,10 +492,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                                      const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
-                                     float p_drop, uint32_t drop_seed, void* stream) {
+                                     float p_drop, uint32_t drop_seed, int causal_from, void* stream) {
   VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0 && ld_rows >= S, "attn_dense_bwd: bad arguments");
   VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_bwd: p_drop %g / ld_rows %d out of range",
              (double)p_drop, ld_rows);
+  VC_REQUIRE(causal_from == 0 || (causal_from >= (S / KT) * KT && causal_from <= S),
+             "attn_dense_bwd: causal_from %d must lie in the last key tile of S=%d", causal_from, S);
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
   const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
@@ -499,11 +506,11 @@ extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const voi
   do {                                                                                                                    \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
                        (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs);                                                                               \
+                       drop_seed, thr, rs, causal_from);                                                                  \
     VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
                        (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
-                       ld_rows, c, scale, drop_seed, thr, rs);                                                            \
+                       ld_rows, c, scale, drop_seed, thr, rs, causal_from);                                               \
     VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
   } while (0)
   if (p_drop > 0.f) VC_BWD_LAUNCH(true);

@@ -265,8 +265,11 @@ __global__ __launch_bounds__(256) void focal_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(out, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
-// sum of squares of a flat fp32 buffer -> out[0] (atomic)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ out) {
+// sum of squares of a flat fp32 buffer -> out[0].  Two fixed-order passes (per-block partials, then one block adds
+// them in index order): the result is bit-reproducible, which data-parallel ranks rely on -- they must derive the SAME
+// clip coefficient from the same all-reduced gradient or their parameters drift apart.
+constexpr int SUMSQ_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ part) {
   __shared__ float s_red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc = 0.f;
@@ -277,7 +280,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if (lane == 0) s_red[w] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  if (threadIdx.x == 0) part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+  __shared__ float s_red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < SUMSQ_BLOCKS / 256; ++i) acc += part[i * 256 + threadIdx.x];
+  acc = wave_sum(acc);
+  if (lane == 0) s_red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // fused clip + AdamW over a flat parameter buffer laid out in 1024-element chunks; chunk_lr/chunk_wd give each chunk's
@@ -459,8 +473,14 @@ extern "C" int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const 
 
 extern "C" int vitcap_sumsq(const float* g, size_t n, float* out, void* stream) {
   VC_REQUIRE(g && out && n % 4 == 0, "sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, g, n / 4, out);
-  VC_LAUNCH_CHECK("sumsq");
+  static float* scratch[64] = {nullptr};          // per-device partials, allocated on first use
+  int dev = 0;
+  VC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "sumsq: bad device");
+  if (!scratch[dev]) VC_REQUIRE(hipMalloc(&scratch[dev], SUMSQ_BLOCKS * sizeof(float)) == hipSuccess, "sumsq: scratch alloc failed");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n / 4, scratch[dev]);
+  VC_LAUNCH_CHECK("sumsq_partial");
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch[dev], out);
+  VC_LAUNCH_CHECK("sumsq_final");
   return VITCAP_OK;
 }
 

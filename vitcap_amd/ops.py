@@ -84,7 +84,7 @@ def attn_dense(qkv, B, S, scale=0.125):
     return out
 
 
-def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0):
+def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0, causal_from=0):
     """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd; ld_rows = rows per image
     in the buffers (>= S; only the first S rows of each image are attended / written)"""
     _dev_bf16(qkv)
@@ -92,20 +92,21 @@ def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0,
     if out is None:
         out = torch.empty((B * ld_rows, 768), device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty((B, 12, S), device=qkv.device, dtype=torch.float32)
-    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, p_drop, drop_seed, _stream()),
+    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, p_drop, drop_seed, causal_from,
+                                          _stream()),
           'attn_dense_train')
     return out, lse
 
 
 def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None, ld_rows=None, dqkv=None, p_drop=0.0,
-                   drop_seed=0):
+                   drop_seed=0, causal_from=0):
     _dev_bf16(qkv); _dev_bf16(out); _dev_bf16(dout); _dev_f32(lse)
     ld_rows = ld_rows or S
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
     check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, ld_rows,
-                                    scale, p_drop, drop_seed, _stream()), 'attn_dense_bwd')
+                                    scale, p_drop, drop_seed, causal_from, _stream()), 'attn_dense_bwd')
     return dqkv
 
 
@@ -225,13 +226,3 @@ def cast_bf16(x):
     check(lib.vitcap_cast_bf16(_p(x), _p(y), x.numel(), _stream()), 'cast_bf16')
     return y
 
-
-def attn_text_fwd(qkv, out, B, S_vis, T, ld_rows, scale=0.125, p_drop=0.0, drop_seed=0):
-    check(lib.vitcap_attn_text_fwd(_p(qkv), _p(out), B, S_vis, T, ld_rows, scale, p_drop, drop_seed, _stream()),
-          'attn_text_fwd')
-
-
-def attn_text_bwd(qkv, dout, dqkv, extra, B, S_vis, T, ld_rows, scale=0.125, p_drop=0.0, drop_seed=0):
-    check(lib.vitcap_attn_text_bwd(_p(qkv), _p(dout), _p(dqkv), _p(extra), B, S_vis, T, ld_rows, scale, p_drop, drop_seed,
-                                   _stream()),
-          'attn_text_bwd')

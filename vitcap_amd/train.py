@@ -400,8 +400,8 @@ class TrainEngine(object):
             pre = 'module.bert.decoder.layer.%d' % l
             xb = ops.cast_bf16(xd)
             qkv = ops.gemm_bias_act(xb, self.wb(pre + '.qkv'), self.qkv_bias(pre))
-            ctx, lse = ops.attn_dense_train(qkv, B, SV, ld_rows=LR, p_drop=pd, drop_seed=dseed[l])
-            ops.attn_text_fwd(qkv, ctx, B, SV, T, LR, p_drop=pd, drop_seed=dseed[l])
+            # visual rows attend visual rows; caption row q attends all visual rows and caption rows <= q (one kernel)
+            ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV)
             t1 = torch.empty(Md, 768, device=dev)
             ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
             ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
@@ -472,11 +472,7 @@ class TrainEngine(object):
             dt1T = ops.transpose_colsum(dt1b, self.g(pre + '.attention.output.dense.bias').view(-1))
             self._wgrad(dt1T, ops.transpose_colsum(ctx), self.g(pre + '.attention.output.dense.weight'))
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
-            dqkv = torch.zeros(Md, 2304, device=dev, dtype=torch.bfloat16)
-            extra = torch.zeros(Md, 2, 768, device=dev, dtype=torch.bfloat16)
-            ops.attn_text_bwd(qkv, dctx, dqkv, extra, B, SV, T, LR, p_drop=pd, drop_seed=dseed[l])
-            ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, SV, extra_dkv=extra, ld_rows=LR, dqkv=dqkv, p_drop=pd,
-                               drop_seed=dseed[l])
+            dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV)
             dqkvT = ops.transpose_colsum(dqkv, self.qkv_bias_grad(pre))
             self._wgrad(dqkvT, ops.transpose_colsum(xb), self.qkv_w_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
