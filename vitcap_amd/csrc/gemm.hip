@@ -833,7 +833,60 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     // ---- epilogue: 4 passes of 32 rows through this wave's 8 KiB patch (XOR-swizzled 16-byte chunks).
     // The residual rows of pass g+1 are requested before pass g is processed, so their HBM latency hides behind a
     // whole pass instead of stalling every 4 rows (proj / fc2: the fp32 residual + fp32 output stream IS the cost).
+    // bf16 output without residual: a lane converts 8 columns and issues ONE 16-byte store (8 lanes = one 128-byte
+    // line of the row) -- the store tail is issue-bound, so half the store instructions is what counts.
     char* ep = smem + ep_buf * BUF_BYTES + w * 8192;
+    constexpr bool WIDE = !OUT_F32 && !HAS_RES;
+    if constexpr (WIDE) {
+      const int er = lane >> 3, ec = lane & 7;            // row within a group of 8, 8-column piece
+      const int ncol = cn0 + wn * 64 + ec * 8;
+      const bool col_ok = ncol < p.N;                      // N % 8 == 0 on this path (checked by the dispatcher)
+      f32x4 bias_lo = f32x4{0.f, 0.f, 0.f, 0.f}, bias_hi = bias_lo;
+      if (p.bias && col_ok) {
+        bias_lo = *(const f32x4*)(p.bias + ncol);
+        bias_hi = *(const f32x4*)(p.bias + ncol + 4);
+      }
+      if (tile + (int)gridDim.x < nwg) {
+        TILE_COORDS(tile + (int)gridDim.x, m0, n0);
+        TILE_PTRS(m0, n0);
+        STAGE_A(pb, 0);
+        STAGE_W(pb, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = i * 16 + frow;
+            *(f32x4*)(ep + row * 256 + (((j * 4 + fk) ^ (row & 15)) * 16)) = acc[g * 2 + i][j];
+          }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = it * 8 + er;
+          f32x4 v0 = *(const f32x4*)(ep + rl * 256 + (((ec * 2) ^ (rl & 15)) * 16));
+          f32x4 v1 = *(const f32x4*)(ep + rl * 256 + (((ec * 2 + 1) ^ (rl & 15)) * 16));
+          const int m = cm0 + wm * 128 + g * 32 + rl;
+          v0 += bias_lo;
+          v1 += bias_hi;
+          if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = gelu_erf(v0[e]);
+              v1[e] = gelu_erf(v1[e]);
+            }
+          }
+          if (m < p.M && col_ok) {
+            uint4 o;
+            o.x = pack2bf(v0[0], v0[1]);
+            o.y = pack2bf(v0[2], v0[3]);
+            o.z = pack2bf(v1[0], v1[1]);
+            o.w = pack2bf(v1[2], v1[3]);
+            *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol) = o;
+          }
+        }
+      }
+    } else {
     const int er = lane >> 4, ec = lane & 15;
     const int ncol = cn0 + wn * 64 + ec * 4;
     const bool col_ok = ncol < p.N;
@@ -889,6 +942,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
       }
     }
 #undef ISSUE_RES
+    }
   }
 #undef TILE_COORDS
 #undef TILE_PTRS
@@ -1180,7 +1234,9 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
   if (hint == 3) return dispatch_big(a, d->act, d->out_dtype, s);
-  if (hint == 12) return dispatch_256p(a, d->act, d->out_dtype, s);
+  // the persistent kernel's bf16 epilogue stores 8 columns (16 bytes) per lane
+  const bool wide_ok = d->out_dtype == VITCAP_OUT_F32 || residual || (d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)C & 15) == 0);
+  if (hint == 12 && wide_ok) return dispatch_256p(a, d->act, d->out_dtype, s);
   if (hint == 6) return dispatch_256<2>(a, d->act, d->out_dtype, s);
   if (hint == 7) return launch_256<0, 0, false, 4 + 16 * 1>(a, s);   // ablation: no DMA in the loop
   if (hint == 8) return launch_256<0, 0, false, 4 + 16 * 2>(a, s);   // ablation: no ds_read in the loop
@@ -1191,7 +1247,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
   static const int use_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
   // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
-  if (hint == 0 && use_persistent && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
+  if (hint == 0 && use_persistent && wide_ok && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);
   return dispatch_256<4>(a, d->act, d->out_dtype, s);
 }
