@@ -78,21 +78,23 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);   // many left-overs: one masked MFMA tile
   const int ntiles = nfull + (tail_tile ? 1 : 0);
 
-  // per-thread source pointers of tile 0 (advanced by 64 rows per tile; clamped only for a masked tail tile)
-  const bf16_t* kp = base + (size_t)k_key * QKV_LD + 768 + k_d;
-  const bf16_t* vp0 = base + (size_t)(v_kg * 4) * QKV_LD + 1536 + v_dg * 4;
+  // tile sources = wave-uniform tile base (SGPR pair, advanced by the scalar unit) + per-lane 32-bit byte offsets that
+  // never change: no vector address arithmetic inside the loop
+  const char* gbase = (const char*)base;
+  const uint32_t k_off = (uint32_t)(k_key * QKV_LD + 768 + k_d) * 2u;
+  const uint32_t v_off0 = (uint32_t)((v_kg * 4) * QKV_LD + 1536 + v_dg * 4) * 2u;
+  const uint32_t v_off1 = v_off0 + QKV_LD * 2u, v_off2 = v_off0 + 2u * QKV_LD * 2u, v_off3 = v_off0 + 3u * QKV_LD * 2u;
   uint4 kreg0, kreg1;
   uint2 vreg0, vreg1, vreg2, vreg3;
 #define LOAD_TILE_FAST(t_)                                                                      \
   do {                                                                                          \
-    const bf16_t* kq_ = kp + (size_t)(t_) * KT * QKV_LD;                                        \
-    const bf16_t* vq_ = vp0 + (size_t)(t_) * KT * QKV_LD;                                       \
-    kreg0 = *(const uint4*)kq_;                                                                 \
-    kreg1 = *(const uint4*)(kq_ + 8);                                                           \
-    vreg0 = *(const uint2*)(vq_);                                                               \
-    vreg1 = *(const uint2*)(vq_ + QKV_LD);                                                      \
-    vreg2 = *(const uint2*)(vq_ + 2 * QKV_LD);                                                  \
-    vreg3 = *(const uint2*)(vq_ + 3 * QKV_LD);                                                  \
+    const char* tb_ = gbase + (size_t)(t_) * (KT * QKV_LD * 2);                                 \
+    kreg0 = *(const uint4*)(tb_ + k_off);                                                       \
+    kreg1 = *(const uint4*)(tb_ + k_off + 16);                                                  \
+    vreg0 = *(const uint2*)(tb_ + v_off0);                                                      \
+    vreg1 = *(const uint2*)(tb_ + v_off1);                                                      \
+    vreg2 = *(const uint2*)(tb_ + v_off2);                                                      \
+    vreg3 = *(const uint2*)(tb_ + v_off3);                                                      \
   } while (0)
 #define LOAD_TILE_CLAMPED(kv0_)                                                                 \
   do {                                                                                          \
@@ -148,10 +150,47 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   float m_i = -1e30f;   // running max, log2 domain, integer valued once set
   float l_i = 0.f;      // this half-wave's partial row sum
 
-  if (ntiles > 0) {
-    LOAD_TILE(0);
-    STORE_TILE(0);
+  if (ntiles > 0) LOAD_TILE(0);
+  // ---- left-over keys (S = 577/578 leaves 1/2) FIRST, while tile 0 is in flight: one online-softmax step per key on
+  // the vector ALU (the online softmax does not care about key order; done after the loop its two dependent global
+  // round trips were fully exposed, ~2 us of the ~8 us a workgroup spent outside its main loop).  The lane owns
+  // 32 of the 64 q dims (its partner lane^32 the rest) and 32 of the 64 output dims.
+  if (active && !tail_tile) {
+    for (int key = nfull * KT; key < S; ++key) {
+      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
+      float sp = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sp += (float)qf[ds][j] * (float)kv[j];
+      }
+      const float sc = sp + __shfl_xor(sp, 32, 64);
+      const float m_new = fmaxf(m_i, ceilf(sc * c_log2));
+      const float alpha = fast_exp2(m_i - m_new);
+      m_i = m_new;
+      const float pv = fast_exp2(fmaf(sc, c_log2, -m_new));
+      l_i = l_i * alpha + (half == 0 ? pv : 0.f);
+      float pb = (float)(__bf16)pv;
+      if (DROP) pb = vc_lowbias32((hq ^ (4u * half)) ^ (uint32_t)key) >= drop_thr ? pb : 0.f;
+      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 vv = *(const bf16x4*)(vr + dt * 32 + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ot[dt][g * 4 + e] = fmaf(pb, (float)vv[e], ot[dt][g * 4 + e] * alpha);
+        }
+    }
   }
+
+  if (ntiles > 0) STORE_TILE(0);
+  // Every load so far (Q fragments, tile 0) must be provably complete on ALL paths into the loop: otherwise the
+  // compiler's waitcnt pass keeps the Q registers "possibly pending" across the loop and puts vmcnt(3..0) in front of
+  // the first four QK^T MFMAs of every iteration, i.e. it waits for the NEXT tile's loads before computing this one
+  // (found by reading the ISA; see DESIGN.md "waitcnt false dependency").
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
 
   // One key-tile step; MASKED_ is a literal so the left-over masking exists only in the peeled tail instance
@@ -240,38 +279,6 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
 #undef LOAD_TILE_FAST
 #undef LOAD_TILE_CLAMPED
 #undef STORE_TILE
-
-  // ---- left-over keys (S = 577/578 leaves 1/2): one online-softmax step per key on the vector ALU.  The lane owns
-  // 32 of the 64 q dims (its partner lane^32 the rest) and 32 of the 64 output dims.
-  if (active && !tail_tile) {
-    for (int key = nfull * KT; key < S; ++key) {
-      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
-      float sp = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sp += (float)qf[ds][j] * (float)kv[j];
-      }
-      const float sc = sp + __shfl_xor(sp, 32, 64);
-      const float m_new = fmaxf(m_i, ceilf(sc * c_log2));
-      const float alpha = fast_exp2(m_i - m_new);
-      m_i = m_new;
-      const float pv = fast_exp2(fmaf(sc, c_log2, -m_new));
-      l_i = l_i * alpha + (half == 0 ? pv : 0.f);
-      float pb = (float)(__bf16)pv;
-      if (DROP) pb = vc_lowbias32((hq ^ (4u * half)) ^ (uint32_t)key) >= drop_thr ? pb : 0.f;
-      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x4 vv = *(const bf16x4*)(vr + dt * 32 + g * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ot[dt][g * 4 + e] = fmaf(pb, (float)vv[e], ot[dt][g * 4 + e] * alpha);
-        }
-    }
-  }
 
   // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
