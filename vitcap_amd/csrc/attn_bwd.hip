@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     LOAD_TILE(0);
     STORE_TILE(0);
   }
+  // all prologue loads provably complete on every path into the loop (see attn.hip: otherwise the waitcnt pass makes
+  // each iteration wait for the NEXT tile's loads before its first MFMAs)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
@@ -345,6 +348,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     LOAD_TILE(0);
     STORE_TILE(0);
   }
+  // all prologue loads provably complete on every path into the loop (see attn.hip: otherwise the waitcnt pass makes
+  // each iteration wait for the NEXT tile's loads before its first MFMAs)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
