@@ -364,6 +364,15 @@ int vitcap_sumsq(const float* g, size_t n, float* out, void* stream);
 int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float* chunk_lr, const float* chunk_wd,
                        const float* gsumsq, float clip, float lr_scale, int step, float b1, float b2, float eps,
                        size_t nchunks, void* stream);
+/* Weight gradient of an nn.Linear, dW[N][K] = dY^T X (autograd of F.linear, e.g. modeling_bert.py:283-287 /
+ * vision_transformer.py:147-150), straight from the row-major backward operands: Y = dY bf16 [M][ldy] (N columns),
+ * X = saved input bf16 [M][ldx] (K columns), reduction over the M = batch x tokens rows.  The M range is cut into
+ * `splits` pieces, piece s writes the fp32 slab C_slabs[s][N][K] (deterministic; sum them with vitcap_reduce_slabs).
+ * N and K multiples of 256. */
+int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
+                   void* stream);
+/* bias gradient: out[n] += sum_m y[m][n]  (bf16 [M][ldy] -> fp32 [N], atomic accumulation into `out`) */
+int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream);
 /* fp32 master W[N][K] -> bf16 W and bf16 W^T[K][N] (the operands of the forward and the dgrad GEMMs) */
 int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, int ldt, void* stream);
 int vitcap_gelu_bwd(const float* dg, const void* z_bf16, void* dz_bf16, size_t n, void* stream);

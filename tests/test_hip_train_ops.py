@@ -133,6 +133,28 @@ def test_attn_joint_causal_forward_backward(ops, p_drop):
         assert r < 1e-2 and rc < 1e-2, name
 
 
+@pytest.mark.parametrize('M,N,K,splits', [(1154, 768, 768, 5), (4099, 2304, 768, 9), (2 * 598, 768, 3072, 3), (640, 256, 256, 1),
+                                          (36928, 768, 768, 28)])
+def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
+    """dW = dY^T X from the row-major operands via LDS transpose reads; slabs summed == fp32 reference (bf16 inputs are
+    exact in fp32, so only the summation order differs: 1e-4 relative)."""
+    y = _bf(_rand((M, N), 31, 1.0))
+    x = _bf(_rand((M, K), 32, 1.0))
+    # transpose-detecting inputs: a single hot element must land at [n][k], not [k][n]
+    y[7, 3] = 64.0
+    x[7, 200] = 32.0
+    slabs = ops.gemm_tn(y.cuda(), x.cuda(), splits)
+    got = slabs.sum(0).cpu()
+    want = y.float().t() @ x.float()
+    assert got.shape == (N, K)
+    err = float((got - want).abs().max() / want.abs().max())
+    print('gemm_tn M=%d N=%d K=%d splits=%d rel err %.2e' % (M, N, K, splits, err))
+    assert err < 1e-4
+    bias = torch.zeros(N, device='cuda')
+    ops.colsum_bf16(y.cuda(), bias)
+    assert _rel(bias, y.float().sum(0)) < 1e-5
+
+
 def test_losses(ops, sd_t):
     from oracle import vitcap_oracle as O
     from vitcap_amd._lib import lib, check

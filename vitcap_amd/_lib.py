@@ -76,6 +76,8 @@ _SIGS = {
     'vitcap_sumsq': (C.c_int, [vp, C.c_size_t, vp, vp]),
     'vitcap_adamw_multi': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_size_t, vp]),
+    'vitcap_gemm_tn': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_colsum_bf16': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),

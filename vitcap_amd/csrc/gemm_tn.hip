@@ -1,0 +1,212 @@
+// Weight-gradient GEMM for gfx950:  C[N][K] (fp32) = sum_m Y[m][n] * X[m][k]   ("TN": both operands are stored with the
+// REDUCTION index m as the slow dimension, exactly as the backward pass produces them -- dY[M][N] and the saved
+// activation X[M][K], row-major).  nn.Linear's dW = dY^T X (what autograd computes for modeling_bert.py / timm Linear
+// layers) therefore needs no transposed copies of the activations.
+//
+// MFMA fragments want 8 consecutive reduction elements per lane for a fixed row; here those are strided by the row
+// pitch.  The tiles are staged row-major ([64 m][256 cols], LDS-DMA, 16 B per lane) and read with the CDNA4 LDS
+// transpose read `ds_read_b64_tr_b16`: a 16-lane group fetches a [4 m][16 col] block and lane i receives column i of
+// the 4 rows (measured semantics: lane i, element j  <-  address of lane 4j + i/4, element i%4).
+//
+// Tile 256(n) x 256(k) per workgroup, 8 waves as 2(n) x 4(k), wave tile 128 x 64, mfma_f32_16x16x32_bf16, two
+// 64-row stages in LDS (128 KiB).  The reduction dimension (M = batch x tokens, 36 928 at B=64) is long and the output
+// small (768..3072 x 768..3072), so the grid is (output tiles) x (splits of M): every split writes its own fp32 slab
+// (deterministic, no atomics), reduced by vitcap_reduce_slabs.
+//
+// LDS bank conflicts: a tile row is 512 B, so all rows alias to the same banks; 32-byte chunk C of row m is stored at
+// chunk C ^ f(m), f(m) = 4*((m>>3)&3) + (m&3).  One transpose read touches rows {8g + j} (g = lane group, j = 0..3):
+// 16 different f values, 8 per half-wave -> 8 distinct bank groups per LDS cycle.  The swizzle is applied by choosing
+// which global 16-byte chunk each DMA lane fetches (the LDS side of the DMA is lane-linear).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int TBN = 256, TBK = 256, TBM = 64;
+constexpr int ROW_B = 512;                       // bytes per tile row (256 bf16)
+constexpr int OP_BYTES = TBM * ROW_B;            // 32 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OP_BYTES;
+
+struct TnArgs {
+  const bf16_t* Y;   // [M][ldy], columns n0.. used
+  const bf16_t* X;   // [M][ldx]
+  float* C;          // [split][N][K]
+  const bf16_t* zeros;   // >= 512 B of zeros (rows past M)
+  int M, N, K, ldy, ldx;
+  int tiles_n, tiles_k, splits, stages_per_split;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ int swz(int m) { return ((m >> 3) & 3) * 4 + (m & 3); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds_lo, const char* lds_hi) {
+  // two transpose reads: reduction rows +0..3 and +4..7 of this lane group's 8-row slab
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_lo);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_hi);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = w >> 2, wk = w & 3;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+  const int n0 = tn * TBN, k0 = tk * TBK;
+  const int s_begin = split * p.stages_per_split;
+  const int total_stages = (p.M + TBM - 1) / TBM;
+  int s_end = s_begin + p.stages_per_split;
+  s_end = s_end < total_stages ? s_end : total_stages;
+  const int nst = s_end > s_begin ? s_end - s_begin : 0;
+
+  // ---- DMA: wave w fills rows 8w .. 8w+7 of each operand tile, 4 instructions of 2 rows each per operand
+  const int drow = lane >> 5;                      // row within the instruction's pair
+  const int dchunk = lane & 31;                    // physical 16-byte chunk within the row
+#define STAGE(buf_, st_)                                                                            \
+  do {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+      const int r_ = w * 8 + i * 2 + drow;           /* tile row 0..63 */                           \
+      const int lc_ = dchunk ^ (swz(r_) << 1);       /* logical 16-byte chunk this lane fetches */  \
+      const int m_ = (st_) * TBM + r_;                                                              \
+      const bf16_t* ys_ = m_ < p.M ? p.Y + (size_t)m_ * p.ldy + n0 + lc_ * 8 : p.zeros + lc_ * 8;   \
+      const bf16_t* xs_ = m_ < p.M ? p.X + (size_t)m_ * p.ldx + k0 + lc_ * 8 : p.zeros + lc_ * 8;   \
+      char* dst_ = smem + (buf_) * STAGE_BYTES + (w * 8 + i * 2) * ROW_B;                           \
+      glds16(ys_, dst_);                                                                            \
+      glds16(xs_, dst_ + OP_BYTES);                                                                 \
+    }                                                                                               \
+  } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transpose-read addressing: lane group g = lane>>4 owns reduction rows 8g..8g+7 of each 32-row step; within the
+  // group, lane i supplies the address of row j = i>>2, 8-byte piece q = i&3 of the 16-column block
+  const int g = lane >> 4, gi = lane & 15;
+  const int tj = gi >> 2, tq = gi & 3;
+  const int fsw = g * 4 + tj;                      // swz(row) for both reads (rows +0..3 and +4..7 share it)
+  const int row_lo = g * 8 + tj;                   // + ms*32 (+4 for the second read)
+
+  if (nst > 0) STAGE(0, s_begin);
+  for (int t = 0; t < nst; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nst) {
+      STAGE(buf ^ 1, s_begin + t + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this stage's 8 pieces landed; the next 8 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const char* ys = smem + buf * STAGE_BYTES;
+    const char* xs = ys + OP_BYTES;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int rbase = (ms * 32 + row_lo) * ROW_B + tq * 8;
+      bf16x8 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int cb = ((wn * 8 + i) ^ fsw) * 32;          // 16-column block (32 B) of this n-tile, swizzled
+        af[i] = tr_frag(ys + rbase + cb, ys + rbase + 4 * ROW_B + cb);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cb = ((wk * 4 + j) ^ fsw) * 32;
+        bfr[j] = tr_frag(xs + rbase + cb, xs + rbase + 4 * ROW_B + cb);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                       // everyone done reading `buf` before it is refilled
+  }
+#undef STAGE
+
+  // ---- store the slab: with the operands swapped the lane holds 4 consecutive k of ONE n (16-byte stores)
+  float* cs = p.C + (size_t)split * p.N * p.K;
+  const int nl = lane & 15, kq = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = n0 + wn * 128 + i * 16 + nl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + kq;
+      if (n < p.N && k < p.K) *(f32x4*)(cs + (size_t)n * p.K + k) = acc[i][j];
+    }
+  }
+}
+
+// column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m y[m][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ y, int ldy, int M, int N, int rows_per_block,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][128];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + tx * 2;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  r1 = r1 < M ? r1 : M;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < N)
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const unsigned v = *(const unsigned*)(y + (size_t)r * ldy + c);
+      a0 += __uint_as_float(v << 16);
+      a1 += __uint_as_float(v & 0xffff0000u);
+    }
+  red[ty][tx * 2] = a0;
+  red[ty][tx * 2 + 1] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < N) {
+    const int i = threadIdx.x;
+    atomicAdd(out + blockIdx.x * 128 + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+  }
+}
+
+}  // namespace
+
+extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
+                              void* stream) {
+  VC_REQUIRE(Y && X && C_slabs && M > 0 && N > 0 && K > 0 && splits >= 1, "gemm_tn: bad arguments");
+  VC_REQUIRE(N % 256 == 0 && K % 256 == 0, "gemm_tn: N=%d and K=%d must be multiples of 256", N, K);
+  VC_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gemm_tn: misaligned operands");
+  static bf16_t* zeros[64] = {nullptr};
+  static bool attr_set = false;
+  int dev = 0;
+  VC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "gemm_tn: bad device");
+  if (!zeros[dev]) {
+    VC_REQUIRE(hipMalloc(&zeros[dev], 1024) == hipSuccess && hipMemset(zeros[dev], 0, 1024) == hipSuccess,
+               "gemm_tn: zero page allocation failed");
+  }
+  constexpr int smem = 2 * STAGE_BYTES;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  TnArgs p;
+  p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.C = C_slabs; p.zeros = zeros[dev];
+  p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx;
+  p.tiles_n = N / TBN; p.tiles_k = K / TBK; p.splits = splits;
+  const int total_stages = (M + TBM - 1) / TBM;
+  p.stages_per_split = (total_stages + splits - 1) / splits;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k, splits), dim3(512), smem, (hipStream_t)stream, p);
+  VC_LAUNCH_CHECK("gemm_tn");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream) {
+  VC_REQUIRE(y && out && M > 0 && N > 0 && N % 2 == 0 && ldy % 2 == 0, "colsum: bad arguments");
+  const int rows_per_block = 512;
+  dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, ldy, M, N, rows_per_block, out);
+  VC_LAUNCH_CHECK("colsum");
+  return VITCAP_OK;
+}

@@ -226,3 +226,22 @@ def cast_bf16(x):
     check(lib.vitcap_cast_bf16(_p(x), _p(y), x.numel(), _stream()), 'cast_bf16')
     return y
 
+
+
+def gemm_tn(y, x, splits, slabs=None):
+    """dW slabs [splits][N][K] fp32 = (pieces of) y^T x for bf16 y [M][N], x [M][K] (row-major, as the backward pass holds them)"""
+    _dev_bf16(y); _dev_bf16(x)
+    M, N = y.shape
+    K = x.shape[1]
+    assert x.shape[0] == M
+    if slabs is None:
+        slabs = torch.empty((splits, N, K), device=y.device, dtype=torch.float32)
+    check(lib.vitcap_gemm_tn(_p(y), y.stride(0), _p(x), x.stride(0), _p(slabs), M, N, K, splits, _stream()), 'gemm_tn')
+    return slabs
+
+
+def colsum_bf16(y, out):
+    """out[n] += sum_m y[m][n]"""
+    _dev_bf16(y); _dev_f32(out)
+    check(lib.vitcap_colsum_bf16(_p(y), y.stride(0), y.shape[0], y.shape[1], _p(out), _stream()), 'colsum')
+    return out

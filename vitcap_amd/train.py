@@ -304,6 +304,19 @@ class TrainEngine(object):
         return self.G[o:o + 2304 * 768].view(2304, 768)
 
     # ------------------------------------------------------------------ helpers
+    def _wgrad_tn(self, dy, x, gview, bias_grad):
+        """gview[N][K] = dy^T x and bias_grad[N] += column sums of dy, straight from the row-major backward operands
+        (LDS transpose reads, no transposed copies); M is split so that about one wave of 256x256 tiles fills the chip."""
+        N, Kin = gview.shape
+        tiles = (N // 256) * (Kin // 256)
+        stages = (dy.shape[0] + 63) // 64
+        S = max(1, min(stages, 256 // tiles))
+        if S == 1:
+            ops.gemm_tn(dy, x, 1, slabs=gview.view(1, N, Kin))
+        else:
+            ops.reduce_slabs(ops.gemm_tn(dy, x, S), gview)
+        ops.colsum_bf16(dy, bias_grad)
+
     def _wgrad(self, dyT, xT, gview, accumulate=False):
         """gview[N][K] (+)= dyT[N][Mp] @ xT[K][Mp]^T with split-K sized to fill the chip."""
         N, Kin = dyT.shape[0], xT.shape[0]
@@ -447,8 +460,7 @@ class TrainEngine(object):
         dgt, _ = self._ln_bwd(gt, dh2, c + '.transform.LayerNorm.weight', c + '.transform.LayerNorm.bias', 1e-12)
         dzt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
         check(lib.vitcap_gelu_bwd(_p(dgt), _p(zt), _p(dzt), n * 768, _s()), 'gelu_bwd')
-        dztT = ops.transpose_colsum(dzt, self.g(c + '.transform.dense.bias').view(-1))
-        self._wgrad(dztT, ops.transpose_colsum(hrows), self.g(c + '.transform.dense.weight'))
+        self._wgrad_tn(dzt, hrows, self.g(c + '.transform.dense.weight'), self.g(c + '.transform.dense.bias').view(-1))
         dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
         self.reducer.stage_done('cls')
         dy = torch.zeros(B, LR, 768, device=dev)
@@ -461,20 +473,16 @@ class TrainEngine(object):
             pre = 'module.bert.decoder.layer.%d' % l
             xb, qkv, ctx, lse, t1, ab, af, z, it, t2 = dsaved[l]
             dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
-            dt2T = ops.transpose_colsum(dt2b, self.g(pre + '.output.dense.bias').view(-1))
-            self._wgrad(dt2T, ops.transpose_colsum(it), self.g(pre + '.output.dense.weight'))
+            self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), self.g(pre + '.output.dense.bias').view(-1))
             dz = ops.gemm_ex(dt2b, self.wt(pre + '.o'), aux=z)                 # [Md,3072] bf16
-            dzT = ops.transpose_colsum(dz, self.g(pre + '.intermediate.dense.bias').view(-1))
-            self._wgrad(dzT, ops.transpose_colsum(ab), self.g(pre + '.intermediate.dense.weight'))
+            self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), self.g(pre + '.intermediate.dense.bias').view(-1))
             da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
             dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias',
                                       1e-12)
-            dt1T = ops.transpose_colsum(dt1b, self.g(pre + '.attention.output.dense.bias').view(-1))
-            self._wgrad(dt1T, ops.transpose_colsum(ctx), self.g(pre + '.attention.output.dense.weight'))
+            self._wgrad_tn(dt1b, ctx, self.g(pre + '.attention.output.dense.weight'), self.g(pre + '.attention.output.dense.bias').view(-1))
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
             dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV)
-            dqkvT = ops.transpose_colsum(dqkv, self.qkv_bias_grad(pre))
-            self._wgrad(dqkvT, ops.transpose_colsum(xb), self.qkv_w_grad(pre))
+            self._wgrad_tn(dqkv, xb, self.qkv_w_grad(pre), self.qkv_bias_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
             if l % 2 == 0:
                 self.reducer.stage_done('dec%d' % (l // 2))
@@ -495,19 +503,15 @@ class TrainEngine(object):
         def block_bwd(pre, dxo):
             xin, h1, qkv, ao, lse, xmid, h2, z, g = saved.pop(pre)
             dxb = ops.cast_bf16(dxo)
-            dxT = ops.transpose_colsum(dxb, self.g(pre + '.mlp.fc2.bias').view(-1))
-            self._wgrad(dxT, ops.transpose_colsum(g), self.g(pre + '.mlp.fc2.weight'))
+            self._wgrad_tn(dxb, g, self.g(pre + '.mlp.fc2.weight'), self.g(pre + '.mlp.fc2.bias').view(-1))
             dz = ops.gemm_ex(dxb, self.wt(pre + '.fc2'), aux=z)
-            dzT = ops.transpose_colsum(dz, self.g(pre + '.mlp.fc1.bias').view(-1))
-            self._wgrad(dzT, ops.transpose_colsum(h2), self.g(pre + '.mlp.fc1.weight'))
+            self._wgrad_tn(dz, h2, self.g(pre + '.mlp.fc1.weight'), self.g(pre + '.mlp.fc1.bias').view(-1))
             dh2 = ops.gemm_ex(dz, self.wt(pre + '.fc1'))
             dmf, dmb = self._ln_bwd(xmid, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo)
-            dmT = ops.transpose_colsum(dmb, self.g(pre + '.attn.proj.bias').view(-1))
-            self._wgrad(dmT, ops.transpose_colsum(ao), self.g(pre + '.attn.proj.weight'))
+            self._wgrad_tn(dmb, ao, self.g(pre + '.attn.proj.weight'), self.g(pre + '.attn.proj.bias').view(-1))
             dao = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
             dqkv = ops.attn_dense_bwd(qkv, ao, dao, lse, B, NV)
-            dqT = ops.transpose_colsum(dqkv, self.g(pre + '.attn.qkv.bias').view(-1))
-            self._wgrad(dqT, ops.transpose_colsum(h1), self.g(pre + '.attn.qkv.weight'))
+            self._wgrad_tn(dqkv, h1, self.g(pre + '.attn.qkv.weight'), self.g(pre + '.attn.qkv.bias').view(-1))
             dh1 = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'))
             dif, _ = self._ln_bwd(xin, dh1, pre + '.norm1.weight', pre + '.norm1.bias', 1e-6, dres=dmf)
             return dif
@@ -530,8 +534,7 @@ class TrainEngine(object):
         check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, B, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
         self.g(ie + 'cls_token').view(-1).copy_(self.g(ie + 'pos_embed').view(NV, 768)[0])
         dpatch = ops.cast_bf16(dxe.view(B, NV, 768)[:, 1:].reshape(B * 576, 768).contiguous())
-        dpT = ops.transpose_colsum(dpatch, self.g(ie + 'patch_embed.proj.bias').view(-1))
-        self._wgrad(dpT, ops.transpose_colsum(patches), self.g(ie + 'patch_embed.proj.weight').view(768, 768))
+        self._wgrad_tn(dpatch, patches, self.g(ie + 'patch_embed.proj.weight').view(768, 768), self.g(ie + 'patch_embed.proj.bias').view(-1))
         self.reducer.stage_done('patch')
         return self.loss_buf[0], self.loss_buf[1]
 
