@@ -146,28 +146,36 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   }
 }
 
-// column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m y[m][n]
+// column sums of a bf16 matrix (bias gradients): out[n] += sum_m y[m][n].  A block covers 256 columns (16-byte loads, 32
+// lanes per row = one 512-byte segment) x 128 rows, 8 rows in flight per step; HBM-bound.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ y, int ldy, int M, int N, int rows_per_block,
                                                      float* __restrict__ out) {
-  __shared__ float red[4][128];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 128 + tx * 2;
+  __shared__ float red[8][256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + tx * 8;
   const int r0 = blockIdx.y * rows_per_block;
   int r1 = r0 + rows_per_block;
   r1 = r1 < M ? r1 : M;
-  float a0 = 0.f, a1 = 0.f;
-  if (c < N)
-    for (int r = r0 + ty; r < r1; r += 4) {
-      const unsigned v = *(const unsigned*)(y + (size_t)r * ldy + c);
-      a0 += __uint_as_float(v << 16);
-      a1 += __uint_as_float(v & 0xffff0000u);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const uint4 v = *(const uint4*)(y + (size_t)r * ldy + c);
+      a[0] += __uint_as_float(v.x << 16); a[1] += __uint_as_float(v.x & 0xffff0000u);
+      a[2] += __uint_as_float(v.y << 16); a[3] += __uint_as_float(v.y & 0xffff0000u);
+      a[4] += __uint_as_float(v.z << 16); a[5] += __uint_as_float(v.z & 0xffff0000u);
+      a[6] += __uint_as_float(v.w << 16); a[7] += __uint_as_float(v.w & 0xffff0000u);
     }
-  red[ty][tx * 2] = a0;
-  red[ty][tx * 2 + 1] = a1;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = a[e];
   __syncthreads();
-  if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < N) {
-    const int i = threadIdx.x;
-    atomicAdd(out + blockIdx.x * 128 + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+  const int i = threadIdx.x;
+  if (blockIdx.x * 256 + i < N) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc += red[k][i];
+    atomicAdd(out + blockIdx.x * 256 + i, sacc);
   }
 }
 
@@ -203,9 +211,9 @@ extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
 }
 
 extern "C" int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream) {
-  VC_REQUIRE(y && out && M > 0 && N > 0 && N % 2 == 0 && ldy % 2 == 0, "colsum: bad arguments");
-  const int rows_per_block = 512;
-  dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block);
+  VC_REQUIRE(y && out && M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0, "colsum: bad arguments");
+  const int rows_per_block = 128;
+  dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, ldy, M, N, rows_per_block, out);
   VC_LAUNCH_CHECK("colsum");
   return VITCAP_OK;
