@@ -387,6 +387,29 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
 int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches);
 int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, int* launches12);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input side of the path: the reference's test-time image transform, get_transform_vit_default
+ * (src/pipelines/uni_pipeline.py:1233-1256) = torchvision Resize(int(384 / crop_pct), PIL BICUBIC) -> CenterCrop(384)
+ * -> ToTensor -> Normalize(.5, .5), on decoded RGB uint8 HWC images that already sit in device memory.
+ * The resize is Pillow's 8-bit two-pass fixed-point resampling (libImaging/Resample.c, third-party, not under
+ * /root/reference) reproduced bit for bit; torchvision's size / crop arithmetic
+ * (transforms/functional.py resize, center_crop) is restated in vitcap_resized_geometry.
+ *   out: [B][3][crop][crop] fp32 or bf16 -- what vitcap_engine_greedy takes; out_u8 (optional) the cropped bytes.
+ *   The descriptor array is host memory; `rgb` members are device pointers (pitch in bytes, >= 3*width).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vitcap_image {
+  const uint8_t* rgb;
+  int height, width, pitch;
+} vitcap_image;
+size_t vitcap_image_preproc_workspace_bytes(const vitcap_image* imgs, int B, int resize_short, int crop);
+int vitcap_image_preproc(const vitcap_image* imgs, int B, int resize_short, int crop, int out_bf16, void* out,
+                         uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
+/* host-only helpers (no GPU): Pillow's bicubic weights for one axis -- bounds[out_size][2] = (first tap, tap count),
+ * kk[out_size][ksize] 22-bit fixed point -- and torchvision's resized size / centre-crop origin */
+int vitcap_resample_coeffs(int in_size, int out_size, int* ksize_out, int* bounds, int* kk, int kk_capacity);
+int vitcap_resized_geometry(int height, int width, int resize_short, int crop, int* out_h, int* out_w, int* crop_y0,
+                            int* crop_x0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,10 @@ class SampleParams(C.Structure):
                 ('seed', C.c_uint32)]
 
 
+class Image(C.Structure):
+    _fields_ = [('rgb', C.c_void_p), ('height', C.c_int), ('width', C.c_int), ('pitch', C.c_int)]
+
+
 class VitBlockW(C.Structure):
     _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
                                   'n1_g', 'n1_b', 'n2_g', 'n2_b')]
@@ -78,6 +82,10 @@ _SIGS = {
                                      C.c_float, C.c_size_t, vp]),
     'vitcap_gemm_tn': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_colsum_bf16': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'vitcap_image_preproc_workspace_bytes': (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
+    'vitcap_image_preproc': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
+    'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),
