@@ -63,3 +63,49 @@ def test_jpeg_rows_to_caption_batch(tmp_path):
     m = ImageCaptioning().load_recipe(0).eval()
     ids, lp = m({'image': batch.contiguous(), 'key': [r[0] for r in rows]})
     assert ids.shape == (4, 1, 20) and torch.isfinite(lp).all()
+
+
+def test_run_py_eval_on_image_tsv(tmp_path, monkeypatch):
+    """run.py -c yaml on the reference's data layout data/<name>/<split>.tsv: predictions come back as the reference's
+    predict TSV (+ .lineidx files), one row per key, equal to captioning the oracle-transformed images directly."""
+    import json
+    import yaml
+    from PIL import Image
+    import run
+    from oracle import image_oracle as IO
+    from vitcap_amd.imageio import decode_image
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.tsv import TSVFile, tsv_writer
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    (enc / 'vocab.txt').write_text('\\n'.join(toks) + '\\n')
+    rows = []
+    for i, (h, w) in enumerate(SIZES[:5]):
+        buf = io.BytesIO()
+        Image.fromarray(_img(h, w, 300 + i), 'RGB').save(buf, format='JPEG', quality=90)
+        rows.append(('coco_%d' % i, base64.b64encode(buf.getvalue())))
+    tsv_writer(rows, str(tmp_path / 'data' / 'toy' / 'test.tsv'))
+    sd = ImageCaptioning().load_recipe(0).state_dict()
+    ck = tmp_path / 'base.pt'
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'iteration': 0}, ck)
+    cfg = {'type': 'pipeline_eval_multi', 'all_test_data': [{'test_data': 'toy', 'test_split': 'test'}],
+           'param': {'full_expid': 'E', 'max_iter': 10, 'basemodel': str(ck), 'text_encoder_type': str(enc), 'tagemb': 'cls',
+                     'test_batch_size': 2, 'force_predict': True, 'crop_pct': 1.0, 'test_crop_size': 384,
+                     'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+    yf = tmp_path / 'exp.yaml'
+    yf.write_text(yaml.safe_dump(cfg))
+    kw = run.parse_general_args(['-c', str(yf)])
+    getattr(run, kw.pop('type'))(**kw)
+    pred = TSVFile(str(ck) + '.toy.test.predict.tsv')
+    assert [r[0] for r in pred] == [r[0] for r in rows]
+    m = ImageCaptioning().load_recipe(0).eval()
+    batch = torch.from_numpy(np.stack([IO.transform_reference(decode_image(r[1]))[1] for r in rows])).cuda().to(torch.bfloat16)
+    ids, lp = m({'image': batch, 'key': None})
+    for i, r in enumerate(pred):
+        cap = json.loads(r[1])[0]
+        want = ' '.join('w%d' % t for t in ids[i, 0].tolist() if t not in (0, 101, 102))
+        assert cap['caption'] == want, (i, cap['caption'], want)
+        assert abs(cap['conf'] - float(torch.exp(lp[i, 0]))) < 1e-5

@@ -47,7 +47,7 @@ class ImagePreprocessor(object):
         for i, im in enumerate(images):
             if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
                 raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
-            t = torch.from_numpy(np.ascontiguousarray(im)).to(self.dev, non_blocking=True)
+            t = torch.from_numpy(np.array(im, copy=True, order='C')).to(self.dev, non_blocking=True)
             dev_imgs.append(t)
             desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
         need = lib.vitcap_image_preproc_workspace_bytes(desc, B, self.resize_short, self.crop)

@@ -217,6 +217,21 @@ class CaptionUniPipeline(object):
                 if i % self.world == self.rank:
                     yield b
             return
+        tsv = self.test_image_tsv()
+        if tsv is not None:
+            # (key, base64 JPEG) rows; rank r takes rows r, r+world, ... like DistributedSampler(shuffle=False)
+            # (uni_pipeline.py:782-850); decode on the host, transform on the GPU (csrc/preproc.hip)
+            from .imageio import ImagePreprocessor, decode_image
+            from .tsv import TSVFile
+            rows = TSVFile(tsv)
+            pre = ImagePreprocessor(torch.device('cuda', self.local_rank), int(self.cfg.test_crop_size),
+                                    float(self.cfg.crop_pct or 1.0))
+            bs = int(self.cfg.test_batch_size)
+            mine = list(range(self.rank, len(rows), self.world))
+            for i in range(0, len(mine), bs):
+                recs = [rows[j] for j in mine[i:i + bs]]
+                yield {'image': pre([decode_image(r[-1]) for r in recs]), 'key': [r[0] for r in recs]}
+            return
         from . import weights as W
         n = int(self.cfg.synthetic_num_images or 8)
         bs = int(self.cfg.test_batch_size)
@@ -228,6 +243,19 @@ class CaptionUniPipeline(object):
             img = torch.from_numpy(W.gen_image_batch(done + b, seed)[done:])
             yield {'image': img, 'key': ['%d_%d' % (self.rank, done + i) for i in range(b)]}
             done += b
+
+    def test_image_tsv(self):
+        """Image rows of the test set: `test_image_tsv: <file>` or the reference layout data/<test_data>/<split>.tsv
+        (TSVDataset, tsv_io.py:1175-1230); None for `test_data: synthetic`."""
+        if self.cfg.test_image_tsv:
+            return self.cfg.test_image_tsv
+        data = self.cfg.test_data
+        if not data or data == 'synthetic':
+            return None
+        f = op.join(self.cfg.data_root or 'data', data, '{}.tsv'.format(self.cfg.test_split or 'test'))
+        if not op.isfile(f):
+            raise FileNotFoundError('test images not found: {} (rows of key <tab> base64 JPEG)'.format(f))
+        return f
 
     def predict_output_to_tsv_row(self, data, output):
         all_caps, all_confs = output[0], torch.exp(output[1])
@@ -241,28 +269,30 @@ class CaptionUniPipeline(object):
         dev = torch.device('cuda', self.local_rank)
         model.pack(dev)
         sub = predict_result_file if self.world == 1 else '{}_{}_{}.tsv'.format(predict_result_file, self.rank, self.world)
-        os.makedirs(op.dirname(sub) or '.', exist_ok=True)
-        with open(sub, 'w') as fp, torch.no_grad():
-            for batch in self.iter_test_batches():
-                batch = dict(batch)
-                batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
-                out = model(batch)
-                out = (out[0].cpu(), out[1].cpu())
-                for key, js in self.predict_output_to_tsv_row(batch, out):
-                    fp.write('{}\t{}\n'.format(key, js))
+        from .tsv import TSVFile, tsv_writer
+
+        def gen_rows():
+            with torch.no_grad():
+                for batch in self.iter_test_batches():
+                    batch = dict(batch)
+                    batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
+                    out = model(batch)
+                    out = (out[0].cpu(), out[1].cpu())
+                    for key, js in self.predict_output_to_tsv_row(batch, out):
+                        yield key, js
+        tsv_writer(gen_rows(), sub)                 # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
         if self.world > 1:
             import torch.distributed as dist
             dist.barrier()
             if self.rank == 0:      # concatenate and de-duplicate by key (uni_pipeline.py:816-831)
-                seen = set()
-                with open(predict_result_file, 'w') as fo:
+                def merged():
+                    seen = set()
                     for r in range(self.world):
-                        with open('{}_{}_{}.tsv'.format(predict_result_file, r, self.world)) as fi:
-                            for line in fi:
-                                k = line.split('\t', 1)[0]
-                                if k not in seen:
-                                    seen.add(k)
-                                    fo.write(line)
+                        for row in TSVFile('{}_{}_{}.tsv'.format(predict_result_file, r, self.world)):
+                            if row[0] not in seen:
+                                seen.add(row[0])
+                                yield row
+                tsv_writer(merged(), predict_result_file)
             dist.barrier()
         return predict_result_file
 
