@@ -81,7 +81,7 @@ def test_run_py_eval_on_image_tsv(tmp_path, monkeypatch):
     enc.mkdir()
     toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
     toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
-    (enc / 'vocab.txt').write_text('\\n'.join(toks) + '\\n')
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
     rows = []
     for i, (h, w) in enumerate(SIZES[:5]):
         buf = io.BytesIO()
