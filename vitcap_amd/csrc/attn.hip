@@ -18,7 +18,6 @@
 //     the prefill's packed qkv buffer) plus the text K/V cache; HBM-bound, 8 lanes per key row.
 #include "common.h"
 #include "rng.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -301,238 +300,6 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// attn_resident: the same attention for S <= 640 with the (image, head)'s WHOLE K and V^T resident in LDS.
-// The streaming kernel above is latency-bound (tools ablation: compute only 112 us, staging only 100 us, prologue /
-// epilogue skeleton 42 us of 150 us at B=64): five 128-query workgroups per (image, head) each re-stage all K/V tiles
-// behind a barrier per tile.  Here ONE 8-wave workgroup per (image, head) stages K (row-major) and V^T once -- 80 KiB +
-// 80 KiB = the full 160 KiB of the CU -- and then its waves run their 32-query groups over the 9 (+1 masked) key tiles
-// with no barrier and no global load in the loop; two waves per SIMD alternate between the MFMA and the softmax VALU
-// work.  LDS images are XOR-swizzled instead of padded (there is no room for padding):
-//   K  : key row r at (r>>1)*256 B, 16-byte chunk ((r&1)*8 + c) ^ ((r>>1)&15)         (c = 0..7 within the row)
-//   V^T: dim row d at d*1280 B, 16-byte chunk index k/8 XOR (d & 15) inside its aligned 16-chunk group
-// (a ds_read_b128 is served in 16-lane groups; both maps give every group 16 distinct 16-byte slots of one 256-byte
-//  bank window).  Left-over keys are handled by one masked MFMA tile (keys >= S read clamped rows and are masked).
-// ------------------------------------------------------------------------------------------------
-constexpr int RS_KEYS = 640;                       // padded key capacity
-constexpr int RS_K_BYTES = RS_KEYS * 128;          // 80 KiB
-constexpr int RS_VT_ROW = RS_KEYS * 2;             // 1280 B per dim row
-constexpr int RS_SMEM = RS_K_BYTES + HD * RS_VT_ROW;
-
-__device__ __forceinline__ int rs_k_off(int r, int c) { return (r >> 1) * 256 + ((((r & 1) * 8 + c) ^ ((r >> 1) & 15)) * 16); }
-__device__ __forceinline__ int rs_vt_off(int d, int kchunk) { return d * RS_VT_ROW + ((kchunk ^ (d & 15)) * 16); }
-
-// LDS fragment reads issued as opaque instructions: the compiler otherwise sinks every ds_read_b128 next to the MFMA
-// that consumes it (s_waitcnt lgkmcnt(0) in front of each of the 16 MFMAs of a tile: 16 exposed LDS round trips per
-// tile).  Issued in batches of 8 they overlap the softmax (V^T fragments) and the P.V MFMAs (next tile's K fragments).
-__device__ __forceinline__ bf16x8 lds_read16_async(const char* p) {
-  bf16x8 v;
-  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
-  return v;
-}
-#define LDS_WAIT_ALL() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-template <bool DROP>
-__global__ __launch_bounds__(512) void attn_resident_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
-                                                            uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                            int causal_from) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kl = smem;
-  char* vl = smem + RS_K_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qi = lane & 31, half = lane >> 5;
-  const int h = blockIdx.x % NH, b = blockIdx.x / NH;
-  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
-  const char* gbase = (const char*)base;
-  const int nfull = S / KT, rem = S - nfull * KT;
-  const int ntiles = nfull + (rem > 0 ? 1 : 0);
-
-  // ---- stage K and V^T: tiles in pairs, each half of the workgroup (256 threads) takes one tile of the pair
-  {
-    const int lt = tid & 255, th = tid >> 8;
-    const int k_key = lt >> 2, k_c = (lt & 3) * 2;                 // K: two 16-byte chunks per thread
-    const int v_kg = lt & 15, v_dg = lt >> 4;                      // V: 4 keys x 4 dims per thread
-    const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);   // permuted key slot
-    for (int tp = 0; tp < ntiles; tp += 2) {
-      const int t = tp + th;
-      if (t < ntiles) {
-        const int kv0 = t * KT;
-        int kr = kv0 + k_key;
-        const int krc = kr < S ? kr : S - 1;
-        const char* kq = gbase + ((size_t)krc * QKV_LD + 768) * 2 + k_c * 16;
-        const uint4 kreg0 = *(const uint4*)kq, kreg1 = *(const uint4*)(kq + 16);
-        uint2 vreg[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int vr = kv0 + v_kg * 4 + j;
-          vr = vr < S ? vr : S - 1;
-          vreg[j] = *(const uint2*)(gbase + ((size_t)vr * QKV_LD + 1536 + v_dg * 4) * 2);
-        }
-        *(uint4*)(kl + rs_k_off(kr, k_c)) = kreg0;
-        *(uint4*)(kl + rs_k_off(kr, k_c + 1)) = kreg1;
-        uint2 tr[4];
-        tr[0].x = __builtin_amdgcn_perm(vreg[1].x, vreg[0].x, 0x05040100);
-        tr[0].y = __builtin_amdgcn_perm(vreg[3].x, vreg[2].x, 0x05040100);
-        tr[1].x = __builtin_amdgcn_perm(vreg[1].x, vreg[0].x, 0x07060302);
-        tr[1].y = __builtin_amdgcn_perm(vreg[3].x, vreg[2].x, 0x07060302);
-        tr[2].x = __builtin_amdgcn_perm(vreg[1].y, vreg[0].y, 0x05040100);
-        tr[2].y = __builtin_amdgcn_perm(vreg[3].y, vreg[2].y, 0x05040100);
-        tr[3].x = __builtin_amdgcn_perm(vreg[1].y, vreg[0].y, 0x07060302);
-        tr[3].y = __builtin_amdgcn_perm(vreg[3].y, vreg[2].y, 0x07060302);
-        const int kslot = kv0 + v_pos;                               // first of 4 consecutive key slots (8 bytes)
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd)
-          *(uint2*)(vl + rs_vt_off(v_dg * 4 + dd, kslot >> 3) + (kslot & 7) * 2) = tr[dd];
-      }
-    }
-  }
-  __syncthreads();
-
-  f32x16 zero16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-  const uint32_t hstream = DROP ? vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) : 0u;
-
-  for (int q0 = w * 32; q0 < S; q0 += 256) {
-    const uint32_t hq = DROP ? (hstream ^ ((uint32_t)(q0 + qi) << 10) ^ (4u * half)) : 0u;
-    bf16x8 qf[4];
-    {
-      int qr = q0 + qi;
-      qr = qr < S ? qr : S - 1;
-      const bf16_t* qp = base + (size_t)qr * QKV_LD + half * 8;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
-    }
-    f32x16 ot[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
-    float m_i = -1e30f, l_i = 0.f;
-
-#define RS_ISSUE_K(t_)                                                                                          \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
-      const int kr_ = (t_) * KT + kt * 32 + qi;                                                                 \
-      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) kfr[kt * 4 + ds] = lds_read16_async(kl + rs_k_off(kr_, ds * 2 + half)); \
-    }
-#define RS_TILE(t_, MASKED_, HAS_NEXT_)                                                                         \
-    do {                                                                                                        \
-      f32x16 st[2];                                                                                             \
-      LDS_WAIT_ALL();                                   /* this tile's K fragments */                           \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                        \
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt * 4], qf[0], zero16, 0, 0, 0);                  \
-        _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                        \
-          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt * 4 + ds], qf[ds], st[kt], 0, 0, 0);          \
-      }                                                                                                         \
-      bf16x8 vfr[8];                                    /* V^T fragments: land while the softmax runs */        \
-      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                                          \
-        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                        \
-          vfr[kb * 2 + dt] = lds_read16_async(vl + rs_vt_off(dt * 32 + qi, (t_) * 8 + kb * 2 + half));          \
-      if (MASKED_) {                                                                                            \
-        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                        \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-            const int key = (t_) * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                            \
-            const bool vis_ = key < S && (causal_from <= 0 || key < causal_from || key <= q0 + qi);             \
-            st[kt][r] = vis_ ? st[kt][r] : -INFINITY;                                                           \
-          }                                                                                                     \
-      }                                                                                                         \
-      float mx0 = fmaxf(st[0][0], st[1][0]), mx1 = fmaxf(st[0][1], st[1][1]);                                   \
-      _Pragma("unroll") for (int r = 2; r < 16; r += 2) {                                                       \
-        mx0 = fmaxf(mx0, fmaxf(st[0][r], st[1][r]));                                                            \
-        mx1 = fmaxf(mx1, fmaxf(st[0][r + 1], st[1][r + 1]));                                                    \
-      }                                                                                                         \
-      float mx = fmaxf(mx0, mx1);                                                                               \
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                   \
-      const float m_new = fmaxf(m_i, ceilf(mx * c_log2));                                                       \
-      if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0) {                                                     \
-        const float alpha = fast_exp2(m_i - m_new);                                                             \
-        l_i *= alpha;                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-          ot[0][r] *= alpha;                                                                                    \
-          ot[1][r] *= alpha;                                                                                    \
-        }                                                                                                       \
-        m_i = m_new;                                                                                            \
-      }                                                                                                         \
-      const float nm = -m_i;                                                                                    \
-      float ps0 = 0.f, ps1 = 0.f;                                                                               \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
-        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                     \
-          const float p0 = fast_exp2(fmaf(st[kt][r], c_log2, nm));                                              \
-          const float p1 = fast_exp2(fmaf(st[kt][r + 1], c_log2, nm));                                          \
-          st[kt][r] = p0;                                                                                       \
-          st[kt][r + 1] = p1;                                                                                   \
-          ps0 += p0;                                                                                            \
-          ps1 += p1;                                                                                            \
-        }                                                                                                       \
-      l_i += ps0 + ps1;                                                                                         \
-      if (DROP) {                                                                                               \
-        const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                         \
-        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                        \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-            const uint32_t kbits = (uint32_t)(kt * 32 + (r & 3) + 8 * (r >> 2));                                \
-            st[kt][r] = vc_lowbias32(hx ^ kbits) >= drop_thr ? st[kt][r] : 0.f;                                 \
-          }                                                                                                     \
-      }                                                                                                         \
-      LDS_WAIT_ALL();                                   /* V^T fragments */                                     \
-      if (HAS_NEXT_) { RS_ISSUE_K((t_) + 1); }          /* next tile's K fragments: land during P.V */          \
-      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                        \
-        const int kt = kb >> 1, ks = kb & 1;                                                                    \
-        bf16x8 pf;                                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];                       \
-        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                        \
-          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb * 2 + dt], pf, ot[dt], 0, 0, 0);              \
-      }                                                                                                         \
-    } while (0)
-
-    bf16x8 kfr[8];
-    RS_ISSUE_K(0);
-    for (int t = 0; t < nfull; ++t) {
-      if (t + 1 < ntiles) RS_TILE(t, false, true);
-      else RS_TILE(t, false, false);
-    }
-    if (rem > 0) RS_TILE(nfull, true, false);
-#undef RS_ISSUE_K
-#undef RS_TILE
-
-    const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
-    const float inv = DROP ? drop_scale / l_tot : 1.0f / l_tot;
-    const int q = q0 + qi;
-    if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);
-    if (q < S) {
-      bf16_t* op = out + ((size_t)b * ld_rows + q) * 768 + h * HD + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 o;
-          o.x = pack2bf(ot[dt][g * 4 + 0] * inv, ot[dt][g * 4 + 1] * inv);
-          o.y = pack2bf(ot[dt][g * 4 + 2] * inv, ot[dt][g * 4 + 3] * inv);
-          *(uint2*)(op + dt * 32 + g * 8) = o;
-        }
-    }
-  }
-}
-
-template <bool DROP>
-static int launch_resident(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float c, uint32_t seed,
-                           uint32_t thr, float rscale, int causal_from, hipStream_t s) {
-  auto kern = attn_resident_kernel<DROP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(NH * B), dim3(512), RS_SMEM, s, (const bf16_t*)qkv, (bf16_t*)out, lse, S, B, ld_rows, c, seed,
-                     thr, rscale, causal_from);
-  return 0;
-}
-
-static bool use_resident(int S) {
-  static const int on = [] { const char* e = getenv("VITCAP_ATTN_RESIDENT"); return e ? atoi(e) : 1; }();
-  return on && S <= RS_KEYS;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Decode step.  One workgroup (256 threads) per (sequence, head).  Keys: S_vis visual rows (packed
 // qkv buffer of the prefill), text rows 0..t-2 from the cache, text row t-1 (this step's row 0) and,
 // for query row 1 only, this step's row 1 ([MASK]).  8 lanes share one key row (16 B each).
@@ -683,10 +450,8 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
-  if (use_resident(S)) launch_resident<false>(qkv, out, nullptr, B, S, S, c, 0u, 0u, 1.0f, 0, (hipStream_t)stream);
-  else
-    hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                       (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0);
+  hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
@@ -700,13 +465,7 @@ extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* ls
              "attn_dense_train: causal_from %d must lie in the last key tile of S=%d", causal_from, S);
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
-  if (use_resident(S)) {
-    if (p_drop > 0.f)
-      launch_resident<true>(qkv, out, lse, B, S, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0),
-                            1.0f / (1.0f - p_drop), causal_from, (hipStream_t)stream);
-    else
-      launch_resident<false>(qkv, out, lse, B, S, ld_rows, c, 0u, 0u, 1.0f, causal_from, (hipStream_t)stream);
-  } else if (p_drop > 0.f)
+  if (p_drop > 0.f)
     hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
                        lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop),
                        causal_from);
