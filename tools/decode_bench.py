@@ -19,7 +19,7 @@ def rb(*s, sc=1.0): return ((torch.rand(*s, device='cuda') * 2 - 1) * sc).to(tor
 x = rb(R, 768); w_qkv = rb(2304, 768, sc=0.05); w_fc1 = rb(3072, 768, sc=0.05); w_ao = rb(768, 768, sc=0.05)
 w_fc2 = rb(768, 3072, sc=0.05); h = rb(R, 3072); bias = torch.rand(3072, device='cuda')
 for name, a, w, act in (('qkv', x, w_qkv, L.ACT_NONE), ('fc1', x, w_fc1, L.ACT_GELU_ERF)):
-    for hint in (1, 4):
+    for hint in (1, 13, 14, 15, 4):
         us = timeit(lambda: ops.gemm_bias_act(a, w, bias[:w.shape[0]], act=act, tile_hint=hint))
         print('%s hint %d: %.1f us' % (name, hint, us))
     for sk in (2, 3, 6):

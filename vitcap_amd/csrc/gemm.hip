@@ -44,7 +44,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
+template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
@@ -110,15 +110,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     t0 = blockIdx.y * p.kt_per_split;
     t1 = t0 + p.kt_per_split < nk ? t0 + p.kt_per_split : nk;
   }
-  if (t0 < t1) {
-    stage(0, t0 * BK);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
+  // NST LDS stages, prefetch distance NST-1: the small-M (decode) shapes are LDS-DMA-latency-bound -- a 64x64 tile has
+  // ~150 cycles of MFMA work per k-tile against ~800 cycles of DMA latency -- so three k-tiles are kept in flight and
+  // tile t is awaited with a counted vmcnt (the newer tiles' pieces stay outstanding).
+  constexpr int PIECES = BM / 32 + BN / 32;              // LDS-DMA instructions per wave per stage
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (t0 + i < t1) stage(i, (t0 + i) * BK);
 
   for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
-    if (t + 1 < t1) stage(buf ^ 1, (t + 1) * BK);
+    const int buf = (t - t0) % NST;
+    {
+      const int newer = t1 - 1 - t < NST - 2 ? t1 - 1 - t : NST - 2;   // k-tiles issued after tile t
+      if (NST > 2 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (NST > 2 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();      // tile t landed for every wave, and every wave finished tile t-1 (whose buffer is refilled now)
+    if (t + NST - 1 < t1) stage((t - t0 + NST - 1) % NST, (t + NST - 1) * BK);
     const char* la = smem + buf * BUF_BYTES + (wm * WM * 16 + frow) * 128;
     const char* lw = smem + buf * BUF_BYTES + A_BYTES + (wn * WN * 16 + frow) * 128;
 #pragma unroll
@@ -135,8 +144,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
   // epilogue: lane holds C[m][n..n+3], m = frow, n = fk*4 within each 16x16 tile
@@ -1134,8 +1141,9 @@ int launch_skinny(const GemmArgs& a, int act, int out_f32, int split_k, hipStrea
 template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
 int launch(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
-  constexpr int smem = 2 * (BM + BN) * 64 * 2;
-  auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES>;
+  constexpr int NST = (WM <= 2 && WN <= 2) ? 4 : 2;     // small tiles (decode shapes): 4 stages
+  constexpr int smem = NST * (BM + BN) * 64 * 2;
+  auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES, NST>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1230,6 +1238,13 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     return d->M <= 64 ? launch_skinny<2>(a, d->act, d->out_dtype, split_k, s)
                       : launch_skinny<4>(a, d->act, d->out_dtype, split_k, s);
   }
+  if (hint == 13) return dispatch<2, 1>(a, d->act, d->out_dtype, s);
+  if (hint == 14) return dispatch<1, 1>(a, d->act, d->out_dtype, s);
+  if (hint == 15) return dispatch<1, 2>(a, d->act, d->out_dtype, s);
+  // decode shapes (M = 2 x sequences): weights stream from HBM once, the kernel is latency-bound, so the smallest
+  // tiles (most workgroups, most bytes in flight) win: cold-weight 128x2304x768 takes 10.8 / 9.4 / 8.9 us with
+  // 64x64 / 64x32 / 32x32 tiles (tools/cold_gemm.py), against a ~4.5 us launch floor
+  if (hint == 0 && d->M <= 128) return dispatch<1, 1>(a, d->act, d->out_dtype, s);
   if (hint == 1 || (hint == 0 && d->M <= 256)) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
