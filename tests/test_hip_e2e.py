@@ -204,3 +204,20 @@ def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch):
     assert [r[0] for r in rows] == ['0_0', '0_1', '0_2']
     cap = json.loads(rows[0][1])[0]
     assert cap['caption'].startswith('w30341 w3203 w29703') and 0 < cap['conf'] < 1     # tokens of the golden caption
+
+
+def test_generate_async_pipeline_equals_generate(model):
+    """Two-slot batch pipeline (encode of batch i+1 overlapping the decode of batch i on a second stream): every batch's
+    ids / log-probs are bit-identical to the one-stream generate(), in order, across slot reuse and changing batch size."""
+    from vitcap_amd import weights as W
+    imgs = [torch.from_numpy(W.gen_image_batch(b, 100 + i)).cuda().to(torch.bfloat16) for i, b in enumerate((8, 8, 5, 8, 3, 8))]
+    want = [tuple(t.clone() for t in model.generate(im)) for im in imgs]
+    torch.cuda.synchronize()
+    pend = [model.generate_async(im) for im in imgs]
+    for (ids_w, lp_w), p in zip(want, pend):
+        ids, lp = p.result()
+        assert torch.equal(ids, ids_w) and torch.equal(lp, lp_w)
+    # non-blocking hand-over to the caller's stream
+    p = model.generate_async(imgs[0])
+    ids, lp = p.wait()
+    assert torch.equal(ids.clone(), want[0][0])

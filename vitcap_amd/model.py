@@ -44,6 +44,23 @@ def _build_tree(root, spec, tie_weights):
     return params
 
 
+class _Pending(object):
+    """Handle of one batch in flight in ImageCaptioning.generate_async."""
+
+    def __init__(self, ids, lp, event, keep):
+        self.ids, self.lp, self.event, self._keep = ids, lp, event, keep
+
+    def wait(self, stream=None):
+        """Makes `stream` (default: the current stream) wait for this batch, without blocking the host."""
+        (stream or torch.cuda.current_stream(self.ids.device)).wait_event(self.event)
+        return self.ids, self.lp
+
+    def result(self):
+        self.event.synchronize()
+        self._keep = None
+        return self.ids, self.lp
+
+
 class ImageCaptioning(nn.Module):
     """ViT-B/16-384 + tag head + 4-layer BERT caption decoder, greedy decode on MI355X."""
 
@@ -230,6 +247,50 @@ class ImageCaptioning(nn.Module):
         if want_tags:
             self.last_tags = (tag_logits, tag_topk)
         return ids, lp
+
+    def generate_async(self, image):
+        """Greedy captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
+        HIP stream while the 19 decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of ~630
+        small latency-bound kernels that leaves most of the chip idle; the encoder is MFMA-bound and has a tail at every
+        GEMM -- interleaved they fill each other's gaps (B=64: 22.2 -> 19.8 ms per batch, tools/pipe_bench.py).
+        Returns a handle; `.result()` waits for this batch only and gives (ids (B,1,20), logprobs (B,1)).  Results are
+        identical to generate()."""
+        if self._packed is None:
+            self.pack(image.device)
+        dev = self._packed[2]
+        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
+        assert image.dtype in (torch.float32, torch.bfloat16)
+        pipe = getattr(self, '_pipe', None)
+        if pipe is None:
+            pipe = self._pipe = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev), 'done': [None, None], 'n': 0}
+        slot = pipe['n'] % 2
+        pipe['n'] += 1
+        B = image.shape[0]
+        ws, need = self._workspace(B, dev, slot='pipe%d' % slot)
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        image.record_stream(pipe['enc'])
+        with torch.cuda.stream(pipe['enc']):
+            pipe['enc'].wait_event(ready)
+            if pipe['done'][slot] is not None:
+                pipe['enc'].wait_event(pipe['done'][slot])         # the slot's previous decode has drained
+            h = C.c_void_p(pipe['enc'].cuda_stream)
+            check(lib.vitcap_engine_encode(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16),
+                                           B, C.c_void_p(ws.data_ptr()), need, h), 'engine_encode')
+            check(lib.vitcap_engine_prefill(self._engine, B, C.c_void_p(ws.data_ptr()), need, h), 'engine_prefill')
+            filled = torch.cuda.Event()
+            filled.record(pipe['enc'])
+        with torch.cuda.stream(pipe['dec']):
+            pipe['dec'].wait_event(filled)
+            ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
+            lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+            check(lib.vitcap_engine_decode(self._engine, B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
+                                           C.c_void_p(lp.data_ptr()), C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
+            done = torch.cuda.Event()
+            done.record(pipe['dec'])
+        pipe['done'][slot] = done
+        return _Pending(ids, lp, done, image)
 
     def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0):
         """Beam search (num_keep_best = 1) -> (ids (B,1,20), logprobs (B,1)) like ViTCAP._generate_beam_search."""

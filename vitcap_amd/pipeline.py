@@ -271,14 +271,24 @@ class CaptionUniPipeline(object):
         sub = predict_result_file if self.world == 1 else '{}_{}_{}.tsv'.format(predict_result_file, self.rank, self.world)
         from .tsv import TSVFile, tsv_writer
 
+        te = model.test_extra_input
+        overlap = te.get('num_beams', 1) == 1 and not te.get('do_sample', False)
+
         def gen_rows():
+            pending = []                          # greedy: batch i decodes while batch i+1 is encoded (generate_async)
             with torch.no_grad():
                 for batch in self.iter_test_batches():
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
-                    out = model(batch)
-                    out = (out[0].cpu(), out[1].cpu())
-                    for key, js in self.predict_output_to_tsv_row(batch, out):
+                    pending.append((batch, model.generate_async(batch['image']) if overlap else model(batch)))
+                    while len(pending) > (1 if overlap else 0):
+                        b, out = pending.pop(0)
+                        out = out.result() if overlap else out
+                        for key, js in self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu())):
+                            yield key, js
+                for b, out in pending:
+                    out = out.result() if overlap else out
+                    for key, js in self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu())):
                         yield key, js
         tsv_writer(gen_rows(), sub)                 # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
         if self.world > 1:
