@@ -381,6 +381,10 @@ int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size
 int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
                       const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
                       float* x_f32, void* x_bf16, int rows, void* stream);
+/* Large GEMMs: 1 = persistent workgroups (default; best when the GEMM has the GPU to itself), 0 = one tile per workgroup
+ * (best when a second stream's small kernels should interleave, e.g. the two-slot batch pipeline).  Process-wide. */
+void vitcap_gemm_set_persistent(int on);
+
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */

@@ -1180,6 +1180,13 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
                               const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
                               void* stream);
 
+// Process-wide choice between the persistent and the one-tile-per-workgroup form of the 256x256 GEMM.  Alone on the
+// GPU the persistent form wins (+2..11 %); when another stream's small kernels should slip in between (the batch
+// pipeline of ImageCaptioning.generate_async) the non-persistent form wins, because a persistent grid owns every CU
+// for the whole GEMM (3277 vs 3133 img/s at B=64).
+static int g_gemm_persistent = 1;
+extern "C" void vitcap_gemm_set_persistent(int on) { g_gemm_persistent = on ? 1 : 0; }
+
 extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                                     void* C, const vitcap_gemm_desc* d, void* stream) {
   return vitcap_gemm_ex(A, W, bias, residual, C, d, nullptr, 0, nullptr, 0, stream);
@@ -1260,7 +1267,8 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   if (hint == 11) return launch_256<0, 0, false, 4 + 16 * 6>(a, s);  // ablation: DMA + barriers only
   // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %);
   // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
-  static const int use_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+  static const int env_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : -1; }();
+  const int use_persistent = env_persistent >= 0 ? env_persistent : g_gemm_persistent;
   // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
   if (hint == 0 && use_persistent && wide_ok && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);

@@ -239,6 +239,7 @@ class ImageCaptioning(nn.Module):
         tag_logits = torch.empty((B, L.VOCAB), dtype=torch.float32, device=dev) if want_tags else None
         tag_topk = torch.empty((B, 50), dtype=torch.int64, device=dev) if want_tags else None
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib.vitcap_gemm_set_persistent(1)
         check(lib.vitcap_engine_greedy(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16),
                                        B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
                                        C.c_void_p(lp.data_ptr()),
@@ -262,9 +263,13 @@ class ImageCaptioning(nn.Module):
         assert image.dtype in (torch.float32, torch.bfloat16)
         pipe = getattr(self, '_pipe', None)
         if pipe is None:
-            pipe = self._pipe = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev), 'done': [None, None], 'n': 0}
+            import os
+            prio = int(os.environ.get('VITCAP_DECODE_PRIORITY', '-1'))     # -1 = high: the latency-bound chain goes first
+            pipe = self._pipe = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
+                                 'done': [None, None], 'n': 0}
         slot = pipe['n'] % 2
         pipe['n'] += 1
+        lib.vitcap_gemm_set_persistent(0)       # let the other slot's decode kernels in between GEMM tiles
         B = image.shape[0]
         ws, need = self._workspace(B, dev, slot='pipe%d' % slot)
         cur = torch.cuda.current_stream(dev)
