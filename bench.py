@@ -175,10 +175,10 @@ def main():
                 cur.wait_stream(st_)
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         model.generate = generate_split
-    piped = bool(args.pipeline) and not args.graph and nstr == 1 and args.beams == 1
+    piped = bool(args.pipeline) and not args.graph and nstr == 1
     with torch.cuda.stream(stream):
         for _ in range(max(args.warmup, 1)):
-            ids, lp = model.generate_async(img).result() if piped else model.generate(img)
+            ids, lp = model.generate_async(img, args.beams).result() if piped else model.generate(img)
         stream.synchronize()
         if args.graph:
             graph = torch.cuda.CUDAGraph()
@@ -198,7 +198,7 @@ def main():
             if graph is not None:
                 graph.replay()
             elif piped:
-                pend = model.generate_async(img)
+                pend = model.generate_async(img, args.beams)
             else:
                 ids, lp = model.generate(img)
         if pend is not None:
@@ -252,13 +252,15 @@ def main():
     except Exception:
         traffic = None
     out = {
-        'metric': 'images/sec end-to-end greedy caption (20 tok), ViT-B/16-384',
+        'metric': 'images/sec end-to-end greedy caption (20 tok), ViT-B/16-384' if args.beams == 1 else
+                  'images/sec end-to-end beam=%d caption (20 tok), ViT-B/16-384' % args.beams,
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: ViT-B/16-384 greedy decode (20 tok), batch %d bf16 per GPU, '
-                               'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM' % B,
+        'config': {'workload': ('BASELINE configs[1]: ViT-B/16-384 greedy decode (20 tok), batch %d bf16 per GPU, ' % B if args.beams == 1
+                                else 'BASELINE configs[2]: ViT-B/16-384 beam=%d decode (20 tok), batch %d bf16 per GPU, ' % (args.beams, B)) +
+                               'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM',
                    'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy' if args.beams == 1 else 'beam%d' % args.beams, 'max_length': 20,
                    'parallelism': 'replicas x%d (no data-path collective)' % world,
                    'launch': 'hipGraph replay' if graph is not None else ('eager, 2-slot batch pipeline (encode of step i+1 || decode of step i)' if piped else 'eager'),

@@ -306,6 +306,10 @@ size_t vitcap_engine_workspace_bytes_beam(int B, int beams);
 int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
                        float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                        float* out_logprobs, void* stream);
+/* The decode phase of vitcap_engine_beam alone (after vitcap_engine_encode + vitcap_engine_prefill on the same
+ * workspace, sized with vitcap_engine_workspace_bytes_beam): lets a caller overlap it with the next batch's encoder. */
+int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, float length_penalty, void* workspace,
+                              size_t workspace_bytes, int64_t* out_ids, float* out_logprobs, void* stream);
 
 int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B,
                          void* workspace, size_t workspace_bytes,

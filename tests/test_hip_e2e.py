@@ -221,3 +221,13 @@ def test_generate_async_pipeline_equals_generate(model):
     p = model.generate_async(imgs[0])
     ids, lp = p.wait()
     assert torch.equal(ids.clone(), want[0][0])
+
+
+def test_generate_async_beam_equals_generate_beam(model):
+    from vitcap_amd import weights as W
+    imgs = [torch.from_numpy(W.gen_image_batch(3, 200 + i)).cuda().to(torch.bfloat16) for i in range(3)]
+    want = [tuple(t.clone() for t in model.generate_beam(im, 3)) for im in imgs]
+    pend = [model.generate_async(im, num_beams=3) for im in imgs]
+    for (ids_w, lp_w), p in zip(want, pend):
+        ids, lp = p.result()
+        assert torch.equal(ids, ids_w) and torch.equal(lp, lp_w)

@@ -127,6 +127,7 @@ _SIGS = {
     'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int]),
     'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
+    'vitcap_engine_beam_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -418,6 +418,16 @@ extern "C" int vitcap_engine_beam(vitcap_engine* e, const void* image, int image
   if (!out_ids || !out_logprobs) { vitcap_set_error("beam: null outputs"); return VITCAP_EINVAL; }
   CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
   CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
+  return vitcap_engine_beam_decode(e, B, beams, length_penalty, workspace, workspace_bytes, out_ids, out_logprobs, s);
+}
+
+extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, float length_penalty, void* workspace,
+                                         size_t workspace_bytes, int64_t* out_ids, float* out_logprobs, void* s) {
+  if (beams < 1 || beams > 8) { vitcap_set_error("beam: num_beams must be 1..8 (got %d)", beams); return VITCAP_EINVAL; }
+  const int NS = B * beams;
+  const Layout lo(B, NS, true);
+  CK(check(e, B, workspace, workspace_bytes, lo.off));
+  if (!out_ids || !out_logprobs) { vitcap_set_error("beam: null outputs"); return VITCAP_EINVAL; }
   g_cur = e;
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;

@@ -249,7 +249,7 @@ class ImageCaptioning(nn.Module):
             self.last_tags = (tag_logits, tag_topk)
         return ids, lp
 
-    def generate_async(self, image):
+    def generate_async(self, image, num_beams=1, length_penalty=1.0):
         """Greedy captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
         HIP stream while the 19 decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of ~630
         small latency-bound kernels that leaves most of the chip idle; the encoder is MFMA-bound and has a tail at every
@@ -271,7 +271,7 @@ class ImageCaptioning(nn.Module):
         pipe['n'] += 1
         lib.vitcap_gemm_set_persistent(0)       # let the other slot's decode kernels in between GEMM tiles
         B = image.shape[0]
-        ws, need = self._workspace(B, dev, slot='pipe%d' % slot)
+        ws, need = self._workspace(B, dev, slot='pipe%d' % slot, beams=num_beams if num_beams > 1 else 0)
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)
@@ -290,8 +290,13 @@ class ImageCaptioning(nn.Module):
             pipe['dec'].wait_event(filled)
             ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
             lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
-            check(lib.vitcap_engine_decode(self._engine, B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
-                                           C.c_void_p(lp.data_ptr()), C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
+            if num_beams > 1:
+                check(lib.vitcap_engine_beam_decode(self._engine, B, num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
+                                                    C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
+                                                    C.c_void_p(pipe['dec'].cuda_stream)), 'engine_beam_decode')
+            else:
+                check(lib.vitcap_engine_decode(self._engine, B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
+                                               C.c_void_p(lp.data_ptr()), C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
             done = torch.cuda.Event()
             done.record(pipe['dec'])
         pipe['done'][slot] = done

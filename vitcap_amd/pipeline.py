@@ -272,7 +272,8 @@ class CaptionUniPipeline(object):
         from .tsv import TSVFile, tsv_writer
 
         te = model.test_extra_input
-        overlap = te.get('num_beams', 1) == 1 and not te.get('do_sample', False)
+        overlap = not te.get('do_sample', False)
+        nb, lpn = int(te.get('num_beams', 1)), float(te.get('length_penalty', 1))
 
         def gen_rows():
             pending = []                          # greedy: batch i decodes while batch i+1 is encoded (generate_async)
@@ -280,7 +281,7 @@ class CaptionUniPipeline(object):
                 for batch in self.iter_test_batches():
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
-                    pending.append((batch, model.generate_async(batch['image']) if overlap else model(batch)))
+                    pending.append((batch, model.generate_async(batch['image'], nb, lpn) if overlap else model(batch)))
                     while len(pending) > (1 if overlap else 0):
                         b, out = pending.pop(0)
                         out = out.result() if overlap else out
