@@ -388,6 +388,7 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
 /* Large GEMMs: 1 = persistent workgroups (default; best when the GEMM has the GPU to itself), 0 = one tile per workgroup
  * (best when a second stream's small kernels should interleave, e.g. the two-slot batch pipeline).  Process-wide. */
 void vitcap_gemm_set_persistent(int on);
+int vitcap_gemm_get_persistent(void);
 
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);

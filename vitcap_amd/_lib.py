@@ -87,6 +87,7 @@ _SIGS = {
     'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'vitcap_gemm_set_persistent': (None, [C.c_int]),
+    'vitcap_gemm_get_persistent': (C.c_int, []),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),

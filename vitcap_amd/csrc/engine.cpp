@@ -13,6 +13,7 @@
 // The 50 tag slots of the text segment are attended by nothing and their outputs are discarded
 // (SURVEY.md headline 5), so they are not materialised; the tag head itself is still computed and exposed.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -37,6 +38,10 @@ struct vitcap_engine {
   bool bound = false;
   bool timing = false;
   vitcap_sample_params sampling = {0, 1.0f, 0, 1.0f, 0u};
+  // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
   size_t used = 0;
 };
@@ -60,7 +65,7 @@ struct Layout {
     return o;
   }
   // image-sized buffers (B images) first, so their offsets do not depend on the number of decode sequences
-  size_t patches, x, xt, h, qkv, mlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
+  size_t patches, x, xt, h, qkv, mlp, th, tqkv, tmlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
   // sequence-sized buffers (NS = B for greedy, B*beams for beam search)
   size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
@@ -75,6 +80,9 @@ struct Layout {
     h = take(b * SV * D * 2);
     qkv = take(b * NV * 3 * D * 2);
     mlp = take(b * SV * 4 * D * 2);
+    th = take(b * NV * D * 2);          // tag branch's own LN / qkv / MLP temporaries (it runs concurrently)
+    tqkv = take(b * NV * 3 * D * 2);
+    tmlp = take(b * NV * 4 * D * 2);
     vis_f = take(b * SV * D * 4);
     vis_b = take(b * SV * D * 2);
     for (int l = 0; l < 4; ++l) dqkv[l] = take(b * SV * 3 * D * 2);
@@ -173,6 +181,10 @@ int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int
 extern "C" int vitcap_engine_create(vitcap_engine** out) {
   if (!out) return VITCAP_EINVAL;
   *out = new (std::nothrow) vitcap_engine();
+  if (*out) {
+    const char* f = getenv("VITCAP_TAG_FORK");     // 0: keep the tag branch on the caller's stream
+    (*out)->fork_tag_branch = f ? atoi(f) != 0 : true;
+  }
   return *out ? VITCAP_OK : VITCAP_EINVAL;
 }
 extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
@@ -181,6 +193,9 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 
@@ -249,11 +264,8 @@ static int check(vitcap_engine* e, int B, void* ws, size_t ws_bytes, size_t need
   return VITCAP_OK;
 }
 
-static int vit_block(const vitcap_vit_block_w& w, float* x, char* ws, const Layout& lo, int B, void* s) {
+static int vit_block(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, void* mlp, int B, void* s) {
   const int M = B * NV;
-  void* h = ws + lo.h;
-  void* qkv = ws + lo.qkv;
-  void* mlp = ws + lo.mlp;
   CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
   CK(gemm(h, D, w.qkv_w, w.qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
   CK(vitcap_attn_dense_fwd(qkv, h, B, NV, 0.125f, s));
@@ -263,6 +275,8 @@ static int vit_block(const vitcap_vit_block_w& w, float* x, char* ws, const Layo
   CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
   return VITCAP_OK;
 }
+
+static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s);
 
 extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
                                     size_t workspace_bytes, void* s) {
@@ -286,7 +300,10 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
     CK(gemm_desc(ws + lo.patches, w.patch_w, w.patch_b, w.pos_embed + D, x, d, s));
   }
   CK(vitcap_cls_rows(w.cls_token, w.pos_embed, x, B, NV, s));
-  // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork
+  // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork.  Run the fork on a side stream when the large GEMMs are
+  // in their one-tile-per-workgroup form (batch pipeline) and the batch is small enough for tile-quantisation gaps to
+  // matter: B=64 pipelined +2.3 %; with persistent GEMMs or at B=512 it costs 1-2 % (measured), so it stays serial there.
+  const bool fork = e->fork_tag_branch && !vitcap_gemm_get_persistent() && B <= 128;
   for (int i = 0; i < 12; ++i) {
     if (i == 8) {
       if (hipMemcpyAsync(xt, x, (size_t)B * NV * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
@@ -294,10 +311,38 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
         return VITCAP_ELAUNCH;
       }
     }
-    CK(vit_block(w.blocks[i], x, ws, lo, B, s));
+    if (i == 8 && fork) {
+      // fork: the tag branch depends only on the copy of x made above
+      if (!e->side) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+          vitcap_set_error("encode: side stream creation failed");
+          return VITCAP_ELAUNCH;
+        }
+      }
+      if (hipEventRecord(e->ev_fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) {
+        vitcap_set_error("encode: fork failed");
+        return VITCAP_ELAUNCH;
+      }
+      CK(tag_branch(e, lo, ws, B, e->side));
+      if (hipEventRecord(e->ev_join, e->side) != hipSuccess) { vitcap_set_error("encode: join record failed"); return VITCAP_ELAUNCH; }
+    }
+    CK(vit_block(w.blocks[i], x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
   }
-  for (int i = 0; i < 4; ++i) CK(vit_block(w.tag_blocks[i], xt, ws, lo, B, s));
-  // a6: tag head on the tag branch CLS row
+  if (fork) {
+    if (hipStreamWaitEvent((hipStream_t)s, e->ev_join, 0) != hipSuccess) { vitcap_set_error("encode: join failed"); return VITCAP_ELAUNCH; }
+  } else {
+    CK(tag_branch(e, lo, ws, B, s));
+  }
+  return VITCAP_OK;
+}
+
+// a5 (tag fork) + a6: 4 tag blocks on the forked stream, then the tag head on the tag branch CLS row
+static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s) {
+  const vitcap_weights& w = e->w;
+  float* xt = (float*)(ws + lo.xt);
+  for (int i = 0; i < 4; ++i) CK(vit_block(w.tag_blocks[i], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
   CK(vitcap_gather_rows_bf16(xt, NV, ws + lo.pool_in, B, D, s));
   CK(gemm(ws + lo.pool_in, D, w.pooler_w, w.pooler_b, nullptr, 0, ws + lo.pooled, D, B, D, D, VITCAP_ACT_TANH,
           VITCAP_OUT_BF16, s));

@@ -1186,6 +1186,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
 // for the whole GEMM (3277 vs 3133 img/s at B=64).
 static int g_gemm_persistent = 1;
 extern "C" void vitcap_gemm_set_persistent(int on) { g_gemm_persistent = on ? 1 : 0; }
+extern "C" int vitcap_gemm_get_persistent(void) { return g_gemm_persistent; }
 
 extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                                     void* C, const vitcap_gemm_desc* d, void* stream) {
