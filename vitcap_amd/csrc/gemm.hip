@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, BUF_BYTES = 2 * A_BYTES;
   constexpr int ABL = PH >> 4;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
-  constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4;
+  constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4, NO_STORE = ABL & 8, NO_EPI = ABL & 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -579,8 +579,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   const int ncol = n0 + wn * 64 + ec;
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
+  if (NO_EPI) return;                 // ablation: no epilogue at all
   // residual rows are requested one chunk (8 iterations = 32 rows) ahead of their use
-  const bool col_ok = ncol < p.N;
+  const bool col_ok = ncol < p.N && !(NO_STORE && m0 >= 0);   // ablation: LDS staging and arithmetic but no global stores
   f32x4 rres[2][8];
 #define ROWS_OF(m_, orow_, rrow_)                                             \
   int orow_ = (m_), rrow_ = (m_);                                             \
@@ -598,6 +599,53 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
       rres[(c_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + ncol)        \
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};                                 \
     }                                                                                                        \
+  }
+  // bf16 output, plain rows, no residual / aux / pre-activation copy: 8 columns per lane, one 16-byte store (8 lanes = one
+  // 128-byte line of the output row) -- half the store instructions of the general path below
+  if constexpr (!OUT_F32 && !HAS_RES) {
+    if (!p.zout && !p.aux && p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
+      const int wr = lane >> 3, wc = (lane & 7) * 8;
+      const int ncw = n0 + wn * 64 + wc;
+      const bool okc = ncw < p.N && !(NO_STORE && m0 >= 0);
+      f32x4 b_lo = f32x4{0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+      if (p.bias && ncw < p.N) {
+        b_lo = *(const f32x4*)(p.bias + ncw);
+        b_hi = *(const f32x4*)(p.bias + ncw + 4);
+      }
+#pragma unroll
+      for (int hm = 0; hm < 2; ++hm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * 4 + i][j];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int rl = it * 8 + wr;
+          f32x4 v0 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4);
+          f32x4 v1 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4 + 16);
+          const int m = m0 + wm * 128 + hm * 64 + rl;
+          v0 += b_lo;
+          v1 += b_hi;
+          if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = gelu_erf(v0[e]);
+              v1[e] = gelu_erf(v1[e]);
+            }
+          }
+          if (m < p.M && okc) {
+            uint4 o;
+            o.x = pack2bf(v0[0], v0[1]);
+            o.y = pack2bf(v0[2], v0[3]);
+            o.z = pack2bf(v1[0], v1[1]);
+            o.w = pack2bf(v1[2], v1[3]);
+            *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncw) = o;
+          }
+        }
+      }
+      return;
+    }
   }
   ISSUE_RES(0);
 #pragma unroll
@@ -1266,6 +1314,8 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   if (hint == 9) return launch_256<0, 0, false, 4 + 16 * 4>(a, s);   // ablation: no MFMA
   if (hint == 10) return launch_256<0, 0, false, 4 + 16 * 3>(a, s);  // ablation: MFMA + barriers only
   if (hint == 11) return launch_256<0, 0, false, 4 + 16 * 6>(a, s);  // ablation: DMA + barriers only
+  if (hint == 16) return launch_256<0, 0, false, 4 + 16 * 8>(a, s);  // ablation: no global stores in the epilogue
+  if (hint == 17) return launch_256<0, 0, false, 4 + 16 * 16>(a, s); // ablation: no epilogue
   // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %);
   // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
   static const int env_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : -1; }();
