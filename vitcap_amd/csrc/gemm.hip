@@ -34,6 +34,7 @@ struct GemmArgs {
   int ldaux;
   bf16_t* zout;        // pre-activation copy (bias added, before the activation) for the backward; bf16 [M][ldz]
   int ldz;
+  int direct_epilogue; // 256x256 kernels: register-transpose epilogue (1) or the LDS-staged one (0)
   int split_k;         // > 1: blockIdx.y = split, ragged k-tile ranges, fp32 partial slabs, no epilogue
   int kt_per_split;
   size_t slab;
@@ -381,6 +382,106 @@ int dispatch_big(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 //   LDS reads complete (lgkmcnt(0)) before the barrier that ends a load segment;
 //   the next k-tile's DMA is awaited (vmcnt(0)) right before the barrier after which group A reads it.
 // ------------------------------------------------------------------------------------------------
+// ---- LDS-free epilogue of the 256x256 kernels -------------------------------------------------------------------
+// After the (operand-swapped) MFMAs a lane (frow = lane&15, fk = lane>>4) holds, for each of the wave's four 16-column
+// tiles j, the 4 columns j*16 + fk*4.. of row frow.  A 4x4 transpose between the lane-group index fk and the tile index
+// j -- two butterfly stages of v_permlane32_swap / v_permlane16_swap, pure VALU, no LDS round trip -- leaves the lane
+// with the 16 CONSECUTIVE columns fk*16.. of its row: 4 lanes cover the wave's whole 64-column row segment (one 128-byte
+// line in bf16, two in fp32) with 16-byte stores.  Replaces staging the accumulators through LDS (measured: the
+// non-store part of that epilogue was ~200 us of a 1.09 ms 295424x2304x768 GEMM).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+template <int NREG>
+__device__ __forceinline__ void lane_tile_transpose(unsigned (&r)[4][NREG]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const u32x2_t t = __builtin_amdgcn_permlane32_swap(r[c][k], r[c + 2][k], false, false);
+      r[c][k] = t[0];
+      r[c + 2][k] = t[1];
+    }
+#pragma unroll
+  for (int c = 0; c < 4; c += 2)
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const u32x2_t t = __builtin_amdgcn_permlane16_swap(r[c][k], r[c + 1][k], false, false);
+      r[c][k] = t[0];
+      r[c + 1][k] = t[1];
+    }
+}
+
+// acc[8][4]: the wave's 128 x 64 block (8 row tiles of 16, 4 column tiles of 16); row0/col0 = its origin in C
+template <int ACT, int OUT_F32, bool HAS_RES>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[8][4], const GemmArgs& p, int row0, int col0, int lane,
+                                                bool no_store) {
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = col0 + j * 16 + fk * 4;
+    bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ncol = col0 + fk * 16;                       // first of this lane's 16 consecutive columns after the transpose
+  const bool col_ok = ncol < p.N && !no_store;           // N % 16 == 0 on this path
+  f32x4 rres[2][4];
+#define ISSUE_RES_D(i_)                                                                                    \
+  if (HAS_RES) {                                                                                           \
+    const int m_ = row0 + (i_) * 16 + frow;                                                                \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+      rres[(i_) & 1][q] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)m_ * p.ldr + ncol + q * 4) \
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};                                \
+  }
+  ISSUE_RES_D(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i + 1 < 8) { ISSUE_RES_D(i + 1); }
+    const int m = row0 + i * 16 + frow;
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = acc[i][j] + bias4[j];
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+      }
+    }
+    if (OUT_F32) {
+      unsigned r[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[j][e] = __float_as_uint(v[j][e]);
+      lane_tile_transpose<4>(r);
+      if (m < p.M && col_ok) {
+        float* dst = (float*)p.C + (size_t)m * p.ldc + ncol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o = f32x4{__uint_as_float(r[q][0]), __uint_as_float(r[q][1]), __uint_as_float(r[q][2]), __uint_as_float(r[q][3])};
+          if (HAS_RES) o += rres[i & 1][q];
+          *(f32x4*)(dst + q * 4) = o;
+        }
+      }
+    } else {
+      unsigned r[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j][0] = pack2bf(v[j][0], v[j][1]);
+        r[j][1] = pack2bf(v[j][2], v[j][3]);
+      }
+      lane_tile_transpose<2>(r);
+      if (m < p.M && col_ok) {
+        bf16_t* dst = (bf16_t*)p.C + (size_t)m * p.ldc + ncol;
+        uint4 o0, o1;
+        o0.x = r[0][0]; o0.y = r[0][1]; o0.z = r[1][0]; o0.w = r[1][1];
+        o1.x = r[2][0]; o1.y = r[2][1]; o1.z = r[3][0]; o1.w = r[3][1];
+        *(uint4*)dst = o0;
+        *(uint4*)(dst + 8) = o1;
+      }
+    }
+  }
+#undef ISSUE_RES_D
+}
+
 template <int ACT, int OUT_F32, bool HAS_RES, int PH>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
@@ -599,6 +700,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
       rres[(c_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + ncol)        \
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};                                 \
     }                                                                                                        \
+  }
+  // plain rows, no aux / pre-activation copy, bf16 output without residual or fp32 output: straight from registers
+  // measured (tools/gemm_res_bench.py, VITCAP_GEMM_DIRECT_EPILOGUE=0/1): +4-5 % for the GELU epilogue (fc1), neutral for
+  // plain bf16 (qkv), SLOWER for the fp32 + residual outputs (proj 0.078 -> 0.106 ms) -- so it is used for GELU only
+  if (p.direct_epilogue && ACT == VITCAP_ACT_GELU_ERF && !OUT_F32 && !HAS_RES && !p.zout && !p.aux && p.row_group == 0 &&
+      (p.N & 15) == 0 && (p.ldc & 7) == 0) {
+    epilogue_direct<ACT, OUT_F32, HAS_RES>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, NO_STORE);
+    return;
   }
   // bf16 output, plain rows, no residual / aux / pre-activation copy: 8 columns per lane, one 16-byte store (8 lanes = one
   // 128-byte line of the output row) -- half the store instructions of the general path below
@@ -1267,6 +1376,10 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.aux = (const bf16_t*)aux_bf16; a.ldaux = ldaux;
   a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
+  {
+    static const int direct = [] { const char* e = getenv("VITCAP_GEMM_DIRECT_EPILOGUE"); return e ? atoi(e) : 1; }();
+    a.direct_epilogue = direct;
+  }
   VC_REQUIRE(!(aux_bf16 && d->act != VITCAP_ACT_NONE), "gemm: aux (gelu') epilogue needs act == none");
   hipStream_t s = (hipStream_t)stream;
   // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K),
