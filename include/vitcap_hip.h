@@ -119,14 +119,17 @@ int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale,
  * logsumexp lse[B][12][S]; the backward returns dqkv (bf16, packed like qkv) from dout, recomputing the probabilities.
  * `dsum` is scratch fp32 [B][12][S]; `extra_dkv` (optional, bf16 [B*S][2][768]) is added to dK/dV. */
 int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float scale,
-                                float p_drop, uint32_t drop_seed, int causal_from, void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
+                                float p_drop, uint32_t drop_seed, int causal_from, int mask_from, void* stream);   /* ld_rows >= S: rows per image in qkv/out (decoder: 598 = 578 visual + 20 text) */
 int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                           const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, float p_drop,
-                          uint32_t drop_seed, int causal_from, void* stream);
+                          uint32_t drop_seed, int causal_from, int mask_from, void* stream);
 /* causal_from > 0: the decoder's joint sequence under teacher forcing, rows [causal_from visual | S - causal_from caption]
  * per image with the seq2seq mask of dataset.py:377-390 + ..._bertemb.py:57-85: a visual row attends visual rows only,
  * caption row q attends every visual row and caption rows <= q.  All caption keys must fall in the last 64-key tile
- * (578 = 9*64 + 2 for ViT-B/16-384).  causal_from = 0: unmasked (ViT blocks). */
+ * (578 = 9*64 + 2 for ViT-B/16-384).  causal_from = 0: unmasked (ViT blocks).
+ * mask_from > 0 (sampled-sequence log-probabilities with gradient, the SCST step): rows [mask_from, S) are [MASK] probe rows,
+ * probe j sees the visual rows, caption tokens 0..j and itself, and is seen by nobody else -- the rows one decode
+ * step's [MASK] query attends (modeling_bert.py:846-876), for all 19 steps in one pass. */
 /* p_drop > 0 (decoder layers in training, attention_probs_dropout_prob of BertSelfAttention, modeling_bert.py:330-333):
  * the probabilities entering P.V are dropped with probability p_drop and the survivors scaled by 1/(1-p_drop); the
  * keep decision of (query row q, key row k) of image b, head h is the counter hash vc_drop_keep() of csrc/rng.h on
@@ -170,8 +173,11 @@ int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mask_token,
 int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_lp, float* cnt, int B, int max_len,
                        int bos, int pad, void* stream);
 int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
-                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
+                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last, int B, int t,
                        int max_len, int eos, int pad, void* stream);
+/* raw_last (optional, int64 [B]): at t == max_len-1 the token actually chosen at the last position, before it is
+ * overwritten by [SEP] for unfinished rows -- the returned log-prob is that of the chosen token (modeling_utils.py:
+ * 850-877), which a teacher-forced re-computation of the sequence probability needs. */
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling variant of the step above (do_sample=True, modeling_utils.py:839-846 + top_k_top_p_filtering
@@ -189,7 +195,7 @@ typedef struct vitcap_sample_params {
   uint32_t seed;
 } vitcap_sample_params;
 int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
-                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
+                       float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last, int B, int t,
                        int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -352,11 +358,14 @@ int vitcap_reduce_slabs(const float* slabs, size_t slab_stride, int S, float* ou
 int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream);
 /* BertEmbeddings backward: scatter-add into word / position / token-type gradient tables (modeling_bert.py:230-234) */
 int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
-                     int rows, void* stream);
+                     int rows, int pos_wrap, void* stream);
 /* BertCaptioningLoss (label-smoothed KL, mean over rows; modeling_bert.py:661-690): loss_sum += loss; dlogits (bf16,
  * [rows][ldd], columns >= V zeroed) = d loss / d logits */
-int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target, float eps, int rows, float* loss_sum,
-                      void* dlogits_bf16, int ldd, void* stream);
+int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target, float eps, int rows,
+                      const float* row_weight, float* loss_sum, void* dlogits_bf16, int ldd, void* stream);
+/* row_weight (optional, fp32 [rows]): row i contributes row_weight[i] * loss_i instead of loss_i / rows -- with eps = 0
+ * the self-critical policy-gradient loss -mean_s(reward_s * mean_t log p(token_st)) (ScstRewardCriterion.forward,
+ * src/tools/captioning/utils_caption_evaluate.py:172-202) with row_weight = reward_s / (n_s * S). */
 /* FocalLossWithLogitsNegLoss(alpha, gamma=1).sum()  (loss.py:5-22, modeling_bert.py:789-791) */
 int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const float* label, float alpha, float* out, int B,
                           void* stream);
@@ -384,7 +393,8 @@ int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size
 /* BertEmbeddings.forward on all rows of the teacher-forced caption (modeling_bert.py:222-237): optional pre-LN sum */
 int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
                       const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
-                      float* x_f32, void* x_bf16, int rows, void* stream);
+                      float* x_f32, void* x_bf16, int rows, int pos_wrap, void* stream);
+/* pos_wrap > 0: rows r >= pos_wrap of a sequence are [MASK] probe rows at positions r - pos_wrap + 1 (0 = positions = r) */
 /* Large GEMMs: 1 = persistent workgroups (default; best when the GEMM has the GPU to itself), 0 = one tile per workgroup
  * (best when a second stream's small kernels should interleave, e.g. the two-slot batch pipeline).  Process-wide. */
 void vitcap_gemm_set_persistent(int on);

@@ -912,3 +912,44 @@ def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, c
     state['lr_scale'] = max(0.0, float(max_iter - step) / float(max(1.0, max_iter)))     # WarmupLinearSchedule, warmup 0
     return {'loss': float(loss), 'tag_loss': float(tag_loss), 'grad_norm': total, 'grads': grads, 'params': new,
             'state': state}
+
+
+# --------------------------------------------------------------------------------------------
+# SCST (BASELINE config 5): spec at src/pipelines/tagger_caption_uni_pipeline_expanding.py:404-478 (dead code as shipped),
+# generation = modeling_utils.py:768-886 with do_sample, criterion = utils_caption_evaluate.py:162-202.
+def sequence_logprob_as_written(sd, image, sample_ids, tagemb='cls', max_length=MAX_LEN, reuse_encoder=True):
+    """Differentiable mean log-probability of GIVEN sampled sequences, computed the way the generator produced them: one
+    full forward per generated position on [tokens so far, MASK, tag slots] (greedy_as_written's loop with the sampled
+    token fed back instead of the argmax), log_softmax gathered at the sampled token, averaged over the positions at
+    which the sequence was still unfinished (modeling_utils.py:850-877).  sample_ids (B,20) starting with [CLS]."""
+    B = image.shape[0]
+    img_feats = patch_embed(sd, image)
+    input_ids0, am = test_text_inputs(B, max_length)
+    full_mask = construct_attn_mask(am, img_feats.shape[1])
+    od_label_ids = input_ids0[:, max_length:]
+    od_len = od_label_ids.shape[1]
+    pos = torch.cat([torch.arange(max_length), torch.arange(max_length, max_length + od_len)])
+    full_pos = pos.unsqueeze(0).expand(B, -1)
+    full_tt = torch.zeros(B, max_length + od_len, dtype=torch.long)
+    enc = split_encoder(sd, img_feats) if reuse_encoder else None
+    unfinished = torch.ones(B, dtype=torch.long)
+    lps, unfs = [], []
+    for cur_len in range(1, max_length):
+        step_ids = torch.cat([sample_ids[:, :cur_len], torch.full((B, 1), MASK, dtype=torch.long)], dim=1)
+        curr = step_ids.shape[1]
+        mask = _remove_rows_cols(full_mask, curr, max_length, curr, max_length)
+        tt = torch.cat([full_tt[:, :curr], full_tt[:, max_length:]], dim=1)
+        pp = torch.cat([full_pos[:, :curr], full_pos[:, max_length:]], dim=1)
+        logits = encode_forward_infer(sd, torch.cat([step_ids, od_label_ids], dim=1), img_feats, mask, pp, tt, tagemb, enc=enc)
+        tok = sample_ids[:, cur_len]
+        lps.append(torch.gather(F.log_softmax(logits[:, cur_len, :], dim=-1), -1, tok.unsqueeze(-1)).squeeze(-1))
+        unfs.append(unfinished)
+        unfinished = unfinished * tok.ne(EOS).long() * tok.ne(PAD).long() if False else unfinished * tok.ne(EOS).long()
+    lp = torch.stack(lps, 1)
+    uh = torch.stack(unfs, 1).float()
+    return (lp * uh).sum(1) / uh.sum(1)
+
+
+def scst_loss_as_written(sd, image, sample_ids, reward):
+    """ScstRewardCriterion.forward: mean over samples of -(logprob * (score - baseline)); reward = score - baseline."""
+    return -(sequence_logprob_as_written(sd, image, sample_ids) * reward).mean()

@@ -278,3 +278,49 @@ def test_two_process_data_parallel_step(tmp_path):
     assert abs(n0 - eng.grad_norm()) < 2e-2 * n0
     d = (eng.P.cpu() - p0).abs()
     assert float(d.mean()) < 2e-6, float(d.mean())          # Adam's sign-like first step: near-zero gradients may flip
+
+
+def test_scst_logprob_gradient_vs_oracle(sd_t):
+    """Self-critical step (BASELINE config 5): loss = -mean_s(reward_s * mean_t log p(sampled token)) and its gradient.
+    Device: ONE pass over [578 visual | 20 token rows | 19 [MASK] probe rows]; oracle: the generator's 19 full forwards
+    (one per generated position) with autograd, as ScstRewardCriterion + _generate_no_beam_search define it.
+    Sequences: a greedy caption with its true last token, and one that ends early ([SEP] at position 7, PAD after)."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    B = 2
+    img = torch.from_numpy(W.gen_image_batch(B, 1234))
+    with torch.no_grad():
+        ids, _, tr = O.greedy_as_written(sd_t, img, reuse_encoder=True, return_trace=True)
+    sample = ids[:, 0].clone()
+    sample[:, -1] = tr[-1]['logits_row'].argmax(-1)            # the chosen last token, not the forced [SEP]
+    sample[1, 7] = 102
+    sample[1, 8:] = 0
+    reward = torch.tensor([0.7, -0.4])
+    leaves, seen = {}, {}
+    for k, t in sd_t.items():
+        if id(t) not in seen:
+            seen[id(t)] = t.detach().clone().requires_grad_(True)
+        leaves[k] = seen[id(t)]
+    loss_o = O.scst_loss_as_written(leaves, img, sample, reward)
+    loss_o.backward()
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    loss, _ = eng.forward_backward({'image': img.cuda(), 'sample_ids': sample.cuda(), 'sample_weight': (reward / B).cuda()})
+    torch.cuda.synchronize()
+    print('scst loss hip %.6f oracle %.6f' % (float(loss), float(loss_o)))
+    assert abs(float(loss) - float(loss_o)) < 3e-3
+    uniq, worst = {}, []
+    for k, t in leaves.items():
+        uniq.setdefault(id(t), (k, t))
+    for k, t in uniq.values():
+        if t.grad is None:
+            continue
+        g_ref = t.grad
+        rel = float((eng.g(k).cpu() - g_ref).norm() / (g_ref.norm() + 1e-20))
+        worst.append((rel, k, float(g_ref.norm())))
+    worst.sort(reverse=True)
+    for rel, k, nrm in worst[:6]:
+        print('%.3e  %-70s |g|=%.3e' % (rel, k, nrm))
+    bad = [(r, k) for r, k, nrm in worst if r > 5e-2 and nrm > 1e-6]
+    assert not bad, bad[:5]

@@ -155,6 +155,42 @@ def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
     assert _rel(bias, y.float().sum(0)) < 1e-5
 
 
+def test_attn_probe_rows_forward_backward(ops):
+    """[578 visual | 20 token rows | 19 [MASK] probe rows]: probe j sees visual + tokens 0..j + itself and nobody sees the
+    probes (mask_from): forward and both backward kernels against autograd through the explicit mask."""
+    B, SV, T, TP = 2, 578, 20, 19
+    Lr = SV + T + TP
+    qkv = _bf(_rand((B, Lr, 2304), 41, 1.5))
+    dout = _bf(_rand((B, Lr, 768), 42))
+    dout[:, :SV] = 0                                     # as in the SCST step, only text rows carry gradient at the top layer
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = x.view(B, Lr, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    mask = torch.zeros(Lr, Lr)
+    mask[:, :SV] = 1
+    mask[SV:SV + T, SV:SV + T] = torch.tril(torch.ones(T, T))
+    for j in range(TP):
+        mask[SV + T + j, SV:SV + j + 1] = 1              # tokens 0..j
+        mask[SV + T + j, SV + T + j] = 1                 # itself
+    s = q @ k.transpose(-1, -2) * 0.125 + (1 - mask) * -10000.0
+    o_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Lr, 768)
+    o_ref.backward(dout.float())
+    want = x.grad
+    qd = qkv.reshape(B * Lr, 2304).cuda().contiguous()
+    dod = dout.reshape(B * Lr, 768).cuda().contiguous()
+    kw = dict(causal_from=SV, mask_from=SV + T)
+    out, lse = ops.attn_dense_train(qd, B, Lr, **kw)
+    for name, sl in (('visual', slice(0, SV)), ('token', slice(SV, SV + T)), ('probe', slice(SV + T, Lr))):
+        r = _rel(out.view(B, Lr, 768)[:, sl], o_ref[:, sl])
+        print('fwd', name, '%.3e' % r)
+        assert r < 6e-3, name
+    got = ops.attn_dense_bwd(qd, out, dod, lse, B, Lr, **kw).view(B, Lr, 2304).float().cpu()
+    for name, lo in (('dq', 0), ('dk', 768), ('dv', 1536)):
+        for rn, sl in (('visual', slice(0, SV)), ('token', slice(SV, SV + T)), ('probe', slice(SV + T, Lr))):
+            r = _rel(got[:, sl, lo:lo + 768], want[:, sl, lo:lo + 768])
+            print(name, rn, 'rel L2 %.3e  (|want| %.3e)' % (r, float(want[:, sl, lo:lo + 768].norm())))
+            assert r < 1.5e-2 or float(want[:, sl, lo:lo + 768].norm()) < 1e-6, (name, rn)
+
+
 def test_losses(ops, sd_t):
     from oracle import vitcap_oracle as O
     from vitcap_amd._lib import lib, check
@@ -168,7 +204,7 @@ def test_losses(ops, sd_t):
     dl = torch.empty(n, ld, device='cuda', dtype=torch.bfloat16)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ld_, tg_ = logits.cuda(), tgt.cuda()
-    check(lib.vitcap_ls_kl_loss(C.c_void_p(ld_.data_ptr()), ld, V, C.c_void_p(tg_.data_ptr()), 0.1, n,
+    check(lib.vitcap_ls_kl_loss(C.c_void_p(ld_.data_ptr()), ld, V, C.c_void_p(tg_.data_ptr()), 0.1, n, None,
                                 C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()), ld, s), 'ls_kl')
     assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want)) + 1e-5
     assert _rel(dl[:, :V], lg.grad) < 4e-3 and float(dl[:, V:].float().abs().sum()) == 0.0

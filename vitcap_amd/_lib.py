@@ -74,8 +74,8 @@ _SIGS = {
     'vitcap_layernorm_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_reduce_slabs': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp]),
     'vitcap_cast_bf16': (C.c_int, [vp, vp, C.c_size_t, vp]),
-    'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
-    'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, C.c_int, vp]),
+    'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_focal_loss_sum': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp]),
     'vitcap_sumsq': (C.c_int, [vp, C.c_size_t, vp, vp]),
     'vitcap_adamw_multi': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
@@ -91,22 +91,22 @@ _SIGS = {
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),
-    'vitcap_embed_rows': (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, vp]),
+    'vitcap_embed_rows': (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'vitcap_attn_dense_fwd_train': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32,
-                                              C.c_int, vp]),
+                                              C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
-                                        C.c_uint32, C.c_int, vp]),
+                                        C.c_uint32, C.c_int, C.c_int, vp]),
     'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, vp]),
     'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,
                                     C.c_int, vp]),
     'vitcap_greedy_init': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    'vitcap_greedy_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+    'vitcap_greedy_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
-    'vitcap_sample_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+    'vitcap_sample_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp, vp]),
     'vitcap_engine_set_sampling': (C.c_int, [vp, vp]),
     'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),

@@ -36,7 +36,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                         int causal_from) {
+                                                         int causal_from, int mask_from) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
       _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
           const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                                    \
-          const bool vis_ = key < S && (causal_from <= 0 || key < causal_from || key <= q0 + qi);               \
+          const bool vis_ = joint_visible(q0 + qi, key, S, causal_from, mask_from);                             \
           st[kt][r] = vis_ ? st[kt][r] : -INFINITY;                                                             \
         }                                                                                                       \
     }                                                                                                           \
@@ -451,27 +451,30 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
   hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0);
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
 
 extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
-                                           float scale, float p_drop, uint32_t drop_seed, int causal_from, void* stream) {
+                                           float scale, float p_drop, uint32_t drop_seed, int causal_from, int mask_from,
+                                           void* stream) {
   VC_REQUIRE(qkv && out && lse && B > 0 && S > 0 && ld_rows >= S, "attn_dense_train: bad arguments");
   VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_train: p_drop %g / ld_rows %d out of range",
              (double)p_drop, ld_rows);
   VC_REQUIRE(causal_from == 0 || (causal_from >= (S / KT) * KT && causal_from <= S),
              "attn_dense_train: causal_from %d must lie in the last key tile of S=%d", causal_from, S);
+  VC_REQUIRE(mask_from == 0 || (causal_from > 0 && mask_from > causal_from && mask_from <= S),
+             "attn_dense_train: mask_from %d must lie in (causal_from %d, S %d]", mask_from, causal_from, S);
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);
   if (p_drop > 0.f)
     hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
                        lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop),
-                       causal_from);
+                       causal_from, mask_from);
   else
     hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from);
+                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }

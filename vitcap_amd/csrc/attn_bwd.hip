@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
                                                           int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                          uint32_t drop_thr, float drop_scale, int causal_from) {
+                                                          uint32_t drop_thr, float drop_scale, int causal_from, int mask_from) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
           float p = fast_exp2(fmaf(st[kt][r], c_log2, -Lq));
           if (masked) {
             const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            p = (key < S && (causal_from <= 0 || key < causal_from || key <= q0 + qi)) ? p : 0.f;
+            p = joint_visible(q0 + qi, key, S, causal_from, mask_from) ? p : 0.f;
           }
           float dp = dpt[kt][r];
           if (DROP) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
                                                            int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                           uint32_t drop_thr, float drop_scale, int causal_from) {
+                                                           uint32_t drop_thr, float drop_scale, int causal_from, int mask_from) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             float p = fast_exp2(fmaf(st[r], c_log2, -L4[e]));
             if (masked) {
               const int q = t * KT + qt * 32 + g * 8 + 4 * half + e;
-              p = (q < S && (causal_from <= 0 || key0 + ki < causal_from || q >= key0 + ki)) ? p : 0.f;
+              p = (q < S && joint_visible(q, key0 + ki, S, causal_from, mask_from)) ? p : 0.f;
             }
             float dp = dpt[r], pd = p;
             if (DROP) {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                                      const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
-                                     float p_drop, uint32_t drop_seed, int causal_from, void* stream) {
+                                     float p_drop, uint32_t drop_seed, int causal_from, int mask_from, void* stream) {
   VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0 && ld_rows >= S, "attn_dense_bwd: bad arguments");
   VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_bwd: p_drop %g / ld_rows %d out of range",
              (double)p_drop, ld_rows);
@@ -512,11 +512,11 @@ extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const voi
   do {                                                                                                                    \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
                        (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs, causal_from);                                                                  \
+                       drop_seed, thr, rs, causal_from, mask_from);                                                       \
     VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
                        (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
-                       ld_rows, c, scale, drop_seed, thr, rs, causal_from);                                               \
+                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from);                                    \
     VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
   } while (0)
   if (p_drop > 0.f) VC_BWD_LAUNCH(true);

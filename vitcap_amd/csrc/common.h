@@ -94,3 +94,16 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Visibility of key row k to query row q in the decoder's joint sequence under teacher forcing, rows laid out as
+// [0, cf) visual | [cf, mf) caption tokens | [mf, S) [MASK] probes (mf = 0: no probe rows):
+//   visual rows see visual rows only; token row i sees visual + tokens <= i (seq2seq mask, dataset.py:377-390);
+//   probe row j (the [MASK] the generator appends at position j+1, modeling_bert.py:846-876) sees visual, tokens <= j
+//   and itself -- exactly the rows one decode step's [MASK] query attends.  cf = 0: plain dense attention.
+__device__ __forceinline__ bool joint_visible(int q, int k, int S, int cf, int mf) {
+  const bool plain = cf <= 0 || k < cf;                                   // visual key (or no mask at all)
+  const bool causal = k <= q;                                             // token row / token key (q >= cf follows from k >= cf)
+  const bool probe_q = mf > 0 && q >= mf, probe_k = mf > 0 && k >= mf;
+  const bool text = probe_k ? (k == q) : (probe_q ? (k - cf) <= (q - mf) : causal);
+  return k < S && (plain || text);
+}

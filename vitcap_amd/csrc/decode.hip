@@ -39,8 +39,8 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
                                                            int64_t* __restrict__ ids, int32_t* __restrict__ unf,
                                                            float* __restrict__ sum_lp, float* __restrict__ cnt,
                                                            float* __restrict__ logprob_out,
-                                                           float* __restrict__ margin_out, int t, int max_len, int eos,
-                                                           int pad) {
+                                                           float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
+                                                           int t, int max_len, int eos, int pad) {
   __shared__ ArgMax s_am[16];
   __shared__ float s_second[16];
   __shared__ float s_sum[16];
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
     int nu = u * (add != eos ? 1 : 0);
     int64_t outtok = add;
     if (t == max_len - 1) {
+      if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
       if (nu) outtok = eos;                          // modeling_utils.py:870-871
       logprob_out[b] = s / c;                        // modeling_utils.py:873-877
     }
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
                                                            int64_t* __restrict__ ids, int32_t* __restrict__ unf,
                                                            float* __restrict__ sum_lp, float* __restrict__ cnt,
                                                            float* __restrict__ logprob_out,
-                                                           float* __restrict__ margin_out, int t, int max_len, int eos,
-                                                           int pad, float temperature, int top_k, float top_p,
-                                                           uint32_t seed) {
+                                                           float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
+                                                           int t, int max_len, int eos, int pad, float temperature, int top_k,
+                                                           float top_p, uint32_t seed) {
   __shared__ unsigned long long s_hist[256];
   __shared__ unsigned long long s_acc;
   __shared__ uint32_t s_sel;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     int nu = u * (add != eos ? 1 : 0);
     int64_t outtok = add;
     if (t == max_len - 1) {
+      if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
       if (nu) outtok = eos;
       logprob_out[b] = s / c;
     }
@@ -547,12 +549,12 @@ extern "C" int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_
 }
 
 extern "C" int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
-                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
-                                  int max_len, int eos, int pad, void* stream) {
+                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last,
+                                  int B, int t, int max_len, int eos, int pad, void* stream) {
   VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out, "greedy_step: null pointer");
   VC_REQUIRE(B > 0 && V > 0 && ldl >= V && t >= 1 && t < max_len, "greedy_step: bad sizes (t=%d)", t);
   hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
-                     sum_lp, cnt, logprob_out, margin_out, t, max_len, eos, pad);
+                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad);
   VC_LAUNCH_CHECK("greedy_step");
   return VITCAP_OK;
 }
@@ -625,8 +627,8 @@ extern "C" int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids
 }
 
 extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
-                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int B, int t,
-                                  int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
+                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last,
+                                  int B, int t, int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
   VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out && sp, "sample_step: null pointer");
   VC_REQUIRE(B > 0 && V > 0 && V <= SM_NPT * 1024 && ldl >= V && t >= 1 && t < max_len,
              "sample_step: bad sizes (V=%d t=%d)", V, t);
@@ -634,8 +636,8 @@ extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* 
              "sample_step: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature, sp->top_k,
              (double)sp->top_p);
   hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
-                     sum_lp, cnt, logprob_out, margin_out, t, max_len, eos, pad, sp->temperature, sp->top_k, sp->top_p,
-                     sp->seed);
+                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, sp->temperature, sp->top_k,
+                     sp->top_p, sp->seed);
   VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
 }

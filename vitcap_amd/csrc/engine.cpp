@@ -70,7 +70,7 @@ struct Layout {
   // sequence-sized buffers (NS = B for greedy, B*beams for beam search)
   size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
   size_t hd_f, hd_b, logits;
-  size_t ids, ids2, unf, sum_lp, cnt, margins, logprob;
+  size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok;
   size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok;
   Layout(int B, int NS, bool beam) {
     const size_t b = (size_t)B, n = (size_t)NS;
@@ -117,6 +117,7 @@ struct Layout {
     cnt = take(n * 4);
     margins = take(n * L * 4);
     logprob = take(n * 4);
+    last_tok = take(n * 8);
     if (beam) {
       cand_val = take(n * 16 * 4);
       cand_idx = take(n * 16 * 4);
@@ -438,10 +439,12 @@ extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, si
     CK(step_forward(w, lo, ws, B, 1, t, ids, ws + lo.tcache, s));
     if (e->sampling.do_sample)
       CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, &e->sampling, s));
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), B, t, L, EOS,
+                            PAD, &e->sampling, s));
     else
       CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), B, t, L, EOS, PAD, s));
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), B, t, L, EOS,
+                            PAD, s));
   }
   if (hipMemcpyAsync(out_ids, ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
       hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
@@ -546,6 +549,7 @@ extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, voi
   if (!e || !name || !workspace || B <= 0) return nullptr;
   const Layout lo(B, B, false);
   char* ws = (char*)workspace;
+  if (!strcmp(name, "last_token")) return ws + lo.last_tok;
   if (!strcmp(name, "hidden")) return ws + lo.x;
   if (!strcmp(name, "tag_hidden")) return ws + lo.xt;
   if (!strcmp(name, "vis")) return ws + lo.vis_f;

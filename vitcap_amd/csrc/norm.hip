@@ -135,12 +135,13 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restri
                                                          const bf16_t* __restrict__ word, const bf16_t* __restrict__ pos,
                                                          const bf16_t* __restrict__ type, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, float* __restrict__ pre,
-                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows) {
+                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows, int pos_wrap) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int64_t tok = ids[row];
-  const int p = row % rows_per_seq;
+  int p = row % rows_per_seq;
+  if (pos_wrap > 0 && p >= pos_wrap) p = p - pos_wrap + 1;     // probe rows: [MASK] at positions 1, 2, ...
   f32x4 v[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -251,11 +252,11 @@ extern "C" int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mas
 
 extern "C" int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,
                                  const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
-                                 float* x_f32, void* x_bf16, int rows, void* stream) {
+                                 float* x_f32, void* x_bf16, int rows, int pos_wrap, void* stream) {
   VC_REQUIRE(ids && word_emb && pos_emb && type_emb && gamma && beta && rows > 0 && rows_per_seq > 0, "embed_rows: bad arguments");
   hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, rows_per_seq,
                      (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta, eps, pre_f32,
-                     x_f32, (bf16_t*)x_bf16, rows);
+                     x_f32, (bf16_t*)x_bf16, rows, pos_wrap);
   VC_LAUNCH_CHECK("embed_rows");
   return VITCAP_OK;
 }

@@ -163,12 +163,13 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 // embedding backward: gword[ids[row]] += d[row]; gpos[pos[row]] += d[row]; gtype[0] += d[row]
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ d, const int64_t* __restrict__ ids,
                                                         int rows_per_seq, float* __restrict__ gword, float* __restrict__ gpos,
-                                                        float* __restrict__ gtype, int rows) {
+                                                        float* __restrict__ gtype, int rows, int pos_wrap) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int64_t tok = ids[row];
-  const int pos = row % rows_per_seq;
+  int pos = row % rows_per_seq;
+  if (pos_wrap > 0 && pos >= pos_wrap) pos = pos - pos_wrap + 1;     // probe rows: [MASK] at positions 1, 2, ...
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * 256 + lane * 4;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // label-smoothed KL (BertCaptioningLoss, modeling_bert.py:661-690): per row loss and d(loss)/d(logits) * (1/n_rows)
 __global__ __launch_bounds__(1024) void ls_kl_kernel(const float* __restrict__ logits, int ldl, int V,
                                                      const int64_t* __restrict__ target, float eps, float inv_rows,
-                                                     float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits, int ldd) {
+                                                     const float* __restrict__ row_weight, float* __restrict__ loss_sum,
+                                                     bf16_t* __restrict__ dlogits, int ldd) {
   __shared__ float s_red[16];
   __shared__ float s_val;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(1024) void ls_kl_kernel(const float* __restrict__ l
   for (int k = 0; k < 16; ++k) sumlogit += s_red[k];
   const float lse = mx + logf(tot);
   const int tgt = (int)target[b];
+  if (row_weight) inv_rows = row_weight[b];        // per-row coefficient instead of the mean (policy-gradient weights)
   const float q_on = 1.0f - eps, q_off = eps / (float)(V - 1);
   if (tid == 0) {
     // sum_v q_v (log q_v - logp_v),  logp_v = x_v - lse
@@ -446,19 +449,19 @@ extern "C" int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream)
 }
 
 extern "C" int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
-                                int rows, void* stream) {
+                                int rows, int pos_wrap, void* stream) {
   VC_REQUIRE(d && ids && gword && gpos && gtype && rows > 0, "embed_bwd: bad arguments");
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, ids, rows_per_seq, gword,
-                     gpos, gtype, rows);
+                     gpos, gtype, rows, pos_wrap);
   VC_LAUNCH_CHECK("embed_bwd");
   return VITCAP_OK;
 }
 
 extern "C" int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target, float eps, int rows,
-                                 float* loss_sum, void* dlogits_bf16, int ldd, void* stream) {
+                                 const float* row_weight, float* loss_sum, void* dlogits_bf16, int ldd, void* stream) {
   VC_REQUIRE(logits && target && loss_sum && rows > 0 && V > 1, "ls_kl_loss: bad arguments");
   hipLaunchKernelGGL(ls_kl_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, target, eps,
-                     1.0f / (float)rows, loss_sum, (bf16_t*)dlogits_bf16, ldd);
+                     1.0f / (float)rows, row_weight, loss_sum, (bf16_t*)dlogits_bf16, ldd);
   VC_LAUNCH_CHECK("ls_kl_loss");
   return VITCAP_OK;
 }

@@ -84,7 +84,7 @@ def attn_dense(qkv, B, S, scale=0.125):
     return out
 
 
-def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0, causal_from=0):
+def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0, causal_from=0, mask_from=0):
     """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd; ld_rows = rows per image
     in the buffers (>= S; only the first S rows of each image are attended / written)"""
     _dev_bf16(qkv)
@@ -93,20 +93,20 @@ def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0,
         out = torch.empty((B * ld_rows, 768), device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty((B, 12, S), device=qkv.device, dtype=torch.float32)
     check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, p_drop, drop_seed, causal_from,
-                                          _stream()),
+                                          mask_from, _stream()),
           'attn_dense_train')
     return out, lse
 
 
 def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None, ld_rows=None, dqkv=None, p_drop=0.0,
-                   drop_seed=0, causal_from=0):
+                   drop_seed=0, causal_from=0, mask_from=0):
     _dev_bf16(qkv); _dev_bf16(out); _dev_bf16(dout); _dev_f32(lse)
     ld_rows = ld_rows or S
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
     check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, ld_rows,
-                                    scale, p_drop, drop_seed, causal_from, _stream()), 'attn_dense_bwd')
+                                    scale, p_drop, drop_seed, causal_from, mask_from, _stream()), 'attn_dense_bwd')
     return dqkv
 
 
@@ -145,8 +145,8 @@ def greedy_step(logits, st, t, V=L.VOCAB, eos=102, pad=0):
     _dev_f32(logits)
     B, max_len = st['ids'].shape
     check(lib.vitcap_greedy_step(_p(logits), logits.stride(0), V, _p(st['ids']), _p(st['unf']), _p(st['sum_lp']),
-                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), B, t, max_len, eos, pad,
-                                 _stream()), 'greedy_step')
+                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), _p(st.get('raw_last')), B, t, max_len, eos,
+                                 pad, _stream()), 'greedy_step')
 
 
 def sample_step(logits, st, t, temperature=1.0, top_k=0, top_p=1.0, seed=0, V=L.VOCAB, eos=102, pad=0):
@@ -156,8 +156,8 @@ def sample_step(logits, st, t, temperature=1.0, top_k=0, top_p=1.0, seed=0, V=L.
     B, max_len = st['ids'].shape
     sp = SampleParams(1, float(temperature), int(top_k), float(top_p), int(seed) & 0xffffffff)
     check(lib.vitcap_sample_step(_p(logits), logits.stride(0), V, _p(st['ids']), _p(st['unf']), _p(st['sum_lp']),
-                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), B, t, max_len, eos, pad,
-                                 C.byref(sp), _stream()), 'sample_step')
+                                 _p(st['cnt']), _p(st['logprob']), _p(st['margin']), _p(st.get('raw_last')), B, t, max_len, eos,
+                                 pad, C.byref(sp), _stream()), 'sample_step')
 
 
 def sigmoid_topk(logits, k=50, thresh=0.2, V=None):

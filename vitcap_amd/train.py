@@ -340,10 +340,20 @@ class TrainEngine(object):
     def forward_backward(self, batch):
         """batch: image (B,3,384,384) fp32/bf16 cuda; input_ids (B,70) int64; masked_pos (B,70) int; masked_ids (B,3) int64;
         label (B,30522) fp32 -- the dict the reference's collate feeds ImageCaptioning.forward in training.
-        Accumulates gradients into self.G (zeroed here) and returns (masked_loss, tag_loss) device scalars."""
+        Accumulates gradients into self.G (zeroed here) and returns (masked_loss, tag_loss) device scalars.
+
+        Self-critical mode (`sample_ids` (B,20) int64 + `sample_weight` (B,) fp32 in the batch instead of the masked-token
+        fields): the loss is sum_b sample_weight[b] * mean_t(-log p(sample_ids[b,t] | sample_ids[b,:t], image)) over the
+        generated positions, i.e. ScstRewardCriterion with sample_weight = (reward - baseline) / B.  The 19 per-step
+        forwards the reference differentiates through (one full re-encode per generated token) collapse into ONE pass:
+        the decoder runs on [578 visual | 20 token rows | 19 [MASK] probe rows], probe j sees tokens 0..j."""
         dev = self.dev
         img = batch['image']
         B = img.shape[0]
+        scst = 'sample_ids' in batch
+        TP = (T - 1) if scst else 0          # probe rows per sequence
+        TT = T + TP                          # text rows per sequence
+        LR = SV + TT                         # decoder rows per image (shadows the module constant on purpose)
         M, Md = B * NV, B * LR
         self.G.zero_()
         self.reducer.begin()
@@ -390,21 +400,26 @@ class TrainEngine(object):
         tbias = torch.zeros(L.VOCAB_PAD, device=dev)
         tbias[:L.VOCAB] = self.vec(tg + '.bias')
         tag_logits = ops.gemm_bias_act(tgb, self.wb('tag.dec'), tbias, out_dtype=torch.float32)
-        label = batch['label'].to(dev).contiguous()
-        check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), B, _s()),
-              'focal')
+        if 'label' in batch:                 # reported only (never back-propagated); the self-critical step has no labels
+            label = batch['label'].to(dev).contiguous()
+            check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), B, _s()),
+                  'focal')
         # ================= forward: decoder on [578 visual | 20 caption] rows per image
         e = 'module.bert.embeddings'
-        ids20 = batch['input_ids'][:, :T].to(dev).contiguous()
-        pre_emb = torch.empty(B * T, 768, device=dev)
-        xtext = torch.empty(B * T, 768, device=dev)
-        check(lib.vitcap_embed_rows(_p(ids20), T, _p(self.wb('word')), _p(self.wb('pos')), _p(self.wb('type')),
+        if scst:
+            sid = batch['sample_ids'].to(dev).view(B, T)
+            ids20 = torch.cat([sid, torch.full((B, TP), 103, dtype=torch.int64, device=dev)], 1).contiguous()   # tokens | [MASK] x19
+        else:
+            ids20 = batch['input_ids'][:, :T].to(dev).contiguous()
+        pre_emb = torch.empty(B * TT, 768, device=dev)
+        xtext = torch.empty(B * TT, 768, device=dev)
+        check(lib.vitcap_embed_rows(_p(ids20), TT, _p(self.wb('word')), _p(self.wb('pos')), _p(self.wb('type')),
                                     _p(self.vec(e + '.LayerNorm.weight')), _p(self.vec(e + '.LayerNorm.bias')), 1e-12,
-                                    _p(pre_emb), _p(xtext), None, B * T, _s()), 'embed_rows')
+                                    _p(pre_emb), _p(xtext), None, B * TT, T if scst else 0, _s()), 'embed_rows')
         dx = torch.empty(B, LR, 768, device=dev)
         dx[:, 0] = xt.view(B, NV, 768)[:, 0]
         dx[:, 1:SV] = x.view(B, NV, 768)
-        dx[:, SV:] = xtext.view(B, T, 768)
+        dx[:, SV:] = xtext.view(B, TT, 768)
         xd = dx.view(Md, 768)
         dsaved = []
         pd = self.attn_dropout
@@ -414,7 +429,8 @@ class TrainEngine(object):
             xb = ops.cast_bf16(xd)
             qkv = ops.gemm_bias_act(xb, self.wb(pre + '.qkv'), self.qkv_bias(pre))
             # visual rows attend visual rows; caption row q attends all visual rows and caption rows <= q (one kernel)
-            ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV)
+            ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
+                                            mask_from=SV + T if scst else 0)
             t1 = torch.empty(Md, 768, device=dev)
             ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
             ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
@@ -428,13 +444,28 @@ class TrainEngine(object):
             dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2))
             xd = yf
         # ================= loss on the masked caption positions
-        mp = batch['masked_pos'][:, :T].to(dev).bool()
-        sel = mp.view(-1).nonzero().view(-1)                                  # rows of the (B*T) caption grid
+        row_w = None
+        if scst:
+            # probe j (grid column T + j) predicts position j+1; a position counts while the sequence is unfinished, i.e. up
+            # to and including its first [SEP] (modeling_utils.py:853-877); coefficient = weight_b / (#counted positions)
+            tok = sid[:, 1:]
+            ended = ((sid[:, :-1] == 102).cumsum(1) > 0)                     # a [SEP] strictly before this position
+            unf = ~ended
+            mp = torch.zeros(B, TT, dtype=torch.bool, device=dev)
+            mp[:, T:] = unf
+            cnt = unf.sum(1).clamp(min=1).to(torch.float32)
+            wrow = (batch['sample_weight'].to(dev).to(torch.float32) / cnt)[:, None].expand(B, TP)
+            row_w = wrow[unf].contiguous()
+            tgt = tok[unf].contiguous()
+        else:
+            mp = torch.zeros(B, TT, dtype=torch.bool, device=dev)
+            mp[:, :T] = batch['masked_pos'][:, :T].to(dev).bool()
+            tgt = batch['masked_ids'].to(dev)
+            tgt = tgt[tgt != 0].contiguous()
+        sel = mp.view(-1).nonzero().view(-1)                                  # rows of the (B*TT) text grid
         n = int(sel.numel())
-        tgt = batch['masked_ids'].to(dev)
-        tgt = tgt[tgt != 0].contiguous()
         assert int(tgt.numel()) == n, 'masked_pos / masked_ids disagree'
-        text_rows = xd.view(B, LR, 768)[:, SV:].reshape(B * T, 768)
+        text_rows = xd.view(B, LR, 768)[:, SV:].reshape(B * TT, 768)
         hrows = ops.cast_bf16(text_rows.index_select(0, sel).contiguous())
         c = 'module.cls.predictions'
         zt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
@@ -445,8 +476,8 @@ class TrainEngine(object):
         cbias[:L.VOCAB] = self.vec(c + '.bias')
         logits = ops.gemm_bias_act(h2b, self.wb('cls.dec'), cbias, out_dtype=torch.float32)
         dlog = torch.empty(n, L.VOCAB_PAD, device=dev, dtype=torch.bfloat16)
-        check(lib.vitcap_ls_kl_loss(_p(logits), L.VOCAB_PAD, L.VOCAB, _p(tgt), self.eps_ls, n, _p(self.loss_buf), _p(dlog),
-                                    L.VOCAB_PAD, _s()), 'ls_kl')
+        check(lib.vitcap_ls_kl_loss(_p(logits), L.VOCAB_PAD, L.VOCAB, _p(tgt), 0.0 if scst else self.eps_ls, n, _p(row_w),
+                                    _p(self.loss_buf), _p(dlog), L.VOCAB_PAD, _s()), 'ls_kl')
         # ================= backward: LM head
         wkey = W.TIED_SRC if self.model.tie_weights else c + '.decoder.weight'
         bsum = torch.zeros(L.VOCAB_PAD, device=dev)
@@ -464,9 +495,9 @@ class TrainEngine(object):
         dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
         self.reducer.stage_done('cls')
         dy = torch.zeros(B, LR, 768, device=dev)
-        dtext = torch.zeros(B * T, 768, device=dev)
+        dtext = torch.zeros(B * TT, 768, device=dev)
         dtext.index_copy_(0, sel, dh)
-        dy[:, SV:] = dtext.view(B, T, 768)
+        dy[:, SV:] = dtext.view(B, TT, 768)
         dy = dy.view(Md, 768)
         # ================= backward: decoder layers
         for l in (3, 2, 1, 0):
@@ -481,18 +512,19 @@ class TrainEngine(object):
                                       1e-12)
             self._wgrad_tn(dt1b, ctx, self.g(pre + '.attention.output.dense.weight'), self.g(pre + '.attention.output.dense.bias').view(-1))
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
-            dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV)
+            dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
+                                      mask_from=SV + T if scst else 0)
             self._wgrad_tn(dqkv, xb, self.qkv_w_grad(pre), self.qkv_bias_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
             if l % 2 == 0:
                 self.reducer.stage_done('dec%d' % (l // 2))
         dyv = dy.view(B, LR, 768)
         # ================= backward: text embeddings
-        demb, _ = self._ln_bwd(pre_emb, dyv[:, SV:].reshape(B * T, 768).contiguous(), e + '.LayerNorm.weight', e + '.LayerNorm.bias',
+        demb, _ = self._ln_bwd(pre_emb, dyv[:, SV:].reshape(B * TT, 768).contiguous(), e + '.LayerNorm.weight', e + '.LayerNorm.bias',
                                1e-12, dres=None)
-        check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), T, _p(self.g(e + '.word_embeddings.weight')),
+        check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), TT, _p(self.g(e + '.word_embeddings.weight')),
                                    _p(self.g(e + '.position_embeddings.weight')), _p(self.g(e + '.token_type_embeddings.weight')),
-                                   B * T, _s()), 'embed_bwd')
+                                   B * TT, T if scst else 0, _s()), 'embed_bwd')
         self.reducer.stage_done('emb')
         # ================= backward: encoder
         dhid = dyv[:, 1:SV].reshape(M, 768).contiguous()
