@@ -110,6 +110,57 @@ def bench_train(args, rank, world, local, dist, D):
         dist.destroy_process_group()
 
 
+def bench_scst(args, rank, world, local, dist, D):
+    """BASELINE configs[4]: SCST step, scst_num_return=5, 16 images per GPU (global 128 on 8 GPUs): greedy baseline decode,
+    5 sampled decodes per image, CIDEr-D advantage on the host (synthetic reference captions), one-pass gradient, AdamW."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.scst import ScstTrainer
+    from vitcap_amd.tokenizer import CaptionDetokenizer
+    from vitcap_amd.train import TrainEngine
+    B = 16 if args.batch == 64 else args.batch
+    K = 5
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    tok = CaptionDetokenizer(tokens=toks)
+    model = ImageCaptioning().load_recipe(0)
+    eng = TrainEngine(model, 'cuda:%d' % local, max_iter=10 ** 6, dist=dist)
+    img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(999, rank))).cuda().to(torch.bfloat16).contiguous()
+    model.eval()
+    g_ids, _ = model.generate(img)
+    gts = [[tok.decode(r.tolist(), skip_special_tokens=True), 'w11 w12 w13 w14 w15'] for r in g_ids[:, 0].cpu()]
+    tr = ScstTrainer(model, eng, tok, num_return=K, seed=rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        out = tr.step(img, gts)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.step(img, gts)
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dist, device='cuda')
+    if rank == 0:
+        value = D.whole_job_rate(B, args.steps, world, elapsed)
+        print(json.dumps({
+            'metric': 'images/sec SCST step (greedy baseline + 5 sampled captions/image + policy gradient), ViT-B/16-384',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[4]: SCST, scst_num_return=5, %d images per GPU (global %d), synthetic '
+                                   'reference captions, CIDEr-D advantage on the host' % (B, B * world),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'sampled_sequences_per_step': B * K * world,
+                       'parallelism': 'dp%d' % world},
+            'scst_loss': float(out['scst_loss']), 'score': out['score']}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -117,7 +168,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mode', default='caption', choices=['caption', 'train'],
+    ap.add_argument('--mode', default='caption', choices=['caption', 'train', 'scst'],
                     help="'caption' = the headline metric; 'train' = cross-entropy training step (BASELINE configs[3])")
     ap.add_argument('--beams', type=int, default=1, help='num_beams (1 = greedy, the headline metric; 5 = BASELINE configs[2])')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
@@ -140,6 +191,8 @@ def main():
     B = args.batch
     if args.mode == 'train':
         return bench_train(args, rank, world, local, dist, D)
+    if args.mode == 'scst':
+        return bench_scst(args, rank, world, local, dist, D)
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:%d' % local)
     img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()

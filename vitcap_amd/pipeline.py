@@ -147,6 +147,9 @@ class CaptionUniPipeline(object):
             seed = D.shard_seed(int(self.cfg.synthetic_seed or 1234), self.rank) + 1000 * it
             batch = synthetic_train_inputs(per_gpu, seed=seed)
             batch['image'] = torch.from_numpy(W.gen_image_batch(per_gpu, seed))
+            if self.cfg.scst:      # ground-truth captions for the CIDEr-D reward: the (synthetic) caption tokens as text
+                ids = batch['input_ids'][:, :20]
+                batch['captions'] = [[self.tokenizer.decode(r.tolist(), skip_special_tokens=True)] for r in ids]
             yield batch
             it += 1
 
@@ -195,10 +198,19 @@ class CaptionUniPipeline(object):
         ckpt = Checkpointer(model=_EngineState(eng), save_dir=self.get_snapshot_dir(), save_to_disk=self.rank == 0)
         t0, log_step = time.time(), int(self.cfg.log_step)
         batches = self.iter_train_batches(per_gpu)
+        scst = None
+        if self.cfg.scst:          # BASELINE config 5 (..._expanding.py:404-478): self-critical step instead of cross-entropy
+            from .scst import ScstTrainer
+            scst = ScstTrainer(model, eng, self.tokenizer, num_return=int(self.cfg.scst_num_return or 5),
+                               seed=int(self.cfg.random_seed or 0) + self.rank)
         for it in range(1, max_iter + 1):
             b = next(batches)
             b = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
-            out = eng.train_step(b)
+            if scst is not None:
+                o = scst.step(b['image'].to(torch.bfloat16).contiguous(), b['captions'])
+                out = {'masked_loss': o['scst_loss']}
+            else:
+                out = eng.train_step(b)
             if it % log_step == 0 or it == max_iter:
                 torch.cuda.synchronize()
                 dt = time.time() - t0

@@ -282,6 +282,60 @@ class TrainEngine(object):
         if self.model.tie_weights:
             self._gemm_w['cls.dec'] = self._gemm_w['word']
 
+    def bind_inference(self):
+        """Points the model's INFERENCE engine at this engine's own device buffers (bf16 matrices refreshed after every
+        optimizer step, fp32 vectors = views of the master buffer): generate() then always decodes with the current
+        weights, with no copy -- what the self-critical step needs between its sampling and its gradient pass."""
+        m, w = self.model, L.Weights()
+        P = lambda t: C.c_void_p(t.data_ptr())       # noqa: E731
+        vec = self.vec
+        ie = 'image_encoder.module.'
+        w.patch_w, w.patch_b = P(self.wb('patch')), P(vec(ie + 'patch_embed.proj.bias'))
+        w.cls_token, w.pos_embed = P(vec(ie + 'cls_token')), P(vec(ie + 'pos_embed'))
+
+        def vit_block(dst, pre):
+            dst.qkv_w, dst.qkv_b = P(self.wb(pre + '.qkv')), P(vec(pre + '.attn.qkv.bias'))
+            dst.proj_w, dst.proj_b = P(self.wb(pre + '.proj')), P(vec(pre + '.attn.proj.bias'))
+            dst.fc1_w, dst.fc1_b = P(self.wb(pre + '.fc1')), P(vec(pre + '.mlp.fc1.bias'))
+            dst.fc2_w, dst.fc2_b = P(self.wb(pre + '.fc2')), P(vec(pre + '.mlp.fc2.bias'))
+            dst.n1_g, dst.n1_b = P(vec(pre + '.norm1.weight')), P(vec(pre + '.norm1.bias'))
+            dst.n2_g, dst.n2_b = P(vec(pre + '.norm2.weight')), P(vec(pre + '.norm2.bias'))
+        for i in range(12):
+            vit_block(w.blocks[i], 'module.bert.encoder.blocks.%d' % i)
+        for i in range(4):
+            vit_block(w.tag_blocks[i], 'module.bert.encoder.tag_blocks.%d' % i)
+        w.pooler_w, w.pooler_b = P(self.wb('pooler')), P(vec('module.bert.pooler.dense.bias'))
+
+        def padded_bias(key):       # the master chunk behind a 30522-vector is zero-padded to 30720 >= VOCAB_PAD
+            o = self.off[key]
+            return self.P[o:o + L.VOCAB_PAD]
+
+        def lm_head(dst, pre, tname, dname):
+            dst.dense_w, dst.dense_b = P(self.wb(tname)), P(vec(pre + '.predictions.transform.dense.bias'))
+            dst.ln_g = P(vec(pre + '.predictions.transform.LayerNorm.weight'))
+            dst.ln_b = P(vec(pre + '.predictions.transform.LayerNorm.bias'))
+            dst.dec_w, dst.dec_b = P(self.wb(dname)), P(padded_bias(pre + '.predictions.bias'))
+        lm_head(w.tag_logit, 'module.bert.tag_logit', 'tag.t', 'tag.dec')
+        lm_head(w.cls, 'module.cls', 'cls.t', 'cls.dec')
+        e = 'module.bert.embeddings'
+        w.word_emb, w.pos_emb, w.type_emb = P(self.wb('word')), P(self.wb('pos')), P(self.wb('type'))
+        w.emb_ln_g, w.emb_ln_b = P(vec(e + '.LayerNorm.weight')), P(vec(e + '.LayerNorm.bias'))
+        for i in range(4):
+            pre, d = 'module.bert.decoder.layer.%d' % i, w.dec[i]
+            d.qkv_w, d.qkv_b = P(self.wb(pre + '.qkv')), P(self.qkv_bias(pre))
+            d.ao_w, d.ao_b = P(self.wb(pre + '.ao')), P(vec(pre + '.attention.output.dense.bias'))
+            d.ao_g, d.ao_beta = P(vec(pre + '.attention.output.LayerNorm.weight')), P(vec(pre + '.attention.output.LayerNorm.bias'))
+            d.i_w, d.i_b = P(self.wb(pre + '.i')), P(vec(pre + '.intermediate.dense.bias'))
+            d.o_w, d.o_b = P(self.wb(pre + '.o')), P(vec(pre + '.output.dense.bias'))
+            d.o_g, d.o_beta = P(vec(pre + '.output.LayerNorm.weight')), P(vec(pre + '.output.LayerNorm.bias'))
+        if m._engine is None:
+            h = C.c_void_p()
+            check(lib.vitcap_engine_create(C.byref(h)), 'engine_create')
+            m._engine = h
+        check(lib.vitcap_engine_bind_weights(m._engine, C.byref(w)), 'bind_weights')
+        m._packed = (w, [self], self.dev)
+        return m
+
     def wb(self, name):
         return self._gemm_w[name][0]
 
