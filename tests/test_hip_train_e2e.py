@@ -185,9 +185,10 @@ def test_data_parallel_invariant_on_one_gpu():
     assert abs((l0 + l1) / 2 - l_all) < 1e-4 and rel < 2e-2
 
 
-def test_pipeline_train_then_eval(tmp_path, monkeypatch):
-    """run.py `pipeline_train_eval_multi` on synthetic data: 2 optimizer steps, snapshot in the reference's format,
-    then the eval pipeline captions from that snapshot."""
+@pytest.mark.parametrize('scst', [False, True])
+def test_pipeline_train_then_eval(tmp_path, monkeypatch, scst):
+    """run.py `pipeline_train_eval_multi` on synthetic data: 2 optimizer steps (cross-entropy, or self-critical with
+    `scst: true`), snapshot in the reference's format, then the eval pipeline captions from that snapshot."""
     import yaml
     import run
     monkeypatch.chdir(tmp_path)
@@ -202,6 +203,8 @@ def test_pipeline_train_then_eval(tmp_path, monkeypatch):
                      'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'test_batch_size': 2,
                      'synthetic_num_images': 2, 'force_train': True, 'force_predict': True,
                      'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+    if scst:
+        cfg['param'].update(scst=True, scst_num_return=2)
     yf = tmp_path / 'exp.yaml'
     yf.write_text(yaml.safe_dump(cfg))
     kw = run.parse_general_args(['-c', str(yf)])
