@@ -114,3 +114,19 @@ def test_model_sampling_vs_oracle(sd_t):
     np.testing.assert_allclose(lp.cpu().numpy()[ok.numpy()], lp_o.numpy()[ok.numpy()], atol=2e-3)
     assert not torch.equal(ids, g_ids), 'sampling returned the greedy caption'
     assert not torch.equal(ids, ids2), 'two sampling calls returned the same draws'
+
+
+def test_num_return_sequences():
+    """do_sample with num_return_sequences = n: n independent draws per image, output (B*n, 1, 20), image-major."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    m = ImageCaptioning().load_recipe(0).eval()
+    img = torch.from_numpy(W.gen_image_batch(2, 9)).cuda().to(torch.bfloat16)
+    m.test_extra_input.update(do_sample=True, num_return_sequences=3, seed=11)
+    ids, lp = m({'image': img, 'key': [0, 1]})
+    assert ids.shape == (6, 1, 20) and lp.shape == (6, 1)
+    assert (ids[:, 0, 0] == 101).all()
+    assert not torch.equal(ids[0], ids[1]) or not torch.equal(ids[1], ids[2])      # draws differ within an image
+    m.test_extra_input.update(do_sample=False)
+    with pytest.raises(NotImplementedError):
+        m({'image': img, 'key': [0, 1]})

@@ -341,8 +341,16 @@ class ImageCaptioning(nn.Module):
                 raise RuntimeError('training-mode forward needs a vitcap_amd.train.TrainEngine(model, ...) attached')
             return eng.loss_dict(data)
         te = self.test_extra_input
-        if te.get('num_keep_best', 1) != 1 or te.get('num_return_sequences', 1) != 1:
-            raise NotImplementedError('num_keep_best / num_return_sequences > 1 are not built')
+        if te.get('num_keep_best', 1) != 1:
+            raise NotImplementedError('num_keep_best > 1 is not built')
+        nret = int(te.get('num_return_sequences', 1))
+        if nret > 1:
+            # ViTCAP.generate expands every input num_return_sequences times (modeling_bert.py:976-979, 994,
+            # _expand_for_beams) and returns (B * n, 1, 20): n independent draws per image, image-major
+            if not te.get('do_sample', False) or te.get('num_beams', 1) > 1:
+                raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
+            data = dict(data)
+            data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
         if te.get('num_beams', 1) > 1:
