@@ -100,6 +100,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   visual rows see visual rows only; token row i sees visual + tokens <= i (seq2seq mask, dataset.py:377-390);
 //   probe row j (the [MASK] the generator appends at position j+1, modeling_bert.py:846-876) sees visual, tokens <= j
 //   and itself -- exactly the rows one decode step's [MASK] query attends.  cf = 0: plain dense attention.
+// (Keep it branch-free: an equivalent early-return formulation of the same predicate produced wrong masks when inlined
+// into the MFMA tile macros by hipcc 7.2 -O3 -- caught by test_attn_joint_causal_forward_backward.)
 __device__ __forceinline__ bool joint_visible(int q, int k, int S, int cf, int mf) {
   const bool plain = cf <= 0 || k < cf;                                   // visual key (or no mask at all)
   const bool causal = k <= q;                                             // token row / token key (q >= cf follows from k >= cf)
