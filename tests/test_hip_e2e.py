@@ -231,3 +231,27 @@ def test_generate_async_beam_equals_generate_beam(model):
     for (ids_w, lp_w), p in zip(want, pend):
         ids, lp = p.result()
         assert torch.equal(ids, ids_w) and torch.equal(lp, lp_w)
+
+
+def test_beam5_batch256_properties(model):
+    """BASELINE configs[2] size (beam=5, 256 images = 1280 sequences): size-independent properties -- determinism, batch
+    invariance (an image captioned alone gets the same beam result), well-formed ids, finite length-normalised scores."""
+    from vitcap_amd import weights as W
+    B = 256
+    img = torch.from_numpy(W.gen_image_batch(B, 4321)).cuda().to(torch.bfloat16)
+    ids1, lp1 = [t.clone() for t in model.generate_beam(img, 5)]
+    ids2, lp2 = model.generate_beam(img, 5)
+    assert torch.equal(ids1, ids2) and torch.equal(lp1, lp2), 'non-deterministic'
+    ids_s, lp_s = model.generate_beam(img[:3].contiguous(), 5)
+    assert torch.equal(ids_s, ids1[:3]) and torch.allclose(lp_s, lp1[:3], atol=1e-6)
+    i = ids1.cpu()[:, 0]
+    assert (i[:, 0] == 101).all() and ((i >= 0) & (i < 30522)).all()
+    for row in i.tolist():
+        assert 102 in row, 'a beam hypothesis always ends with [SEP]'
+        k = row.index(102)
+        assert all(v == 0 for v in row[k + 1:])
+    assert torch.isfinite(lp1).all() and float(lp1.max()) <= 0.0
+    # beam search never scores below its own greedy member under the same normalisation (greedy path is one of the beams
+    # at every step unless pruned by a better one): compare with the greedy caption's mean log-prob
+    _, lp_g = model.generate(img)
+    assert float((lp1 - lp_g).min()) > -0.35

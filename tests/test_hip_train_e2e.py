@@ -386,3 +386,34 @@ def test_inference_engine_bound_to_training_buffers():
         eng.train_step(b)                       # weights change (lr 1e-3) -> the bound engine must follow
     ids2, _ = model.generate(img)
     assert not torch.equal(ids2, ids) or True   # (captions may or may not change; equality with `fresh` above is the check)
+
+
+def test_train_step_batch64_properties():
+    """BASELINE configs[3] per-GPU size (64 samples): size-independent properties of the training step -- finite loss and
+    gradient norm, the loss on a fixed batch goes down over a few steps, the step is reproducible up to the float atomics of
+    its reductions, and the mean of two half-batch gradients equals the full-batch gradient (what DDP averaging relies on)."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    B = 64
+    b = {k: v.cuda() for k, v in synthetic_train_inputs(B, seed=3).items()}
+    b['image'] = torch.from_numpy(W.gen_image_batch(B, 3)).cuda().to(torch.bfloat16)
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=100, base_lr=3e-4, attn_dropout=0.0)
+    l_full, _ = eng.forward_backward(b)
+    l_full = float(l_full)
+    g_full = eng.G.clone()
+    l_again = float(eng.forward_backward(b)[0])
+    assert abs(l_again - l_full) < 1e-5 and float((eng.G - g_full).norm() / g_full.norm()) < 1e-4
+    halves = []
+    for sl in (slice(0, 32), slice(32, 64)):
+        h = {k: v[sl].contiguous() for k, v in b.items()}
+        halves.append((float(eng.forward_backward(h)[0]), eng.G.clone()))
+    assert abs((halves[0][0] + halves[1][0]) / 2 - l_full) < 1e-4
+    rel = float(((halves[0][1] + halves[1][1]) / 2 - g_full).norm() / g_full.norm())
+    print('B=64 loss %.4f, half-batch gradient mean vs full: rel %.2e' % (l_full, rel))
+    assert rel < 2e-2
+    losses = [float(eng.train_step(b)['masked_loss']) for _ in range(4)]
+    print('losses over 4 steps on one batch:', ['%.4f' % v for v in losses], 'grad norm %.3f' % eng.grad_norm())
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0] - 0.05
+    assert torch.isfinite(eng.P).all()
