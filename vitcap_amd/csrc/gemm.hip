@@ -13,6 +13,7 @@
 //
 // The accumulators are computed transposed (first MFMA operand = W fragment): each lane then holds
 // 4 consecutive n for one m, so bias/residual loads and the C store are 8/16-byte vectors.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -38,7 +39,20 @@ struct GemmArgs {
   int split_k;         // > 1: blockIdx.y = split, ragged k-tile ranges, fp32 partial slabs, no epilogue
   int kt_per_split;
   size_t slab;
+  int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
+  unsigned long long* trace;   // instrumentation (tools/gemm_trace.py): [workgroup][8 tiles][4] s_memtime stamps, else null
 };
+
+unsigned long long* g_gemm_trace = nullptr;
+
+// width (in 256-column tiles) of the column groups the 256x256 kernels walk; VITCAP_GEMM_GROUP_N overrides (experiments)
+int tile_group_n(int tiles_n) {
+  static const int env_gn = [] { const char* e = getenv("VITCAP_GEMM_GROUP_N"); return e ? atoi(e) : 0; }();
+  // measured at M = 36928 (tools/group_sweep.sh): N = 3072 214 -> 199 us with groups of 2..6 tiles (W = 4.7 MB does not fit
+  // one XCD's 4 MB L2 next to the A tiles); N = 2304 and N = 768 unchanged
+  int g = env_gn > 0 ? env_gn : (tiles_n >= 6 ? 3 : tiles_n);
+  return g > tiles_n ? tiles_n : g;
+}
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -183,8 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
       }
       if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        v = gelu_erf4(v);
       } else if (ACT == VITCAP_ACT_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -318,8 +331,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmArgs p) {
       f32x4 v = acc[i][j];
       if (p.bias) v += *(const f32x4*)(p.bias + n);
       if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        v = gelu_erf4(v);
       } else if (ACT == VITCAP_ACT_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -441,8 +453,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[8][4], const GemmAr
     for (int j = 0; j < 4; ++j) {
       v[j] = acc[i][j] + bias4[j];
       if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+        v[j] = gelu_erf4(v[j]);
       }
     }
     if (OUT_F32) {
@@ -502,7 +513,13 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  // column groups of group_n tiles, as in the persistent form (TILE_COORDS there): workgroups are dispatched in blockIdx
+  // order, so the ones an XCD runs at once are consecutive positions of its chunk
+  const int per_g = p.tiles_m * p.group_n;
+  const int gi = bid / per_g, rem = bid - gi * per_g;
+  const int gleft = p.tiles_n - gi * p.group_n;
+  const int gw = gleft < p.group_n ? gleft : p.group_n;
+  const int tm = rem / gw, tn = gi * p.group_n + rem - tm * gw;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int srow = lane >> 3;
@@ -737,11 +754,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
           v0 += b_lo;
           v1 += b_hi;
           if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = gelu_erf(v0[e]);
-              v1[e] = gelu_erf(v1[e]);
-            }
+            v0 = gelu_erf4(v0);
+            v1 = gelu_erf4(v1);
           }
           if (m < p.M && okc) {
             uint4 o;
@@ -789,8 +803,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
           for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
         }
         if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          v = gelu_erf4(v);
         }
         if (HAS_RES) v += rres[c & 1][it];
         if (ok) {
@@ -822,6 +835,7 @@ int launch_256(const GemmArgs& a, hipStream_t s) {
   GemmArgs p = a;
   p.tiles_m = (a.M + 255) / 256;
   p.tiles_n = (a.N + 255) / 256;
+  p.group_n = tile_group_n(p.tiles_n);
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256");
   return VITCAP_OK;
@@ -879,9 +893,16 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     int bid_ = (tile_);                                                                      \
     const int q_ = nwg >> 3, r_ = nwg & 7, xcd_ = bid_ & 7;                                  \
     bid_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + (bid_ >> 3);   \
-    const int tm_ = bid_ / p.tiles_n;                                                        \
+    /* column groups of group_n tiles: the 32 tiles an XCD works on at once span few W tiles (which then live in  */ \
+    /* its L2 for the whole walk down M) and 32/group_n A tiles, each fetched once for group_n consumers          */ \
+    const int per_g_ = p.tiles_m * p.group_n;                                                \
+    const int g_ = bid_ / per_g_;                                                            \
+    const int rem_ = bid_ - g_ * per_g_;                                                     \
+    const int left_ = p.tiles_n - g_ * p.group_n;                                            \
+    const int gw_ = left_ < p.group_n ? left_ : p.group_n;                                   \
+    const int tm_ = rem_ / gw_;                                                              \
     m0_ = tm_ * BM;                                                                          \
-    n0_ = (bid_ - tm_ * p.tiles_n) * BN;                                                     \
+    n0_ = (g_ * p.group_n + rem_ - tm_ * gw_) * BN;                                          \
   } while (0)
 #define TILE_PTRS(m0_, n0_)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
@@ -944,6 +965,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int tslot = (tile - (int)blockIdx.x) / (int)gridDim.x;
+#define TRACE(i_)                                                                                         \
+  if (p.trace && lane == 0 && (w & 3) == 0 && tslot < 8)                                                  \
+    p.trace[(((size_t)blockIdx.x * 2 + grp) * 8 + tslot) * 4 + (i_)] = __builtin_amdgcn_s_memtime()
+    TRACE(0);
     // every wave has left the previous epilogue (its staging patch lives in buffer pb^1) before anyone DMAs into it
     __builtin_amdgcn_s_barrier();
     if (nk > 1) {
@@ -989,6 +1015,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    TRACE(1);
 
     // ---- prefetch k-tile 0 of the next tile into the buffer the last k-tile did NOT use
     const int ep_buf = (pb + nk - 1) & 1;      // last k-tile's buffer: free now, used for epilogue staging
@@ -1034,11 +1061,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
           v0 += bias_lo;
           v1 += bias_hi;
           if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = gelu_erf(v0[e]);
-              v1[e] = gelu_erf(v1[e]);
-            }
+            v0 = gelu_erf4(v0);
+            v1 = gelu_erf4(v1);
           }
           if (m < p.M && col_ok) {
             uint4 o;
@@ -1089,8 +1113,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
         const int m = cm0 + wm * 128 + g * 32 + rl;
         v += bias4;
         if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          v = gelu_erf4(v);
         }
         if (HAS_RES) v += rres[g & 1][it];
         if (m < p.M && col_ok) {
@@ -1107,7 +1130,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     }
 #undef ISSUE_RES
     }
+    TRACE(2);
   }
+#undef TRACE
 #undef TILE_COORDS
 #undef TILE_PTRS
 #undef STAGE_A
@@ -1137,6 +1162,8 @@ int launch_256p(const GemmArgs& a, hipStream_t s) {
   p.tiles_m = (a.M + 255) / 256;
   p.tiles_n = (a.N + 255) / 256;
   const int nwg = p.tiles_m * p.tiles_n;
+  p.trace = g_gemm_trace;
+  p.group_n = tile_group_n(p.tiles_n);
   hipLaunchKernelGGL(kern, dim3(nwg < n_cu ? nwg : n_cu), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256p");
   return VITCAP_OK;
@@ -1246,8 +1273,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs q) {
       }
       if (p.bias) v += *(const f32x4*)(p.bias + n);
       if (ACT == VITCAP_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        v = gelu_erf4(v);
       } else if (ACT == VITCAP_ACT_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -1342,6 +1368,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
 // pipeline of ImageCaptioning.generate_async) the non-persistent form wins, because a persistent grid owns every CU
 // for the whole GEMM (3277 vs 3133 img/s at B=64).
 static int g_gemm_persistent = 1;
+extern "C" void vitcap_gemm_set_trace(unsigned long long* buf) { g_gemm_trace = buf; }
 extern "C" void vitcap_gemm_set_persistent(int on) { g_gemm_persistent = on ? 1 : 0; }
 extern "C" int vitcap_gemm_get_persistent(void) { return g_gemm_persistent; }
 

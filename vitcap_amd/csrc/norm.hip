@@ -88,8 +88,7 @@ __global__ __launch_bounds__(64) void sum_layernorm768_kernel(const float* __res
   if (act) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = gelu_erf(v[i][e]);
+      v[i] = gelu_erf4(v[i]);
   }
   if (res) {
 #pragma unroll

@@ -249,7 +249,7 @@ class ImageCaptioning(nn.Module):
             self.last_tags = (tag_logits, tag_topk)
         return ids, lp
 
-    def generate_async(self, image, num_beams=1, length_penalty=1.0):
+    def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0):
         """Greedy captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
         HIP stream while the 19 decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of ~630
         small latency-bound kernels that leaves most of the chip idle; the encoder is MFMA-bound and has a tail at every
@@ -261,17 +261,20 @@ class ImageCaptioning(nn.Module):
         dev = self._packed[2]
         assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
         assert image.dtype in (torch.float32, torch.bfloat16)
-        pipe = getattr(self, '_pipe', None)
+        pipes = getattr(self, '_pipes', None)
+        if pipes is None:
+            pipes = self._pipes = {}
+        pipe = pipes.get(lane)
         if pipe is None:
             import os
             prio = int(os.environ.get('VITCAP_DECODE_PRIORITY', '-1'))     # -1 = high: the latency-bound chain goes first
-            pipe = self._pipe = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
-                                 'done': [None, None], 'n': 0}
+            pipe = pipes[lane] = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
+                                  'done': [None, None], 'n': 0}
         slot = pipe['n'] % 2
         pipe['n'] += 1
         lib.vitcap_gemm_set_persistent(0)       # let the other slot's decode kernels in between GEMM tiles
         B = image.shape[0]
-        ws, need = self._workspace(B, dev, slot='pipe%d' % slot, beams=num_beams if num_beams > 1 else 0)
+        ws, need = self._workspace(B, dev, slot='pipe%d_%d' % (lane, slot), beams=num_beams if num_beams > 1 else 0)
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)
