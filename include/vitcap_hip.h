@@ -208,14 +208,15 @@ int vitcap_sigmoid_topk(const float* logits, int ldl, int V, int k, float thresh
 
 /* ------------------------------------------------------------------------------------------------
  * Beam search, device side (ViTCAP._generate_beam_search + BeamHypotheses, modeling_utils.py:888-1100, 1138-1180,
- * with num_keep_best = 1, early_stopping = False):
+ * early_stopping = False):
  *   vitcap_row_topk_lse   per row: logsumexp over V and the k = 2*beams largest logits (sorted, lowest index first
  *                         on ties) -- the candidates `log_softmax(scores) + beam_scores` -> view(B, beams*V) ->
  *                         topk(2*beams) can take from that row                       (modeling_utils.py:988-996)
  *   vitcap_beam_step      per image: merge, sort, `is_done`, EOS / last-step candidates -> hypotheses, next beams,
  *                         re-ordered + extended input_ids, parent indices            (modeling_utils.py:1003-1054)
  *   vitcap_beam_reorder_cache   text K/V cache rows gathered by parent (the `past` re-ordering, 1056-1068)
- *   vitcap_beam_finalize  best hypothesis + EOS, padded to max_len; logprob = sum_logprobs / len**lp (1076-1100)
+ *   vitcap_beam_finalize  the n_keep best hypotheses + EOS, best first, padded to max_len -> out_ids [B][n_keep][max_len],
+ *                         out_logprobs [B][n_keep] = sum_logprobs / len**lp, -1e5 where fewer finished (1076-1100)
  * All state lives in caller-provided device arrays.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -224,10 +225,11 @@ typedef struct {
   float* beam_scores; /* [B*beams] */
   int32_t* parent;    /* [B*beams] row each new beam was expanded from */
   int32_t* done;      /* [B] */
-  int32_t* has_hyp;   /* [B] */
-  float* hyp_score;   /* [B] length-normalised score of the kept hypothesis */
-  int32_t* hyp_len;   /* [B] */
-  int64_t* hyp_tok;   /* [B][max_len] */
+  int32_t* has_hyp;   /* [B] number of hypotheses kept so far (0..n_keep) */
+  float* hyp_score;   /* [B][n_keep] length-normalised scores of the kept hypotheses, insertion order */
+  int32_t* hyp_len;   /* [B][n_keep] */
+  int64_t* hyp_tok;   /* [B][n_keep][max_len] */
+  int32_t n_keep;     /* BeamHypotheses.n_hyp = num_keep_best (modeling_utils.py:1138-1180), 1..8 */
 } vitcap_beam_state;
 
 int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, float* out_val, int32_t* out_idx,
@@ -307,8 +309,12 @@ size_t vitcap_engine_workspace_bytes(int B);
 /* image: [B,3,384,384] fp32 or bf16, normalised as the reference's Normalize(.5,.5)
  * out_ids int64 [B,1,20]; out_logprobs fp32 [B,1]  (what ImageCaptioning.forward returns at test time).
  * Optional taps (may be NULL): tag_logits fp32 [B,30522], tag_topk int64 [B,50]. */
-/* Beam search variant (num_beams <= 8): same outputs; workspace from vitcap_engine_workspace_bytes_beam(B, beams). */
+/* Beam search variant (num_beams <= 8); workspace from vitcap_engine_workspace_bytes_beam(B, beams).
+ * Outputs: out_ids int64 [B, num_keep_best, 20], out_logprobs fp32 [B, num_keep_best], best hypothesis first, rows of
+ * images with fewer finished hypotheses padded with 0 / -1e5 (modeling_utils.py:1076-1100).  num_keep_best is engine
+ * state (default 1) set by vitcap_engine_set_num_keep_best, 1..8. */
 size_t vitcap_engine_workspace_bytes_beam(int B, int beams);
+int vitcap_engine_set_num_keep_best(vitcap_engine* e, int num_keep_best);
 int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
                        float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                        float* out_logprobs, void* stream);

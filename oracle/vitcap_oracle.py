@@ -681,7 +681,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     return decoded, logprobs
 
 
-def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN):
+def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1):
     """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
     B = image.shape[0]
     K = num_beams
@@ -704,10 +704,11 @@ def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN):
         tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
         logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
         return logits[:, cur, :]
-    return beam_bookkeeping(step, B, K, max_length)
+    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best)
 
 
-def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False):
+def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
+                     num_keep_best=1):
     """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
     image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
     r = _R(emulate_bf16)
@@ -765,7 +766,7 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
         if return_trace:
             trace.append(logits.clone())
         return logits
-    out = beam_bookkeeping(step, B, K, max_length)
+    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best)
     return out + (trace,) if return_trace else out
 
 

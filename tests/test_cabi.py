@@ -82,8 +82,8 @@ def test_model_surface(L, sd_np):
     with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    m.test_extra_input['num_keep_best'] = 3
-    with pytest.raises(NotImplementedError):
+    m.test_extra_input['num_keep_best'] = 3                        # greedy + n-best: the reference asserts (modeling_utils.py:790)
+    with pytest.raises(AssertionError, match='greedy'):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
 
 

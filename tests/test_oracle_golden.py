@@ -135,6 +135,27 @@ def test_beam2_as_written_matches_reference(golden, sd_t, img):
     np.testing.assert_allclose(lp.numpy(), vec['beam2_b1_logprobs'], rtol=1e-5, atol=1e-5)
 
 
+def test_beam_nbest_incremental_matches_reference(sd_t):
+    """a11/a13 with num_keep_best > 1: BeamHypotheses' n-best list (add / worst_score / is_done, modeling_utils.py:1138-1180)
+    and the final best-first selection, against the reference's own output (tests/golden/make_golden_nbest.py).  The
+    incremental fp32 formulation is used (equal to the as-written one, next test) so the case runs in seconds."""
+    import os
+    from vitcap_amd import weights as W
+    vec = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_nbest.npz'))
+    n = 0
+    while 'case%d_cfg' % n in vec:
+        beams, keep, lp, B = vec['case%d_cfg' % n]
+        im = torch.from_numpy(W.gen_image_batch(int(B), int(vec['image_seed'])))
+        with torch.no_grad():
+            ids, logp = O.beam_incremental(sd_t, im, num_beams=int(beams), emulate_bf16=False, length_penalty=float(lp),
+                                           num_keep_best=int(keep))
+        assert tuple(ids.shape) == (int(B), int(keep), 20)
+        np.testing.assert_array_equal(ids.numpy(), vec['case%d_ids' % n])
+        np.testing.assert_allclose(logp.numpy(), vec['case%d_logprobs' % n], rtol=2e-5, atol=2e-5)
+        n += 1
+    assert n == 2
+
+
 def test_beam_incremental_equals_as_written(sd_t, img):
     with torch.no_grad():
         a = O.beam_as_written(sd_t, img[:1], num_beams=3)

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 
 class BeamState(C.Structure):
     _fields_ = [(n, vp) for n in ('ids_in', 'ids_out', 'beam_scores', 'parent', 'done', 'has_hyp', 'hyp_score',
-                                  'hyp_len', 'hyp_tok')]
+                                  'hyp_len', 'hyp_tok')] + [('n_keep', C.c_int32)]
 
 
 class SampleParams(C.Structure):
@@ -128,6 +128,7 @@ _SIGS = {
     'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int]),
     'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
+    'vitcap_engine_set_num_keep_best': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_beam_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),

@@ -419,10 +419,11 @@ struct BeamState {
   float* beam_scores;   // [B*K]
   int* parent;          // [B*K]
   int* done;            // [B]
-  int* has_hyp;         // [B]
-  float* hyp_score;     // [B]
-  int* hyp_len;         // [B]
-  int64_t* hyp_tok;     // [B][max_len]
+  int* has_hyp;         // [B]               number of hypotheses kept (0..n_keep)
+  float* hyp_score;     // [B][n_keep]       in insertion order, like BeamHypotheses.hyp
+  int* hyp_len;         // [B][n_keep]
+  int64_t* hyp_tok;     // [B][n_keep][max_len]
+  int n_keep;           // BeamHypotheses.n_hyp = num_keep_best
 };
 
 __global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bos, int pad) {
@@ -438,10 +439,12 @@ __global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bo
   if (i < B) {
     st.done[i] = 0;
     st.has_hyp[i] = 0;
+  }
+  if (i < B * st.n_keep) {
     st.hyp_score[i] = -1e30f;
     st.hyp_len[i] = 0;
   }
-  if (i < B * max_len) st.hyp_tok[i] = pad;
+  if (i < B * st.n_keep * max_len) st.hyp_tok[i] = pad;
 }
 
 __global__ void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
@@ -469,10 +472,17 @@ __global__ void beam_step_kernel(const float* __restrict__ cval, const int* __re
     const float ts = sc[r]; sc[r] = sc[best]; sc[best] = ts;
     const int tf = fl[r]; fl[r] = fl[best]; fl[best] = tf;
   }
+  const int NH = st.n_keep;
+  float* hsc = st.hyp_score + (size_t)b * NH;
+  int* hln = st.hyp_len + (size_t)b * NH;
+  int64_t* htk = st.hyp_tok + (size_t)b * NH * max_len;
+  int nh = st.has_hyp[b];
   int done = st.done[b];
-  if (!done && st.has_hyp[b]) {
-    // BeamHypotheses.is_done with n_hyp = 1: worst_score is the kept hypothesis' score
-    if (st.hyp_score[b] >= sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
+  if (!done && nh >= NH) {
+    // BeamHypotheses.is_done: the list is full and its worst score already beats what the best open beam can reach
+    float worst = hsc[0];
+    for (int i = 1; i < nh; ++i) worst = fminf(worst, hsc[i]);
+    if (worst >= sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
   }
   st.done[b] = done;
   float nsc[MAXBEAM];
@@ -483,13 +493,30 @@ __global__ void beam_step_kernel(const float* __restrict__ cval, const int* __re
     for (int r = 0; r < C && cnt < K; ++r) {
       const int beam = fl[r] / V, word = fl[r] - beam * V;
       if (word == eos || last) {
+        // BeamHypotheses.add (modeling_utils.py:1157-1170): append when the list is not full or the score beats the worst
+        // kept one; when that makes n_hyp + 1 entries, delete the lowest (first of equals) and keep the insertion order
         const float hs = sc[r] / powf((float)t, length_penalty);     // len(hyp) == cur_len == t
-        if (!st.has_hyp[b] || hs > st.hyp_score[b]) {
-          st.has_hyp[b] = 1;
-          st.hyp_score[b] = hs;
-          st.hyp_len[b] = t;
+        int slot = -1;
+        if (nh < NH) {
+          slot = nh++;
+        } else {
+          int lo = 0;
+          for (int i = 1; i < nh; ++i)
+            if (hsc[i] < hsc[lo]) lo = i;
+          if (hs > hsc[lo]) {
+            for (int i = lo; i + 1 < nh; ++i) {
+              hsc[i] = hsc[i + 1];
+              hln[i] = hln[i + 1];
+              for (int q = 0; q < max_len; ++q) htk[(size_t)i * max_len + q] = htk[(size_t)(i + 1) * max_len + q];
+            }
+            slot = nh - 1;
+          }
+        }
+        if (slot >= 0) {
+          hsc[slot] = hs;
+          hln[slot] = t;
           const int64_t* src = st.ids_in + (size_t)(b * K + beam) * max_len;
-          for (int i = 0; i < t; ++i) st.hyp_tok[(size_t)b * max_len + i] = src[i];
+          for (int i = 0; i < max_len; ++i) htk[(size_t)slot * max_len + i] = i < t ? src[i] : (int64_t)pad;
         }
       } else {
         nsc[cnt] = sc[r];
@@ -499,6 +526,7 @@ __global__ void beam_step_kernel(const float* __restrict__ cval, const int* __re
       }
     }
   }
+  st.has_hyp[b] = nh;
   if (cnt < K) {   // finished image (or the last step): filler beams, ignored from here on
     for (int i = 0; i < K; ++i) { nsc[i] = 0.f; nword[i] = pad; npar[i] = b * K; }
   }
@@ -523,17 +551,30 @@ __global__ __launch_bounds__(192) void beam_reorder_kernel(const uint4* __restri
   for (int q = 0; q < t; ++q) dp[q * rowv + threadIdx.x] = sp[q * rowv + threadIdx.x];
 }
 
+// decoded[b][j] = the j-th best kept hypothesis + EOS, padded; logprobs -1e5 where fewer than n_keep finished
+// (modeling_utils.py:1076-1100: topk over the kept scores, best first; equal scores: earlier insertion first)
 __global__ void beam_finalize_kernel(BeamState st, int64_t* out_ids, float* out_lp, int B, int max_len, int eos, int pad) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int L = st.hyp_len[b];
-  for (int i = 0; i < max_len; ++i) {
-    int64_t v = pad;
-    if (i < L) v = st.hyp_tok[(size_t)b * max_len + i];
-    else if (i == L) v = eos;
-    out_ids[(size_t)b * max_len + i] = v;
+  const int NH = st.n_keep, nh = st.has_hyp[b];
+  const float* hsc = st.hyp_score + (size_t)b * NH;
+  unsigned used = 0;
+  for (int j = 0; j < NH; ++j) {
+    int best = -1;
+    for (int i = 0; i < nh; ++i)
+      if (!(used >> i & 1) && (best < 0 || hsc[i] > hsc[best])) best = i;
+    int64_t* dst = out_ids + ((size_t)b * NH + j) * max_len;
+    if (best < 0) {
+      for (int i = 0; i < max_len; ++i) dst[i] = pad;
+      out_lp[(size_t)b * NH + j] = -1e5f;
+      continue;
+    }
+    used |= 1u << best;
+    const int Lh = st.hyp_len[(size_t)b * NH + best];
+    const int64_t* src = st.hyp_tok + ((size_t)b * NH + best) * max_len;
+    for (int i = 0; i < max_len; ++i) dst[i] = i < Lh ? src[i] : (i == Lh ? (int64_t)eos : (int64_t)pad);
+    out_lp[(size_t)b * NH + j] = hsc[best];
   }
-  out_lp[b] = st.has_hyp[b] ? st.hyp_score[b] : -1e5f;
 }
 
 }  // namespace
@@ -585,12 +626,14 @@ static BeamState make_state(const vitcap_beam_state* s) {
   st.ids_in = s->ids_in; st.ids_out = s->ids_out; st.beam_scores = s->beam_scores; st.parent = s->parent;
   st.done = s->done; st.has_hyp = s->has_hyp; st.hyp_score = s->hyp_score; st.hyp_len = s->hyp_len;
   st.hyp_tok = s->hyp_tok;
+  st.n_keep = s->n_keep;
   return st;
 }
 
 extern "C" int vitcap_beam_init(const vitcap_beam_state* s, int B, int K, int max_len, int bos, int pad, void* stream) {
   VC_REQUIRE(s && B > 0 && K >= 1 && K <= MAXBEAM && max_len > 1, "beam_init: bad arguments (beams <= %d)", MAXBEAM);
-  const int n = B * K * max_len;
+  VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_init: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
+  const int n = B * (K > s->n_keep ? K : s->n_keep) * max_len;
   hipLaunchKernelGGL(beam_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, make_state(s), B, K,
                      max_len, bos, pad);
   VC_LAUNCH_CHECK("beam_init");
@@ -602,6 +645,7 @@ extern "C" int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, 
                                 float length_penalty, void* stream) {
   VC_REQUIRE(cand_val && cand_idx && lse && s && B > 0 && K >= 1 && K <= MAXBEAM, "beam_step: bad arguments");
   VC_REQUIRE(t >= 1 && t < max_len, "beam_step: t=%d out of range", t);
+  VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_step: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
   hipLaunchKernelGGL(beam_step_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
                      make_state(s), B, K, V, t, max_len, eos, pad, length_penalty);
   VC_LAUNCH_CHECK("beam_step");
@@ -620,6 +664,7 @@ extern "C" int vitcap_beam_reorder_cache(const void* src, void* dst, const int32
 extern "C" int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B,
                                     int max_len, int eos, int pad, void* stream) {
   VC_REQUIRE(s && out_ids && out_logprobs && B > 0, "beam_finalize: bad arguments");
+  VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_finalize: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
   hipLaunchKernelGGL(beam_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, make_state(s),
                      out_ids, out_logprobs, B, max_len, eos, pad);
   VC_LAUNCH_CHECK("beam_finalize");

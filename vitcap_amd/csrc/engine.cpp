@@ -41,6 +41,7 @@ struct vitcap_engine {
   // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int keep_best = 1;            // num_keep_best of the beam search (BeamHypotheses.n_hyp)
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
   size_t used = 0;
@@ -126,9 +127,9 @@ struct Layout {
       parent = take(n * 4);
       done = take(b * 4);
       has_hyp = take(b * 4);
-      hyp_score = take(b * 4);
-      hyp_len = take(b * 4);
-      hyp_tok = take(b * L * 8);
+      hyp_score = take(b * 8 * 4);          // up to 8 kept hypotheses per image (num_keep_best)
+      hyp_len = take(b * 8 * 4);
+      hyp_tok = take(b * 8 * L * 8);
     }
   }
 };
@@ -489,6 +490,7 @@ extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, flo
   st.hyp_score = (float*)(ws + lo.hyp_score);
   st.hyp_len = (int32_t*)(ws + lo.hyp_len);
   st.hyp_tok = (int64_t*)(ws + lo.hyp_tok);
+  st.n_keep = e->keep_best;
   CK(vitcap_beam_init(&st, B, beams, L, BOS, PAD, s));
   char* tc_cur = ws + lo.tcache;
   char* tc_alt = ws + lo.tcache2;
@@ -506,6 +508,12 @@ extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, flo
     int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
   }
   CK(vitcap_beam_finalize(&st, out_ids, out_logprobs, B, L, EOS, PAD, s));
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_set_num_keep_best(vitcap_engine* e, int n) {
+  if (!e || n < 1 || n > 8) { vitcap_set_error("set_num_keep_best: need an engine and 1 <= n <= 8 (got %d)", n); return VITCAP_EINVAL; }
+  e->keep_best = n;
   return VITCAP_OK;
 }
 

@@ -294,6 +294,7 @@ class ImageCaptioning(nn.Module):
             ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
             lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
             if num_beams > 1:
+                check(lib.vitcap_engine_set_num_keep_best(self._engine, 1), 'set_num_keep_best')
                 check(lib.vitcap_engine_beam_decode(self._engine, B, num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
                                                     C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
                                                     C.c_void_p(pipe['dec'].cuda_stream)), 'engine_beam_decode')
@@ -305,17 +306,20 @@ class ImageCaptioning(nn.Module):
         pipe['done'][slot] = done
         return _Pending(ids, lp, done, image)
 
-    def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0):
-        """Beam search (num_keep_best = 1) -> (ids (B,1,20), logprobs (B,1)) like ViTCAP._generate_beam_search."""
+    def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0, num_keep_best=1):
+        """Beam search -> (ids (B,num_keep_best,20), logprobs (B,num_keep_best)), best hypothesis first, like
+        ViTCAP._generate_beam_search (modeling_utils.py:888-1100)."""
         if self._packed is None:
             self.pack(image.device)
         dev = self._packed[2]
         assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
         B = image.shape[0]
         ws, need = self._workspace(B, dev, slot, beams=num_beams)
-        ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
-        lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        keep = int(num_keep_best)
+        ids = torch.empty((B, keep, L.MAXLEN), dtype=torch.int64, device=dev)
+        lp = torch.empty((B, keep), dtype=torch.float32, device=dev)
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vitcap_engine_set_num_keep_best(self._engine, keep), 'set_num_keep_best')
         check(lib.vitcap_engine_beam(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B,
                                      num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
                                      C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()), s), 'engine_beam')
@@ -344,8 +348,10 @@ class ImageCaptioning(nn.Module):
                 raise RuntimeError('training-mode forward needs a vitcap_amd.train.TrainEngine(model, ...) attached')
             return eng.loss_dict(data)
         te = self.test_extra_input
-        if te.get('num_keep_best', 1) != 1:
-            raise NotImplementedError('num_keep_best > 1 is not built')
+        keep = int(te.get('num_keep_best', 1))
+        if keep != 1 and te.get('num_beams', 1) == 1:
+            # modeling_utils.py:790: "cannot generate >1 sentences in greedy search"
+            raise AssertionError('cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)')
         nret = int(te.get('num_return_sequences', 1))
         if nret > 1:
             # ViTCAP.generate expands every input num_return_sequences times (modeling_bert.py:976-979, 994,
@@ -357,7 +363,7 @@ class ImageCaptioning(nn.Module):
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
         if te.get('num_beams', 1) > 1:
-            return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)))
+            return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)), num_keep_best=keep)
         if te.get('do_sample', False):
             # every forward() call advances the stream of draws, like consecutive torch.multinomial calls would
             self._sample_calls = getattr(self, '_sample_calls', 0) + 1
