@@ -435,6 +435,24 @@ int vitcap_resample_coeffs(int in_size, int out_size, int* ksize_out, int* bound
 int vitcap_resized_geometry(int height, int width, int resize_short, int crop, int* out_h, int* out_w, int* crop_y0,
                             int* crop_x0);
 
+/* Train-time image transform, get_inception_train_transform (src/data_layer/transform.py:52-81; selected by
+ * get_transform_vit_default, uni_pipeline.py:1258-1264): RandomResizedCrop(size, PIL BILINEAR) -> ColorJitter(brightness,
+ * contrast, saturation) -> RandomHorizontalFlip -> ToTensor -> Normalize(.5, .5).
+ * The random parameters are drawn on the host (vitcap_amd/augment.py restates torchvision 0.7's get_params) and passed in;
+ * the image arithmetic is Pillow's (Resample.c triangle filter on the cropped image, Blend.c float32 blend with the
+ * black / mean-gray / grayscale degenerate image, Convert.c rgb2l, left-right transpose) and is reproduced bit for bit.
+ *   op[3]: colour operations in application order, 0 = brightness, 1 = contrast, 2 = saturation, -1 = none;
+ *   factor[3]: the enhancement factors (>= 0);  out: [B][3][size][size] fp32 or bf16;  out_u8 optional bytes. */
+typedef struct vitcap_train_aug {
+  int32_t top, left, height, width; /* crop box in source pixels (RandomResizedCrop.get_params' i, j, h, w) */
+  int32_t op[3];
+  float factor[3];
+  int32_t flip;
+} vitcap_train_aug;
+size_t vitcap_image_train_preproc_workspace_bytes(const vitcap_image* imgs, const vitcap_train_aug* aug, int B, int size);
+int vitcap_image_train_preproc(const vitcap_image* imgs, const vitcap_train_aug* aug, int B, int size, int out_bf16,
+                               void* out, uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,3 +109,47 @@ def test_run_py_eval_on_image_tsv(tmp_path, monkeypatch):
         want = ' '.join('w%d' % t for t in ids[i, 0].tolist() if t not in (0, 101, 102))
         assert cap['caption'] == want, (i, cap['caption'], want)
         assert abs(cap['conf'] - float(torch.exp(lp[i, 0]))) < 1e-5
+
+
+def test_train_transform_bit_exact():
+    """Train-time transform (crop + bilinear resize, colour jitter in the drawn order, flip, normalise) on the device ==
+    Pillow doing the same operations (oracle.image_oracle.train_transform_reference), bytes and fp32 tensor, for drawn
+    parameters plus hand-picked corner cases: whole-image box, a 1:1 box of exactly 384x384 (no resampling), up-scaling of
+    a tiny box, factors at both ends of the jitter range, a single operation, no operation."""
+    from oracle import image_oracle as IO
+    from vitcap_amd.augment import TrainAugmentation
+    from vitcap_amd.imageio import TrainImagePreprocessor
+    imgs = [_img(h, w, 31 * i + 5) for i, (h, w) in enumerate(SIZES)]
+    aug = TrainAugmentation(seed=3)
+    params = [aug.params(im.shape[0], im.shape[1], index=i, epoch=1) for i, im in enumerate(imgs)]
+    extra = [
+        (imgs[0], {'box': (0, 0, 480, 640), 'ops': [(0, 1.4), (1, 1.4), (2, 1.4)], 'flip': True}),
+        (imgs[6], {'box': (100, 200, 384, 384), 'ops': [(2, 0.6), (1, 0.6), (0, 0.6)], 'flip': False}),
+        (imgs[1], {'box': (10, 20, 17, 23), 'ops': [(1, 1.0), (0, 0.9999)], 'flip': True}),
+        (imgs[2], {'box': (0, 0, 333, 500), 'ops': [], 'flip': False}),
+        (imgs[5], {'box': (1, 0, 384, 1201), 'ops': [(2, 0.0), (0, 1.25)], 'flip': True}),
+        (imgs[4], {'box': (0, 0, 384, 384), 'ops': [(1, 0.0)], 'flip': False}),
+    ]
+    all_imgs = imgs + [e[0] for e in extra]
+    all_params = params + [e[1] for e in extra]
+    pre = TrainImagePreprocessor('cuda', out_dtype=torch.float32)
+    out, u8 = pre(all_imgs, all_params, want_u8=True)
+    torch.cuda.synchronize()
+    for i, (im, pr) in enumerate(zip(all_imgs, all_params)):
+        want_u8, want_f = IO.train_transform_reference(im, pr['box'], pr['ops'], pr['flip'])
+        got = u8[i].cpu().numpy()
+        assert np.array_equal(got, want_u8), 'bytes differ for case %d %r: %d pixels, max %d' % (
+            i, pr, int((got != want_u8).sum()), int(np.abs(got.astype(int) - want_u8.astype(int)).max()))
+        assert np.array_equal(out[i].cpu().numpy(), want_f), 'normalised tensor differs for case %d' % i
+    out_b = TrainImagePreprocessor('cuda', out_dtype=torch.bfloat16)(all_imgs, all_params)
+    assert torch.equal(out_b, out.to(torch.bfloat16))
+
+
+def test_train_transform_rejects_bad_parameters():
+    from vitcap_amd.imageio import TrainImagePreprocessor
+    pre = TrainImagePreprocessor('cuda')
+    im = _img(100, 120, 1)
+    with pytest.raises(RuntimeError, match='crop box'):
+        pre([im], [{'box': (50, 0, 60, 120), 'ops': [], 'flip': False}])
+    with pytest.raises(RuntimeError, match='twice'):
+        pre([im], [{'box': (0, 0, 100, 120), 'ops': [(0, 1.0), (0, 1.1)], 'flip': False}])

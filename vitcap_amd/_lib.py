@@ -40,6 +40,13 @@ class Image(C.Structure):
     _fields_ = [('rgb', C.c_void_p), ('height', C.c_int), ('width', C.c_int), ('pitch', C.c_int)]
 
 
+class TrainAug(C.Structure):
+    """vitcap_train_aug: RandomResizedCrop box, ColorJitter operations in order (0 brightness, 1 contrast, 2 saturation,
+    -1 none) with their factors, horizontal flip."""
+    _fields_ = [('top', C.c_int32), ('left', C.c_int32), ('height', C.c_int32), ('width', C.c_int32),
+                ('op', C.c_int32 * 3), ('factor', C.c_float * 3), ('flip', C.c_int32)]
+
+
 class VitBlockW(C.Structure):
     _fields_ = [(n, vp) for n in ('qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
                                   'n1_g', 'n1_b', 'n2_g', 'n2_b')]
@@ -84,6 +91,8 @@ _SIGS = {
     'vitcap_colsum_bf16': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_image_preproc_workspace_bytes': (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
     'vitcap_image_preproc': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    'vitcap_image_train_preproc_workspace_bytes': (C.c_size_t, [vp, vp, C.c_int, C.c_int]),
+    'vitcap_image_train_preproc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'vitcap_gemm_set_persistent': (None, [C.c_int]),

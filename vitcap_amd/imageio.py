@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ._lib import Image as _ImageDesc
+from ._lib import TrainAug as _TrainAug
 from ._lib import check, lib
 
 
@@ -60,4 +61,47 @@ class ImagePreprocessor(object):
                                        C.c_void_p(out.data_ptr()), C.c_void_p(u8.data_ptr()) if want_u8 else None,
                                        C.c_void_p(self._ws.data_ptr()), need, s), 'image_preproc')
         self._keep = dev_imgs             # the raw images must outlive the enqueued kernels
+        return (out, u8) if want_u8 else out
+
+
+class TrainImagePreprocessor(object):
+    """get_transform_vit_default(is_train=True) (uni_pipeline.py:1258-1264) = get_inception_train_transform for a list of
+    decoded images and their drawn parameters (vitcap_amd/augment.py): crop + bilinear resize, colour jitter, flip,
+    ToTensor, Normalize on the GPU (csrc/preproc.hip), bit-identical to torchvision-on-Pillow for the same parameters."""
+
+    def __init__(self, device='cuda', train_crop_size=384, out_dtype=torch.bfloat16):
+        self.dev = torch.device(device)
+        self.size = int(train_crop_size)
+        assert out_dtype in (torch.bfloat16, torch.float32)
+        self.out_dtype = out_dtype
+        self._ws = None
+
+    def __call__(self, images, params, want_u8=False):
+        B = len(images)
+        assert len(params) == B
+        dev_imgs, desc, aug = [], (_ImageDesc * B)(), (_TrainAug * B)()
+        for i, (im, pr) in enumerate(zip(images, params)):
+            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+                raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
+            t = torch.from_numpy(np.array(im, copy=True, order='C')).to(self.dev, non_blocking=True)
+            dev_imgs.append(t)
+            desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
+            top, left, h, w = pr['box']
+            a = aug[i]
+            a.top, a.left, a.height, a.width, a.flip = int(top), int(left), int(h), int(w), int(bool(pr['flip']))
+            ops = list(pr['ops'])
+            if len(ops) > 3:
+                raise ValueError('image %d: at most three colour operations' % i)
+            for o in range(3):
+                a.op[o], a.factor[o] = (int(ops[o][0]), float(ops[o][1])) if o < len(ops) else (-1, 1.0)
+        need = lib.vitcap_image_train_preproc_workspace_bytes(desc, aug, B, self.size)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = torch.empty((B, 3, self.size, self.size), dtype=self.out_dtype, device=self.dev)
+        u8 = torch.empty((B, 3, self.size, self.size), dtype=torch.uint8, device=self.dev) if want_u8 else None
+        s = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        check(lib.vitcap_image_train_preproc(desc, aug, B, self.size, int(self.out_dtype == torch.bfloat16),
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(u8.data_ptr()) if want_u8 else None,
+                                             C.c_void_p(self._ws.data_ptr()), need, s), 'image_train_preproc')
+        self._keep = dev_imgs
         return (out, u8) if want_u8 else out
