@@ -62,6 +62,38 @@ def main():
                 after = random.random()
                 out['cases'].append({'kw': kw, 'text': ti, 'text_b': text_b, 'seed': seed, 'rng_after': after,
                                      'out': {k: (pack(v) if k == 'attention_mask' else v.tolist()) for k, v in r.items()}})
+    # ---- CaptionTaggerTensorizer (dataset.py:774-820), same in-place class statement; nltk is absent, so the 'nltk' branch
+    # runs on a stand-in whose word_tokenize is str.split and whose pos_tag replays a fixed table (stored with the case):
+    # what is pinned is the reference's use of the tags (JJ / NN / NNP words -> vocabulary ids), not nltk itself
+    a = src.index('class CaptionTaggerTensorizer(object):')
+    b = src.index('\nclass ', a + 10)
+    POS = {'man': 'NN', 'horse': 'NN', 'red': 'JJ', 'street': 'NN', 'riding': 'VBG', 'a': 'DT', 'on': 'IN', 'the': 'DT',
+           'pizza': 'NNP', 'two': 'CD', 'people': 'NNS', 'large': 'JJ', 'zzzz': 'NN'}
+
+    class _Nltk(object):
+        @staticmethod
+        def word_tokenize(c):
+            return c.split()
+
+        @staticmethod
+        def pos_tag(words):
+            return [(w, POS.get(w, 'XX')) for w in words]
+    ns2 = {'torch': torch, 'nltk': _Nltk}
+    exec(compile(src[a:b], '/root/reference/src/data_layer/dataset.py', 'exec'), ns2)
+    Tagger = ns2['CaptionTaggerTensorizer']
+    labels = [{'class': 'dog', 'conf': 0.9}, {'class': 'tennis court', 'conf': 0.2}, {'class': 'cat', 'conf': 0.19},
+              {'class': 'frisbee', 'conf': 0.8}]
+    caps = ['a man riding a red horse on the street', 'two people pizza zzzz large', None]
+    out['tagger'] = {'labels': labels, 'pos_table': POS, 'cases': []}
+    for encode in ('nltk', 'bert', None):
+        for caption_only in (False, True):
+            for ci, cap in enumerate(caps):
+                if cap is not None and encode is None:
+                    continue               # the reference asserts encode is not None when a caption is given
+                tz = Tagger(None, tok, threshold=0.2, category='bert', encode=encode, caption_only=caption_only)
+                v = tz.tensorize(labels, cap)['label']
+                out['tagger']['cases'].append({'encode': encode, 'caption_only': caption_only, 'caption': cap,
+                                               'size': int(v.numel()), 'nonzero': v.nonzero().view(-1).tolist()})
     with open(os.path.join(HERE, 'reference_tensorizer.json'), 'w') as fp:
         json.dump(out, fp)
     print(len(out['cases']), 'cases;', out['tokenize'][2], out['tokenize'][4])

@@ -417,3 +417,80 @@ def test_train_step_batch64_properties():
     print('losses over 4 steps on one batch:', ['%.4f' % v for v in losses], 'grad norm %.3f' % eng.grad_norm())
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0] - 0.05
     assert torch.isfinite(eng.P).all()
+
+
+@pytest.mark.parametrize('scst', [False, True])
+def test_pipeline_trains_on_tsv_data(tmp_path, monkeypatch, scst):
+    """run.py `pipeline_train_eval_multi` (no test sets) on a toy TSV dataset in the reference's layout (data/<name>/train.tsv + train.caption.tsv +
+    train.label.v<ver>.tsv): JPEG decode, device-side train augmentation, caption tensorizer, tag labels, 3 optimizer steps
+    (cross-entropy or self-critical), losses finite, snapshot written; and the first batch of the loader is exactly the
+    oracle's transform of the decoded bytes under the drawn parameters."""
+    import base64
+    import io
+    import json
+    import yaml
+    import numpy as np
+    from PIL import Image
+    import run
+    from oracle import image_oracle as IO
+    from vitcap_amd.tsv import tsv_writer
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    words = 'a man woman dog cat horse riding sitting on the street bench red blue two people table pizza'.split()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    for i, w in enumerate(words):
+        toks[2000 + i] = w
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
+    d = tmp_path / 'data' / 'toy'
+    d.mkdir(parents=True)
+    g = np.random.default_rng(1)
+    img_rows, cap_rows, lab_rows = [], [], []
+    for i in range(6):
+        h, w = int(g.integers(120, 300)), int(g.integers(120, 400))
+        base = g.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(base, 'RGB').resize((w, h), Image.BICUBIC).save(buf, format='JPEG', quality=90)
+        caps = [{'caption': ' '.join(g.choice(words, size=int(g.integers(4, 10))))} for _ in range(2)]
+        img_rows.append(('k%d' % i, base64.b64encode(buf.getvalue())))
+        cap_rows.append(('k%d' % i, json.dumps(caps)))
+        lab_rows.append(('k%d' % i, json.dumps([{'class': 'dog', 'conf': 0.7}])))
+    tsv_writer(img_rows, str(d / 'train.tsv'))
+    tsv_writer(cap_rows, str(d / 'train.caption.tsv'))
+    tsv_writer(lab_rows, str(d / 'train.label.vvinvl.tsv'))
+    param = {'full_expid': 'R', 'max_iter': 3, 'effective_batch_size': 4, 'init_recipe_seed': 0, 'log_step': 1, 'data': 'toy',
+             'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'force_train': True, 'max_seq_a_length': 20,
+             'train_label_version': 'vinvl', 'encode': 'bert', 'input_small_scale': 0.08, 'num_workers': 2, 'random_seed': 5,
+             'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}
+    if scst:
+        param.update(scst=True, scst_num_return=2)
+    yf = tmp_path / 'exp.yaml'
+    yf.write_text(yaml.safe_dump({'type': 'pipeline_train_eval_multi', 'all_test_data': [], 'param': param}))
+    kw = run.parse_general_args(['-c', str(yf)])
+    fn = kw.pop('type')
+    getattr(run, fn)(**kw)
+    ck = torch.load(tmp_path / 'output' / 'R' / 'snapshot' / 'model_iter_0000003.pt', weights_only=False)
+    assert ck['iteration'] == 3 and all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
+    if scst:
+        return
+    # the loader's first batch == the oracle's transform of the same decoded images with the same drawn parameters
+    from vitcap_amd.pipeline import CaptionUniPipeline
+    from vitcap_amd.imageio import decode_image
+    pip = CaptionUniPipeline(**param)
+    ld = pip.real_train_batches(4)
+    b = next(ld)
+    ld.close()
+    assert b['image'].shape == (4, 3, 384, 384) and b['image'].dtype == torch.bfloat16 and b['input_ids'].shape == (4, 70)
+    keys = [r[0] for r in img_rows]
+    for j, k in enumerate(b['key']):
+        s = ld.ds.sample([i for i in range(len(ld.ds)) if ld.ds.idx[i][0] == k][0], 0)      # any caption of that image
+        rgb = decode_image(img_rows[keys.index(k)][1])
+        # the augmentation belongs to the (image, caption) sample: find the sample whose tensors match the batch row
+        cands = [ld.ds.sample(i, 0) for i in range(len(ld.ds)) if ld.ds.idx[i][0] == k]
+        hit = [c for c in cands if torch.equal(c['input_ids'], b['input_ids'][j])]
+        assert hit, 'batch row %d matches no sample of image %s' % (j, k)
+        pr = hit[0]['aug']
+        _, want = IO.train_transform_reference(rgb, pr['box'], pr['ops'], pr['flip'])
+        assert torch.equal(b['image'][j].cpu(), torch.from_numpy(want).to(torch.bfloat16)), 'image %s differs from the oracle' % k
+        assert b['label'][j, 2000 + words.index('dog')] == 1

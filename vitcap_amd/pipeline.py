@@ -114,9 +114,9 @@ class CaptionUniPipeline(object):
         return self._tokenizer
 
     def get_raw_model(self, is_train):
-        if is_train:
-            raise NotImplementedError('the HIP training step is not built yet (round 2+)')
         from .model import ImageCaptioning
+        if is_train:       # ensure_train attaches the TrainEngine; the module itself is the same tree in train mode
+            return ImageCaptioning(tie_weights=bool(self.cfg.tie_weights), tagemb=self.cfg.tagemb or 'bert', cfg=self.cfg).train()
         extra = {'max_length': self.cfg.max_gen_length, 'num_beams': self.cfg.num_beams,
                  'temperature': self.cfg.temperature, 'top_k': self.cfg.top_k, 'top_p': self.cfg.top_p,
                  'add_od_labels': self.cfg.add_od_labels, 'od_labels_start_posid': self.cfg.max_seq_a_length}
@@ -140,6 +140,10 @@ class CaptionUniPipeline(object):
             while True:
                 for b in self.cfg.train_batches:
                     yield b
+        if self.cfg.data and self.cfg.data != 'synthetic':
+            for b in self.real_train_batches(per_gpu):
+                yield b
+            return
         from . import weights as W
         from .synthetic import synthetic_train_inputs
         it = 0
@@ -152,6 +156,37 @@ class CaptionUniPipeline(object):
                 batch['captions'] = [[self.tokenizer.decode(r.tolist(), skip_special_tokens=True)] for r in ids]
             yield batch
             it += 1
+
+    def real_train_batches(self, per_gpu):
+        """`data: <name>` -> data/<name>/train.tsv (+ .caption.tsv, optional .label / .num_caption): the reference's training
+        transform chain (get_transform(is_train=True), ..._bertemb.py:373-518) via vitcap_amd/dataset.py; images are cropped,
+        resized, jittered, flipped and normalised on this rank's GPU."""
+        from .dataset import CaptionTrainSet, TagLabelTensorizer, TrainBatchLoader
+        from .augment import TrainAugmentation
+        from .imageio import TrainImagePreprocessor
+        from .tensorizer import CaptionTensorizer
+        from .tokenizer import BertWordPieceTokenizer
+        c = self.cfg
+        if int(c.max_seq_a_length) > 20:
+            raise NotImplementedError('the training engine is built for max_seq_a_length <= 20 (the shipped YAML value), got %s'
+                                      % c.max_seq_a_length)
+        vf = op.join(c.text_encoder_type or '.', 'vocab.txt')
+        tok = BertWordPieceTokenizer(vf)
+        tz = CaptionTensorizer(tok, max_img_seq_length=int(c.max_img_seq_length), max_seq_length=int(c.max_seq_length),
+                               max_seq_a_length=int(c.max_seq_a_length), mask_prob=float(c.mask_prob),
+                               max_masked_tokens=int(c.max_masked_tokens), mask_type=c.mask_type, is_train=True,
+                               mask_b=bool(c.mask_b), replace_by_mask_prob=float(c.replace_by_mask_prob),
+                               replace_by_rand_prob=float(c.replace_by_rand_prob), ignore_sep=bool(c.ignore_sep))
+        tagger = TagLabelTensorizer(tok, threshold=float(c.od_label_conf if c.od_label_conf is not None else 0.2),
+                                    encode=c.encode if c.encode is not None else 'nltk', caption_only=bool(c.caption_only),
+                                    pos_tagger=c.pos_tagger)
+        seed = int(c.random_seed or 0)
+        ds = CaptionTrainSet(c.data_root or 'data', c.data, tz, tagger, split='train', caption_version=c.train_version,
+                             label_version=c.train_label_version,
+                             augmentation=TrainAugmentation(seed=seed, small_scale=c.input_small_scale))
+        tf = TrainImagePreprocessor(torch.device('cuda', self.local_rank), train_crop_size=int(c.train_crop_size))
+        return TrainBatchLoader(ds, per_gpu, tf, rank=self.rank, world=self.world, seed=seed, workers=int(c.num_workers),
+                                want_captions=bool(c.scst))
 
     def ensure_train(self):
         """do_train_dict (trainer.py:33-213) on the HIP training engine: per-GPU batch = effective_batch_size // world,

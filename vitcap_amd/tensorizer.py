@@ -24,8 +24,10 @@ class CaptionTensorizer(object):
         self.mask_type, self.is_train, self.mask_b, self.ignore_sep = mask_type, is_train, mask_b, ignore_sep
         self.p_mask, self.p_rand = replace_by_mask_prob, replace_by_rand_prob
 
-    def tensorize_ab(self, text_a, text_b=None, pad_to_max=True, real_text_a_in_test=True):
+    def tensorize_ab(self, text_a, text_b=None, pad_to_max=True, real_text_a_in_test=True, rng=None):
+        """`rng`: a random.Random for the masking draws (default: Python's global generator, as in the reference)."""
         t = self.tok
+        R = rng if rng is not None else random
         if not real_text_a_in_test and not self.is_train:
             ta = [t.mask_token] * (self.La - 2)
         else:
@@ -60,14 +62,14 @@ class CaptionTensorizer(object):
                 k = min(max(round(self.mask_prob * (len_a - 1)), 1), self.max_masked)
             if self.mask_prob == 0:
                 k = 0
-            random.shuffle(cand)
+            R.shuffle(cand)
             picked = sorted(cand[:int(k)])
             targets = [toks[i] for i in picked]
             for i in picked:
-                if random.random() <= self.p_mask:
+                if R.random() <= self.p_mask:
                     toks[i] = t.mask_token
-                elif random.random() <= self.p_rand / (1 - self.p_mask):
-                    toks[i] = t.get_random_token()
+                elif R.random() <= self.p_rand / (1 - self.p_mask):
+                    toks[i] = t.get_random_token(R) if rng is not None else t.get_random_token()
             masked_pos = torch.zeros(n, dtype=torch.int)
             masked_pos[picked] = 1
             if len(picked) < self.max_masked and pad_to_max:

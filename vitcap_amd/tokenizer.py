@@ -140,8 +140,8 @@ class BertWordPieceTokenizer(CaptionDetokenizer):
                     out.extend(self._pieces(w))
         return out
 
-    def get_random_token(self):
+    def get_random_token(self, rng=None):
         """tokenization_bert.py:208-210 draws randint(0, len(vocab)) -- inclusive, so one draw in 30 523 indexes past the
         vocabulary (a KeyError upstream); that draw maps to [UNK] here, every other draw is identical."""
-        i = _random.randint(0, len(self.vocab))
+        i = (rng or _random).randint(0, len(self.vocab))
         return self.ids_to_tokens[i] if i < len(self.ids_to_tokens) else self.unk_token
