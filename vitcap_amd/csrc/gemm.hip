@@ -49,8 +49,9 @@ unsigned long long* g_gemm_trace = nullptr;
 int tile_group_n(int tiles_n) {
   static const int env_gn = [] { const char* e = getenv("VITCAP_GEMM_GROUP_N"); return e ? atoi(e) : 0; }();
   // measured at M = 36928 (tools/group_sweep.sh): N = 3072 214 -> 199 us with groups of 2..6 tiles (W = 4.7 MB does not fit
-  // one XCD's 4 MB L2 next to the A tiles); N = 2304 and N = 768 unchanged
-  int g = env_gn > 0 ? env_gn : (tiles_n >= 6 ? 3 : tiles_n);
+  // one XCD's 4 MB L2 next to the A tiles; HBM fetch 169 -> 152 MiB per launch); N = 2304 (W = 3.5 MB fits) same time with
+  // 7 % MORE fetch when grouped, so only wider outputs are grouped
+  int g = env_gn > 0 ? env_gn : (tiles_n > 9 ? 3 : tiles_n);
   return g > tiles_n ? tiles_n : g;
 }
 
