@@ -110,6 +110,29 @@ __device__ __forceinline__ float gelu_grad(float z) {
   return 0.5f * one_plus_erf + z * e * 0.3989422804014327f;
 }
 
+// gelu_grad on four pre-activations with the polynomial / products on the packed fp32 pipe (same formula as gelu_grad)
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 z) {
+  const f32x2 az = f32x2{fabsf(z[0]) * 0.70710678118654752f, fabsf(z[1]) * 0.70710678118654752f};
+#define VC_C2(c_) f32x2{c_, c_}
+  const f32x2 den = __builtin_elementwise_fma(VC_C2(0.3275911f), az, VC_C2(1.0f));
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 p = __builtin_elementwise_fma(VC_C2(1.061405429f), t, VC_C2(-1.453152027f));
+  p = __builtin_elementwise_fma(p, t, VC_C2(1.421413741f));
+  p = __builtin_elementwise_fma(p, t, VC_C2(-0.284496736f));
+  p = __builtin_elementwise_fma(p, t, VC_C2(0.254829592f));
+  const f32x2 arg = (VC_C2(-1.4426950408889634f) * az) * az;
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 erfc_abs = (p * t) * e;
+  const f32x2 two_minus = VC_C2(2.0f) - erfc_abs;
+  const f32x2 ope = f32x2{z[0] >= 0.f ? two_minus[0] : erfc_abs[0], z[1] >= 0.f ? two_minus[1] : erfc_abs[1]};
+  return __builtin_elementwise_fma(VC_C2(0.5f), ope, (z * e) * VC_C2(0.3989422804014327f));
+#undef VC_C2
+}
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 z) {
+  const f32x2 a = gelu_grad2(f32x2{z[0], z[1]}), b = gelu_grad2(f32x2{z[2], z[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -727,10 +727,13 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     epilogue_direct<ACT, OUT_F32, HAS_RES>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, NO_STORE);
     return;
   }
-  // bf16 output, plain rows, no residual / aux / pre-activation copy: 8 columns per lane, one 16-byte store (8 lanes = one
-  // 128-byte line of the output row) -- half the store instructions of the general path below
+  // bf16 output, plain rows, no residual: 8 columns per lane, one 16-byte store (8 lanes = one 128-byte line of the output
+  // row) -- half the store instructions of the general path below.  The training extras ride along in the same shape: the
+  // pre-activation copy (zout, fc1 forward) leaves as a second 16-byte store, the gelu'(aux) factor (fc2's input gradient)
+  // arrives as 16-byte loads issued for a whole 64-row half BEFORE the LDS staging, so their latency hides behind it
+  // (before: 8-byte loads used immediately, scalar gelu': 337 us per call at M = 36928, N = 3072)
   if constexpr (!OUT_F32 && !HAS_RES) {
-    if (!p.zout && !p.aux && p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
+    if (p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.zout || (p.ldz & 7) == 0) && (!p.aux || (p.ldaux & 7) == 0)) {
       const int wr = lane >> 3, wc = (lane & 7) * 8;
       const int ncw = n0 + wn * 64 + wc;
       const bool okc = ncw < p.N && !(NO_STORE && m0 >= 0);
@@ -741,6 +744,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
+        uint4 axv[8];
+        if (p.aux) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int m = m0 + wm * 128 + hm * 64 + it * 8 + wr;
+            axv[it] = (m < p.M && okc) ? *(const uint4*)(p.aux + (size_t)m * p.ldaux + ncw) : uint4{0u, 0u, 0u, 0u};
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -752,13 +763,29 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
           f32x4 v0 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4);
           f32x4 v1 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4 + 16);
           const int m = m0 + wm * 128 + hm * 64 + rl;
+          const bool ok = m < p.M && okc;
           v0 += b_lo;
           v1 += b_hi;
+          if (p.zout && ok) {
+            uint4 zo;
+            zo.x = pack2bf(v0[0], v0[1]);
+            zo.y = pack2bf(v0[2], v0[3]);
+            zo.z = pack2bf(v1[0], v1[1]);
+            zo.w = pack2bf(v1[2], v1[3]);
+            *(uint4*)(p.zout + (size_t)m * p.ldz + ncw) = zo;
+          }
+          if (p.aux) {
+            const uint4 a = axv[it];
+            v0 *= gelu_grad4(f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16),
+                                   __uint_as_float(a.y & 0xffff0000u)});
+            v1 *= gelu_grad4(f32x4{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16),
+                                   __uint_as_float(a.w & 0xffff0000u)});
+          }
           if (ACT == VITCAP_ACT_GELU_ERF) {
             v0 = gelu_erf4(v0);
             v1 = gelu_erf4(v1);
           }
-          if (m < p.M && okc) {
+          if (ok) {
             uint4 o;
             o.x = pack2bf(v0[0], v0[1]);
             o.y = pack2bf(v0[2], v0[3]);
@@ -800,8 +827,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
         }
         if (p.aux && ok) {
           const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
+          v *= gelu_grad4(f32x4{(float)za[0], (float)za[1], (float)za[2], (float)za[3]});
         }
         if (ACT == VITCAP_ACT_GELU_ERF) {
           v = gelu_erf4(v);

@@ -1,6 +1,8 @@
 // Training-step kernels other than GEMM/attention (gfx950): transposes for the weight-gradient GEMMs, LayerNorm
 // backward, split-K slab reduction, embedding backward, losses, global-norm clip + fused AdamW, weight re-packing.
 // All are HBM-bound streaming kernels (vectorised 8/16-byte accesses, one wave per 768-wide row where rows matter).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -48,14 +50,14 @@ __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __r
 // of the output; dres: optional fp32 gradient arriving through the residual path (added to the result).
 //   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) + dres ;  dgamma += sum dy*xhat ; dbeta += sum dy
 // ---------------------------------------------------------------------------------------------------------------
-template <bool DY_F32>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dyv,
+template <bool DY_F32, int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dyv,
                                                             const float* __restrict__ gamma, float eps,
                                                             const float* __restrict__ dres, float* __restrict__ dxf,
                                                             bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, int rows_per_wave) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * NW + (threadIdx.x >> 6);
   f32x4 g[3], ag[3], ab[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int rr = 0; rr < rows_per_wave; ++rr) {
-    const int row = wave * rows_per_wave + rr;
-    if (row >= M) break;   // (no early return: every wave reaches the workgroup reduction below)
+  // rows are dealt round-robin over ALL waves of the grid (rows_per_wave = the stride = total waves): the grid is a whole
+  // number of workgroups per CU, so nobody waits for a ragged last round (289 workgroups on 256 CUs cost two rounds)
+  for (int row = wave; row < M; row += rows_per_wave) {   // (no early return: every wave reaches the reduction below)
     f32x4 v[3], dy[3];
     float s = 0.f;
 #pragma unroll
@@ -123,19 +125,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  // workgroup-level reduction of the 4 waves' partial dgamma/dbeta through LDS, then ONE atomic per column per workgroup
-  // (per-wave atomics: 3.5 M atomics on 1536 addresses per call made this kernel 7x slower than its HBM time)
-  __shared__ float red[2][4][D768];
+  // workgroup-level reduction of the NW waves' partial dgamma/dbeta through LDS, then ONE atomic per column per workgroup
+  // (per-wave atomics: 3.5 M atomics on 1536 addresses per call made this kernel 7x slower than its HBM time).
+  // Measured at M = 36928 (tools/lnbwd_bench.py): 4 waves x 32 consecutive rows in 289 workgroups 130 us (two rounds on 256
+  // CUs); 8 waves, 2 workgroups per CU, rows dealt round-robin 90 us = 5.0 TB/s
+  extern __shared__ float red[];            // [2][NW][768]
   const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    *(f32x4*)(&red[0][wv][i * 256 + lane * 4]) = ag[i];
-    *(f32x4*)(&red[1][wv][i * 256 + lane * 4]) = ab[i];
+    *(f32x4*)(&red[(0 * NW + wv) * D768 + i * 256 + lane * 4]) = ag[i];
+    *(f32x4*)(&red[(1 * NW + wv) * D768 + i * 256 + lane * 4]) = ab[i];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < D768; c += 256) {
-    atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-    atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  for (int c = threadIdx.x; c < D768; c += NW * 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      sg += red[(0 * NW + q) * D768 + c];
+      sb += red[(1 * NW + q) * D768 + c];
+    }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
   }
 }
 
@@ -416,15 +426,30 @@ extern "C" int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int
                                     const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, int M,
                                     int D, void* stream) {
   VC_REQUIRE(x && dy && gamma && dgamma && dbeta && (dx_f32 || dx_bf16) && D == D768 && M > 0, "layernorm_bwd: bad arguments");
-  const int rpw = 32;
-  const int waves = (M + rpw - 1) / rpw;
-  dim3 grid((waves + 3) / 4);
-  if (dy_is_f32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres,
-                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres,
-                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);
+  static const int nw = [] { const char* e = getenv("VITCAP_LNBWD_WAVES"); const int v = e ? atoi(e) : 8; return v == 4 || v == 16 ? v : 8; }();
+  static const int wg_per_cu = [] { const char* e = getenv("VITCAP_LNBWD_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+  static const int n_cu = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount : 256;
+  }();
+  int wgs = n_cu * wg_per_cu;
+  if ((long long)wgs * nw > M) wgs = (M + nw - 1) / nw;
+  dim3 grid(wgs);
+  const int rpw = wgs * nw;                       // the row stride = total waves
+  const size_t lds = (size_t)2 * nw * D768 * sizeof(float);
+#define LNB(F32_, NW_)                                                                                                   \
+  do {                                                                                                                  \
+    auto kern = layernorm_bwd_kernel<F32_, NW_>;                                                                         \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), lds, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres, dx_f32,       \
+                       (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);                                                         \
+  } while (0)
+  if (dy_is_f32) { if (nw == 4) LNB(true, 4); else if (nw == 8) LNB(true, 8); else LNB(true, 16); }
+  else { if (nw == 4) LNB(false, 4); else if (nw == 8) LNB(false, 8); else LNB(false, 16); }
+#undef LNB
   VC_LAUNCH_CHECK("layernorm_bwd");
   return VITCAP_OK;
 }
