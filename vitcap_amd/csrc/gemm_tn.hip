@@ -57,7 +57,19 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = w >> 2, wk = w & 3;
-  const int tile = blockIdx.x, split = blockIdx.y;
+  // XCD-aware work order: workgroup id b runs on XCD b % 8 (observed dispatch rule), so XCD x takes the x-th contiguous
+  // chunk of the (split-major, tile-minor) work list -- the ~32 workgroups an XCD runs at once are then the tiles of ONE
+  // split, which share their Y row-slab across tiles_k workgroups and their X row-slab across tiles_n in that XCD's L2
+  // (dealt round-robin, every operand tile crossed the fabric once per consumer: 1.0 GB per qkv weight gradient against
+  // 227 MB of unique data).  Worth 2-10 % (tools/wgrad_bench.py); the kernel is bound elsewhere, see below.
+  const int tiles = p.tiles_n * p.tiles_k;
+  const int nwg = tiles * p.splits;
+  int pos = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = pos & 7;
+    pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pos >> 3);
+  }
+  const int split = pos / tiles, tile = pos - split * tiles;
   const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
   const int n0 = tn * TBN, k0 = tk * TBK;
   const int s_begin = split * p.stages_per_split;
@@ -96,6 +108,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   const int fsw = g * 4 + tj;                      // swz(row) for both reads (rows +0..3 and +4..7 share it)
   const int row_lo = g * 8 + tj;                   // + ms*32 (+4 for the second read)
 
+  // Measured anatomy (M = 36928, N = 2304, K = 768, 9 splits; us incl. the 12 us slab reduction): full 200 | no DMA 116 | no
+  // transpose reads 136 | no MFMA 180 | DMA only 127 | reads only 79 | MFMA only 107 | barriers + slab stores only 41.
+  // The MFMAs are already hidden; the critical path is LDS-DMA in (25 B/clk/CU, the same ceiling the NT kernel sees) PLUS
+  // the transpose reads out, which do not overlap each other.  Tried and measured, both slower or equal, both reverted:
+  // the two n-halves one phase apart as in gemm_nt_256_kernel (+3 %), and a ring of four 32-row stages with the request
+  // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242).  SQ counters: no LDS bank conflicts, 67 % of
+  // wave cycles in s_waitcnt/barriers, MFMA pipe 33 % busy.
   if (nst > 0) STAGE(0, s_begin);
   for (int t = 0; t < nst; ++t) {
     const int buf = t & 1;
@@ -205,7 +224,7 @@ extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
   p.tiles_n = N / TBN; p.tiles_k = K / TBK; p.splits = splits;
   const int total_stages = (M + TBM - 1) / TBM;
   p.stages_per_split = (total_stages + splits - 1) / splits;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k, splits), dim3(512), smem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * splits), dim3(512), smem, (hipStream_t)stream, p);
   VC_LAUNCH_CHECK("gemm_tn");
   return VITCAP_OK;
 }
