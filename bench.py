@@ -230,6 +230,8 @@ def main():
         model.generate = generate_split
     piped = bool(args.pipeline) and not args.graph and nstr == 1
     with torch.cuda.stream(stream):
+        if piped:
+            model.prime_pipeline(img.shape[0], img.device, args.beams)   # both slots' workspaces exist before any step runs
         for _ in range(max(args.warmup, 1)):
             ids, lp = model.generate_async(img, args.beams).result() if piped else model.generate(img)
         stream.synchronize()

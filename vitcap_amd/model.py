@@ -306,6 +306,15 @@ class ImageCaptioning(nn.Module):
         pipe['done'][slot] = done
         return _Pending(ids, lp, done, image)
 
+    def prime_pipeline(self, B, device, num_beams=1, lane=0):
+        """Allocate (and touch) both workspaces of generate_async's two-slot pipeline for batches of B images, so that no
+        allocation lands inside a caller's timed or latency-critical region.  No kernels of the captioning path run."""
+        if self._packed is None:
+            self.pack(device)
+        for slot in range(2):
+            ws, _ = self._workspace(B, self._packed[2], slot='pipe%d_%d' % (lane, slot), beams=num_beams if num_beams > 1 else 0)
+            ws.zero_()
+
     def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0, num_keep_best=1):
         """Beam search -> (ids (B,num_keep_best,20), logprobs (B,num_keep_best)), best hypothesis first, like
         ViTCAP._generate_beam_search (modeling_utils.py:888-1100)."""
