@@ -315,6 +315,11 @@ size_t vitcap_engine_workspace_bytes(int B);
  * state (default 1) set by vitcap_engine_set_num_keep_best, 1..8. */
 size_t vitcap_engine_workspace_bytes_beam(int B, int beams);
 int vitcap_engine_set_num_keep_best(vitcap_engine* e, int num_keep_best);
+/* repetition_penalty of generate() (CTRL, modeling_utils.py:828-836, 955-963): engine state, default 1 (off); applies to the
+ * greedy / sampled / beam decode loops.  The kernel alone: rows of logits [rows][ldl], prefixes ids[rows][ld_ids][0..t). */
+int vitcap_engine_set_repetition_penalty(vitcap_engine* e, float penalty);
+int vitcap_repetition_penalty(float* logits, int ldl, int V, const int64_t* ids, int ld_ids, int t, float penalty, int rows,
+                              void* stream);
 int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
                        float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                        float* out_logprobs, void* stream);

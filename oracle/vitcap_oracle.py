@@ -268,8 +268,22 @@ def _remove_rows_cols(t, rs, re, cs, ce):
     return torch.cat([torch.cat([t00, t01], dim=2), torch.cat([t10, t11], dim=2)], dim=1)
 
 
+def apply_repetition_penalty(logits, prefix_ids, penalty):
+    """CTRL penalty as generate() applies it (modeling_utils.py:828-836, 955-963): for every distinct token of the
+    sequence so far, logit < 0 ? logit * penalty : logit / penalty.  In place on (rows, V) logits."""
+    if penalty == 1.0:
+        return logits
+    for i in range(logits.shape[0]):
+        for tok in set(prefix_ids[i].tolist()):
+            if logits[i, tok] < 0:
+                logits[i, tok] *= penalty
+            else:
+                logits[i, tok] /= penalty
+    return logits
+
+
 def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_start_posid=20,
-                      reuse_encoder=False, return_trace=False):
+                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0):
     """Reference greedy decode.  ``reuse_encoder=True`` computes the (step-invariant) ViT encoder
     once instead of 19 times -- same numbers, used only to keep CPU tests fast."""
     B = image.shape[0]
@@ -296,7 +310,7 @@ def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_sta
         pp = torch.cat([full_pos[:, :curr], full_pos[:, max_length:]], dim=1)
         step_ids = torch.cat([step_ids, od_label_ids], dim=1)
         logits = encode_forward_infer(sd, step_ids, img_feats, mask, pp, tt, tagemb, enc=enc)
-        nxt_logits = logits[:, cur_len, :]
+        nxt_logits = apply_repetition_penalty(logits[:, cur_len, :].clone(), ids, repetition_penalty)
         nxt = torch.argmax(nxt_logits, dim=-1)
         sc = torch.gather(F.log_softmax(nxt_logits, dim=-1), -1, nxt.unsqueeze(-1))
         if return_trace:
@@ -430,7 +444,8 @@ def _post(sdw, p, ctx, x, r):
     return _ln(sdw, p + '.output.LayerNorm', _lin(sdw, p + '.output.dense', i) + a, 1e-12)
 
 
-def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, sampler=None):
+def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, sampler=None,
+                       repetition_penalty=1.0):
     """Greedy caption via encoder-once + visual prefill + 2-row incremental steps.
 
     Equivalent to ``greedy_as_written`` under the shipped test mask: caption row i attends caption
@@ -489,6 +504,7 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         c = 'module.cls.predictions'
         h = _ln(sdw, c + '.transform.LayerNorm', gelu_erf(_lin(sdw, c + '.transform.dense', r(hrow))), 1e-12)
         logits = F.linear(r(h), sdw[c + '.decoder.weight']) + sdw[c + '.bias']
+        apply_repetition_penalty(logits, ids[:, :t], repetition_penalty)
         if sampler is not None:                                                # do_sample branch (a12)
             nxt, lp, smargin = sampler(logits, t)
             if return_trace:
@@ -623,7 +639,8 @@ class BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
 
 
-def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1):
+def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
+                     repetition_penalty=1.0):
     """The reference's beam driver around an abstract model: ``step_logits_fn(input_ids (B*beams, cur_len), beam_idx)``
     returns the next-token logits (B*beams, V) for the current prefixes (``beam_idx`` = the re-ordering applied since
     the previous call, None at the first).  Returns (decoded (B,keep,max_length), logprobs (B,keep))."""
@@ -637,7 +654,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     cur_len = 1
     beam_idx = None
     while cur_len < max_length:
-        logits = step_logits_fn(input_ids, beam_idx)
+        logits = apply_repetition_penalty(step_logits_fn(input_ids, beam_idx).clone(), input_ids, repetition_penalty)
         scores = F.log_softmax(logits, dim=-1)
         Vn = scores.shape[1]
         _scores = (scores + beam_scores[:, None]).view(B, K * Vn)
@@ -681,7 +698,8 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     return decoded, logprobs
 
 
-def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1):
+def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
+                    repetition_penalty=1.0):
     """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
     B = image.shape[0]
     K = num_beams
@@ -704,11 +722,11 @@ def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, leng
         tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
         logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
         return logits[:, cur, :]
-    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best)
+    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty)
 
 
 def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
-                     num_keep_best=1):
+                     num_keep_best=1, repetition_penalty=1.0):
     """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
     image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
     r = _R(emulate_bf16)
@@ -766,7 +784,7 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
         if return_trace:
             trace.append(logits.clone())
         return logits
-    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best)
+    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty)
     return out + (trace,) if return_trace else out
 
 

@@ -194,6 +194,40 @@ def test_beam_nbest_vs_oracle(model, sd_t):
     assert n_same >= B * keep - 2
 
 
+@pytest.mark.parametrize('beams,rp', [(1, 1.3), (3, 1.3), (1, 0.8)])
+def test_repetition_penalty_vs_oracle(model, sd_t, beams, rp):
+    """generate(repetition_penalty=rp) through ImageCaptioning.forward, greedy and beam, against the bf16-emulating oracle
+    (itself pinned to the reference by tests/test_oracle_golden.py); and the penalty really changes the caption."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    B = 3
+    img = torch.from_numpy(W.gen_image_batch(B, 1234))
+    with torch.no_grad():
+        if beams == 1:
+            ids_o, lp_o = O.greedy_incremental(sd_t, img, emulate_bf16=True, repetition_penalty=rp)
+        else:
+            ids_o, lp_o = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True, repetition_penalty=rp)
+    plain, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
+    plain = plain.clone()
+    model.test_extra_input.update(num_beams=beams, repetition_penalty=rp)
+    try:
+        ids, lp = model({'image': img.cuda(), 'key': [0, 1, 2]})
+        ids, lp = ids.cpu(), lp.cpu()
+    finally:
+        model.test_extra_input.update(num_beams=1, repetition_penalty=1)
+    again, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
+    assert torch.equal(again, plain), 'the penalty must be switched off again with repetition_penalty=1'
+    same = (ids == ids_o).all(-1).all(-1)
+    print('hip', ids[:, 0].tolist(), lp.flatten().tolist(), 'oracle', lp_o.flatten().tolist())
+    assert int(same.sum()) >= B - 1
+    np.testing.assert_allclose(lp.numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=3e-3)
+    if beams == 1:
+        assert not torch.equal(ids, plain.cpu())
+        if rp > 1:       # a penalised greedy caption repeats fewer tokens than the plain one
+            rep = lambda t: sum(len(r) - len(set(r)) for r in t[:, 0].tolist())
+            assert rep(ids) < rep(plain.cpu())
+
+
 def test_beam1_equals_greedy_tokens(model):
     """Beam search with one beam must pick the greedy tokens (scores are length-normalised differently)."""
     from vitcap_amd import weights as W

@@ -156,6 +156,28 @@ def test_beam_nbest_incremental_matches_reference(sd_t):
     assert n == 2
 
 
+def test_repetition_penalty_matches_reference(sd_t):
+    """generate(repetition_penalty != 1), greedy and beam: the oracle's CTRL penalty (distinct prefix tokens, multiply negative
+    logits / divide positive ones, applied before argmax / log_softmax) against the reference's own output
+    (tests/golden/make_golden_reppen.py)."""
+    import os
+    from vitcap_amd import weights as W
+    vec = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_reppen.npz'))
+    n = 0
+    while 'case%d_cfg' % n in vec:
+        beams, rp, B = vec['case%d_cfg' % n]
+        im = torch.from_numpy(W.gen_image_batch(int(B), int(vec['image_seed'])))
+        with torch.no_grad():
+            if int(beams) == 1:
+                ids, logp = O.greedy_incremental(sd_t, im, emulate_bf16=False, repetition_penalty=float(rp))
+            else:
+                ids, logp = O.beam_incremental(sd_t, im, num_beams=int(beams), emulate_bf16=False, repetition_penalty=float(rp))
+        np.testing.assert_array_equal(ids.numpy(), vec['case%d_ids' % n])
+        np.testing.assert_allclose(logp.numpy(), vec['case%d_logprobs' % n], rtol=2e-5, atol=2e-5)
+        n += 1
+    assert n == 3
+
+
 def test_beam_incremental_equals_as_written(sd_t, img):
     with torch.no_grad():
         a = O.beam_as_written(sd_t, img[:1], num_beams=3)

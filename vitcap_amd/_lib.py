@@ -138,6 +138,8 @@ _SIGS = {
     'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_engine_set_num_keep_best': (C.c_int, [vp, C.c_int]),
+    'vitcap_engine_set_repetition_penalty': (C.c_int, [vp, C.c_float]),
+    'vitcap_repetition_penalty': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     'vitcap_engine_beam_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),

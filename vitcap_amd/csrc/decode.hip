@@ -577,7 +577,35 @@ __global__ void beam_finalize_kernel(BeamState st, int64_t* out_ids, float* out_
   }
 }
 
+// CTRL repetition penalty as generate() applies it (modeling_utils.py:828-836 greedy / sampling, 955-963 beam): for every
+// DISTINCT token already in the sequence (`set(input_ids[i].tolist())`, [CLS] included), logit < 0 ? logit * p : logit / p.
+// One wave per row; lane j owns prefix position j and acts if no earlier position holds the same token.
+__global__ __launch_bounds__(256) void repetition_penalty_kernel(float* __restrict__ logits, int ldl, int V,
+                                                                 const int64_t* __restrict__ ids, int ld_ids, int t,
+                                                                 float penalty, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows || lane >= t) return;
+  const int64_t* r = ids + (size_t)row * ld_ids;
+  const int64_t tok = r[lane];
+  for (int j = 0; j < lane; ++j)
+    if (r[j] == tok) return;
+  if (tok < 0 || tok >= V) return;
+  float* x = logits + (size_t)row * ldl + tok;
+  const float v = *x;
+  *x = v < 0.f ? v * penalty : v / penalty;
+}
+
 }  // namespace
+
+extern "C" int vitcap_repetition_penalty(float* logits, int ldl, int V, const int64_t* ids, int ld_ids, int t, float penalty,
+                                         int rows, void* stream) {
+  VC_REQUIRE(logits && ids && rows > 0 && V > 0 && ldl >= V && t >= 1 && t <= ld_ids && t <= 64 && penalty > 0.f,
+             "repetition_penalty: bad arguments (t=%d, penalty=%g)", t, (double)penalty);
+  hipLaunchKernelGGL(repetition_penalty_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, ids,
+                     ld_ids, t, penalty, rows);
+  VC_LAUNCH_CHECK("repetition_penalty");
+  return VITCAP_OK;
+}
 
 extern "C" int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_lp, float* cnt, int B, int max_len,
                                   int bos, int pad, void* stream) {

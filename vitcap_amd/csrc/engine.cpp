@@ -42,6 +42,7 @@ struct vitcap_engine {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int keep_best = 1;            // num_keep_best of the beam search (BeamHypotheses.n_hyp)
+  float repetition_penalty = 1.0f;
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
   size_t used = 0;
@@ -438,6 +439,8 @@ extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, si
   CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, B, L, BOS, PAD, s));
   for (int t = 1; t < L; ++t) {
     CK(step_forward(w, lo, ws, B, 1, t, ids, ws + lo.tcache, s));
+    if (e->repetition_penalty != 1.0f)
+      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, e->repetition_penalty, B, s));
     if (e->sampling.do_sample)
       CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
                             (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), B, t, L, EOS,
@@ -497,6 +500,8 @@ extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, flo
   const int C = 2 * beams;
   for (int t = 1; t < L; ++t) {
     CK(step_forward(w, lo, ws, NS, beams, t, st.ids_in, tc_cur, s));
+    if (e->repetition_penalty != 1.0f)
+      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, e->repetition_penalty, NS, s));
     CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),
                            (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), NS, s));
     CK(vitcap_beam_step((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
@@ -508,6 +513,12 @@ extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, flo
     int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
   }
   CK(vitcap_beam_finalize(&st, out_ids, out_logprobs, B, L, EOS, PAD, s));
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_set_repetition_penalty(vitcap_engine* e, float penalty) {
+  if (!e || !(penalty > 0.f)) { vitcap_set_error("set_repetition_penalty: need an engine and penalty > 0 (got %g)", (double)penalty); return VITCAP_EINVAL; }
+  e->repetition_penalty = penalty;
   return VITCAP_OK;
 }
 

@@ -371,6 +371,12 @@ class ImageCaptioning(nn.Module):
             data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
+        rp = float(te.get('repetition_penalty', 1) or 1)
+        if rp != getattr(self, '_rep_penalty', 1.0):
+            if self._packed is None:
+                self.pack(data['image'].device)
+            check(lib.vitcap_engine_set_repetition_penalty(self._engine, rp), 'set_repetition_penalty')
+            self._rep_penalty = rp
         if te.get('num_beams', 1) > 1:
             return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)), num_keep_best=keep)
         if te.get('do_sample', False):
