@@ -82,6 +82,13 @@ def test_model_surface(L, sd_np):
     with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
+    for bad in ({'eos_token_ids': [102, 1012]}, {'bos_token_id': 1}, {'num_beams': 3, 'do_sample': True}, {'use_cbs': True},
+                {'max_length': 30}):
+        keep = dict(m.test_extra_input)
+        m.test_extra_input.update(bad)
+        with pytest.raises(NotImplementedError):                    # unsupported generate() options are refused, not ignored
+            m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
+        m.test_extra_input = keep
     m.test_extra_input['num_keep_best'] = 3                        # greedy + n-best: the reference asserts (modeling_utils.py:790)
     with pytest.raises(AssertionError, match='greedy'):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})

@@ -371,6 +371,16 @@ class ImageCaptioning(nn.Module):
             data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
+        # fail loudly on generate() options this build does not implement instead of silently ignoring them
+        fixed = {'bos_token_id': 101, 'pad_token_id': 0, 'mask_token_id': 103, 'eos_token_ids': [102]}
+        for k, v in fixed.items():
+            got = te.get(k, v)
+            if (list(got) if isinstance(got, (list, tuple)) else got) != v:
+                raise NotImplementedError('%s is fixed to %r in this build (got %r)' % (k, v, got))
+        if te.get('num_beams', 1) > 1 and te.get('do_sample', False):
+            raise NotImplementedError('beam sampling (num_beams > 1 with do_sample, modeling_utils.py:966-985) is not built')
+        if te.get('use_cbs', False):
+            raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
         rp = float(te.get('repetition_penalty', 1) or 1)
         if rp != getattr(self, '_rep_penalty', 1.0):
             if self._packed is None:
