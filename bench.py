@@ -31,6 +31,10 @@ sys.path.insert(0, REPO)
 
 TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r01_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
+# What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
+# visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row
+# attention block 0.23.  Reported next to the algorithmic figure; `value` (images/s) does not depend on either.
+FLOP_EXECUTED_PER_IMAGE = FLOP_PER_IMAGE - (9.19e9 - 1.36e9 - 0.23e9)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4>', 0: 'void gemm_nt_256p_kernel<0, 0, false>',
               4: 'void gemm_nt_256p_kernel<1, 0, false>'}
@@ -321,6 +325,7 @@ def main():
                    'launch': 'hipGraph replay' if graph is not None else ('eager, 2-slot batch pipeline (encode of step i+1 || decode of step i)' if piped else 'eager'),
                    'streams_per_gpu': 2 if piped else nstr},
         'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),
+        'end_to_end_tflops_executed': round(value / world * (FLOP_EXECUTED_PER_IMAGE if args.beams == 1 else FLOP_EXECUTED_PER_IMAGE + 13.35e9) / 1e12, 2),
         'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),
         'roofline': {
             'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),

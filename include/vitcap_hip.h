@@ -113,6 +113,10 @@ int vitcap_cls_rows(const float* cls_token, const float* pos_embed, float* x, in
  *    modeling_bert.py:320-340 for the visual rows of the decoder, which attend visual rows only).
  * ---------------------------------------------------------------------------------------------- */
 int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream);
+/* Same, but only the first q_rows query rows of every image are wanted (rounded up to blocks of 128; all S keys count).
+ * Used for the LAST tag block of TIMMVitSplitEncoder: of its output only the CLS row is ever read
+ * (modeling_bert.py:1424 pooler(tag_hidden), 1493 tag_hidden[:, 0] as the first visual token). */
+int vitcap_attn_dense_fwd_rows(const void* qkv, void* out, int B, int S, int q_rows, float scale, void* stream);
 
 /* Training forms of the dense attention (ViT blocks and the visual rows of the decoder in
  * ViTCAP.encode_forward(is_training=True), modeling_bert.py:751-807): the forward additionally stores the log2-domain

@@ -104,6 +104,7 @@ _SIGS = {
     'vitcap_patch_gather': (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_cls_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    'vitcap_attn_dense_fwd_rows': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     'vitcap_attn_dense_fwd_train': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32,
                                               C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

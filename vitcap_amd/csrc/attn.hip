@@ -36,14 +36,14 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                         int causal_from, int mask_from) {
+                                                         int causal_from, int mask_from, int q_rows) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
   // XCD-aware work mapping (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the q-blocks of one
   // (image, head) -- which share that head's K/V -- are made consecutive *within* an XCD and hit its L2 instead of
   // fetching K/V once per XCD (measured: 3.7x algorithmic fetch with the naive 3-D grid).
-  const int nqb = (S + 127) / 128;
+  const int nqb = (q_rows + 127) / 128;   // q_rows < S: only the leading query rows are wanted (all S keys still count)
   const int nwork = nqb * NH * B;
   int wid = blockIdx.x;
   {
@@ -451,8 +451,19 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
   hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0);
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, S);
   VC_LAUNCH_CHECK("attn_dense");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_dense_fwd_rows(const void* qkv, void* out, int B, int S, int q_rows, float scale, void* stream) {
+  VC_REQUIRE(qkv && out && B > 0 && S > 0 && q_rows >= 1 && q_rows <= S, "attn_dense_rows: bad arguments");
+  VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense_rows: misaligned");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid(((q_rows + 127) / 128) * NH * B);
+  hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, q_rows);
+  VC_LAUNCH_CHECK("attn_dense_rows");
   return VITCAP_OK;
 }
 
@@ -471,10 +482,10 @@ extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* ls
   if (p_drop > 0.f)
     hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
                        lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop),
-                       causal_from, mask_from);
+                       causal_from, mask_from, S);
   else
     hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from);
+                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from, S);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }

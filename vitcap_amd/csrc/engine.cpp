@@ -43,6 +43,7 @@ struct vitcap_engine {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int keep_best = 1;            // num_keep_best of the beam search (BeamHypotheses.n_hyp)
   float repetition_penalty = 1.0f;
+  bool full_last_tag_block = false;   // VITCAP_FULL_TAG_BLOCK=1: compute all 577 rows of tag_blocks[3] (parity taps / measurements)
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
   size_t used = 0;
@@ -187,6 +188,8 @@ extern "C" int vitcap_engine_create(vitcap_engine** out) {
   if (*out) {
     const char* f = getenv("VITCAP_TAG_FORK");     // 0: keep the tag branch on the caller's stream
     (*out)->fork_tag_branch = f ? atoi(f) != 0 : true;
+    const char* t = getenv("VITCAP_FULL_TAG_BLOCK");
+    (*out)->full_last_tag_block = t ? atoi(t) != 0 : false;
   }
   return *out ? VITCAP_OK : VITCAP_EINVAL;
 }
@@ -279,6 +282,25 @@ static int vit_block(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, 
   return VITCAP_OK;
 }
 
+// The LAST tag block: only row 0 (CLS) of its output is ever read -- the pooler takes tag_hidden[:, 0]
+// (modeling_bert.py:1424) and the joint sequence takes tag_hidden[:, 0] as its first visual token (1493).  So: LN1 and the
+// K/V projections on all 577 rows (the CLS query attends every key), Q / attention / proj / LN2 / MLP for the CLS rows only
+// (strided views of the same buffers: row b*577).  Rows 1..576 of `x` keep the previous block's output.
+static int vit_block_cls_only(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, void* mlp, void* cls_h, int B, void* s) {
+  const int M = B * NV;
+  const int RS = NV * D;                      // row stride between CLS rows
+  CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  CK(gemm(h, D, (const char*)w.qkv_w + (size_t)D * D * 2, w.qkv_b + D, nullptr, 0, (char*)qkv + (size_t)D * 2, 3 * D, M, 2 * D, D,
+          VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));                                         // K | V of every row
+  CK(gemm(h, RS, w.qkv_w, w.qkv_b, nullptr, 0, qkv, NV * 3 * D, B, D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));   // Q of the CLS rows
+  CK(vitcap_attn_dense_fwd_rows(qkv, h, B, NV, 1, 0.125f, s));
+  CK(gemm(h, RS, w.proj_w, w.proj_b, x, RS, x, RS, B, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  CK(vitcap_layernorm_fwd(x, RS, w.n2_g, w.n2_b, 1e-6f, cls_h, nullptr, B, D, s));
+  CK(gemm(cls_h, D, w.fc1_w, w.fc1_b, nullptr, 0, mlp, 4 * D, B, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
+  CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, RS, x, RS, B, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  return VITCAP_OK;
+}
+
 static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s);
 
 extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
@@ -345,7 +367,11 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
 static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s) {
   const vitcap_weights& w = e->w;
   float* xt = (float*)(ws + lo.xt);
-  for (int i = 0; i < 4; ++i) CK(vit_block(w.tag_blocks[i], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+  for (int i = 0; i < 3; ++i) CK(vit_block(w.tag_blocks[i], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+  if (e->full_last_tag_block)
+    CK(vit_block(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+  else
+    CK(vit_block_cls_only(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, ws + lo.pool_in, B, s));
   CK(vitcap_gather_rows_bf16(xt, NV, ws + lo.pool_in, B, D, s));
   CK(gemm(ws + lo.pool_in, D, w.pooler_w, w.pooler_b, nullptr, 0, ws + lo.pooled, D, B, D, D, VITCAP_ACT_TANH,
           VITCAP_OUT_BF16, s));
