@@ -127,6 +127,17 @@ int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, i
 int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                           const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, float p_drop,
                           uint32_t drop_seed, int causal_from, int mask_from, void* stream);
+/* The same two with the QUERY rows restricted to [q_lo, q_hi) (q_lo a multiple of 128; every key still counts): for layers
+ * of which only some output rows are ever read -- the last tag block (CLS row) and the last decoder layer (caption rows).
+ * Forward: out / lse are written for the 128-row blocks covering the range only.  Backward: dQ is written for those blocks
+ * only (the caller zero-fills dqkv's Q columns elsewhere); dK / dV for every key, accumulated over the 64-row query tiles
+ * that intersect the range -- rows of those tiles outside [q_lo, q_hi) must carry dout = 0 and finite out / lse. */
+int vitcap_attn_dense_fwd_train_rows(const void* qkv, void* out, float* lse, int B, int S, int ld_rows, float scale,
+                                     float p_drop, uint32_t drop_seed, int causal_from, int mask_from, int q_lo, int q_hi,
+                                     void* stream);
+int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                               const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale, float p_drop,
+                               uint32_t drop_seed, int causal_from, int mask_from, int q_lo, int q_hi, void* stream);
 /* causal_from > 0: the decoder's joint sequence under teacher forcing, rows [causal_from visual | S - causal_from caption]
  * per image with the seq2seq mask of dataset.py:377-390 + ..._bertemb.py:57-85: a visual row attends visual rows only,
  * caption row q attends every visual row and caption rows <= q.  All caption keys must fall in the last 64-key tile

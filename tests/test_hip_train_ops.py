@@ -247,3 +247,29 @@ def test_adamw_clip_matches_oracle(ops):
     assert abs(float(ss.sqrt()) - float(g.norm())) < 1e-3
     np.testing.assert_allclose(P.cpu().numpy(), pref.numpy(), rtol=1e-5, atol=1e-7)
     assert torch.equal(P.cpu()[2048:3072], p[2048:3072])          # lr 0 chunk untouched
+
+
+@pytest.mark.parametrize('case', ['cls_row', 'caption_rows', 'caption_rows_dropout'])
+def test_attention_query_range_equals_full(ops, case):
+    """Row-restricted attention (last tag block: only the CLS query; last decoder layer: only the caption queries) against
+    the full kernels: forward rows of the covered blocks bit-identical, backward dqkv bit-identical when dout is zero
+    outside the range (the skipped query tiles would only have added exact zeros)."""
+    B = 3
+    if case == 'cls_row':
+        S, cf, q_range, keep, pd = 577, 0, (0, 1), slice(0, 1), 0.0
+    else:
+        S, cf, q_range, keep, pd = 598, 578, (512, 598), slice(578, 598), (0.1 if case.endswith('dropout') else 0.0)
+    qkv = _bf(_rand((B * S, 2304), 70, 1.5)).cuda()
+    out_f, lse_f = ops.attn_dense_train(qkv, B, S, p_drop=pd, drop_seed=9, causal_from=cf)
+    out_r, lse_r = ops.attn_dense_train(qkv, B, S, p_drop=pd, drop_seed=9, causal_from=cf, q_range=q_range)
+    blk = slice(q_range[0], min(S, (q_range[1] + 127) // 128 * 128))
+    assert torch.equal(out_r.view(B, S, 768)[:, blk], out_f.view(B, S, 768)[:, blk])
+    assert torch.equal(lse_r[:, :, blk], lse_f[:, :, blk])
+    assert float(out_r.view(B, S, 768)[:, :q_range[0]].abs().max() if q_range[0] else 0.0) == 0.0
+    dout = torch.zeros(B, S, 768, device='cuda', dtype=torch.bfloat16)
+    dout[:, keep] = _bf(_rand((B, keep.stop - keep.start, 768), 71, 1.0)).cuda()
+    dout = dout.view(B * S, 768)
+    d_full = ops.attn_dense_bwd(qkv, out_f, dout, lse_f, B, S, p_drop=pd, drop_seed=9, causal_from=cf)
+    d_rows = ops.attn_dense_bwd(qkv, out_r, dout, lse_r, B, S, p_drop=pd, drop_seed=9, causal_from=cf, q_range=q_range)
+    assert torch.equal(d_rows, d_full), 'max diff %g' % float((d_rows.float() - d_full.float()).abs().max())
+    assert float(d_full.float().abs().max()) > 0

@@ -109,6 +109,10 @@ _SIGS = {
                                               C.c_int, C.c_int, vp]),
     'vitcap_attn_dense_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_uint32, C.c_int, C.c_int, vp]),
+    'vitcap_attn_dense_fwd_train_rows': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_attn_dense_bwd_rows': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                             C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, vp]),
     'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,

@@ -36,21 +36,22 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                         int causal_from, int mask_from, int q_rows) {
+                                                         int causal_from, int mask_from, int q_lo, int q_rows) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
   // XCD-aware work mapping (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the q-blocks of one
   // (image, head) -- which share that head's K/V -- are made consecutive *within* an XCD and hit its L2 instead of
   // fetching K/V once per XCD (measured: 3.7x algorithmic fetch with the naive 3-D grid).
-  const int nqb = (q_rows + 127) / 128;   // q_rows < S: only the leading query rows are wanted (all S keys still count)
+  // only the query blocks covering rows [q_lo, q_lo + q_rows) are computed (q_lo a multiple of 128; all S keys still count)
+  const int nqb = (q_rows + 127) / 128;
   const int nwork = nqb * NH * B;
   int wid = blockIdx.x;
   {
     const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
     wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
   }
-  const int qb = wid % nqb;
+  const int qb = (q_lo >> 7) + wid % nqb;
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;        // waves past the last query row only help with staging
@@ -451,7 +452,7 @@ extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, f
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
   hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, S);
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, S);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
@@ -462,15 +463,16 @@ extern "C" int vitcap_attn_dense_fwd_rows(const void* qkv, void* out, int B, int
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((q_rows + 127) / 128) * NH * B);
   hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, q_rows);
+                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, q_rows);
   VC_LAUNCH_CHECK("attn_dense_rows");
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
-                                           float scale, float p_drop, uint32_t drop_seed, int causal_from, int mask_from,
-                                           void* stream) {
+extern "C" int vitcap_attn_dense_fwd_train_rows(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
+                                                float scale, float p_drop, uint32_t drop_seed, int causal_from, int mask_from,
+                                                int q_lo, int q_hi, void* stream) {
   VC_REQUIRE(qkv && out && lse && B > 0 && S > 0 && ld_rows >= S, "attn_dense_train: bad arguments");
+  VC_REQUIRE(q_lo >= 0 && q_lo < q_hi && q_hi <= S && (q_lo & 127) == 0, "attn_dense_train: query range [%d, %d) must start on a multiple of 128 inside S=%d", q_lo, q_hi, S);
   VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_train: p_drop %g / ld_rows %d out of range",
              (double)p_drop, ld_rows);
   VC_REQUIRE(causal_from == 0 || (causal_from >= (S / KT) * KT && causal_from <= S),
@@ -478,16 +480,23 @@ extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* ls
   VC_REQUIRE(mask_from == 0 || (causal_from > 0 && mask_from > causal_from && mask_from <= S),
              "attn_dense_train: mask_from %d must lie in (causal_from %d, S %d]", mask_from, causal_from, S);
   const float c = scale * 1.4426950408889634f;
-  dim3 grid(((S + 127) / 128) * NH * B);
+  dim3 grid(((q_hi - q_lo + 127) / 128) * NH * B);
   if (p_drop > 0.f)
     hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
                        lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop),
-                       causal_from, mask_from, S);
+                       causal_from, mask_from, q_lo, q_hi - q_lo);
   else
     hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from, S);
+                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from, q_lo, q_hi - q_lo);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* lse, int B, int S, int ld_rows,
+                                           float scale, float p_drop, uint32_t drop_seed, int causal_from, int mask_from,
+                                           void* stream) {
+  return vitcap_attn_dense_fwd_train_rows(qkv, out, lse, B, S, ld_rows, scale, p_drop, drop_seed, causal_from, mask_from, 0, S,
+                                          stream);
 }
 
 extern "C" int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B,

@@ -81,18 +81,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
                                                           int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                          uint32_t drop_thr, float drop_scale, int causal_from, int mask_from) {
+                                                          uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
+                                                          int q_lo, int q_hi) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
-  const int nqb = (S + 127) / 128;
+  const int nqb = (q_hi - q_lo + 127) / 128;     // query blocks covering rows [q_lo, q_hi), q_lo a multiple of 128
   const int nwork = nqb * NH * B;
   int wid = blockIdx.x;
   {
     const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
     wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
   }
-  const int qb = wid % nqb;
+  const int qb = (q_lo >> 7) + wid % nqb;
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
                                                            int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                           uint32_t drop_thr, float drop_scale, int causal_from, int mask_from) {
+                                                           uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
+                                                           int q_lo, int q_hi) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -308,6 +310,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int nfull = S / KT, rem = S - nfull * KT;
   const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);
   const int ntiles = nfull + (tail_tile ? 1 : 0);
+  // only the query tiles that intersect [q_lo, q_hi) are visited (rows of those tiles outside the range must carry dO = 0)
+  const int t_lo = q_lo / KT;
+  int t_hi = (q_hi + KT - 1) / KT;
+  t_hi = t_hi < ntiles ? t_hi : ntiles;
   // a caption key (>= causal_from) only hears from caption queries q >= key: waves that own such keys mask every tile
   const bool wave_causal = causal_from > 0 && key0 + 31 >= causal_from;
   constexpr int BUF = 4 * TILE_B + 512;
@@ -344,17 +350,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   for (int r = 0; r < 16; ++r) {
     dvt[0][r] = 0.f; dvt[1][r] = 0.f; dkt[0][r] = 0.f; dkt[1][r] = 0.f; zero16[r] = 0.f;
   }
-  if (ntiles > 0) {
-    LOAD_TILE(0);
+  if (t_hi > t_lo) {
+    LOAD_TILE(t_lo);
     STORE_TILE(0);
   }
   // all prologue loads provably complete on every path into the loop (see attn.hip: otherwise the waitcnt pass makes
   // each iteration wait for the NEXT tile's loads before its first MFMAs)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) LOAD_TILE(t + 1);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int buf = (t - t_lo) & 1;
+    if (t + 1 < t_hi) LOAD_TILE(t + 1);
     if (active) {
       const char* ql = smem + buf * BUF;
       const char* dl = ql + TILE_B;
@@ -419,14 +425,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         }
       }
     }
-    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
+    if (t + 1 < t_hi) STORE_TILE(buf ^ 1);
     __syncthreads();
   }
 #undef LOAD_TILE
 #undef STORE_TILE
   // left-over queries on the vector ALU
   if (active && !tail_tile) {
-    for (int q = nfull * KT; q < S; ++q) {
+    for (int q = (nfull * KT > q_lo ? nfull * KT : q_lo); q < (S < q_hi ? S : q_hi); ++q) {
       const bf16_t* qr = base + (size_t)q * QKV_LD + half * 8;
       const bf16_t* dr = dob + (size_t)q * 768 + half * 8;
       float sp = 0.f, dp = 0.f;
@@ -496,31 +502,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 }  // namespace
 
-extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
-                                     const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
-                                     float p_drop, uint32_t drop_seed, int causal_from, int mask_from, void* stream) {
+extern "C" int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                                          const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
+                                          float p_drop, uint32_t drop_seed, int causal_from, int mask_from, int q_lo, int q_hi,
+                                          void* stream) {
   VC_REQUIRE(qkv && out && dout && lse && dsum && dqkv && B > 0 && S > 0 && ld_rows >= S, "attn_dense_bwd: bad arguments");
   VC_REQUIRE(p_drop >= 0.f && p_drop < 1.f && ld_rows < 1024, "attn_dense_bwd: p_drop %g / ld_rows %d out of range",
              (double)p_drop, ld_rows);
   VC_REQUIRE(causal_from == 0 || (causal_from >= (S / KT) * KT && causal_from <= S),
              "attn_dense_bwd: causal_from %d must lie in the last key tile of S=%d", causal_from, S);
+  VC_REQUIRE(q_lo >= 0 && q_lo < q_hi && q_hi <= S && (q_lo & 127) == 0,
+             "attn_dense_bwd: query range [%d, %d) must start on a multiple of 128 inside S=%d", q_lo, q_hi, S);
   const float c = scale * 1.4426950408889634f;
-  dim3 grid(((S + 127) / 128) * NH * B);
+  dim3 grid(((S + 127) / 128) * NH * B);                 // dK/dV: every key block
+  dim3 grid_q(((q_hi - q_lo + 127) / 128) * NH * B);     // dQ: the query blocks of the range
   const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
   const float rs = 1.0f / (1.0f - p_drop);
 #define VC_BWD_LAUNCH(DROP_)                                                                                              \
   do {                                                                                                                    \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
                        (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs, causal_from, mask_from);                                                       \
+                       drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi);                                          \
     VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
                        (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
-                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from);                                    \
+                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi);                       \
     VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
   } while (0)
   if (p_drop > 0.f) VC_BWD_LAUNCH(true);
   else VC_BWD_LAUNCH(false);
 #undef VC_BWD_LAUNCH
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_dense_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                                     const void* extra_dkv, void* dqkv, int B, int S, int ld_rows, float scale,
+                                     float p_drop, uint32_t drop_seed, int causal_from, int mask_from, void* stream) {
+  return vitcap_attn_dense_bwd_rows(qkv, out, dout, lse, dsum, extra_dkv, dqkv, B, S, ld_rows, scale, p_drop, drop_seed,
+                                    causal_from, mask_from, 0, S, stream);
 }

@@ -399,8 +399,12 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, s
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
     void* dq = ws + lo.dqkv[l];
+    if (l == 3) {        // the last layer's visual-row outputs feed nothing: only its K/V are needed (no Q either)
+      CK(gemm(vis_b, D, (const char*)lw.qkv_w + (size_t)D * D * 2, lw.qkv_b + D, nullptr, 0, (char*)dq + (size_t)D * 2, 3 * D, M,
+              2 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+      break;
+    }
     CK(gemm(vis_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, dq, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
-    if (l == 3) break;   // the last layer's visual-row outputs feed nothing: only its K/V are needed
     CK(vitcap_attn_dense_fwd(dq, ws + lo.h, B, SV, 0.125f, s));
     CK(gemm(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, D, ws + lo.dtmp, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
     CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,

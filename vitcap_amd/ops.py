@@ -84,29 +84,36 @@ def attn_dense(qkv, B, S, scale=0.125):
     return out
 
 
-def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0, causal_from=0, mask_from=0):
+def attn_dense_train(qkv, B, S, scale=0.125, ld_rows=None, out=None, p_drop=0.0, drop_seed=0, causal_from=0, mask_from=0,
+                     q_range=None):
     """forward that also returns the log2-domain logsumexp (B,12,S) needed by attn_dense_bwd; ld_rows = rows per image
-    in the buffers (>= S; only the first S rows of each image are attended / written)"""
+    in the buffers (>= S; only the first S rows of each image are attended / written).  q_range = (lo, hi): only the query
+    rows of the 128-row blocks covering [lo, hi) are computed (lo % 128 == 0); the other rows of out / lse are zeros."""
     _dev_bf16(qkv)
     ld_rows = ld_rows or S
+    lo, hi = q_range or (0, S)
+    alloc = torch.zeros if q_range else torch.empty
     if out is None:
-        out = torch.empty((B * ld_rows, 768), device=qkv.device, dtype=torch.bfloat16)
-    lse = torch.empty((B, 12, S), device=qkv.device, dtype=torch.float32)
-    check(lib.vitcap_attn_dense_fwd_train(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, p_drop, drop_seed, causal_from,
-                                          mask_from, _stream()),
+        out = alloc((B * ld_rows, 768), device=qkv.device, dtype=torch.bfloat16)
+    lse = alloc((B, 12, S), device=qkv.device, dtype=torch.float32)
+    check(lib.vitcap_attn_dense_fwd_train_rows(_p(qkv), _p(out), _p(lse), B, S, ld_rows, scale, p_drop, drop_seed, causal_from,
+                                               mask_from, lo, hi, _stream()),
           'attn_dense_train')
     return out, lse
 
 
 def attn_dense_bwd(qkv, out, dout, lse, B, S, scale=0.125, extra_dkv=None, ld_rows=None, dqkv=None, p_drop=0.0,
-                   drop_seed=0, causal_from=0, mask_from=0):
+                   drop_seed=0, causal_from=0, mask_from=0, q_range=None):
+    """q_range = (lo, hi): the forward ran for those query rows only; `dout` must be zero outside them (inside the 64-row
+    tiles that intersect the range).  dQ outside the range's 128-row blocks is zero-filled here."""
     _dev_bf16(qkv); _dev_bf16(out); _dev_bf16(dout); _dev_f32(lse)
     ld_rows = ld_rows or S
+    lo, hi = q_range or (0, S)
     if dqkv is None:
-        dqkv = torch.empty_like(qkv)
-    dsum = torch.empty_like(lse)
-    check(lib.vitcap_attn_dense_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, ld_rows,
-                                    scale, p_drop, drop_seed, causal_from, mask_from, _stream()), 'attn_dense_bwd')
+        dqkv = torch.zeros_like(qkv) if q_range else torch.empty_like(qkv)
+    dsum = torch.zeros_like(lse) if q_range else torch.empty_like(lse)
+    check(lib.vitcap_attn_dense_bwd_rows(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(extra_dkv), _p(dqkv), B, S, ld_rows,
+                                         scale, p_drop, drop_seed, causal_from, mask_from, lo, hi, _stream()), 'attn_dense_bwd')
     return dqkv
 
 
