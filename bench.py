@@ -67,6 +67,9 @@ def cpu_baseline(max_seconds=40.0):
 
 
 TRAIN_FLOP_PER_SAMPLE = 569.3e9     # fwd+bwd, SURVEY.md section 8d (algorithmic)
+# executed: rows nobody reads are not computed -- rows 1..576 of the last tag block (7.6 GF forward) and the 578 visual rows
+# of the last decoder layer's attention / output / MLP (6.9 GF forward), forward + backward = 3x
+TRAIN_FLOP_EXECUTED_PER_SAMPLE = TRAIN_FLOP_PER_SAMPLE - 3 * (7.6e9 + 6.9e9)
 
 
 def bench_train(args, rank, world, local, dist, D):
@@ -107,6 +110,7 @@ def bench_train(args, rank, world, local, dist, D):
                                    'decoder attention dropout 0.1 on, fp32 master weights + AdamW, gradient all-reduce over RCCL' % (B, B * world),
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
             'end_to_end_tflops_algorithmic': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12, 2),
+            'end_to_end_tflops_executed': round(value / world * TRAIN_FLOP_EXECUTED_PER_SAMPLE / 1e12, 2),
             'end_to_end_frac_of_bf16_peak': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_TFLOPS, 4),
             'masked_loss': float(out['masked_loss']), 'tag_loss': float(out['tag_loss'])}), flush=True)
     if dist is not None:

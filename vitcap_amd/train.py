@@ -199,6 +199,10 @@ class TrainEngine(object):
         self.clip, self.max_iter, self.eps_ls = clip, max_iter, label_smoothing
         self.dist = dist
         self.attn_dropout = float(attn_dropout)
+        # outputs nobody reads are not computed: rows 1..576 of the last tag block, the visual rows of the last decoder layer
+        # (forward and backward; same loss and gradients).  VITCAP_TRAIN_FULL_ROWS=1 computes them anyway (A/B measurements).
+        import os
+        self.prune_dead_rows = os.environ.get('VITCAP_TRAIN_FULL_ROWS', '0') != '1'
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
         self.dropout_seed = mix32(int(dropout_seed) & 0xffffffff, rank)      # every rank drops differently
         self.step_no = 0
@@ -437,16 +441,41 @@ class TrainEngine(object):
             saved[pre] = (xin, h1, qkv, ao, lse, xmid, h2, z, g)
             return xout
 
+        def block_fwd_cls(pre, xin):
+            """The same block when only row 0 (CLS) of its output is ever read -- the last tag block: tag_hidden feeds the pooler
+            and the joint sequence through tag_hidden[:, 0] alone (modeling_bert.py:1424, 1493).  LN1 and the qkv projection
+            run on every row (the CLS query attends all keys, and K/V carry gradient to every row); attention, proj, LN2 and
+            the MLP run for the B CLS rows.  Returns (B,768)."""
+            h1, _ = ops.layernorm(xin, self.vec(pre + '.norm1.weight'), self.vec(pre + '.norm1.bias'), 1e-6)
+            qkv = ops.gemm_bias_act(h1, self.wb(pre + '.qkv'), self.vec(pre + '.attn.qkv.bias'))
+            ao, lse = ops.attn_dense_train(qkv, B, NV, q_range=(0, 1))
+            ao_c = ao.view(B, NV, 768)[:, 0].contiguous()
+            xin_c = xin.view(B, NV, 768)[:, 0].contiguous()
+            xmid_c = torch.empty(B, 768, device=dev)
+            ops.gemm_bias_act(ao_c, self.wb(pre + '.proj'), self.vec(pre + '.attn.proj.bias'), residual=xin_c, out=xmid_c)
+            h2_c, _ = ops.layernorm(xmid_c, self.vec(pre + '.norm2.weight'), self.vec(pre + '.norm2.bias'), 1e-6)
+            z_c = torch.empty(B, 3072, device=dev, dtype=torch.bfloat16)
+            g_c = ops.gemm_ex(h2_c, self.wb(pre + '.fc1'), bias=self.vec(pre + '.mlp.fc1.bias'), act=L.ACT_GELU_ERF, zout=z_c)
+            xout_c = torch.empty(B, 768, device=dev)
+            ops.gemm_bias_act(g_c, self.wb(pre + '.fc2'), self.vec(pre + '.mlp.fc2.bias'), residual=xmid_c, out=xout_c)
+            saved[pre] = (xin, h1, qkv, ao, lse, xmid_c, h2_c, z_c, g_c, ao_c)
+            return xout_c
+
+        prune = self.prune_dead_rows
         xt = None
         for i in range(12):
             if i == 8:
                 xt = x
             x = block_fwd('module.bert.encoder.blocks.%d' % i, x)
-        for i in range(4):
+        for i in range(3):
             xt = block_fwd('module.bert.encoder.tag_blocks.%d' % i, xt)
+        if prune:
+            xt_cls = block_fwd_cls('module.bert.encoder.tag_blocks.3', xt)
+        else:
+            xt_cls = block_fwd('module.bert.encoder.tag_blocks.3', xt).view(B, NV, 768)[:, 0].contiguous()
         # ================= forward: tag head (value of tag_loss only)
         tg = 'module.bert.tag_logit.predictions'
-        pin = ops.cast_bf16(xt.view(B, NV, 768)[:, 0].contiguous())
+        pin = ops.cast_bf16(xt_cls)
         pooled = ops.gemm_bias_act(pin, self.wb('pooler'), self.vec('module.bert.pooler.dense.bias'), act=L.ACT_TANH)
         tgf = ops.gemm_bias_act(pooled, self.wb('tag.t'), self.vec(tg + '.transform.dense.bias'), act=L.ACT_GELU_ERF,
                                 out_dtype=torch.float32)
@@ -471,17 +500,37 @@ class TrainEngine(object):
                                     _p(self.vec(e + '.LayerNorm.weight')), _p(self.vec(e + '.LayerNorm.bias')), 1e-12,
                                     _p(pre_emb), _p(xtext), None, B * TT, T if scst else 0, _s()), 'embed_rows')
         dx = torch.empty(B, LR, 768, device=dev)
-        dx[:, 0] = xt.view(B, NV, 768)[:, 0]
+        dx[:, 0] = xt_cls
         dx[:, 1:SV] = x.view(B, NV, 768)
         dx[:, SV:] = xtext.view(B, TT, 768)
         xd = dx.view(Md, 768)
         dsaved = []
         pd = self.attn_dropout
         dseed = [mix32(mix32(self.dropout_seed, self.step_no), l) for l in range(4)]      # per step, per layer
+        QLO = (SV // 128) * 128                       # first 128-row query block that holds text rows
         for l in range(4):
             pre = 'module.bert.decoder.layer.%d' % l
             xb = ops.cast_bf16(xd)
             qkv = ops.gemm_bias_act(xb, self.wb(pre + '.qkv'), self.qkv_bias(pre))
+            if l == 3 and prune:
+                # Last layer: only the text rows' outputs are read (LM head on the masked / probe rows); the visual rows' K/V
+                # are still needed (and carry gradient), their attention / output / MLP are not.  Text rows only from here.
+                ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
+                                                mask_from=SV + T if scst else 0, q_range=(QLO, LR))
+                ctx_t = ctx.view(B, LR, 768)[:, SV:].reshape(B * TT, 768).contiguous()
+                xd_t = xd.view(B, LR, 768)[:, SV:].reshape(B * TT, 768).contiguous()
+                t1 = torch.empty(B * TT, 768, device=dev)
+                ops.gemm_bias_act(ctx_t, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd_t, out=t1)
+                ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
+                                       self.vec(pre + '.attention.output.LayerNorm.bias'), 1e-12, want_f32=True)
+                z = torch.empty(B * TT, 3072, device=dev, dtype=torch.bfloat16)
+                it = ops.gemm_ex(ab, self.wb(pre + '.i'), bias=self.vec(pre + '.intermediate.dense.bias'), act=L.ACT_GELU_ERF, zout=z)
+                t2 = torch.empty(B * TT, 768, device=dev)
+                ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
+                _, text_out = ops.layernorm(t2, self.vec(pre + '.output.LayerNorm.weight'), self.vec(pre + '.output.LayerNorm.bias'),
+                                            1e-12, want_bf16=False, want_f32=True)
+                dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2, ctx_t))
+                break
             # visual rows attend visual rows; caption row q attends all visual rows and caption rows <= q (one kernel)
             ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
                                             mask_from=SV + T if scst else 0)
@@ -497,6 +546,8 @@ class TrainEngine(object):
                                   want_bf16=False, want_f32=True)
             dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2))
             xd = yf
+        if not prune:
+            text_out = xd.view(B, LR, 768)[:, SV:].reshape(B * TT, 768)
         # ================= loss on the masked caption positions
         row_w = None
         if scst:
@@ -519,8 +570,7 @@ class TrainEngine(object):
         sel = mp.view(-1).nonzero().view(-1)                                  # rows of the (B*TT) text grid
         n = int(sel.numel())
         assert int(tgt.numel()) == n, 'masked_pos / masked_ids disagree'
-        text_rows = xd.view(B, LR, 768)[:, SV:].reshape(B * TT, 768)
-        hrows = ops.cast_bf16(text_rows.index_select(0, sel).contiguous())
+        hrows = ops.cast_bf16(text_out.index_select(0, sel).contiguous())
         c = 'module.cls.predictions'
         zt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
         gt = ops.gemm_ex(hrows, self.wb('cls.t'), bias=self.vec(c + '.transform.dense.bias'), act=L.ACT_GELU_ERF, zout=zt,
@@ -548,14 +598,38 @@ class TrainEngine(object):
         self._wgrad_tn(dzt, hrows, self.g(c + '.transform.dense.weight'), self.g(c + '.transform.dense.bias').view(-1))
         dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
         self.reducer.stage_done('cls')
-        dy = torch.zeros(B, LR, 768, device=dev)
         dtext = torch.zeros(B * TT, 768, device=dev)
         dtext.index_copy_(0, sel, dh)
-        dy[:, SV:] = dtext.view(B, TT, 768)
-        dy = dy.view(Md, 768)
+        if prune:
+            dy = dtext                               # the last layer's backward runs on the text rows (see the forward)
+        else:
+            dy = torch.zeros(B, LR, 768, device=dev)
+            dy[:, SV:] = dtext.view(B, TT, 768)
+            dy = dy.view(Md, 768)
         # ================= backward: decoder layers
         for l in (3, 2, 1, 0):
             pre = 'module.bert.decoder.layer.%d' % l
+            if l == 3 and prune:
+                xb, qkv, ctx, lse, t1, ab, af, z, it, t2, ctx_t = dsaved[l]
+                dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
+                self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), self.g(pre + '.output.dense.bias').view(-1))
+                dz = ops.gemm_ex(dt2b, self.wt(pre + '.o'), aux=z)
+                self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), self.g(pre + '.intermediate.dense.bias').view(-1))
+                da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
+                dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight',
+                                          pre + '.attention.output.LayerNorm.bias', 1e-12)
+                self._wgrad_tn(dt1b, ctx_t, self.g(pre + '.attention.output.dense.weight'),
+                               self.g(pre + '.attention.output.dense.bias').view(-1))
+                dctx_t = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
+                dctx = torch.zeros(B, LR, 768, device=dev, dtype=torch.bfloat16)
+                dctx[:, SV:] = dctx_t.view(B, TT, 768)
+                dqkv = ops.attn_dense_bwd(qkv, ctx, dctx.view(Md, 768), lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
+                                          mask_from=SV + T if scst else 0, q_range=(QLO, LR))
+                self._wgrad_tn(dqkv, xb, self.qkv_w_grad(pre), self.qkv_bias_grad(pre))
+                res = torch.zeros(B, LR, 768, device=dev)
+                res[:, SV:] = dt1f.view(B, TT, 768)               # the residual path reaches the layer input on the text rows only
+                dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=res.view(Md, 768), out_dtype=torch.float32)
+                continue
             xb, qkv, ctx, lse, t1, ab, af, z, it, t2 = dsaved[l]
             dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
             self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), self.g(pre + '.output.dense.bias').view(-1))
@@ -582,9 +656,32 @@ class TrainEngine(object):
         self.reducer.stage_done('emb')
         # ================= backward: encoder
         dhid = dyv[:, 1:SV].reshape(M, 768).contiguous()
-        dtag = torch.zeros(B, NV, 768, device=dev)
-        dtag[:, 0] = dyv[:, 0]
-        dtag = dtag.view(M, 768)
+        if not prune:
+            dtag = torch.zeros(B, NV, 768, device=dev)
+            dtag[:, 0] = dyv[:, 0]
+            dtag = dtag.view(M, 768)
+
+        def block_bwd_cls(pre, dxo_c):
+            """Backward of block_fwd_cls: dxo_c (B,768) = gradient of the block's CLS output; returns the gradient of the block's
+            input on all rows (the CLS query's attention spreads it over every row through K and V)."""
+            xin, h1, qkv, ao, lse, xmid_c, h2_c, z_c, g_c, ao_c = saved.pop(pre)
+            dxb = ops.cast_bf16(dxo_c)
+            self._wgrad_tn(dxb, g_c, self.g(pre + '.mlp.fc2.weight'), self.g(pre + '.mlp.fc2.bias').view(-1))
+            dz = ops.gemm_ex(dxb, self.wt(pre + '.fc2'), aux=z_c)
+            self._wgrad_tn(dz, h2_c, self.g(pre + '.mlp.fc1.weight'), self.g(pre + '.mlp.fc1.bias').view(-1))
+            dh2 = ops.gemm_ex(dz, self.wt(pre + '.fc1'))
+            dmf, dmb = self._ln_bwd(xmid_c, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo_c)
+            self._wgrad_tn(dmb, ao_c, self.g(pre + '.attn.proj.weight'), self.g(pre + '.attn.proj.bias').view(-1))
+            dao_c = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
+            dao = torch.zeros(B, NV, 768, device=dev, dtype=torch.bfloat16)
+            dao[:, 0] = dao_c
+            dqkv = ops.attn_dense_bwd(qkv, ao, dao.view(M, 768), lse, B, NV, q_range=(0, 1))
+            self._wgrad_tn(dqkv, h1, self.g(pre + '.attn.qkv.weight'), self.g(pre + '.attn.qkv.bias').view(-1))
+            dh1 = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'))
+            res = torch.zeros(B, NV, 768, device=dev)
+            res[:, 0] = dmf
+            dif, _ = self._ln_bwd(xin, dh1, pre + '.norm1.weight', pre + '.norm1.bias', 1e-6, dres=res.view(M, 768))
+            return dif
 
         def block_bwd(pre, dxo):
             xin, h1, qkv, ao, lse, xmid, h2, z, g = saved.pop(pre)
@@ -603,7 +700,10 @@ class TrainEngine(object):
             return dif
 
         for i in (3, 2, 1, 0):
-            dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
+            if i == 3 and prune:
+                dtag = block_bwd_cls('module.bert.encoder.tag_blocks.3', dyv[:, 0].contiguous())
+            else:
+                dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
             if i % 2 == 0:
                 self.reducer.stage_done('tag%d' % (i // 2))
         for i in (11, 10, 9, 8):
