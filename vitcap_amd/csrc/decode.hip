@@ -353,60 +353,125 @@ __global__ __launch_bounds__(1024) void sigmoid_topk_kernel(const float* __restr
 //                         replays the reference's python candidate loop + BeamHypotheses (n_hyp = 1) on the device;
 //   beam_reorder_kernel : gathers the text K/V cache rows of the chosen parent beams.
 // ------------------------------------------------------------------------------------------------
+// (value, index) as ONE sortable 64-bit key: high word = the float mapped monotonically onto unsigned, low word = ~index, so
+// "larger value first, lower index on ties" (torch.topk on CPU) is a plain unsigned max -- one compare per element instead of
+// the two-field comparison (the k rescans of 32 register values per thread are what this kernel spends its time on).
+__device__ __forceinline__ unsigned long long tk_key(float f, int i) {
+  unsigned u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned)(~i);
+}
+__device__ __forceinline__ float tk_val(unsigned long long k) {
+  unsigned u = (unsigned)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ int tk_idx(unsigned long long k) { return (int)(~(unsigned)k); }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)a, o, 64), hi = __shfl_xor((unsigned)(a >> 32), o, 64);
+    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+    a = b > a ? b : a;
+  }
+  return a;
+}
+
 __global__ __launch_bounds__(1024) void row_topk_lse_kernel(const float* __restrict__ logits, int ldl, int V, int k,
                                                             float* __restrict__ out_val, int* __restrict__ out_idx,
                                                             float* __restrict__ out_lse) {
-  __shared__ ArgMax s_am[16];
+  // Threshold selection -- three scans of the 32 register values per thread instead of 2 per extracted element (k rounds of
+  // rescanning + removing made this kernel VALU-bound: 150-210 us for 1280 rows):
+  //   1. every thread's maximum; the k largest of the 1024 thread maxima (cheap: one value per thread);
+  //   2. T = the k-th of those.  Keys are unique, so exactly k threads own a key >= T and every key of the row's top k is
+  //      >= T: all keys >= T (at most 32 per such thread, <= 32 k in total) go to a list in LDS;
+  //   3. wave 0 orders the list's k best.
+  constexpr int CAP = TK_PER_THREAD * 16;
+  __shared__ unsigned long long s_cand[16][16];      // [wave][round], k <= 16
+  __shared__ unsigned long long s_list[CAP];
+  __shared__ unsigned long long s_thr;
   __shared__ float s_sum[16];
-  __shared__ ArgMax s_best;
+  __shared__ int s_n;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* row = logits + (size_t)b * ldl;
-  float pv[TK_PER_THREAD];
+  unsigned long long key[TK_PER_THREAD];
+  unsigned long long tmax = 0ull;
 #pragma unroll
   for (int j = 0; j < TK_PER_THREAD; ++j) {
     const int i = tid + j * 1024;
-    pv[j] = i < V ? row[i] : -INFINITY;
+    key[j] = i < V ? tk_key(row[i], i) : 0ull;        // 0 = nothing here (below every real key)
+    tmax = key[j] > tmax ? key[j] : tmax;
   }
-  float rowmax = 0.f;
-  for (int r = 0; r < k; ++r) {
-    ArgMax best{-INFINITY, 0x7fffffff};
-#pragma unroll
-    for (int j = 0; j < TK_PER_THREAD; ++j) {
-      ArgMax c{pv[j], tid + j * 1024};
-      if (tid + j * 1024 < V) best = am_better(best, c);
+  if (tid == 0) s_n = 0;
+  {
+    unsigned long long mine = tmax;                    // k best thread maxima of this wave
+    for (int r = 0; r < k; ++r) {
+      const unsigned long long best = wave_max_u64(mine);
+      if (lane == 0) s_cand[w][r] = best;
+      if (mine == best) mine = 0ull;
     }
-    best = wave_argmax(best);
-    if (lane == 0) s_am[w] = best;
-    __syncthreads();
-    if (tid == 0) {
-      ArgMax bb = s_am[0];
-      for (int q = 1; q < 16; ++q) bb = am_better(bb, s_am[q]);
-      s_best = bb;
-      out_val[(size_t)b * k + r] = bb.v;
-      out_idx[(size_t)b * k + r] = bb.i;
-    }
-    __syncthreads();
-    const ArgMax bb = s_best;
-    if (r == 0) {   // logsumexp with the row max, before anything is removed
-      rowmax = bb.v;
-      float se = 0.f;
+  }
+  __syncthreads();
+  if (w == 0) {
+    unsigned long long c[4];
 #pragma unroll
-      for (int j = 0; j < TK_PER_THREAD; ++j)
-        if (tid + j * 1024 < V) se += expf(pv[j] - rowmax);
-      se = wave_sum(se);
-      if (lane == 0) s_sum[w] = se;
-      __syncthreads();
-      if (tid == 0) {
-        float tot = 0.f;
-        for (int q = 0; q < 16; ++q) tot += s_sum[q];
-        out_lse[b] = rowmax + logf(tot);
+    for (int u = 0; u < 4; ++u) {
+      const int idx = lane + u * 64;
+      c[u] = idx < 16 * k ? s_cand[idx / k][idx % k] : 0ull;
+    }
+    unsigned long long best = 0ull;
+    for (int r = 0; r < k; ++r) {
+      best = c[0] > c[1] ? c[0] : c[1];
+      best = c[2] > best ? c[2] : best;
+      best = c[3] > best ? c[3] : best;
+      best = wave_max_u64(best);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c[u] == best) c[u] = 0ull;
+      if (r == 0 && lane == 0) s_cand[0][0] = best;    // the row maximum (slot reused; everyone has read the candidates)
+    }
+    if (lane == 0) s_thr = best;                       // k-th largest thread maximum (0 when the row has fewer than k values)
+  }
+  __syncthreads();
+  const unsigned long long thr = s_thr;
+  const float rowmax = tk_val(s_cand[0][0]);
+  float se = 0.f;                                      // logsumexp with the row max
+#pragma unroll
+  for (int j = 0; j < TK_PER_THREAD; ++j) {
+    if (tid + j * 1024 < V) se += expf(tk_val(key[j]) - rowmax);
+    if (key[j] != 0ull && key[j] >= thr) {
+      const int pos = atomicAdd(&s_n, 1);
+      if (pos < CAP) s_list[pos] = key[j];
+    }
+  }
+  se = wave_sum(se);
+  if (lane == 0) s_sum[w] = se;
+  __syncthreads();
+  if (w == 0) {
+    const int n = s_n < CAP ? s_n : CAP;
+    unsigned long long c[CAP / 64];
+#pragma unroll
+    for (int u = 0; u < CAP / 64; ++u) {
+      const int idx = lane + u * 64;
+      c[u] = idx < n ? s_list[idx] : 0ull;
+    }
+    for (int r = 0; r < k; ++r) {
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int u = 0; u < CAP / 64; ++u) best = c[u] > best ? c[u] : best;
+      best = wave_max_u64(best);
+      if (lane == 0) {
+        out_val[(size_t)b * k + r] = tk_val(best);
+        out_idx[(size_t)b * k + r] = tk_idx(best);
       }
-    }
-    if ((bb.i & 1023) == tid) {
-      const int jj = bb.i >> 10;
 #pragma unroll
-      for (int j = 0; j < TK_PER_THREAD; ++j)
-        if (j == jj) pv[j] = -INFINITY;
+      for (int u = 0; u < CAP / 64; ++u)
+        if (c[u] == best) c[u] = 0ull;
+    }
+    if (lane == 0) {
+      float tot = 0.f;
+      for (int q = 0; q < 16; ++q) tot += s_sum[q];
+      out_lse[b] = rowmax + logf(tot);
     }
   }
 }
@@ -447,97 +512,128 @@ __global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bo
   if (i < B * st.n_keep * max_len) st.hyp_tok[i] = pad;
 }
 
-__global__ void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
-                                 const float* __restrict__ lse, BeamState st, int B, int K, int V, int t, int max_len,
-                                 int eos, int pad, float length_penalty) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per image (before: one thread per image, ~150 dependent global accesses in series = 108 us per step at 256 images).
+//   1. lanes load the beams x 2*beams candidates (score = value - lse + beam score, flat index = beam * V + word) into LDS;
+//   2. every candidate computes its RANK under (score desc, flat index asc) against all others: rank r < 2*beams = position r
+//      of the reference's sorted topk;
+//   3. lane 0 replays the reference's candidate loop + BeamHypotheses on metadata only (scores, lengths, and for every kept
+//      hypothesis WHERE its tokens come from: an old slot or a beam of this step);
+//   4. all lanes materialise the token rows (hypotheses first read into registers, then written: slots may permute) and the
+//      new beams' prefixes.
+__global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
+                                                       const float* __restrict__ lse, BeamState st, int B, int K, int V, int t,
+                                                       int max_len, int eos, int pad, float length_penalty) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
-  const int C = 2 * K;
-  float sc[MAXBEAM * 2 * MAXBEAM];
-  int fl[MAXBEAM * 2 * MAXBEAM];
-  const int n = K * C;
-  for (int k = 0; k < K; ++k) {
-    const int row = b * K + k;
-    const float shift = st.beam_scores[row] - lse[row];
-    for (int j = 0; j < C; ++j) {
-      sc[k * C + j] = cval[(size_t)row * C + j] + shift;       // log_softmax + beam score
-      fl[k * C + j] = k * V + cidx[(size_t)row * C + j];       // index into the (beams*V) view
-    }
+  const int C = 2 * K, n = K * C, NH = st.n_keep;
+  __shared__ float s_sc[MAXBEAM * 2 * MAXBEAM];
+  __shared__ int s_fl[MAXBEAM * 2 * MAXBEAM];
+  __shared__ float s_top_sc[2 * MAXBEAM];
+  __shared__ int s_top_fl[2 * MAXBEAM];
+  __shared__ float s_hsc[MAXBEAM];       // kept hypotheses after this step
+  __shared__ int s_hln[MAXBEAM];
+  __shared__ int s_hsrc[MAXBEAM];        // >= 0: old slot; < 0: -(1 + beam) of this step
+  __shared__ int s_nh;
+  __shared__ float s_nsc[MAXBEAM];
+  __shared__ int s_nword[MAXBEAM], s_npar[MAXBEAM];
+  for (int i = lane; i < n; i += 64) {
+    const int k = i / C, row = b * K + k;
+    s_sc[i] = cval[(size_t)row * C + (i - k * C)] + (st.beam_scores[row] - lse[row]);   // log_softmax + beam score
+    s_fl[i] = k * V + cidx[(size_t)row * C + (i - k * C)];                              // index into the (beams*V) view
   }
-  // partial selection sort: the 2*beams best by (score desc, flat index asc)
-  for (int r = 0; r < C; ++r) {
-    int best = r;
-    for (int i = r + 1; i < n; ++i)
-      if (sc[i] > sc[best] || (sc[i] == sc[best] && fl[i] < fl[best])) best = i;
-    const float ts = sc[r]; sc[r] = sc[best]; sc[best] = ts;
-    const int tf = fl[r]; fl[r] = fl[best]; fl[best] = tf;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const float v = s_sc[i];
+    const int f = s_fl[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (s_sc[j] > v || (s_sc[j] == v && s_fl[j] < f)) ? 1 : 0;
+    if (rank < C) { s_top_sc[rank] = v; s_top_fl[rank] = f; }
   }
-  const int NH = st.n_keep;
   float* hsc = st.hyp_score + (size_t)b * NH;
   int* hln = st.hyp_len + (size_t)b * NH;
   int64_t* htk = st.hyp_tok + (size_t)b * NH * max_len;
-  int nh = st.has_hyp[b];
-  int done = st.done[b];
-  if (!done && nh >= NH) {
-    // BeamHypotheses.is_done: the list is full and its worst score already beats what the best open beam can reach
-    float worst = hsc[0];
-    for (int i = 1; i < nh; ++i) worst = fminf(worst, hsc[i]);
-    if (worst >= sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
+  // old hypothesis rows into registers (NH * max_len <= 8 * 20 = 160 values, <= 3 per lane)
+  int64_t old_tok[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = lane + u * 64;
+    old_tok[u] = i < NH * max_len ? htk[i] : 0;
   }
-  st.done[b] = done;
-  float nsc[MAXBEAM];
-  int nword[MAXBEAM], npar[MAXBEAM];
-  int cnt = 0;
-  if (!done) {
-    const bool last = (t + 1 == max_len);
-    for (int r = 0; r < C && cnt < K; ++r) {
-      const int beam = fl[r] / V, word = fl[r] - beam * V;
-      if (word == eos || last) {
-        // BeamHypotheses.add (modeling_utils.py:1157-1170): append when the list is not full or the score beats the worst
-        // kept one; when that makes n_hyp + 1 entries, delete the lowest (first of equals) and keep the insertion order
-        const float hs = sc[r] / powf((float)t, length_penalty);     // len(hyp) == cur_len == t
-        int slot = -1;
-        if (nh < NH) {
-          slot = nh++;
-        } else {
-          int lo = 0;
-          for (int i = 1; i < nh; ++i)
-            if (hsc[i] < hsc[lo]) lo = i;
-          if (hs > hsc[lo]) {
-            for (int i = lo; i + 1 < nh; ++i) {
-              hsc[i] = hsc[i + 1];
-              hln[i] = hln[i + 1];
-              for (int q = 0; q < max_len; ++q) htk[(size_t)i * max_len + q] = htk[(size_t)(i + 1) * max_len + q];
+  __syncthreads();
+  if (lane == 0) {
+    int nh = st.has_hyp[b];
+    for (int i = 0; i < nh; ++i) { s_hsc[i] = hsc[i]; s_hln[i] = hln[i]; s_hsrc[i] = i; }
+    int done = st.done[b];
+    if (!done && nh >= NH) {
+      // BeamHypotheses.is_done: the list is full and its worst score already beats what the best open beam can reach
+      float worst = s_hsc[0];
+      for (int i = 1; i < nh; ++i) worst = fminf(worst, s_hsc[i]);
+      if (worst >= s_top_sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
+    }
+    int cnt = 0;
+    if (!done) {
+      const bool last = (t + 1 == max_len);
+      for (int r = 0; r < C && cnt < K; ++r) {
+        const int beam = s_top_fl[r] / V, word = s_top_fl[r] - beam * V;
+        if (word == eos || last) {
+          // BeamHypotheses.add (modeling_utils.py:1157-1170): append when the list is not full or the score beats the worst
+          // kept one; when that makes n_hyp + 1 entries, delete the lowest (first of equals) and keep the insertion order
+          const float hs = s_top_sc[r] / powf((float)t, length_penalty);     // len(hyp) == cur_len == t
+          int slot = -1;
+          if (nh < NH) {
+            slot = nh++;
+          } else {
+            int lo = 0;
+            for (int i = 1; i < nh; ++i)
+              if (s_hsc[i] < s_hsc[lo]) lo = i;
+            if (hs > s_hsc[lo]) {
+              for (int i = lo; i + 1 < nh; ++i) { s_hsc[i] = s_hsc[i + 1]; s_hln[i] = s_hln[i + 1]; s_hsrc[i] = s_hsrc[i + 1]; }
+              slot = nh - 1;
             }
-            slot = nh - 1;
           }
+          if (slot >= 0) { s_hsc[slot] = hs; s_hln[slot] = t; s_hsrc[slot] = -(1 + beam); }
+        } else {
+          s_nsc[cnt] = s_top_sc[r];
+          s_nword[cnt] = word;
+          s_npar[cnt] = b * K + beam;
+          ++cnt;
         }
-        if (slot >= 0) {
-          hsc[slot] = hs;
-          hln[slot] = t;
-          const int64_t* src = st.ids_in + (size_t)(b * K + beam) * max_len;
-          for (int i = 0; i < max_len; ++i) htk[(size_t)slot * max_len + i] = i < t ? src[i] : (int64_t)pad;
-        }
-      } else {
-        nsc[cnt] = sc[r];
-        nword[cnt] = word;
-        npar[cnt] = b * K + beam;
-        ++cnt;
       }
     }
+    if (cnt < K) {   // finished image (or the last step): filler beams, ignored from here on
+      for (int i = 0; i < K; ++i) { s_nsc[i] = 0.f; s_nword[i] = pad; s_npar[i] = b * K; }
+    }
+    s_nh = nh;
+    st.done[b] = done;
+    st.has_hyp[b] = nh;
+    for (int i = 0; i < nh; ++i) { hsc[i] = s_hsc[i]; hln[i] = s_hln[i]; }
   }
-  st.has_hyp[b] = nh;
-  if (cnt < K) {   // finished image (or the last step): filler beams, ignored from here on
-    for (int i = 0; i < K; ++i) { nsc[i] = 0.f; nword[i] = pad; npar[i] = b * K; }
+  __syncthreads();
+  // hypothesis token rows: slot i <- old slot s_hsrc[i] (from the registers, via LDS exchange) or beam -(s_hsrc[i]+1)'s prefix
+  __shared__ int64_t s_old[MAXBEAM * 24];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = lane + u * 64;
+    if (i < NH * max_len && i < MAXBEAM * 24) s_old[i] = old_tok[u];
   }
-  for (int i = 0; i < K; ++i) {
-    const int row = b * K + i;
-    const int64_t* src = st.ids_in + (size_t)npar[i] * max_len;
-    int64_t* dst = st.ids_out + (size_t)row * max_len;
-    for (int q = 0; q < t; ++q) dst[q] = src[q];
-    dst[t] = nword[i];
-    st.beam_scores[row] = nsc[i];
-    st.parent[row] = npar[i];
+  __syncthreads();
+  const int nh = s_nh;
+  for (int i = lane; i < nh * max_len; i += 64) {
+    const int slot = i / max_len, q = i - slot * max_len;
+    const int src = s_hsrc[slot];
+    int64_t v;
+    if (src >= 0) v = s_old[src * max_len + q];
+    else v = q < t ? st.ids_in[(size_t)(b * K + (-src - 1)) * max_len + q] : (int64_t)pad;
+    htk[i] = v;
+  }
+  // the K beams leaving the step: parent prefix + the chosen word
+  for (int i = lane; i < K * (t + 1); i += 64) {
+    const int k = i / (t + 1), q = i - k * (t + 1);
+    st.ids_out[(size_t)(b * K + k) * max_len + q] = q < t ? st.ids_in[(size_t)s_npar[k] * max_len + q] : (int64_t)s_nword[k];
+  }
+  if (lane < K) {
+    st.beam_scores[b * K + lane] = s_nsc[lane];
+    st.parent[b * K + lane] = s_npar[lane];
   }
 }
 
@@ -672,9 +768,9 @@ extern "C" int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, 
                                 const vitcap_beam_state* s, int B, int K, int V, int t, int max_len, int eos, int pad,
                                 float length_penalty, void* stream) {
   VC_REQUIRE(cand_val && cand_idx && lse && s && B > 0 && K >= 1 && K <= MAXBEAM, "beam_step: bad arguments");
-  VC_REQUIRE(t >= 1 && t < max_len, "beam_step: t=%d out of range", t);
+  VC_REQUIRE(t >= 1 && t < max_len && max_len <= 24, "beam_step: t=%d out of range (max_len %d <= 24)", t, max_len);
   VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_step: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
-  hipLaunchKernelGGL(beam_step_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
                      make_state(s), B, K, V, t, max_len, eos, pad, length_penalty);
   VC_LAUNCH_CHECK("beam_step");
   return VITCAP_OK;
