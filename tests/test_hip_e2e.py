@@ -321,3 +321,31 @@ def test_beam5_batch256_properties(model):
     # at every step unless pruned by a better one): compare with the greedy caption's mean log-prob
     _, lp_g = model.generate(img)
     assert float((lp1 - lp_g).min()) > -0.35
+
+
+@pytest.mark.parametrize('B', [1, 5, 63, 65, 129])
+def test_ragged_batch_sizes(model, B):
+    """Edge batch sizes (row counts B*577 that end inside a GEMM tile, a single image, one more / one fewer than the
+    benchmark batch): every caption equals the one the image gets in another batch composition, for the one-stream path,
+    the two-slot pipeline and (small B) beam search; fp32 and bf16 image inputs agree."""
+    from vitcap_amd import weights as W
+    img = torch.from_numpy(W.gen_image_batch(max(B, 6), 1234)).cuda()
+    ref_ids, ref_lp = model.generate(img[:6].to(torch.bfloat16).contiguous())
+    ref_ids, ref_lp = ref_ids.clone(), ref_lp.clone()
+    x = img[:B].to(torch.bfloat16).contiguous()
+    ids, lp = model.generate(x)
+    ids, lp = ids.clone(), lp.clone()
+    n = min(B, 6)
+    assert ids.shape == (B, 1, 20) and torch.equal(ids[:n], ref_ids[:n])
+    np.testing.assert_allclose(lp[:n].cpu().numpy(), ref_lp[:n].cpu().numpy(), atol=1e-6)
+    ids32, lp32 = model.generate(img[:B].to(torch.bfloat16).float().contiguous())      # fp32 input holding bf16 values
+    assert torch.equal(ids32, ids) and torch.equal(lp32, lp)
+    a1, a2 = model.generate_async(x), model.generate_async(x)
+    for h in (a1, a2):
+        i2, l2 = h.result()
+        assert torch.equal(i2, ids) and torch.equal(l2, lp)
+    if B <= 5:
+        bi, bl = model.generate_beam(x, 3)
+        bi = bi.clone()
+        bi6, _ = model.generate_beam(img[:6].to(torch.bfloat16).contiguous(), 3)
+        assert torch.equal(bi, bi6[:B])
