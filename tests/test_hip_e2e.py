@@ -349,3 +349,28 @@ def test_ragged_batch_sizes(model, B):
         bi = bi.clone()
         bi6, _ = model.generate_beam(img[:6].to(torch.bfloat16).contiguous(), 3)
         assert torch.equal(bi, bi6[:B])
+
+
+def test_cls_only_tag_block_equals_full_block(monkeypatch):
+    """The last tag block computed for the CLS row alone (default) against the full 577-row block (VITCAP_FULL_TAG_BLOCK=1):
+    same captions, log-probabilities and tag logits -- the rows that are skipped feed nothing."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    img = torch.from_numpy(W.gen_image_batch(5, 77)).cuda().to(torch.bfloat16)
+    outs = []
+    for full in ('0', '1'):
+        monkeypatch.setenv('VITCAP_FULL_TAG_BLOCK', full)
+        m = ImageCaptioning().load_recipe(0).eval()
+        m.pack('cuda')
+        ids, lp = m.generate(img, want_tags=True)
+        torch.cuda.synchronize()
+        tag_logits = m.tap('tag_logits', 5, (5, 30592)).cpu()[:, :30522]
+        tag_cls = m.tap('tag_hidden', 5, (5, 577, 768)).cpu()[:, 0]
+        outs.append((ids.cpu().clone(), lp.cpu().clone(), tag_logits.clone(), tag_cls.clone()))
+    (i0, l0, t0, c0), (i1, l1, t1, c1) = outs
+    assert torch.equal(i0, i1)
+    np.testing.assert_allclose(l0.numpy(), l1.numpy(), atol=2e-5)
+    rel = float((c0 - c1).norm() / c1.norm())
+    print('tag CLS row rel diff %.2e, tag logits max diff %.2e' % (rel, float((t0 - t1).abs().max())))
+    assert rel < 2e-3
+    np.testing.assert_allclose(t0.numpy(), t1.numpy(), atol=2e-2)

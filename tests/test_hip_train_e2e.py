@@ -494,3 +494,27 @@ def test_pipeline_trains_on_tsv_data(tmp_path, monkeypatch, scst):
         _, want = IO.train_transform_reference(rgb, pr['box'], pr['ops'], pr['flip'])
         assert torch.equal(b['image'][j].cpu(), torch.from_numpy(want).to(torch.bfloat16)), 'image %s differs from the oracle' % k
         assert b['label'][j, 2000 + words.index('dog')] == 1
+
+
+def test_pruned_rows_equal_full_rows(monkeypatch):
+    """Training with the dead rows skipped (last tag block CLS-only, last decoder layer text rows only; the default) against
+    VITCAP_TRAIN_FULL_ROWS=1: same loss and the same gradient on every parameter (up to the float atomics of the LayerNorm
+    weight-gradient reductions), with attention dropout on."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    B = 3
+    b = {k: v.cuda() for k, v in synthetic_train_inputs(B, seed=11).items()}
+    b['image'] = torch.from_numpy(W.gen_image_batch(B, 11)).cuda().to(torch.bfloat16)
+    res = []
+    for full in ('0', '1'):
+        monkeypatch.setenv('VITCAP_TRAIN_FULL_ROWS', full)
+        eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.1, dropout_seed=5)
+        assert eng.prune_dead_rows == (full == '0')
+        loss, tag_loss = eng.forward_backward(b)
+        res.append((float(loss), float(tag_loss), eng.G.clone()))
+    (l0, t0, g0), (l1, t1, g1) = res
+    rel = float((g0 - g1).norm() / g1.norm())
+    print('loss %.6f vs %.6f, tag loss %.4f vs %.4f, gradient rel diff %.2e' % (l0, l1, t0, t1, rel))
+    assert abs(l0 - l1) < 1e-5 and abs(t0 - t1) < 1e-3 * max(1.0, abs(t1)) and rel < 1e-4
