@@ -342,6 +342,13 @@ int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, i
  * workspace, sized with vitcap_engine_workspace_bytes_beam): lets a caller overlap it with the next batch's encoder. */
 int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, float length_penalty, void* workspace,
                               size_t workspace_bytes, int64_t* out_ids, float* out_logprobs, void* stream);
+/* Greedy / sampled decode of seqs_per_image sequences per image after vitcap_engine_encode + vitcap_engine_prefill on the same
+ * workspace (sized with vitcap_engine_workspace_bytes_beam(B, seqs_per_image)): what ViTCAP.generate does for
+ * num_return_sequences > 1 (inputs expanded, modeling_bert.py:976-994), with the copies of an image sharing its encoder output
+ * and visual K/V.  out_ids [B*seqs][20], out_logprobs [B*seqs] image-major; out_last_tok (optional) [B*seqs] = the token chosen
+ * at the last position, which the returned ids overwrite with the forced [SEP] (modeling_utils.py:870-871). */
+int vitcap_engine_decode_multi(vitcap_engine* e, int B, int seqs_per_image, void* workspace, size_t workspace_bytes,
+                               int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* stream);
 
 int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B,
                          void* workspace, size_t workspace_bytes,

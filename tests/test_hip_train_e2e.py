@@ -518,3 +518,43 @@ def test_pruned_rows_equal_full_rows(monkeypatch):
     rel = float((g0 - g1).norm() / g1.norm())
     print('loss %.6f vs %.6f, tag loss %.4f vs %.4f, gradient rel diff %.2e' % (l0, l1, t0, t1, rel))
     assert abs(l0 - l1) < 1e-5 and abs(t0 - t1) < 1e-3 * max(1.0, abs(t1)) and rel < 1e-4
+
+
+def test_shared_encoder_for_samples_of_an_image():
+    """Self-critical step with K samples per image: running the ViT once per image (`seq_per_image`: the samples share the
+    encoder forward, their visual-row gradients are summed before its backward) gives the loss and gradients of the
+    reference's formulation on K-times expanded inputs; and generate_multi draws the sequences generate() draws on the
+    repeated batch (same per-sequence random streams), with the same last-position tokens."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    Bi, K = 3, 4
+    img = torch.from_numpy(W.gen_image_batch(Bi, 21)).cuda().to(torch.bfloat16)
+    model = ImageCaptioning().load_recipe(0).eval()
+    model.pack('cuda')
+    rep = img.repeat_interleave(K, 0).contiguous()
+    model.set_sampling(True, 1.0, 0, 1.0, 1234)
+    try:
+        a_ids, a_lp = [t.clone() for t in model.generate(rep)]
+        a_last = model.tap('last_token', Bi * K, (Bi * K,), torch.int64).clone()
+        b_ids, b_lp, b_last = model.generate_multi(img, K, want_last=True)
+    finally:
+        model.set_sampling(False)
+    assert torch.equal(a_ids, b_ids) and torch.equal(a_last, b_last)
+    np.testing.assert_allclose(a_lp.cpu().numpy(), b_lp.cpu().numpy(), atol=1e-6)
+    assert len({tuple(r) for r in b_ids[:K, 0].tolist()}) > 1, 'the samples of one image should differ'
+    fed = b_ids[:, 0].clone()
+    fed[:, -1] = b_last
+    g = torch.Generator().manual_seed(3)
+    w = (torch.rand(Bi * K, generator=g) - 0.5).cuda() / (Bi * K)
+    res = []
+    for shared in (False, True):
+        eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.1, dropout_seed=2)
+        batch = {'sample_ids': fed, 'sample_weight': w}
+        batch.update({'image': img, 'seq_per_image': K} if shared else {'image': rep})
+        loss, _ = eng.forward_backward(batch)
+        res.append((float(loss), eng.G.clone()))
+    (l0, g0), (l1, g1) = res
+    rel = float((g0 - g1).norm() / g0.norm())
+    print('scst loss expanded %.6f shared %.6f, gradient rel diff %.2e' % (l0, l1, rel))
+    assert abs(l0 - l1) < 2e-5 * max(1.0, abs(l0)) and rel < 2e-3

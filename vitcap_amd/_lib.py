@@ -146,6 +146,7 @@ _SIGS = {
     'vitcap_engine_set_repetition_penalty': (C.c_int, [vp, C.c_float]),
     'vitcap_repetition_penalty': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     'vitcap_engine_beam_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
+    'vitcap_engine_decode_multi': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]),
     'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -454,39 +454,59 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, char* ws, int
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
-                                    float* out_logprobs, void* s) {
-  CK(check(e, B, workspace, workspace_bytes));
+// Greedy / sampled decode of NS = B * K sequences, K per image (K > 1: ViTCAP.generate with num_return_sequences = K expands
+// every input K times, modeling_bert.py:976-994; the K copies of an image share its encoder output and visual K/V here, as
+// the beams of a beam search do).  K > 1 uses the beam workspace layout (vitcap_engine_workspace_bytes_beam(B, K)).
+static int decode_sequences(vitcap_engine* e, int B, int K, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                            float* out_logprobs, int64_t* out_last_tok, void* s) {
+  const int NS = B * K;
+  const Layout lo(B, NS, K > 1);
+  CK(check(e, B, workspace, workspace_bytes, K > 1 ? lo.off : 0));
   g_cur = e;
   if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
-  const Layout lo(B, B, false);
   char* ws = (char*)workspace;
   const vitcap_weights& w = e->w;
   int64_t* ids = (int64_t*)(ws + lo.ids);
   int32_t* unf = (int32_t*)(ws + lo.unf);
   float* sum_lp = (float*)(ws + lo.sum_lp);
   float* cnt = (float*)(ws + lo.cnt);
-  CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, B, L, BOS, PAD, s));
+  CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, NS, L, BOS, PAD, s));
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, ws, B, 1, t, ids, ws + lo.tcache, s));
+    CK(step_forward(w, lo, ws, NS, K, t, ids, ws + lo.tcache, s));
     if (e->repetition_penalty != 1.0f)
-      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, e->repetition_penalty, B, s));
+      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, e->repetition_penalty, NS, s));
     if (e->sampling.do_sample)
       CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), B, t, L, EOS,
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L, EOS,
                             PAD, &e->sampling, s));
     else
       CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), B, t, L, EOS,
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L, EOS,
                             PAD, s));
   }
-  if (hipMemcpyAsync(out_ids, ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
-      hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
+  if (hipMemcpyAsync(out_ids, ids, (size_t)NS * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
+      hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)NS * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
           hipSuccess) {
     vitcap_set_error("decode: output copy failed");
     return VITCAP_ELAUNCH;
   }
+  // the token chosen at the last position before the forced [SEP] (its log-probability is what the score holds)
+  if (out_last_tok && hipMemcpyAsync(out_last_tok, ws + lo.last_tok, (size_t)NS * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
+    vitcap_set_error("decode: last-token copy failed");
+    return VITCAP_ELAUNCH;
+  }
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                                    float* out_logprobs, void* s) {
+  return decode_sequences(e, B, 1, workspace, workspace_bytes, out_ids, out_logprobs, nullptr, s);
+}
+
+extern "C" int vitcap_engine_decode_multi(vitcap_engine* e, int B, int seqs_per_image, void* workspace, size_t workspace_bytes,
+                                          int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* s) {
+  if (seqs_per_image < 1 || seqs_per_image > 8) { vitcap_set_error("decode_multi: seqs_per_image must be 1..8 (got %d)", seqs_per_image); return VITCAP_EINVAL; }
+  return decode_sequences(e, B, seqs_per_image, workspace, workspace_bytes, out_ids, out_logprobs, out_last_tok, s);
 }
 
 // Beam search (a13): encoder + prefill once per image, B*beams sequences in the step loop, all bookkeeping on device.

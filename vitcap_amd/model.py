@@ -249,6 +249,30 @@ class ImageCaptioning(nn.Module):
             self.last_tags = (tag_logits, tag_topk)
         return ids, lp
 
+    def generate_multi(self, image, seqs_per_image, slot=0, want_last=False):
+        """`seqs_per_image` greedy / sampled sequences per image (num_return_sequences of ViTCAP.generate): the encoder and the
+        visual prefill run once per image, the sequences of an image share its visual K/V.  Returns (ids (B*n,1,20),
+        logprobs (B*n,1)) image-major -- the same sequences generate() gives on the n-times repeated batch -- and, with
+        want_last, the token chosen at the last position (before the forced [SEP]) of every sequence."""
+        if self._packed is None:
+            self.pack(image.device)
+        dev = self._packed[2]
+        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
+        B, n = image.shape[0], int(seqs_per_image)
+        ws, need = self._workspace(B, dev, slot, beams=n)
+        ids = torch.empty((B * n, 1, L.MAXLEN), dtype=torch.int64, device=dev)
+        lp = torch.empty((B * n, 1), dtype=torch.float32, device=dev)
+        last = torch.empty((B * n,), dtype=torch.int64, device=dev) if want_last else None
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib.vitcap_gemm_set_persistent(1)
+        wp = C.c_void_p(ws.data_ptr())
+        check(lib.vitcap_engine_encode(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B, wp, need, s),
+              'engine_encode')
+        check(lib.vitcap_engine_prefill(self._engine, B, wp, need, s), 'engine_prefill')
+        check(lib.vitcap_engine_decode_multi(self._engine, B, n, wp, need, C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
+                                             C.c_void_p(last.data_ptr()) if want_last else None, s), 'engine_decode_multi')
+        return (ids, lp, last) if want_last else (ids, lp)
+
     def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0):
         """Greedy captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
         HIP stream while the 19 decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of ~630
@@ -367,8 +391,10 @@ class ImageCaptioning(nn.Module):
             # _expand_for_beams) and returns (B * n, 1, 20): n independent draws per image, image-major
             if not te.get('do_sample', False) or te.get('num_beams', 1) > 1:
                 raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
-            data = dict(data)
-            data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
+            if nret > 8:       # beyond the engine's sequences-per-image limit: expand the inputs like the reference does
+                data = dict(data)
+                data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
+                nret = 1
         if te.get('max_length', 20) != L.MAXLEN:
             raise NotImplementedError('max_length is fixed to 20 in this build')
         # fail loudly on generate() options this build does not implement instead of silently ignoring them
@@ -397,7 +423,7 @@ class ImageCaptioning(nn.Module):
             self.set_sampling(True, te.get('temperature', 1), te.get('top_k', 0), te.get('top_p', 1),
                               int(te.get('seed', 0)) + 0x632be5ab * (self._sample_calls - 1))
             try:
-                return self.generate(data['image'])
+                return self.generate_multi(data['image'], nret) if nret > 1 else self.generate(data['image'])
             finally:
                 self.set_sampling(False)
         return self.generate(data['image'])

@@ -137,18 +137,23 @@ class ScstTrainer(object):
         self._sync_inference_weights()
         self.model.eval()
         g_ids, _ = self.model.generate(images)
-        rep = images.repeat_interleave(K, 0).contiguous()
+        g_ids = g_ids.clone()
+        # the K samples of an image share its encoder pass and visual K/V (generation) and its encoder forward / backward
+        # (training): what the reference computes on K-times expanded inputs, without the K-fold repetition of the ViT
         self.model.set_sampling(True, 1.0, 0, 1.0, self.seed + 0x9e3779b1 * self.iter)
         try:
-            s_ids, _ = self.model.generate(rep)
-            raw_last = self.model.tap('last_token', B * K, (B * K,), torch.int64)
+            if K <= 8:
+                s_ids, _, raw_last = self.model.generate_multi(images, K, want_last=True)
+            else:
+                s_ids, _ = self.model.generate(images.repeat_interleave(K, 0).contiguous())
+                raw_last = self.model.tap('last_token', B * K, (B * K,), torch.int64)
         finally:
             self.model.set_sampling(False)
         s_ids = s_ids[:, 0].clone()
         reward, score = scst_rewards(gt_captions, self._decode(g_ids[:, 0].cpu()), self._decode(s_ids.cpu()), self.scorer)
         fed = s_ids.clone()
         fed[:, -1] = raw_last            # the token whose log-prob the generator recorded, not the forced [SEP]
-        loss, _ = self.eng.forward_backward({'image': rep, 'sample_ids': fed,
+        loss, _ = self.eng.forward_backward({'image': images, 'seq_per_image': K, 'sample_ids': fed,
                                              'sample_weight': (reward / float(B * K)).to(images.device)})
         self.eng.all_reduce_grads()
         self.eng.optimizer_step()

@@ -407,12 +407,14 @@ class TrainEngine(object):
         the decoder runs on [578 visual | 20 token rows | 19 [MASK] probe rows], probe j sees tokens 0..j."""
         dev = self.dev
         img = batch['image']
-        B = img.shape[0]
+        Be = img.shape[0]                       # images the encoder runs on
+        KS = int(batch.get('seq_per_image', 1))   # decoder sequences per image (self-critical step: the samples of an image
+        B = Be * KS                             # share its encoder pass; their visual-row gradients are summed before its backward)
         scst = 'sample_ids' in batch
         TP = (T - 1) if scst else 0          # probe rows per sequence
         TT = T + TP                          # text rows per sequence
         LR = SV + TT                         # decoder rows per image (shadows the module constant on purpose)
-        M, Md = B * NV, B * LR
+        M, Md = Be * NV, B * LR
         self.G.zero_()
         self.reducer.begin()
         self.loss_buf.zero_()
@@ -423,14 +425,14 @@ class TrainEngine(object):
         pos = self.p(ie + 'pos_embed').view(NV, 768)
         ops.gemm_bias_act(patches, self.wb('patch'), self.vec(ie + 'patch_embed.proj.bias'), residual=pos[1:], out=x,
                           row_group=576, out_group_rows=NV, out_row_off=1, res_periodic=1)
-        check(lib.vitcap_cls_rows(_p(self.vec(ie + 'cls_token')), _p(pos), _p(x), B, NV, _s()), 'cls_rows')
+        check(lib.vitcap_cls_rows(_p(self.vec(ie + 'cls_token')), _p(pos), _p(x), Be, NV, _s()), 'cls_rows')
         # ================= forward: 12 blocks + 4 tag blocks, activations kept
         saved = {}
 
         def block_fwd(pre, xin):
             h1, _ = ops.layernorm(xin, self.vec(pre + '.norm1.weight'), self.vec(pre + '.norm1.bias'), 1e-6)
             qkv = ops.gemm_bias_act(h1, self.wb(pre + '.qkv'), self.vec(pre + '.attn.qkv.bias'))
-            ao, lse = ops.attn_dense_train(qkv, B, NV)
+            ao, lse = ops.attn_dense_train(qkv, Be, NV)
             xmid = torch.empty(M, 768, device=dev)
             ops.gemm_bias_act(ao, self.wb(pre + '.proj'), self.vec(pre + '.attn.proj.bias'), residual=xin, out=xmid)
             h2, _ = ops.layernorm(xmid, self.vec(pre + '.norm2.weight'), self.vec(pre + '.norm2.bias'), 1e-6)
@@ -448,15 +450,15 @@ class TrainEngine(object):
             the MLP run for the B CLS rows.  Returns (B,768)."""
             h1, _ = ops.layernorm(xin, self.vec(pre + '.norm1.weight'), self.vec(pre + '.norm1.bias'), 1e-6)
             qkv = ops.gemm_bias_act(h1, self.wb(pre + '.qkv'), self.vec(pre + '.attn.qkv.bias'))
-            ao, lse = ops.attn_dense_train(qkv, B, NV, q_range=(0, 1))
-            ao_c = ao.view(B, NV, 768)[:, 0].contiguous()
-            xin_c = xin.view(B, NV, 768)[:, 0].contiguous()
-            xmid_c = torch.empty(B, 768, device=dev)
+            ao, lse = ops.attn_dense_train(qkv, Be, NV, q_range=(0, 1))
+            ao_c = ao.view(Be, NV, 768)[:, 0].contiguous()
+            xin_c = xin.view(Be, NV, 768)[:, 0].contiguous()
+            xmid_c = torch.empty(Be, 768, device=dev)
             ops.gemm_bias_act(ao_c, self.wb(pre + '.proj'), self.vec(pre + '.attn.proj.bias'), residual=xin_c, out=xmid_c)
             h2_c, _ = ops.layernorm(xmid_c, self.vec(pre + '.norm2.weight'), self.vec(pre + '.norm2.bias'), 1e-6)
-            z_c = torch.empty(B, 3072, device=dev, dtype=torch.bfloat16)
+            z_c = torch.empty(Be, 3072, device=dev, dtype=torch.bfloat16)
             g_c = ops.gemm_ex(h2_c, self.wb(pre + '.fc1'), bias=self.vec(pre + '.mlp.fc1.bias'), act=L.ACT_GELU_ERF, zout=z_c)
-            xout_c = torch.empty(B, 768, device=dev)
+            xout_c = torch.empty(Be, 768, device=dev)
             ops.gemm_bias_act(g_c, self.wb(pre + '.fc2'), self.vec(pre + '.mlp.fc2.bias'), residual=xmid_c, out=xout_c)
             saved[pre] = (xin, h1, qkv, ao, lse, xmid_c, h2_c, z_c, g_c, ao_c)
             return xout_c
@@ -472,7 +474,7 @@ class TrainEngine(object):
         if prune:
             xt_cls = block_fwd_cls('module.bert.encoder.tag_blocks.3', xt)
         else:
-            xt_cls = block_fwd('module.bert.encoder.tag_blocks.3', xt).view(B, NV, 768)[:, 0].contiguous()
+            xt_cls = block_fwd('module.bert.encoder.tag_blocks.3', xt).view(Be, NV, 768)[:, 0].contiguous()
         # ================= forward: tag head (value of tag_loss only)
         tg = 'module.bert.tag_logit.predictions'
         pin = ops.cast_bf16(xt_cls)
@@ -485,7 +487,7 @@ class TrainEngine(object):
         tag_logits = ops.gemm_bias_act(tgb, self.wb('tag.dec'), tbias, out_dtype=torch.float32)
         if 'label' in batch:                 # reported only (never back-propagated); the self-critical step has no labels
             label = batch['label'].to(dev).contiguous()
-            check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), B, _s()),
+            check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), Be, _s()),
                   'focal')
         # ================= forward: decoder on [578 visual | 20 caption] rows per image
         e = 'module.bert.embeddings'
@@ -500,8 +502,8 @@ class TrainEngine(object):
                                     _p(self.vec(e + '.LayerNorm.weight')), _p(self.vec(e + '.LayerNorm.bias')), 1e-12,
                                     _p(pre_emb), _p(xtext), None, B * TT, T if scst else 0, _s()), 'embed_rows')
         dx = torch.empty(B, LR, 768, device=dev)
-        dx[:, 0] = xt_cls
-        dx[:, 1:SV] = x.view(B, NV, 768)
+        dx[:, 0] = xt_cls if KS == 1 else xt_cls.repeat_interleave(KS, 0)
+        dx[:, 1:SV] = x.view(Be, NV, 768) if KS == 1 else x.view(Be, NV, 768).repeat_interleave(KS, 0)
         dx[:, SV:] = xtext.view(B, TT, 768)
         xd = dx.view(Md, 768)
         dsaved = []
@@ -655,10 +657,14 @@ class TrainEngine(object):
                                    B * TT, T if scst else 0, _s()), 'embed_bwd')
         self.reducer.stage_done('emb')
         # ================= backward: encoder
-        dhid = dyv[:, 1:SV].reshape(M, 768).contiguous()
+        if KS > 1:      # the KS sequences of an image saw the same visual rows: their gradients add up
+            dyv_vis = dyv[:, :SV].reshape(Be, KS, SV, 768).sum(1)
+        else:
+            dyv_vis = dyv[:, :SV]
+        dhid = dyv_vis[:, 1:SV].reshape(M, 768).contiguous()
         if not prune:
-            dtag = torch.zeros(B, NV, 768, device=dev)
-            dtag[:, 0] = dyv[:, 0]
+            dtag = torch.zeros(Be, NV, 768, device=dev)
+            dtag[:, 0] = dyv_vis[:, 0]
             dtag = dtag.view(M, 768)
 
         def block_bwd_cls(pre, dxo_c):
@@ -673,12 +679,12 @@ class TrainEngine(object):
             dmf, dmb = self._ln_bwd(xmid_c, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo_c)
             self._wgrad_tn(dmb, ao_c, self.g(pre + '.attn.proj.weight'), self.g(pre + '.attn.proj.bias').view(-1))
             dao_c = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
-            dao = torch.zeros(B, NV, 768, device=dev, dtype=torch.bfloat16)
+            dao = torch.zeros(Be, NV, 768, device=dev, dtype=torch.bfloat16)
             dao[:, 0] = dao_c
-            dqkv = ops.attn_dense_bwd(qkv, ao, dao.view(M, 768), lse, B, NV, q_range=(0, 1))
+            dqkv = ops.attn_dense_bwd(qkv, ao, dao.view(M, 768), lse, Be, NV, q_range=(0, 1))
             self._wgrad_tn(dqkv, h1, self.g(pre + '.attn.qkv.weight'), self.g(pre + '.attn.qkv.bias').view(-1))
             dh1 = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'))
-            res = torch.zeros(B, NV, 768, device=dev)
+            res = torch.zeros(Be, NV, 768, device=dev)
             res[:, 0] = dmf
             dif, _ = self._ln_bwd(xin, dh1, pre + '.norm1.weight', pre + '.norm1.bias', 1e-6, dres=res.view(M, 768))
             return dif
@@ -693,7 +699,7 @@ class TrainEngine(object):
             dmf, dmb = self._ln_bwd(xmid, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo)
             self._wgrad_tn(dmb, ao, self.g(pre + '.attn.proj.weight'), self.g(pre + '.attn.proj.bias').view(-1))
             dao = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
-            dqkv = ops.attn_dense_bwd(qkv, ao, dao, lse, B, NV)
+            dqkv = ops.attn_dense_bwd(qkv, ao, dao, lse, Be, NV)
             self._wgrad_tn(dqkv, h1, self.g(pre + '.attn.qkv.weight'), self.g(pre + '.attn.qkv.bias').view(-1))
             dh1 = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'))
             dif, _ = self._ln_bwd(xin, dh1, pre + '.norm1.weight', pre + '.norm1.bias', 1e-6, dres=dmf)
@@ -701,7 +707,7 @@ class TrainEngine(object):
 
         for i in (3, 2, 1, 0):
             if i == 3 and prune:
-                dtag = block_bwd_cls('module.bert.encoder.tag_blocks.3', dyv[:, 0].contiguous())
+                dtag = block_bwd_cls('module.bert.encoder.tag_blocks.3', dyv_vis[:, 0].contiguous())
             else:
                 dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
             if i % 2 == 0:
@@ -717,9 +723,9 @@ class TrainEngine(object):
             if i % 2 == 0:
                 self.reducer.stage_done('blk%d' % (i // 2))
         # ================= backward: patch embed, cls token, position embedding
-        check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, B, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
+        check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, Be, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
         self.g(ie + 'cls_token').view(-1).copy_(self.g(ie + 'pos_embed').view(NV, 768)[0])
-        dpatch = ops.cast_bf16(dxe.view(B, NV, 768)[:, 1:].reshape(B * 576, 768).contiguous())
+        dpatch = ops.cast_bf16(dxe.view(Be, NV, 768)[:, 1:].reshape(Be * 576, 768).contiguous())
         self._wgrad_tn(dpatch, patches, self.g(ie + 'patch_embed.proj.weight').view(768, 768), self.g(ie + 'patch_embed.proj.bias').view(-1))
         self.reducer.stage_done('patch')
         return self.loss_buf[0], self.loss_buf[1]
