@@ -113,8 +113,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   // The MFMAs are already hidden; the critical path is LDS-DMA in (25 B/clk/CU, the same ceiling the NT kernel sees) PLUS
   // the transpose reads out, which do not overlap each other.  Tried and measured, both slower or equal, both reverted:
   // the two n-halves one phase apart as in gemm_nt_256_kernel (+3 %), and a ring of four 32-row stages with the request
-  // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242).  SQ counters: no LDS bank conflicts, 67 % of
-  // wave cycles in s_waitcnt/barriers, MFMA pipe 33 % busy.
+  // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242); register-staged tiles (global_load -> VGPR ->
+  // ds_write_b128) instead of LDS-DMA: 195 -> 499 us.  SQ counters: no LDS bank conflicts, 67 % of wave cycles in
+  // s_waitcnt/barriers, MFMA pipe 33 % busy.
   if (nst > 0) STAGE(0, s_begin);
   for (int t = 0; t < nst; ++t) {
     const int buf = t & 1;
