@@ -172,15 +172,15 @@ def bench_scst(args, rank, world, local, dist, D):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200, help='timed steps (200 x ~18 ms keeps the timed region above 3 s)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', default='caption', choices=['caption', 'train', 'scst'],
                     help="'caption' = the headline metric; 'train' = cross-entropy training step (BASELINE configs[3])")
     ap.add_argument('--beams', type=int, default=1, help='num_beams (1 = greedy, the headline metric; 5 = BASELINE configs[2])')
-    ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
-    ap.add_argument('--graph', type=int, default=0, help='replay the step from a captured hipGraph (1) or launch eagerly (0)')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: the decode loop is captured once into a hipGraph inside the engine (vitcap_gen_opts.use_graph) and replayed')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1: two-slot batch pipeline (encode+prefill of step i+1 overlaps the decode of step i on a second '
                          'stream; same results); 0: one stream, steps strictly back to back')
@@ -204,9 +204,10 @@ def main():
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:%d' % local)
     img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
-    if args.beams > 1:
-        _greedy = model.generate
-        model.generate = lambda im, **kw: model.generate_beam(im, args.beams, slot=kw.get('slot', 0))
+    from vitcap_amd import _lib as L
+    gen_kw = dict(num_beams=args.beams, num_keep_best=1, do_sample=False, num_return_sequences=1, use_graph=bool(args.graph))
+    opts = model.gen_options(**gen_kw)                               # one stream: persistent GEMMs
+    popts = model.gen_options(gemm_mode=L.GEMM_TILES, **gen_kw)      # batch pipeline: one tile per workgroup
 
     def barrier():
         torch.cuda.synchronize()
@@ -216,83 +217,64 @@ def main():
 
     stream = torch.cuda.Stream()
     ids = lp = None
-    graph = None
-    nstr = args.streams
-    side = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else []
-    chunks = list(img.chunk(nstr)) if nstr > 1 else [img]
-    chunks = [c.contiguous() for c in chunks]
-    if nstr > 1:
-        plain_generate = model.generate
-
-        def generate_split(_img):
-            """Sub-batches on separate streams: the tail of one sub-batch's kernels overlaps the other's work."""
-            cur = torch.cuda.current_stream()
-            outs = []
-            for i, (st_, ch) in enumerate(zip(side, chunks)):
-                st_.wait_stream(cur)
-                with torch.cuda.stream(st_):
-                    outs.append(plain_generate(ch, slot=i))
-            for st_ in side:
-                cur.wait_stream(st_)
-            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
-        model.generate = generate_split
-    piped = bool(args.pipeline) and not args.graph and nstr == 1
+    piped = bool(args.pipeline)
     with torch.cuda.stream(stream):
         if piped:
-            model.prime_pipeline(img.shape[0], img.device, args.beams)   # both slots' workspaces exist before any step runs
+            model.prime_pipeline(img.shape[0], img.device, opts=popts)   # both slots' workspaces exist before any step runs
         for _ in range(max(args.warmup, 1)):
-            ids, lp = model.generate_async(img, args.beams).result() if piped else model.generate(img)
+            ids, lp = model.generate_async(img, opts=popts).result() if piped else model.run(img, opts)
         stream.synchronize()
-        if args.graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                ids, lp = model.generate(img)
-            graph.replay()
-            stream.synchronize()
 
         # ---- timed region: exactly K steps -------------------------------------------------------
-        use_events = graph is None
-        if use_events:
-            check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
+        check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
         barrier()
         t0 = time.perf_counter()
         pend = None
         for _ in range(args.steps):
-            if graph is not None:
-                graph.replay()
-            elif piped:
-                pend = model.generate_async(img, args.beams)
+            if piped:
+                pend = model.generate_async(img, opts=popts)
             else:
-                ids, lp = model.generate(img)
+                ids, lp = model.run(img, opts)
         if pend is not None:
             ids, lp = pend.result()            # the last batch; earlier ones completed before it (in-order streams)
         stream.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
 
-        # ---- live per-launch timing of the dominant kernel.  Under graph replay the events are recorded in a
-        # second, eager pass of the same K steps (events cannot be queried across replays of one graph node).
-        if not use_events:
-            check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
-            for _ in range(args.steps):
-                model.generate(img)
-            stream.synchronize()
+        # ---- live per-launch timing of the dominant kernel (hipEvents on the launch stream around every large GEMM)
         ms = (C.c_double * 12)()
         fl = (C.c_double * 12)()
         ln = (C.c_int * 12)()
         check(lib.vitcap_engine_timing_end(model._engine, ms, fl, ln), 'timing_end')
         # With the batch pipeline the GEMMs of the timed region share the chip with the other slot's decode kernels, so
-        # their launch durations are longer than the kernel alone needs.  A second, untimed pass of the same K steps on
-        # ONE stream gives the kernel's own rate (reported next to, not instead of, the timed-region figure).
+        # their launch durations are longer than the kernel alone needs.  A second, untimed pass of (at most 20 of) the same
+        # steps on ONE stream gives the kernel's own rate (reported next to, not instead of, the timed-region figure).
         iso = None
         if piped:
+            n_iso = min(args.steps, 20)
             ms2, fl2, ln2 = (C.c_double * 12)(), (C.c_double * 12)(), (C.c_int * 12)()
-            check(lib.vitcap_engine_timing_begin(model._engine, args.steps * 160), 'timing_begin')
-            for _ in range(args.steps):
-                model.generate(img)
+            check(lib.vitcap_engine_timing_begin(model._engine, n_iso * 160), 'timing_begin')
+            for _ in range(n_iso):
+                model.run(img, opts)
             stream.synchronize()
             check(lib.vitcap_engine_timing_end(model._engine, ms2, fl2, ln2), 'timing_end')
             iso = (list(ms2), list(fl2), list(ln2))
+        # decode phase alone (one stream, after an encode + prefill): GPU time of the step loop per batch
+        dec_ms = None
+        if args.beams >= 1:
+            ws, need = model._workspace(B, img.device, 0, opts)
+            o_ids, o_lp = model._out_buffers(B, opts, img.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sp = C.c_void_p(stream.cuda_stream)
+            n_dec = 5
+            for i in range(n_dec + 1):
+                if i == 1:
+                    e0.record(stream)
+                check(lib.vitcap_engine_decode(model._engine, B, C.byref(opts), C.c_void_p(ws.data_ptr()), need,
+                                               C.c_void_p(o_ids.data_ptr()), C.c_void_p(o_lp.data_ptr()), None, sp), 'decode')
+            e1.record(stream)
+            stream.synchronize()
+            dec_ms = e0.elapsed_time(e1) / n_dec
 
     elapsed = D.max_over_ranks(elapsed, dist, device='cuda')
     if rank != 0:
@@ -326,8 +308,10 @@ def main():
                                'seeded random-init weights, uniform(-1,1) 384x384 images resident in HBM',
                    'batch_per_gpu': B, 'global_batch': B * world, 'decode': 'greedy' if args.beams == 1 else 'beam%d' % args.beams, 'max_length': 20,
                    'parallelism': 'replicas x%d (no data-path collective)' % world,
-                   'launch': 'hipGraph replay' if graph is not None else ('eager, 2-slot batch pipeline (encode of step i+1 || decode of step i)' if piped else 'eager'),
-                   'streams_per_gpu': 2 if piped else nstr},
+                   'launch': ('2-slot batch pipeline (encode of step i+1 || decode of step i)' if piped else 'one stream, steps back to back') +
+                             (', decode loop replayed from an engine-owned hipGraph' if args.graph else ', eager launches'),
+                   'streams_per_gpu': 2 if piped else 1},
+        'decode_phase_ms_per_batch': None if dec_ms is None else round(dec_ms, 3),
         'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),
         'end_to_end_tflops_executed': round(value / world * (FLOP_EXECUTED_PER_IMAGE if args.beams == 1 else FLOP_EXECUTED_PER_IMAGE + 13.35e9) / 1e12, 2),
         'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -335,7 +319,8 @@ def main():
             'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),
             'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-            'traffic_note': 'bytes/launch, rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_hbm_traffic_pmc.json' if traffic else None,
+            'traffic_note': ('HBM bytes per launch from a COMMITTED rocprofv3 PMC pass, not measured in this run: (2*FETCH_SIZE+WRITE_SIZE)*1024 '
+                             'in %s (tools/pmc_traffic.sh regenerates it)' % os.path.relpath(TRAFFIC_FILE, REPO)) if traffic else None,
             'launches': int(ln[dom]), 'avg_launch_ms': round(ms[dom] / max(1, ln[dom]), 4),
             'avg_launch_gflop': round(fl[dom] / max(1, ln[dom]) / 1e9, 3),
             'all_large_gemm_tflops': round(gemm_all, 2),

@@ -67,9 +67,14 @@ typedef struct {
   int act;
   int out_dtype;
   int row_group, out_group_rows, out_row_off, res_periodic;
-  int tile_hint; /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x128 three-stage, 4 = skinny (tuning/tests) */
+  int tile_hint; /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x128 three-stage, 4 = skinny (tuning/tests);
+                    5 = 256x256 one tile per workgroup, 12 = 256x256 persistent workgroups (auto picks 12 where it wins
+                    on an otherwise idle GPU; a caller that overlaps a second stream asks for 5 per call) */
   int split_k;   /* > 1: C is fp32 [split_k][M][ldc] partial slabs (no bias/act/residual applied); the consumer
                     (vitcap_sum_layernorm) reduces them.  K must be a multiple of 128*split_k. */
+  const int32_t* live; /* optional device counter: the kernel returns at entry when *live == 0 (decode loop after every
+                          sequence has finished -- the reference's `if cur_unfinished.max() == 0: break`,
+                          modeling_utils.py:866; NULL = always run).  Honoured by the small-M (decode) kernels. */
 } vitcap_gemm_desc;
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
@@ -319,56 +324,74 @@ typedef struct vitcap_engine vitcap_engine;
 int vitcap_engine_create(vitcap_engine** out);
 void vitcap_engine_destroy(vitcap_engine* e);
 int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w);
-size_t vitcap_engine_workspace_bytes(int B);
 
-/* image: [B,3,384,384] fp32 or bf16, normalised as the reference's Normalize(.5,.5)
- * out_ids int64 [B,1,20]; out_logprobs fp32 [B,1]  (what ImageCaptioning.forward returns at test time).
- * Optional taps (may be NULL): tag_logits fp32 [B,30522], tag_topk int64 [B,50]. */
-/* Beam search variant (num_beams <= 8); workspace from vitcap_engine_workspace_bytes_beam(B, beams).
- * Outputs: out_ids int64 [B, num_keep_best, 20], out_logprobs fp32 [B, num_keep_best], best hypothesis first, rows of
- * images with fewer finished hypotheses padded with 0 / -1e5 (modeling_utils.py:1076-1100).  num_keep_best is engine
- * state (default 1) set by vitcap_engine_set_num_keep_best, 1..8. */
-size_t vitcap_engine_workspace_bytes_beam(int B, int beams);
-int vitcap_engine_set_num_keep_best(vitcap_engine* e, int num_keep_best);
-/* repetition_penalty of generate() (CTRL, modeling_utils.py:828-836, 955-963): engine state, default 1 (off); applies to the
- * greedy / sampled / beam decode loops.  The kernel alone: rows of logits [rows][ldl], prefixes ids[rows][ld_ids][0..t). */
-int vitcap_engine_set_repetition_penalty(vitcap_engine* e, float penalty);
+/* Options of one generate() call -- the kwargs ViTCAP.generate takes (modeling_bert.py:928-933), which the pipeline passes
+ * through test_extra_input (..._bertemb.py:588-608), plus how the work is launched.  Passed BY VALUE SEMANTICS to every
+ * engine call (the engine keeps no option state between calls; two host threads may drive one engine with different
+ * options on different streams and workspaces).  NULL anywhere below means vitcap_gen_opts_init() defaults. */
+#define VITCAP_MAXLEN_CAP 40     /* largest max_length the decode kernels are sized for (max_seq_a_length default 40) */
+#define VITCAP_GEMM_AUTO 0       /* large GEMMs as persistent workgroups where that wins (the GEMM has the GPU to itself) */
+#define VITCAP_GEMM_TILES 1      /* one tile per workgroup: a second stream's small kernels interleave (batch pipeline) */
+typedef struct vitcap_gen_opts {
+  int32_t num_beams;          /* 1 = greedy / sampling (_generate_no_beam_search); 2..8 = beam search                  */
+  int32_t seqs_per_image;     /* num_return_sequences, 1..8; > 1 needs num_beams == 1 (inputs expanded,
+                                 modeling_bert.py:976-994; the copies share the image's encoder output and visual K/V)  */
+  int32_t num_keep_best;      /* BeamHypotheses.n_hyp, 1..8; > 1 needs num_beams > 1 (modeling_utils.py:790)            */
+  int32_t max_length;         /* 2..VITCAP_MAXLEN_CAP; output rows are max_length wide                                  */
+  int32_t bos_token_id, eos_token_id, pad_token_id, mask_token_id;   /* 101 / 102 / 0 / 103; eos_token_ids has one entry */
+  float length_penalty;       /* beam search                                                                            */
+  float repetition_penalty;   /* CTRL penalty, 1 = off (modeling_utils.py:828-836, 955-963)                             */
+  vitcap_sample_params sampling;   /* do_sample / temperature / top_k / top_p / seed; needs num_beams == 1             */
+  int32_t gemm_mode;          /* VITCAP_GEMM_AUTO | VITCAP_GEMM_TILES                                                   */
+  int32_t early_exit;         /* 1 (default): once every sequence (beam search: image) has finished, the remaining
+                                 steps' kernels return at entry -- `if cur_unfinished.max() == 0: break`
+                                 (modeling_utils.py:866, 1072) without a host synchronisation; results are identical   */
+  int32_t use_graph;          /* 1: the decode loop is captured once per (B, workspace, options) into a hipGraph owned
+                                 by the engine and replayed by later calls (greedy and beam search; not sampling, whose
+                                 seed changes per call)                                                                 */
+} vitcap_gen_opts;
+void vitcap_gen_opts_init(vitcap_gen_opts* o);
+/* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */
+int vitcap_gen_opts_check(const vitcap_gen_opts* o);
+
+/* bytes of caller-provided workspace for B images under `opts` (beams / seqs_per_image / max_length size it) */
+size_t vitcap_engine_workspace_bytes(int B, const vitcap_gen_opts* opts);
+
+/* The whole captioning forward (ImageCaptioning.forward test branch, ..._bertemb.py:87-184 -> ViTCAP.generate) by ONE call.
+ * image: [B,3,384,384] fp32 or bf16, normalised as the reference's Normalize(.5,.5).
+ * Outputs (what ViTCAP.generate returns, modeling_utils.py:883-886 / 1097-1100), rows max_length wide:
+ *   num_beams == 1: out_ids int64 [B*seqs_per_image, 1, max_length], out_logprobs fp32 [B*seqs_per_image, 1], image-major;
+ *   num_beams  > 1: out_ids int64 [B, num_keep_best, max_length], out_logprobs fp32 [B, num_keep_best], best first, rows of
+ *                   images with fewer finished hypotheses padded with pad / -1e5.
+ * Optional taps (may be NULL): tag_logits fp32 [B,30522], tag_topk int64 [B,50] (modeling_bert.py:1424-1432). */
+int vitcap_engine_generate(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts* opts,
+                           void* workspace, size_t workspace_bytes, int64_t* out_ids, float* out_logprobs,
+                           float* tag_logits_out, int64_t* tag_topk_out, void* stream);
+
+/* The three stages of vitcap_engine_generate on one workspace, for callers that overlap them across batches (encoder +
+ * prefill of batch i+1 on one stream, decode of batch i on another) and for profiling / per-stage parity:
+ *   encode  a1-a6: patch embed, 12 + 4 ViT blocks, tag head;  prefill  a8/a9: visual rows through the decoder once, K/V kept;
+ *   decode  a9-a13: the step loop + bookkeeping; out_last_tok (optional, num_beams == 1) [B*seqs] = the token chosen at the
+ *   last position, which the returned ids overwrite with the forced [SEP] (modeling_utils.py:870-871). */
+int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts* opts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int vitcap_engine_prefill(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int vitcap_engine_decode(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, size_t workspace_bytes,
+                         int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* stream);
+/* copies the tag head's outputs of the last encode on this workspace (either pointer may be NULL) */
+int vitcap_engine_tags(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, float* tag_logits_out,
+                       int64_t* tag_topk_out, void* stream);
+/* number of decode-loop hipGraphs the engine currently holds (tests) */
+int vitcap_engine_graph_count(vitcap_engine* e);
+
+/* CTRL repetition penalty kernel alone: rows of logits [rows][ldl], prefixes ids[rows][ld_ids][0..t). */
 int vitcap_repetition_penalty(float* logits, int ldl, int V, const int64_t* ids, int ld_ids, int t, float penalty, int rows,
                               void* stream);
-int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
-                       float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
-                       float* out_logprobs, void* stream);
-/* The decode phase of vitcap_engine_beam alone (after vitcap_engine_encode + vitcap_engine_prefill on the same
- * workspace, sized with vitcap_engine_workspace_bytes_beam): lets a caller overlap it with the next batch's encoder. */
-int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, float length_penalty, void* workspace,
-                              size_t workspace_bytes, int64_t* out_ids, float* out_logprobs, void* stream);
-/* Greedy / sampled decode of seqs_per_image sequences per image after vitcap_engine_encode + vitcap_engine_prefill on the same
- * workspace (sized with vitcap_engine_workspace_bytes_beam(B, seqs_per_image)): what ViTCAP.generate does for
- * num_return_sequences > 1 (inputs expanded, modeling_bert.py:976-994), with the copies of an image sharing its encoder output
- * and visual K/V.  out_ids [B*seqs][20], out_logprobs [B*seqs] image-major; out_last_tok (optional) [B*seqs] = the token chosen
- * at the last position, which the returned ids overwrite with the forced [SEP] (modeling_utils.py:870-871). */
-int vitcap_engine_decode_multi(vitcap_engine* e, int B, int seqs_per_image, void* workspace, size_t workspace_bytes,
-                               int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* stream);
 
-int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B,
-                         void* workspace, size_t workspace_bytes,
-                         int64_t* out_ids, float* out_logprobs,
-                         float* tag_logits_out, int64_t* tag_topk_out, void* stream);
-/* Token choice of the decode loop: greedy (default) or sampled (a12 do_sample branch, modeling_utils.py:839-846;
- * the pipeline passes do_sample / temperature / top_k / top_p through test_extra_input, ..._bertemb.py:590-606).
- * Takes effect at the next vitcap_engine_decode / vitcap_engine_greedy. */
-int vitcap_engine_set_sampling(vitcap_engine* e, const vitcap_sample_params* sp);
-
-/* Debug/parity taps into the workspace after vitcap_engine_greedy (device pointers, valid until the next
- * call): name in {"img_feats","hidden","tag_hidden","vis","logits_last","margins"} */
-const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B);
-
-/* Stages, for profiling and per-stage parity: encoder only / prefill only / one decode step. */
-int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
-                         size_t workspace_bytes, void* stream);
-int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* stream);
-int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes,
-                         int64_t* out_ids, float* out_logprobs, void* stream);
+/* Debug/parity taps into the workspace after a generate call (device pointers, valid until the next call): name in
+ * {"hidden","tag_hidden","vis","logits_last","margins","tag_logits","tag_prob","tag_len","ids","last_token","live"} */
+const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B, const vitcap_gen_opts* opts);
 
 /* ================================================================================================
  * Cross-entropy TRAINING step (ViTCAP.encode_forward(is_training=True) + backward + optimizer:
@@ -428,11 +451,6 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
                       const void* type_emb, const float* gamma, const float* beta, float eps, float* pre_f32,
                       float* x_f32, void* x_bf16, int rows, int pos_wrap, void* stream);
 /* pos_wrap > 0: rows r >= pos_wrap of a sequence are [MASK] probe rows at positions r - pos_wrap + 1 (0 = positions = r) */
-/* Large GEMMs: 1 = persistent workgroups (default; best when the GEMM has the GPU to itself), 0 = one tile per workgroup
- * (best when a second stream's small kernels should interleave, e.g. the two-slot batch pipeline).  Process-wide. */
-void vitcap_gemm_set_persistent(int on);
-int vitcap_gemm_get_persistent(void);
-
 /* Live per-launch timing of the large-tile GEMM kernel (bench.py roofline): hipEvents recorded on the launch
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */

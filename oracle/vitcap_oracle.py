@@ -283,7 +283,7 @@ def apply_repetition_penalty(logits, prefix_ids, penalty):
 
 
 def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_start_posid=20,
-                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0):
+                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0, eos=EOS):
     """Reference greedy decode.  ``reuse_encoder=True`` computes the (step-invariant) ViT encoder
     once instead of 19 times -- same numbers, used only to keep CPU tests fast."""
     B = image.shape[0]
@@ -320,12 +320,12 @@ def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_sta
         unf_hist.append(unfinished)
         add = nxt * unfinished + PAD * (1 - unfinished)
         ids = torch.cat([ids, add.unsqueeze(-1)], dim=-1)
-        unfinished = unfinished * add.ne(EOS).long()
+        unfinished = unfinished * add.ne(eos).long()
         cur_len += 1
         if unfinished.max() == 0:
             break
     if cur_len == max_length:
-        ids[:, -1].masked_fill_(unfinished.bool(), EOS)
+        ids[:, -1].masked_fill_(unfinished.bool(), eos)
     lp = torch.cat(logprobs, dim=1)
     uh = torch.stack(unf_hist, dim=1).float()
     lp = (lp * uh).sum(dim=1) / uh.sum(dim=1)
@@ -445,7 +445,7 @@ def _post(sdw, p, ctx, x, r):
 
 
 def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, sampler=None,
-                       repetition_penalty=1.0):
+                       repetition_penalty=1.0, eos=EOS):
     """Greedy caption via encoder-once + visual prefill + 2-row incremental steps.
 
     Equivalent to ``greedy_as_written`` under the shipped test mask: caption row i attends caption
@@ -519,8 +519,8 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         cnt += unf
         add = nxt * unf + PAD * (1 - unf)
         ids[:, t] = add
-        unf = unf * add.ne(EOS).long()
-    ids[:, -1].masked_fill_(unf.bool(), EOS)
+        unf = unf * add.ne(eos).long()
+    ids[:, -1].masked_fill_(unf.bool(), eos)
     out = (ids.unsqueeze(1), (sum_lp / cnt).unsqueeze(1))
     if return_trace:
         return out + ({'steps': trace, 'hidden': hidden, 'tag_hidden': tag_hidden, 'tags': tags},)
@@ -613,7 +613,8 @@ def sample_incremental(sd, image, temperature=1.0, top_k=0, top_p=1.0, seed=0, e
 # a13  beam search   (modeling_utils.py:888-1100, BeamHypotheses 1138-1180)
 # --------------------------------------------------------------------------------------------
 class BeamHypotheses:
-    """n-best list exactly as modeling_utils.py:1138-1180 (n_hyp = num_keep_best, max_length-1, length_penalty)."""
+    """n-best list exactly as modeling_utils.py:1138-1180 (n_hyp = num_keep_best, max_length-1, length_penalty).
+    ``margin`` tracks the smallest gap of any comparison that decided something (test conditioning only)."""
 
     def __init__(self, n_hyp, max_length, length_penalty):
         self.max_length = max_length - 1
@@ -621,9 +622,12 @@ class BeamHypotheses:
         self.n_hyp = n_hyp
         self.hyp = []
         self.worst_score = 1e9
+        self.margin = float('inf')
 
     def add(self, hyp, sum_logprobs):
         score = sum_logprobs / len(hyp) ** self.length_penalty
+        if len(self.hyp) >= self.n_hyp:
+            self.margin = min(self.margin, abs(score - self.worst_score))
         if len(self.hyp) < self.n_hyp or score > self.worst_score:
             self.hyp.append((score, hyp))
             if len(self.hyp) > self.n_hyp:
@@ -636,14 +640,22 @@ class BeamHypotheses:
     def is_done(self, best_sum_logprobs):
         if len(self.hyp) < self.n_hyp:
             return False
-        return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
+        bound = best_sum_logprobs / self.max_length ** self.length_penalty
+        self.margin = min(self.margin, abs(self.worst_score - bound))
+        return self.worst_score >= bound
 
 
 def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
-                     repetition_penalty=1.0):
+                     repetition_penalty=1.0, eos=EOS, return_margins=False):
     """The reference's beam driver around an abstract model: ``step_logits_fn(input_ids (B*beams, cur_len), beam_idx)``
     returns the next-token logits (B*beams, V) for the current prefixes (``beam_idx`` = the re-ordering applied since
-    the previous call, None at the first).  Returns (decoded (B,keep,max_length), logprobs (B,keep))."""
+    the previous call, None at the first).  Returns (decoded (B,keep,max_length), logprobs (B,keep)).
+
+    With ``return_margins`` also (B, max_length-1): per image and step the smallest score gap among the comparisons that
+    decided the step's outcome -- the gap between the last candidate the scan consumed and the next one (a swap there
+    changes which beams survive / which hypotheses finish), every ``BeamHypotheses.add`` / ``is_done`` comparison, and at
+    the end the gaps between the kept hypotheses' final scores.  Order WITHIN the consumed candidates does not matter (the
+    surviving set and the hypothesis scores are the same).  inf for steps of images that were already done."""
     K = num_beams
     input_ids = torch.full((B * K, 1), BOS, dtype=torch.long)
     hyps = [BeamHypotheses(num_keep_best, max_length, length_penalty) for _ in range(B)]
@@ -653,28 +665,39 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     done = [False] * B
     cur_len = 1
     beam_idx = None
+    margins = torch.full((B, max_length - 1), float('inf'))
     while cur_len < max_length:
         logits = apply_repetition_penalty(step_logits_fn(input_ids, beam_idx).clone(), input_ids, repetition_penalty)
         scores = F.log_softmax(logits, dim=-1)
         Vn = scores.shape[1]
         _scores = (scores + beam_scores[:, None]).view(B, K * Vn)
         next_scores, next_words = torch.topk(_scores, 2 * K, dim=1, largest=True, sorted=True)
+        ext = torch.topk(_scores, 2 * K + 1, dim=1, largest=True, sorted=True).values if return_margins else None
         nb = []
         for b in range(B):
+            hyps[b].margin = float('inf')
             done[b] = done[b] or hyps[b].is_done(next_scores[b].max().item())
             if done[b]:
                 nb.extend([(0, PAD, 0)] * K)
+                margins[b, cur_len - 1] = hyps[b].margin
                 continue
             sent = []
+            used = 0
             for idx, sc in zip(next_words[b], next_scores[b]):
                 beam_id = int(idx) // Vn
                 word_id = int(idx) % Vn
-                if word_id == EOS or cur_len + 1 == max_length:
+                used += 1
+                if word_id == eos or cur_len + 1 == max_length:
                     hyps[b].add(input_ids[b * K + beam_id, :cur_len].clone(), sc.item())
                 else:
                     sent.append((sc, word_id, b * K + beam_id))
                 if len(sent) == K:
                     break
+            if return_margins:
+                m = hyps[b].margin
+                if cur_len + 1 < max_length:         # at the last step every candidate becomes a hypothesis: no boundary
+                    m = min(m, float(ext[b, used - 1] - ext[b, used]))
+                margins[b, cur_len - 1] = m
             if len(sent) == 0:
                 sent = [(0, PAD, 0)] * K
             nb.extend(sent)
@@ -694,12 +717,17 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
             conf, hyp = h.hyp[int(hi)]
             logprobs[i, bi] = conf
             decoded[i, bi, :len(hyp)] = hyp
-            decoded[i, bi, len(hyp)] = EOS
+            decoded[i, bi, len(hyp)] = eos
+        if len(hs) > 1:
+            srt = torch.sort(hs, descending=True).values
+            margins[i, -1] = min(float(margins[i, -1]), float((srt[:-1] - srt[1:]).min()))
+    if return_margins:
+        return decoded, logprobs, margins
     return decoded, logprobs
 
 
 def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
-                    repetition_penalty=1.0):
+                    repetition_penalty=1.0, eos=EOS):
     """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
     B = image.shape[0]
     K = num_beams
@@ -722,11 +750,11 @@ def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, leng
         tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
         logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
         return logits[:, cur, :]
-    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty)
+    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos)
 
 
 def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
-                     num_keep_best=1, repetition_penalty=1.0):
+                     num_keep_best=1, repetition_penalty=1.0, eos=EOS, return_margins=False):
     """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
     image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
     r = _R(emulate_bf16)
@@ -784,7 +812,8 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
         if return_trace:
             trace.append(logits.clone())
         return logits
-    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty)
+    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos,
+                           return_margins=return_margins)
     return out + (trace,) if return_trace else out
 
 

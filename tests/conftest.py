@@ -34,3 +34,43 @@ def sd_np():
 def sd_t(sd_np):
     from oracle import vitcap_oracle as O
     return O.to_torch(sd_np)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Token-exact comparison with the REFERENCE's own fp32 output (tests/golden, produced by running /root/reference).
+# The device computes in bf16 with fp32 accumulation; its logits differ from the reference's fp32 logits by activation
+# rounding noise (measured on the recipe: 1.8e-3 rms per logit, 9e-3 max over a 30522-wide row).  The
+# goldens carry, for every discrete decision the reference took, the margin of that decision (greedy: top-1 minus top-2
+# logit; beam: smallest gap between neighbours among the 2*beams+1 best candidate scores).  Above the floor the device must
+# reproduce the reference's decision exactly; the first sub-floor decision ends the comparable prefix of that sequence.
+GREEDY_MARGIN_FLOOR = 0.012      # logit units: > 4 sigma of the noise on a logit difference (sqrt(2) * 1.8e-3 = 2.5e-3)
+BEAM_MARGIN_FLOOR = 0.03         # cumulative log-prob scores: noise grows with sqrt(steps), plus the logsumexp term
+
+
+def comparable_prefix(margins_row, floor):
+    """Number of leading decisions (steps) whose reference margin is >= floor."""
+    import numpy as np
+    below = np.nonzero(np.asarray(margins_row) < floor)[0]
+    return int(below[0]) if len(below) else len(margins_row)
+
+
+def assert_tokens_match_reference(got_ids, want_ids, margins, floor, min_full=1, what=''):
+    """got_ids / want_ids: (B, n_best, 20) with n_best == 1 for the comparison; margins (B, 19), decision t-1 picks the
+    token at position t.  Asserts got == want on every sequence's comparable prefix (positions 0..p where p = number of
+    leading above-floor decisions) and on the WHOLE sequence when all its decisions are above the floor; at least `min_full`
+    sequences must be whole-sequence comparable so that the test cannot pass vacuously.  Returns the per-sequence status."""
+    import numpy as np
+    got, want = np.asarray(got_ids)[:, 0], np.asarray(want_ids)[:, 0]
+    full, report = 0, []
+    for b in range(want.shape[0]):
+        p = comparable_prefix(margins[b], floor)
+        whole = p == margins.shape[1]
+        full += int(whole)
+        n = want.shape[1] if whole else p + 1              # positions 0..p inclusive (position 0 is [CLS])
+        ok = bool((got[b, :n] == want[b, :n]).all())
+        report.append((b, p, whole, ok, bool((got[b] == want[b]).all())))
+        assert ok, ('%s sequence %d differs from the reference inside its comparable prefix (%d decisions above the %.3g '
+                    'floor, min margin %.4g):\n got  %s\n want %s' % (what, b, p, floor, float(np.min(margins[b, :max(p, 1)])),
+                                                                      got[b].tolist(), want[b].tolist()))
+    assert full >= min_full, '%s: only %d sequences are whole-sequence comparable (need %d): %s' % (what, full, min_full, report)
+    return report

@@ -46,13 +46,26 @@ def test_argument_validation_without_gpu(L):
 def test_engine_lifecycle_and_workspace(L):
     h = C.c_void_p()
     assert L.lib.vitcap_engine_create(C.byref(h)) == 0 and h.value
-    w1, w64 = L.lib.vitcap_engine_workspace_bytes(1), L.lib.vitcap_engine_workspace_bytes(64)
+    w1, w64 = L.lib.vitcap_engine_workspace_bytes(1, None), L.lib.vitcap_engine_workspace_bytes(64, None)
     assert 0 < w1 < w64 < 64 * w1 * 1.01 and w64 % 256 == 0
-    assert L.lib.vitcap_engine_workspace_bytes(0) == 0
+    assert L.lib.vitcap_engine_workspace_bytes(0, None) == 0
+    # options are a per-call struct with the reference's test-time defaults; beams / max_length size the workspace
+    o = L.gen_opts()
+    assert (o.num_beams, o.max_length, o.eos_token_id, o.bos_token_id, o.mask_token_id, o.pad_token_id) == (1, 20, 102, 101, 103, 0)
+    assert o.early_exit == 1 and o.use_graph == 0 and o.gemm_mode == L.GEMM_AUTO and abs(o.repetition_penalty - 1.0) < 1e-9
+    assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(o)) == w64
+    assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(num_beams=5))) > w64
+    assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(max_length=40))) > w64
+    for bad in (dict(num_beams=9), dict(max_length=41), dict(max_length=1), dict(num_beams=1, num_keep_best=2),
+                dict(num_beams=2, seqs_per_image=2), dict(repetition_penalty=0.0), dict(eos_token_id=30522), dict(gemm_mode=7)):
+        ob = L.gen_opts(**bad)
+        assert L.lib.vitcap_gen_opts_check(C.byref(ob)) == -1 and L.lib.vitcap_last_error(), bad
+        assert L.lib.vitcap_engine_workspace_bytes(4, C.byref(ob)) == 0
     # using the engine before binding weights is an error, not a crash
     buf = (C.c_char * 1024)()
     a = C.c_void_p((C.addressof(buf) + 255) & ~255)
-    assert L.lib.vitcap_engine_prefill(h, 1, a, 512, None) == -4
+    assert L.lib.vitcap_engine_prefill(h, 1, None, a, 512, None) == -4
+    assert L.lib.vitcap_engine_graph_count(h) == 0
     w = L.Weights()
     assert L.lib.vitcap_engine_bind_weights(h, C.byref(w)) == -1 and b'NULL' in L.lib.vitcap_last_error()
     L.lib.vitcap_engine_destroy(h)
@@ -62,7 +75,8 @@ def test_struct_sizes_match_header(L):
     # every field is one pointer: 12/12/6 per block struct, total as laid out in vitcap_hip.h
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6) * 8
-    assert C.sizeof(L.GemmDesc) == 15 * 4
+    assert C.sizeof(L.GemmDesc) == 16 * 4 + 8           # 15 ints, padding, one pointer (live)
+    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 3 * 4
 
 
 def test_model_surface(L, sd_np):
@@ -82,8 +96,8 @@ def test_model_surface(L, sd_np):
     with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    for bad in ({'eos_token_ids': [102, 1012]}, {'bos_token_id': 1}, {'num_beams': 3, 'do_sample': True}, {'use_cbs': True},
-                {'max_length': 30}):
+    for bad in ({'eos_token_ids': [102, 1012]}, {'num_beams': 3, 'do_sample': True}, {'use_cbs': True}, {'max_length': 41},
+                {'num_return_sequences': 2}):
         keep = dict(m.test_extra_input)
         m.test_extra_input.update(bad)
         with pytest.raises(NotImplementedError):                    # unsupported generate() options are refused, not ignored
@@ -96,9 +110,15 @@ def test_model_surface(L, sd_np):
 
 def test_recipe_is_reproducible():
     from vitcap_amd import weights as W
-    a = W.gen_tensor('module.cls.predictions.bias', (30522,), 'bias', 0)
-    b = W.gen_tensor('module.cls.predictions.bias', (30522,), 'bias', 0)
+    a = W.gen_tensor('module.cls.predictions.bias', (30522,), 'vbias', 0)
+    b = W.gen_tensor('module.cls.predictions.bias', (30522,), 'vbias', 0)
     assert (a == b).all() and W.tensor_digest(a) == W.tensor_digest(b)
-    assert abs(float(a.std()) - 0.02) < 1e-3 and abs(float(a.mean())) < 1e-3
+    assert abs(float(a.std()) - 1.0) < 2e-2 and abs(float(a.mean())) < 2e-2 and a[102] == a.max()     # unigram-like prior, [SEP] on top
+    w = W.gen_tensor('module.bert.encoder.blocks.0.attn.qkv.weight', (2304, 768), 'w', 0)
+    assert abs(float(w.std()) - 0.02) < 1e-3
+    t = torch.from_numpy(w)
+    assert torch.equal(t.to(torch.bfloat16).float(), t), 'recipe matrices are exactly representable in bf16'
+    v = W.gen_tensor('module.bert.encoder.blocks.0.attn.qkv.bias', (2304,), 'bias', 0)
+    assert abs(float(v.std()) - 0.02) < 1e-3
     img4, img2 = W.gen_image_batch(4, 7), W.gen_image_batch(2, 7)
     assert (img4[:2] == img2).all() and img4.min() >= -1 and img4.max() < 1

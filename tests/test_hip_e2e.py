@@ -1,23 +1,30 @@
-"""End-to-end parity of the HIP greedy-captioning engine against the CPU oracle and the reference goldens.
+"""End-to-end parity of the HIP captioning engine against the REFERENCE's own outputs (tests/golden) and the CPU oracle.
 
-What is asserted (tolerances stated inline):
-  1. bf16 HIP path vs the oracle's bf16-rounding emulation of the SAME incremental algorithm:
-     encoder activations within 2e-2 relative L2 (a handful of 1-ulp bf16 rounding flips per layer),
-     greedy token ids BIT-IDENTICAL on every sequence whose smallest oracle top-2 logit margin along the
-     path exceeds MARGIN_TOL, caption log-probs within 2e-3.
-  2. bf16 HIP path vs the reference's own fp32 tokens (tests/golden): identical wherever the reference's
-     margin exceeds the bf16 noise floor; reported otherwise (random-init logits are nearly flat, SURVEY
-     section 7 "hard parts").
-  3. properties at the benchmark batch size (B=64): batch invariance (sequence b of a batch == the same
-     image run alone), determinism (two runs bit-identical), ids well-formed.
+What is asserted (tolerances stated inline; the noise floors are defined in tests/conftest.py):
+  1. bf16 HIP path vs the reference's fp32 tokens (goldens produced by running /root/reference itself): token ids
+     IDENTICAL on every decision whose reference margin exceeds the bf16 noise floor -- whole captions on the four
+     well-conditioned images, comparable prefixes elsewhere -- for the pipeline flow (tied, tagemb='cls'), the notebook flow
+     (untied, tagemb=None: BASELINE configs[0]) and a run with another EOS token (captions of different lengths); caption
+     log-probs within 1e-2 (bf16 vs fp32).
+  2. bf16 HIP path vs the oracle's bf16-rounding emulation of the SAME incremental algorithm (differences: fp32 summation
+     order only): encoder activations within 2e-2 relative L2, last-step logits within 1e-2, token ids identical wherever the
+     emulation's margin exceeds 2e-3, log-probs within 2e-3; beam search, n-best lists and the repetition penalty likewise,
+     conditioned on the oracle's decision gaps.
+  3. properties at the benchmark sizes (B=64 greedy, 256 x beam 5): determinism, batch-composition invariance, well-formed
+     ids; hipGraph replay, early exit, max_length != 20, option and text-input validation, two host threads on one engine.
 """
+import threading
+
 import numpy as np
 import pytest
 import torch
 
+from conftest import (BEAM_MARGIN_FLOOR, GREEDY_MARGIN_FLOOR, assert_tokens_match_reference)
+
 pytestmark = pytest.mark.gpu
 
 MARGIN_TOL = 2e-3     # logit units; oracle-emulation vs device differ by fp32 summation order only
+BEAM_GAP_TOL = 2e-4   # same, for accumulated beam scores (sums of up to 19 log-probs + logsumexp)
 
 
 @pytest.fixture(scope='module')
@@ -40,6 +47,15 @@ def oracle_run(sd_t):
     return img, ids, lp, tr
 
 
+def _images(n, seed=1234):
+    from vitcap_amd import weights as W
+    return torch.from_numpy(W.gen_image_batch(n, seed))
+
+
+def _selected(vec, key='sel_index'):
+    return _images(16, int(vec['sel_image_seed'][0]))[torch.from_numpy(vec[key])]
+
+
 def test_state_dict_roundtrip(model, sd_np):
     sd = model.state_dict()
     assert list(sd.keys()) == list(sd_np.keys())
@@ -49,6 +65,84 @@ def test_state_dict_roundtrip(model, sd_np):
         sd['module.bert.embeddings.word_embeddings.weight'].data_ptr()
 
 
+# ------------------------------------------------------------------------------------------------ vs the reference
+def test_greedy_tokens_equal_reference_goldens(model, golden):
+    """Token ids of the reference itself (fp32, full re-encode per step) on the same seeded weights / images."""
+    vec, _ = golden
+    # (a) the four well-conditioned images: every decision is above the floor -> whole captions must be identical
+    ids, lp = model.generate(_selected(vec).cuda())
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), vec['greedy_sel_ids'], vec['greedy_sel_margins'],
+                                        GREEDY_MARGIN_FLOOR, min_full=4, what='greedy/selected')
+    assert all(r[4] for r in rep)
+    np.testing.assert_allclose(lp.cpu().numpy(), vec['greedy_sel_logprobs'], rtol=0, atol=1e-2)
+    # (b) the default images 0..3: identical up to each caption's first ill-conditioned decision
+    ids, lp = model.generate(_images(4).cuda())
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), vec['greedy_b4_ids'], vec['greedy_b4_margins'],
+                                        GREEDY_MARGIN_FLOOR, min_full=0, what='greedy/B=4')
+    print('greedy B=4 (sequence, comparable decisions, whole, prefix ok, whole caption equal):', rep)
+    np.testing.assert_allclose(lp.cpu().numpy(), vec['greedy_b4_logprobs'], rtol=0, atol=1e-2)
+    # B=1 and B=2 goldens are the same images in smaller batches (batch invariance of the reference and of the engine)
+    assert np.array_equal(vec['greedy_b4_ids'][:2], vec['greedy_b2_ids']) and np.array_equal(vec['greedy_b4_ids'][:1], vec['greedy_b1_ids'])
+    ids1, _ = model.generate(_images(1).cuda())
+    assert torch.equal(ids1, ids[:1])
+
+
+def test_greedy_alternative_eos_equals_reference(model, golden):
+    """generate(eos_token_ids=[x]) with a frequently generated token: captions end at different lengths; PAD after EOS, the
+    score counts the EOS step, forced EOS at the last position for unfinished rows (modeling_utils.py:855-877)."""
+    vec, _ = golden
+    eos = int(vec['alt_eos_id'][0])
+    ids, lp = model.generate(_images(4).cuda(), eos_token_ids=[eos])
+    want = vec['greedy_alteos_b4_ids']
+    assert_tokens_match_reference(ids.cpu().numpy(), want, vec['greedy_alteos_b4_margins'], GREEDY_MARGIN_FLOOR, min_full=1,
+                                  what='greedy/alt-eos')
+    got = ids.cpu().numpy()
+    same = (got == want).all(-1).all(-1)
+    np.testing.assert_allclose(lp.cpu().numpy()[same], vec['greedy_alteos_b4_logprobs'][same], rtol=0, atol=1e-2)
+    assert len({int((r != 0).sum()) for r in got[:, 0]}) >= 2, 'captions of different lengths expected'
+
+
+def test_untied_notebook_flow_equals_reference(golden):
+    """BASELINE configs[0]: the notebook's model (tie_weights=False, tagemb=None, Loading Script.ipynb cell 10) on the device."""
+    from vitcap_amd.model import ImageCaptioning
+    vec, _ = golden
+    m = ImageCaptioning(tie_weights=False, tagemb=None).load_recipe(0).eval()
+    m.pack('cuda')
+    sd = m.state_dict()
+    assert sd['module.cls.predictions.decoder.weight'].data_ptr() != sd['module.bert.embeddings.word_embeddings.weight'].data_ptr()
+    img = _images(2).cuda()
+    ids, lp = m({'image': img, 'key': [0, 1]})
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), vec['greedy_untied_nocls_b2_ids'], vec['greedy_untied_nocls_b2_margins'],
+                                        GREEDY_MARGIN_FLOOR, min_full=2, what='untied notebook flow')
+    assert all(r[4] for r in rep)
+    np.testing.assert_allclose(lp.cpu().numpy(), vec['greedy_untied_nocls_b2_logprobs'], rtol=0, atol=1e-2)
+    ids1, lp1 = m.generate(img[:1].contiguous())
+    assert np.array_equal(ids1.cpu().numpy(), vec['greedy_untied_nocls_b1_ids'])
+
+
+@pytest.mark.parametrize('name,beams', [('beam2_b1', 2), ('beam5_b1', 5), ('beam5_b2', 5), ('beam5_sel', 5), ('beam3_alteos_b2', 3)])
+def test_beam_search_vs_reference_goldens(model, golden, name, beams):
+    """a13 against the reference's own beam output.  Beam decisions on random-init logits are ill-conditioned (the stored
+    decision gaps are 1e-5..1e-3 against a bf16 floor of 3e-2), so: identical ids where every gap clears the floor, else
+    identical ids OR a length-normalised score within 1e-2 of the reference's (a near-tie resolved the other way)."""
+    vec, _ = golden
+    want, want_lp, gaps = vec[name + '_ids'], vec[name + '_logprobs'], vec[name + '_margins']
+    B = want.shape[0]
+    img = _selected(vec, 'beam_sel_index') if name == 'beam5_sel' else _images(B)
+    kw = {'eos_token_ids': [int(vec['alt_eos_id'][0])]} if 'alteos' in name else {}
+    ids, lp = model.generate_beam(img.cuda(), beams, **kw)
+    got, got_lp = ids.cpu().numpy(), lp.cpu().numpy()
+    for b in range(B):
+        same = bool((got[b] == want[b]).all())
+        print('%s image %d: min decision gap %.2e, ids equal: %s, score %.5f vs %.5f' % (name, b, float(gaps[b].min()), same,
+                                                                                         float(got_lp[b, 0]), float(want_lp[b, 0])))
+        if float(gaps[b].min()) >= BEAM_MARGIN_FLOOR:
+            assert same, 'beam result differs from the reference although every decision gap clears the floor'
+        assert same or abs(float(got_lp[b, 0]) - float(want_lp[b, 0])) < 1e-2
+        assert abs(float(got_lp[b, 0]) - float(want_lp[b, 0])) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ vs the bf16 emulation
 def test_engine_vs_oracle_emulation(model, oracle_run):
     img, ids_o, lp_o, tr = oracle_run
     B = img.shape[0]
@@ -64,40 +158,18 @@ def test_engine_vs_oracle_emulation(model, oracle_run):
         rel = float((got - want).norm() / want.norm())
         print('%s rel L2 err vs emulation: %.3e' % (name, rel))
         assert rel < 2e-2, name
-    # last-step logits
-    logits = model.tap('logits_last', B, (B, 30592)).cpu()[:, :30522]
-    want = tr['steps'][-1]['logits_row']
     margins = torch.stack([s['margin'] for s in tr['steps']], 1)        # (B,19)
     print('oracle margins min %.4f median %.4f' % (float(margins.min()), float(margins.median())))
-    ok = margins.min(1).values > MARGIN_TOL
-    print('sequences above margin tol: %d/%d' % (int(ok.sum()), B))
-    assert ok.sum() >= B - 1
-    ids_c = ids.cpu()
-    same = (ids_c[:, 0] == ids_o[:, 0]).all(1)
-    print('ids identical per sequence:', same.tolist())
-    assert bool(same[ok].all()), 'token ids differ on a sequence whose margins are above tolerance'
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), ids_o.numpy(), margins.numpy(), MARGIN_TOL, min_full=2,
+                                        what='device vs bf16 emulation')
+    same = torch.tensor([r[4] for r in rep])
+    np.testing.assert_allclose(lp.cpu().numpy()[same.numpy()], lp_o.numpy()[same.numpy()], rtol=0, atol=2e-3)
     if bool(same.all()):
+        logits = model.tap('logits_last', B, (B, 30592)).cpu()[:, :30522]
+        want = tr['steps'][-1]['logits_row']
         err = float((logits - want).abs().max())
         print('last-step logits max abs err %.3e (logit std %.3f)' % (err, float(want.std())))
-        assert err < 5e-2
-        np.testing.assert_allclose(lp.cpu().numpy(), lp_o.numpy(), rtol=0, atol=2e-3)
-
-
-def test_engine_vs_reference_golden(model, golden):
-    """Tokens of the reference itself (fp32, full re-encode per step) on the same seeded weights/images."""
-    from vitcap_amd import weights as W
-    vec, _ = golden
-    img = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
-    ids, lp = model.generate(img)
-    got = ids.cpu().numpy()
-    want = vec['greedy_b2_ids']
-    agree = (got == want).mean()
-    print('token agreement with the fp32 reference: %.3f' % agree)
-    print('got ', got[:, 0].tolist())
-    print('want', want[:, 0].tolist())
-    # bf16 vs fp32: logprob must agree to 1e-2 even if a near-tie flips a token
-    np.testing.assert_allclose(lp.cpu().numpy(), vec['greedy_b2_logprobs'], rtol=0, atol=2e-2)
-    assert got[:, 0, 0].tolist() == [101, 101] and (got[:, 0, -1] == 102).all()
+        assert err < 1e-2
 
 
 def test_tag_head(model, oracle_run):
@@ -109,7 +181,7 @@ def test_tag_head(model, oracle_run):
     err = float((logits.cpu() - o_logit).abs().max())
     print('tag logits max abs err %.3e' % err)
     assert err < 2e-2
-    # top-50 as a set, allowing swaps among candidates whose probabilities differ by < 1e-4
+    # top-50 as a set, allowing swaps among candidates whose probabilities differ by < 1e-3
     for b in range(B):
         got, want = set(topk[b].cpu().tolist()), set(o_pred[b].tolist())
         diff = got ^ want
@@ -118,11 +190,104 @@ def test_tag_head(model, oracle_run):
     assert torch.equal(model.tap('tag_len', B, (B,), torch.int64).cpu(), o_len)
 
 
+@pytest.mark.parametrize('beams,keep', [(2, 1), (5, 1), (3, 3)])
+def test_beam_search_vs_oracle(model, sd_t, beams, keep):
+    """a13 (and a11 num_keep_best): device beam search == the oracle's driver on the bf16-emulated incremental model, for every
+    image whose smallest decision gap in the oracle run exceeds the fp32-summation-order floor; all kept hypotheses, in order."""
+    from oracle import vitcap_oracle as O
+    B = 3
+    img = _images(B)
+    with torch.no_grad():
+        ids_o, lp_o, gaps = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True, num_keep_best=keep, return_margins=True)
+    model.test_extra_input.update(num_beams=beams, num_keep_best=keep)
+    try:
+        ids, lp = model({'image': img.cuda(), 'key': list(range(B))})
+    finally:
+        model.test_extra_input.update(num_beams=1, num_keep_best=1)
+    torch.cuda.synchronize()
+    ids, lp = ids.cpu(), lp.cpu()
+    assert ids.shape == (B, keep, 20) and lp.shape == (B, keep)
+    assert bool((lp[:, :-1] >= lp[:, 1:]).all())
+    ok = gaps.min(1).values > BEAM_GAP_TOL
+    print('min decision gaps', gaps.min(1).values.tolist(), 'hip', lp.tolist(), 'oracle', lp_o.tolist())
+    assert int(ok.sum()) >= 1, 'no image is comparable: pick other inputs'
+    same = (ids == ids_o).all(-1).all(-1)
+    assert bool(same[ok].all()), 'beam result differs from the emulation on an image whose decision gaps clear the floor'
+    np.testing.assert_allclose(lp.numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=2e-3)
+    np.testing.assert_allclose(lp.numpy(), lp_o.numpy(), atol=1e-2)
+    if keep > 1:
+        ids1, lp1 = model.generate_beam(img.cuda(), beams)
+        assert torch.equal(ids[:, :1], ids1.cpu()) and torch.equal(lp[:, :1], lp1.cpu())
+
+
+@pytest.mark.parametrize('beams,rp', [(1, 1.3), (3, 1.3), (1, 0.8)])
+def test_repetition_penalty_vs_oracle(model, sd_t, beams, rp):
+    """generate(repetition_penalty=rp) through ImageCaptioning.forward, greedy and beam, against the bf16-emulating oracle
+    (itself pinned to the reference by tests/test_oracle_golden.py); and the penalty really changes the caption."""
+    from oracle import vitcap_oracle as O
+    B = 3
+    img = _images(B)
+    with torch.no_grad():
+        if beams == 1:
+            ids_o, lp_o, tr = O.greedy_incremental(sd_t, img, emulate_bf16=True, repetition_penalty=rp, return_trace=True)
+            ok = torch.stack([s['margin'] for s in tr['steps']], 1).min(1).values > MARGIN_TOL
+        else:
+            ids_o, lp_o, gaps = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True, repetition_penalty=rp,
+                                                   return_margins=True)
+            ok = gaps.min(1).values > BEAM_GAP_TOL
+    plain, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
+    plain = plain.clone()
+    model.test_extra_input.update(num_beams=beams, repetition_penalty=rp)
+    try:
+        ids, lp = model({'image': img.cuda(), 'key': [0, 1, 2]})
+        ids, lp = ids.cpu(), lp.cpu()
+    finally:
+        model.test_extra_input.update(num_beams=1, repetition_penalty=1)
+    again, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
+    assert torch.equal(again, plain), 'options are per call: repetition_penalty=1 restores the plain caption'
+    same = (ids == ids_o).all(-1).all(-1)
+    print('hip', ids[:, 0].tolist(), lp.flatten().tolist(), 'oracle', lp_o.flatten().tolist(), 'comparable', ok.tolist())
+    assert int(ok.sum()) >= 1
+    assert bool(same[ok].all())
+    np.testing.assert_allclose(lp.numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=3e-3)
+    if beams == 1:
+        assert not torch.equal(ids, plain.cpu())
+        if rp > 1:       # a penalised greedy caption repeats fewer tokens than the plain one
+            rep = lambda t: sum(len(r) - len(set(r)) for r in t[:, 0].tolist())
+            assert rep(ids) < rep(plain.cpu())
+
+
+@pytest.mark.parametrize('max_length', [8, 33])
+def test_max_length_other_than_20(model, sd_t, max_length):
+    """max_length is a generate() kwarg (modeling_bert.py:928-933; max_gen_length in the YAML): 8 and 33 tokens against the
+    oracle's bf16 emulation, greedy and beam; output rows are max_length wide."""
+    from oracle import vitcap_oracle as O
+    B = 2
+    img = _images(B)
+    with torch.no_grad():
+        ids_o, lp_o, tr = O.greedy_incremental(sd_t, img, emulate_bf16=True, max_length=max_length, return_trace=True)
+    ids, lp = model.generate(img.cuda(), max_length=max_length)
+    assert ids.shape == (B, 1, max_length)
+    margins = torch.stack([s['margin'] for s in tr['steps']], 1)
+    assert_tokens_match_reference(ids.cpu().numpy(), ids_o.numpy(), margins.numpy(), MARGIN_TOL, min_full=0, what='max_length=%d' % max_length)
+    same = (ids.cpu() == ids_o).all(-1).all(-1)
+    np.testing.assert_allclose(lp.cpu().numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=2e-3)
+    with torch.no_grad():
+        bi_o, bl_o, gaps = O.beam_incremental(sd_t, img, num_beams=2, emulate_bf16=True, max_length=max_length, return_margins=True)
+    bi, bl = model.generate_beam(img.cuda(), 2, max_length=max_length)
+    assert bi.shape == (B, 1, max_length)
+    ok = gaps.min(1).values > BEAM_GAP_TOL
+    assert bool(((bi.cpu() == bi_o).all(-1).all(-1))[ok].all())
+    np.testing.assert_allclose(bl.cpu().numpy(), bl_o.numpy(), atol=1e-2)
+    # the default length is untouched by the per-call override
+    assert model.generate(img.cuda())[0].shape == (B, 1, 20)
+
+
+# ------------------------------------------------------------------------------------------------ properties / behaviour
 def test_batch64_properties(model):
     """Size-independent properties at the benchmark batch size."""
-    from vitcap_amd import weights as W
     B = 64
-    img = torch.from_numpy(W.gen_image_batch(B, 1234)).cuda().to(torch.bfloat16)
+    img = _images(B).cuda().to(torch.bfloat16)
     ids1, lp1 = model.generate(img)
     ids1, lp1 = ids1.clone(), lp1.clone()
     ids2, lp2 = model.generate(img)
@@ -140,112 +305,144 @@ def test_batch64_properties(model):
     assert torch.isfinite(lp1).all()
 
 
-@pytest.mark.parametrize('beams', [2, 5])
-def test_beam_search_vs_oracle(model, sd_t, golden, beams):
-    """a13: device beam search == the oracle's beam driver on the bf16-emulated incremental model."""
-    from oracle import vitcap_oracle as O
-    from vitcap_amd import weights as W
+def test_early_exit_and_finished_rows(model, golden):
+    """`if cur_unfinished.max() == 0: break` (modeling_utils.py:866) on the device: with a frequent token as EOS and a batch in
+    which every caption ends early, the live counter reaches 0, the remaining steps' kernels return at entry, and ids / scores
+    equal the run with early_exit off bit for bit; mixed batches (some rows finished, some not) are covered by the
+    alternative-EOS golden above."""
     vec, _ = golden
-    B = 3
-    img = torch.from_numpy(W.gen_image_batch(B, 1234))
-    with torch.no_grad():
-        ids_o, lp_o = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True)
-    model.test_extra_input['num_beams'] = beams
-    try:
-        ids, lp = model({'image': img.cuda(), 'key': list(range(B))})
-    finally:
-        model.test_extra_input['num_beams'] = 1
-    torch.cuda.synchronize()
-    print('hip   ', ids.cpu()[:, 0].tolist(), lp.cpu().flatten().tolist())
-    print('oracle', ids_o[:, 0].tolist(), lp_o.flatten().tolist())
-    assert ids.shape == (B, 1, 20) and lp.shape == (B, 1)
-    same = (ids.cpu() == ids_o).all(-1).all(-1)
-    assert int(same.sum()) >= B - 1, 'more than one beam result differs from the oracle'
-    np.testing.assert_allclose(lp.cpu().numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=2e-3)
-    if beams == 2:
-        assert np.array_equal(ids.cpu().numpy()[:1], vec['beam2_b1_ids']), 'differs from the reference beam=2 golden'
+    img = _images(6).cuda()
+    full, _ = model.generate(img)
+    full = full.cpu()[:, 0]
+    # a token every caption contains (position 1..6) ends all of them early
+    common = [t for t in full[0, 1:8].tolist() if all(t in r[1:8].tolist() for r in full)]
+    assert common, full.tolist()
+    eos = common[0]
+    a_ids, a_lp = [t.clone() for t in model.generate(img, eos_token_ids=[eos], early_exit=True)]
+    live = int(model.tap('live', 6, (1,), torch.int32)[0])
+    b_ids, b_lp = [t.clone() for t in model.generate(img, eos_token_ids=[eos], early_exit=False)]
+    assert live == 0, 'every sequence finished, the live counter must have reached 0'
+    assert torch.equal(a_ids, b_ids) and torch.equal(a_lp, b_lp)
+    rows = a_ids.cpu()[:, 0].tolist()
+    for r in rows:
+        k = r.index(eos)
+        assert k < 8 and all(v == 0 for v in r[k + 1:])
+    # not finished -> counter stays positive with the default EOS
+    model.generate(img)
+    assert int(model.tap('live', 6, (1,), torch.int32)[0]) == 6
+    # beam search: `if all(done): break` (modeling_utils.py:1072)
+    c_ids, c_lp = [t.clone() for t in model.generate_beam(img, 3, eos_token_ids=[eos], early_exit=True)]
+    d_ids, d_lp = model.generate_beam(img, 3, eos_token_ids=[eos], early_exit=False)
+    assert torch.equal(c_ids, d_ids) and torch.equal(c_lp, d_lp)
 
 
-def test_beam_nbest_vs_oracle(model, sd_t):
-    """a11/a13 with num_keep_best = 3 through ImageCaptioning.forward: (B,3,20) ids and (B,3) scores, best first; the best row
-    equals the num_keep_best = 1 result; against the bf16-emulating oracle the kept hypotheses agree (random-init logits are
-    nearly flat, so scores 1e-4 apart may swap places between bf16 pipelines: compare as sets, scores within tolerance)."""
+def test_decode_loop_hipgraph_replay(model):
+    """vitcap_gen_opts.use_graph: the decode loop is captured once per (batch, workspace, options) and replayed; ids and scores
+    are identical to eager launches, for greedy and beam search (BASELINE configs[2] asks for a graph-captured beam step)."""
+    img = _images(5, 77).cuda().to(torch.bfloat16)
+    img2 = _images(5, 78).cuda().to(torch.bfloat16)
+    n0 = model.graph_count()
+    for kind in ('greedy', 'beam'):
+        run = (lambda im, **kw: model.generate(im, **kw)) if kind == 'greedy' else (lambda im, **kw: model.generate_beam(im, 4, **kw))
+        e1 = [t.clone() for t in run(img)]
+        e2 = [t.clone() for t in run(img2)]
+        g1 = [t.clone() for t in run(img, use_graph=True)]        # captures
+        g2 = [t.clone() for t in run(img2, use_graph=True)]       # replays on another input
+        g3 = [t.clone() for t in run(img, use_graph=True)]        # replays again
+        for a, b in ((e1, g1), (e2, g2), (e1, g3)):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), kind
+    assert model.graph_count() == n0 + 2, 'one graph per (batch, workspace, options), reused by later calls'
+
+
+def test_text_inputs_are_validated(model):
+    """a8 / a16: forward() checks the caller's text tensors against the mask structure the kernels implement."""
     from oracle import vitcap_oracle as O
-    from vitcap_amd import weights as W
-    B, beams, keep = 2, 3, 3
-    img = torch.from_numpy(W.gen_image_batch(B, 1234))
-    with torch.no_grad():
-        ids_o, lp_o = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True, num_keep_best=keep)
-    model.test_extra_input.update(num_beams=beams, num_keep_best=keep)
-    try:
-        ids, lp = model({'image': img.cuda(), 'key': list(range(B))})
-    finally:
-        model.test_extra_input.update(num_beams=1, num_keep_best=1)
-    ids1, lp1 = model.generate_beam(img.cuda(), beams)
+    B = 2
+    img = _images(B).cuda()
+    input_ids, am = O.test_text_inputs(B)                  # what CaptionTensorizer emits at test time (dataset.py:218-219, 377-390)
+    data = {'image': img, 'key': [0, 1], 'input_ids': input_ids.cuda(), 'attention_mask': am.cuda(),
+            'token_type_ids': torch.zeros(B, 70, dtype=torch.long).cuda(), 'masked_pos': torch.ones(B, 70, dtype=torch.int32).cuda()}
+    ids, _ = model(data)
+    ref, _ = model({'image': img, 'key': [0, 1]})
+    assert torch.equal(ids, ref)
+    bad = dict(data)
+    m2 = am.clone()
+    m2[:, :20, 20:] = 1                                    # caption rows attending the tag slots: not the shipped pattern
+    bad['attention_mask'] = m2.cuda()
+    with pytest.raises(NotImplementedError, match='attention_mask'):
+        model(bad)
+    bad = dict(data)
+    m3 = am.clone()
+    m3[1, 3, 5] = 1                                        # one extra visible position in one sample
+    bad['attention_mask'] = m3.cuda()
+    with pytest.raises(NotImplementedError, match='attention_mask'):
+        model(bad)
+    bad = dict(data)
+    bad['token_type_ids'] = torch.ones(B, 70, dtype=torch.long).cuda()
+    with pytest.raises(NotImplementedError, match='token_type_ids'):
+        model(bad)
+    bad = dict(data)
+    bad['attention_mask'] = am[:1].cuda()
+    with pytest.raises(ValueError, match='batch'):
+        model(bad)
+
+
+def test_two_host_threads_share_one_engine(model):
+    """Options are per call and the engine serialises its enqueues: one thread running generate() (persistent GEMMs, its own
+    stream and workspace slot) while another drives the two-slot pipeline (one tile per workgroup) gets the results each gets
+    alone."""
+    img_a = _images(6, 300).cuda().to(torch.bfloat16)
+    img_b = _images(7, 301).cuda().to(torch.bfloat16)
+    want_a = [t.clone() for t in model.generate(img_a)]
+    want_b = [t.clone() for t in model.generate(img_b)]
     torch.cuda.synchronize()
-    ids, lp = ids.cpu(), lp.cpu()
-    assert ids.shape == (B, keep, 20) and lp.shape == (B, keep)
-    assert torch.equal(ids[:, :1], ids1.cpu()) and torch.equal(lp[:, :1], lp1.cpu())
-    assert bool((lp[:, :-1] >= lp[:, 1:]).all())
-    np.testing.assert_allclose(lp.numpy(), lp_o.numpy(), atol=3e-3)
-    n_same = 0
-    for b in range(B):
-        got, want = set(map(tuple, ids[b].tolist())), set(map(tuple, ids_o[b].tolist()))
-        n_same += len(got & want)
-    print('hip', lp.tolist(), 'oracle', lp_o.tolist(), 'shared hypotheses', n_same, 'of', B * keep)
-    assert n_same >= B * keep - 2
+    errs = []
 
+    def plain():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    ids, lp = model.generate(img_a, slot='thread_a')
+                    st.synchronize()
+                    assert torch.equal(ids, want_a[0]) and torch.equal(lp, want_a[1])
+        except BaseException as e:       # noqa: BLE001
+            errs.append(e)
 
-@pytest.mark.parametrize('beams,rp', [(1, 1.3), (3, 1.3), (1, 0.8)])
-def test_repetition_penalty_vs_oracle(model, sd_t, beams, rp):
-    """generate(repetition_penalty=rp) through ImageCaptioning.forward, greedy and beam, against the bf16-emulating oracle
-    (itself pinned to the reference by tests/test_oracle_golden.py); and the penalty really changes the caption."""
-    from oracle import vitcap_oracle as O
-    from vitcap_amd import weights as W
-    B = 3
-    img = torch.from_numpy(W.gen_image_batch(B, 1234))
-    with torch.no_grad():
-        if beams == 1:
-            ids_o, lp_o = O.greedy_incremental(sd_t, img, emulate_bf16=True, repetition_penalty=rp)
-        else:
-            ids_o, lp_o = O.beam_incremental(sd_t, img, num_beams=beams, emulate_bf16=True, repetition_penalty=rp)
-    plain, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
-    plain = plain.clone()
-    model.test_extra_input.update(num_beams=beams, repetition_penalty=rp)
-    try:
-        ids, lp = model({'image': img.cuda(), 'key': [0, 1, 2]})
-        ids, lp = ids.cpu(), lp.cpu()
-    finally:
-        model.test_extra_input.update(num_beams=1, repetition_penalty=1)
-    again, _ = model({'image': img.cuda(), 'key': [0, 1, 2]})
-    assert torch.equal(again, plain), 'the penalty must be switched off again with repetition_penalty=1'
-    same = (ids == ids_o).all(-1).all(-1)
-    print('hip', ids[:, 0].tolist(), lp.flatten().tolist(), 'oracle', lp_o.flatten().tolist())
-    assert int(same.sum()) >= B - 1
-    np.testing.assert_allclose(lp.numpy()[same.numpy()], lp_o.numpy()[same.numpy()], atol=3e-3)
-    if beams == 1:
-        assert not torch.equal(ids, plain.cpu())
-        if rp > 1:       # a penalised greedy caption repeats fewer tokens than the plain one
-            rep = lambda t: sum(len(r) - len(set(r)) for r in t[:, 0].tolist())
-            assert rep(ids) < rep(plain.cpu())
+    def piped():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                pend = [model.generate_async(img_b, lane=7) for _ in range(6)]
+                for p in pend:
+                    ids, lp = p.result()
+                    assert torch.equal(ids, want_b[0]) and torch.equal(lp, want_b[1])
+        except BaseException as e:       # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=plain), threading.Thread(target=piped)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
 
 
 def test_beam1_equals_greedy_tokens(model):
     """Beam search with one beam must pick the greedy tokens (scores are length-normalised differently)."""
-    from vitcap_amd import weights as W
-    img = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+    img = _images(2).cuda()
     g_ids, _ = model.generate(img)
     b_ids, _ = model.generate_beam(img, 1)
     assert torch.equal(g_ids, b_ids)
 
 
-def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch):
+def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch, golden):
     """run.py -c yaml flow: plugin-loaded pipeline, seeded weights saved as a reference-style checkpoint
-    (DDP 'module.' prefixes), suffix-matching load, captions written as the reference's predict TSV rows."""
+    (DDP 'module.' prefixes) named by `model_file`, suffix-matching load, captions written as the reference's predict TSV rows."""
     import json
     import yaml
     import run
     from vitcap_amd.model import ImageCaptioning
+    vec, _ = golden
     monkeypatch.chdir(tmp_path)
     enc = tmp_path / 'enc'
     enc.mkdir()
@@ -257,7 +454,7 @@ def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch):
     torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'iteration': 0}, ck)
     cfg = {'type': 'pipeline_eval_multi',
            'all_test_data': [{'test_data': 'synthetic', 'test_split': 'test'}],
-           'param': {'full_expid': 'E', 'max_iter': 10, 'basemodel': str(ck), 'text_encoder_type': str(enc),
+           'param': {'full_expid': 'E', 'max_iter': 10, 'model_file': str(ck), 'text_encoder_type': str(enc),
                      'tagemb': 'cls', 'test_batch_size': 2, 'synthetic_num_images': 3, 'force_predict': True,
                      'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
     yf = tmp_path / 'exp.yaml'
@@ -269,7 +466,8 @@ def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch):
     rows = [l.rstrip('\n').split('\t') for l in open(out)]
     assert [r[0] for r in rows] == ['0_0', '0_1', '0_2']
     cap = json.loads(rows[0][1])[0]
-    assert cap['caption'].startswith('w30341 w3203 w29703') and 0 < cap['conf'] < 1     # tokens of the golden caption
+    first = ' '.join('w%d' % t for t in vec['greedy_b1_ids'][0, 0, 1:4])          # tokens of the golden caption of image 0
+    assert cap['caption'].startswith(first) and 0 < cap['conf'] < 1
 
 
 def test_generate_async_pipeline_equals_generate(model):
@@ -300,14 +498,15 @@ def test_generate_async_beam_equals_generate_beam(model):
 
 
 def test_beam5_batch256_properties(model):
-    """BASELINE configs[2] size (beam=5, 256 images = 1280 sequences): size-independent properties -- determinism, batch
-    invariance (an image captioned alone gets the same beam result), well-formed ids, finite length-normalised scores."""
-    from vitcap_amd import weights as W
+    """BASELINE configs[2] size (beam=5, 256 images = 1280 sequences, decode loop replayed from a hipGraph): determinism, graph
+    replay == eager, batch invariance (an image captioned alone gets the same beam result), well-formed ids, finite scores."""
     B = 256
-    img = torch.from_numpy(W.gen_image_batch(B, 4321)).cuda().to(torch.bfloat16)
-    ids1, lp1 = [t.clone() for t in model.generate_beam(img, 5)]
-    ids2, lp2 = model.generate_beam(img, 5)
+    img = _images(B, 4321).cuda().to(torch.bfloat16)
+    ids1, lp1 = [t.clone() for t in model.generate_beam(img, 5, use_graph=True)]
+    ids2, lp2 = model.generate_beam(img, 5, use_graph=True)
     assert torch.equal(ids1, ids2) and torch.equal(lp1, lp2), 'non-deterministic'
+    ids3, lp3 = model.generate_beam(img, 5, use_graph=False)
+    assert torch.equal(ids1, ids3) and torch.equal(lp1, lp3), 'hipGraph replay differs from eager launches'
     ids_s, lp_s = model.generate_beam(img[:3].contiguous(), 5)
     assert torch.equal(ids_s, ids1[:3]) and torch.allclose(lp_s, lp1[:3], atol=1e-6)
     i = ids1.cpu()[:, 0]
@@ -317,8 +516,7 @@ def test_beam5_batch256_properties(model):
         k = row.index(102)
         assert all(v == 0 for v in row[k + 1:])
     assert torch.isfinite(lp1).all() and float(lp1.max()) <= 0.0
-    # beam search never scores below its own greedy member under the same normalisation (greedy path is one of the beams
-    # at every step unless pruned by a better one): compare with the greedy caption's mean log-prob
+    # beam search never scores far below its own greedy member under the same normalisation
     _, lp_g = model.generate(img)
     assert float((lp1 - lp_g).min()) > -0.35
 
@@ -328,8 +526,7 @@ def test_ragged_batch_sizes(model, B):
     """Edge batch sizes (row counts B*577 that end inside a GEMM tile, a single image, one more / one fewer than the
     benchmark batch): every caption equals the one the image gets in another batch composition, for the one-stream path,
     the two-slot pipeline and (small B) beam search; fp32 and bf16 image inputs agree."""
-    from vitcap_amd import weights as W
-    img = torch.from_numpy(W.gen_image_batch(max(B, 6), 1234)).cuda()
+    img = _images(max(B, 6)).cuda()
     ref_ids, ref_lp = model.generate(img[:6].to(torch.bfloat16).contiguous())
     ref_ids, ref_lp = ref_ids.clone(), ref_lp.clone()
     x = img[:B].to(torch.bfloat16).contiguous()
@@ -354,9 +551,8 @@ def test_ragged_batch_sizes(model, B):
 def test_cls_only_tag_block_equals_full_block(monkeypatch):
     """The last tag block computed for the CLS row alone (default) against the full 577-row block (VITCAP_FULL_TAG_BLOCK=1):
     same captions, log-probabilities and tag logits -- the rows that are skipped feed nothing."""
-    from vitcap_amd import weights as W
     from vitcap_amd.model import ImageCaptioning
-    img = torch.from_numpy(W.gen_image_batch(5, 77)).cuda().to(torch.bfloat16)
+    img = _images(5, 77).cuda().to(torch.bfloat16)
     outs = []
     for full in ('0', '1'):
         monkeypatch.setenv('VITCAP_FULL_TAG_BLOCK', full)

@@ -533,13 +533,9 @@ def test_shared_encoder_for_samples_of_an_image():
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda')
     rep = img.repeat_interleave(K, 0).contiguous()
-    model.set_sampling(True, 1.0, 0, 1.0, 1234)
-    try:
-        a_ids, a_lp = [t.clone() for t in model.generate(rep)]
-        a_last = model.tap('last_token', Bi * K, (Bi * K,), torch.int64).clone()
-        b_ids, b_lp, b_last = model.generate_multi(img, K, want_last=True)
-    finally:
-        model.set_sampling(False)
+    samp = dict(temperature=1.0, top_k=0, top_p=1.0, seed=1234)
+    a_ids, a_lp, a_last = [t.clone() for t in model.generate_multi(rep, 1, want_last=True, **samp)]
+    b_ids, b_lp, b_last = model.generate_multi(img, K, want_last=True, **samp)
     assert torch.equal(a_ids, b_ids) and torch.equal(a_last, b_last)
     np.testing.assert_allclose(a_lp.cpu().numpy(), b_lp.cpu().numpy(), atol=1e-6)
     assert len({tuple(r) for r in b_ids[:K, 0].tolist()}) > 1, 'the samples of one image should differ'

@@ -107,12 +107,43 @@ def test_greedy_as_written_token_exact(golden, sd_t, img):
 
 
 def test_greedy_incremental_equals_as_written(golden, sd_t, img):
-    """The incremental formulation (what the HIP path computes) reproduces the reference's tokens."""
+    """The incremental formulation (what the HIP path computes) reproduces the reference's tokens, log-probs AND the
+    reference's own per-step top-2 margins (recorded by hooking torch.argmax inside the reference's generate loop)."""
     vec, _ = golden
+    img4 = torch.from_numpy(W.gen_image_batch(4, 1234))
     with torch.no_grad():
-        ids, lp, trace = O.greedy_incremental(sd_t, img, emulate_bf16=False, return_trace=True)
-    np.testing.assert_array_equal(ids.numpy(), vec['greedy_b2_ids'])
-    np.testing.assert_allclose(lp.numpy(), vec['greedy_b2_logprobs'], rtol=1e-5, atol=1e-5)
+        ids, lp, trace = O.greedy_incremental(sd_t, img4, emulate_bf16=False, return_trace=True)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_b4_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_b4_logprobs'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(ids[:2].numpy(), vec['greedy_b2_ids'])
+    m = torch.stack([s['margin'] for s in trace['steps']], 1).numpy()
+    np.testing.assert_allclose(m, vec['greedy_b4_margins'], rtol=0, atol=5e-5)
+
+
+def test_greedy_alternative_eos_matches_reference(golden, sd_t):
+    """eos_token_ids is a generate() kwarg (modeling_bert.py:928-933): with a frequently generated token as EOS the captions
+    stop at data-dependent lengths -- finished rows emit PAD, the score counts the EOS step, unfinished rows get the forced
+    EOS at position 19 (modeling_utils.py:855-877)."""
+    vec, _ = golden
+    eos = int(vec['alt_eos_id'][0])
+    img4 = torch.from_numpy(W.gen_image_batch(4, 1234))
+    with torch.no_grad():
+        ids, lp = O.greedy_incremental(sd_t, img4, emulate_bf16=False, eos=eos)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_alteos_b4_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_alteos_b4_logprobs'], rtol=1e-5, atol=1e-5)
+    lens = [(r != 0).sum() for r in vec['greedy_alteos_b4_ids'][:, 0]]
+    assert len(set(lens)) >= 2, 'the alternative-EOS golden is meant to exercise different caption lengths'
+
+
+def test_greedy_selected_images_match_reference(golden, sd_t):
+    """The 4 best-conditioned of 16 candidate images (tests/golden/make_golden.py): whole captions comparable in bf16."""
+    vec, _ = golden
+    cand = torch.from_numpy(W.gen_image_batch(16, int(vec['sel_image_seed'][0])))[torch.from_numpy(vec['sel_index'])]
+    with torch.no_grad():
+        ids, lp = O.greedy_incremental(sd_t, cand, emulate_bf16=False)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_sel_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_sel_logprobs'], rtol=1e-5, atol=1e-5)
+    assert float(vec['greedy_sel_margins'].min()) > 0.012
 
 
 @pytest.mark.slow
@@ -126,6 +157,16 @@ def test_greedy_untied_notebook_flow(golden, img):
     np.testing.assert_allclose(lp.numpy(), vec['greedy_untied_nocls_b1_logprobs'], rtol=1e-5, atol=1e-5)
 
 
+def test_greedy_untied_incremental_matches_reference(golden):
+    """BASELINE configs[0] flow (tie_weights=False, tagemb=None) on the incremental formulation, B=2."""
+    vec, _ = golden
+    sd = O.to_torch(W.make_state_dict(seed=0, tie_weights=False))
+    with torch.no_grad():
+        ids, lp = O.greedy_incremental(sd, torch.from_numpy(W.gen_image_batch(2, 1234)), emulate_bf16=False)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_untied_nocls_b2_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_untied_nocls_b2_logprobs'], rtol=1e-5, atol=1e-5)
+
+
 def test_beam2_as_written_matches_reference(golden, sd_t, img):
     """a13: the beam driver + BeamHypotheses restatement against the reference's own beam=2 output."""
     vec, _ = golden
@@ -133,6 +174,26 @@ def test_beam2_as_written_matches_reference(golden, sd_t, img):
         ids, lp = O.beam_as_written(sd_t, img[:1], num_beams=2)
     np.testing.assert_array_equal(ids.numpy(), vec['beam2_b1_ids'])
     np.testing.assert_allclose(lp.numpy(), vec['beam2_b1_logprobs'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name,nb,B', [('beam5_b2', 5, 2), ('beam3_alteos_b2', 3, 2), ('beam5_sel', 5, 2)])
+def test_beam_incremental_matches_reference(golden, sd_t, name, nb, B):
+    """beam=5 at B=2, beam=3 with the alternative EOS (hypotheses finishing at many lengths), beam=5 on the two
+    best-conditioned candidate images: ids, scores and the decision margins the generator stored."""
+    vec, _ = golden
+    if name == 'beam5_sel':
+        im = torch.from_numpy(W.gen_image_batch(16, int(vec['sel_image_seed'][0])))[torch.from_numpy(vec['beam_sel_index'])]
+    else:
+        im = torch.from_numpy(W.gen_image_batch(B, 1234))
+    eos = int(vec['alt_eos_id'][0]) if 'alteos' in name else 102
+    with torch.no_grad():
+        ids, lp, mg = O.beam_incremental(sd_t, im, num_beams=nb, emulate_bf16=False, eos=eos, return_margins=True)
+    np.testing.assert_array_equal(ids.numpy(), vec[name + '_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec[name + '_logprobs'], rtol=2e-5, atol=2e-5)
+    got, want = mg.numpy(), vec[name + '_margins']
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all()
+    np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=5e-5)
 
 
 def test_beam_nbest_incremental_matches_reference(sd_t):

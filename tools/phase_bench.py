@@ -23,8 +23,8 @@ for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '32,64').split(
     ids = torch.empty(B, 20, dtype=torch.int64, device='cuda'); lp = torch.empty(B, dtype=torch.float32, device='cuda')
     s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
-    enc = lambda: check(lib.vitcap_engine_encode(m._engine, p(img), 1, B, p(ws), need, s()), 'enc')
-    pre = lambda: check(lib.vitcap_engine_prefill(m._engine, B, p(ws), need, s()), 'pre')
-    dec = lambda: check(lib.vitcap_engine_decode(m._engine, B, p(ws), need, p(ids), p(lp), s()), 'dec')
+    enc = lambda: check(lib.vitcap_engine_encode(m._engine, p(img), 1, B, None, p(ws), need, s()), 'enc')
+    pre = lambda: check(lib.vitcap_engine_prefill(m._engine, B, None, p(ws), need, s()), 'pre')
+    dec = lambda: check(lib.vitcap_engine_decode(m._engine, B, None, p(ws), need, p(ids), p(lp), None, s()), 'dec')
     enc(); pre(); dec()
     print('B=%d encode %.3f ms  prefill %.3f ms  decode %.3f ms' % (B, ev_time(enc), ev_time(pre), ev_time(dec)))

@@ -28,14 +28,14 @@ def run(K, pipelined):
             if pipelined and i >= 2:
                 a.wait_event(evB[i - 2])            # slot free again
             h = C.c_void_p(a.cuda_stream)
-            check(lib.vitcap_engine_encode(m._engine, p(img), 1, B, p(ws), need, h), 'enc')
-            check(lib.vitcap_engine_prefill(m._engine, B, p(ws), need, h), 'pre')
+            check(lib.vitcap_engine_encode(m._engine, p(img), 1, B, None, p(ws), need, h), 'enc')
+            check(lib.vitcap_engine_prefill(m._engine, B, None, p(ws), need, h), 'pre')
             evA[i].record(a)
         with torch.cuda.stream(b):
             if pipelined:
                 b.wait_event(evA[i])
             h = C.c_void_p(b.cuda_stream)
-            check(lib.vitcap_engine_decode(m._engine, B, p(ws), need, p(ids[i % 2]), p(lp[i % 2]), h), 'dec')
+            check(lib.vitcap_engine_decode(m._engine, B, None, p(ws), need, p(ids[i % 2]), p(lp[i % 2]), None, h), 'dec')
             evB[i].record(b)
 
 for mode in (False, True, False, True):

@@ -14,6 +14,8 @@ VOCAB_PAD = 30592
 HID = 768
 NVIS = 577
 MAXLEN = 20
+MAXLEN_CAP = 40
+GEMM_AUTO, GEMM_TILES = 0, 1
 
 ACT_NONE, ACT_GELU_ERF, ACT_TANH = 0, 1, 2
 OUT_BF16, OUT_F32 = 0, 1
@@ -23,7 +25,8 @@ vp = C.c_void_p
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
-                                       'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')]
+                                       'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')] \
+        + [('live', C.c_void_p)]
 
 
 class BeamState(C.Structure):
@@ -34,6 +37,15 @@ class BeamState(C.Structure):
 class SampleParams(C.Structure):
     _fields_ = [('do_sample', C.c_int), ('temperature', C.c_float), ('top_k', C.c_int), ('top_p', C.c_float),
                 ('seed', C.c_uint32)]
+
+
+class GenOpts(C.Structure):
+    """vitcap_gen_opts: the kwargs of ViTCAP.generate (modeling_bert.py:928-933) + launch form, passed per call."""
+    _fields_ = [('num_beams', C.c_int32), ('seqs_per_image', C.c_int32), ('num_keep_best', C.c_int32),
+                ('max_length', C.c_int32), ('bos_token_id', C.c_int32), ('eos_token_id', C.c_int32),
+                ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
+                ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
+                ('early_exit', C.c_int32), ('use_graph', C.c_int32)]
 
 
 class Image(C.Structure):
@@ -95,8 +107,6 @@ _SIGS = {
     'vitcap_image_train_preproc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    'vitcap_gemm_set_persistent': (None, [C.c_int]),
-    'vitcap_gemm_get_persistent': (C.c_int, []),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),
@@ -122,7 +132,6 @@ _SIGS = {
                                      C.c_int, C.c_int, vp]),
     'vitcap_sample_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp, vp]),
-    'vitcap_engine_set_sampling': (C.c_int, [vp, vp]),
     'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
     'vitcap_row_topk_lse': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_beam_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -135,19 +144,17 @@ _SIGS = {
     'vitcap_engine_create': (C.c_int, [C.POINTER(vp)]),
     'vitcap_engine_destroy': (None, [vp]),
     'vitcap_engine_bind_weights': (C.c_int, [vp, C.POINTER(Weights)]),
-    'vitcap_engine_workspace_bytes': (C.c_size_t, [C.c_int]),
-    'vitcap_engine_workspace_bytes_beam': (C.c_size_t, [C.c_int, C.c_int]),
-    'vitcap_engine_beam': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
-    'vitcap_engine_greedy': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp]),
-    'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int]),
-    'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
-    'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
-    'vitcap_engine_set_num_keep_best': (C.c_int, [vp, C.c_int]),
-    'vitcap_engine_set_repetition_penalty': (C.c_int, [vp, C.c_float]),
+    'vitcap_gen_opts_init': (None, [C.POINTER(GenOpts)]),
+    'vitcap_gen_opts_check': (C.c_int, [C.POINTER(GenOpts)]),
+    'vitcap_engine_workspace_bytes': (C.c_size_t, [C.c_int, C.POINTER(GenOpts)]),
+    'vitcap_engine_generate': (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(GenOpts), vp, C.c_size_t, vp, vp, vp, vp, vp]),
+    'vitcap_engine_encode': (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(GenOpts), vp, C.c_size_t, vp]),
+    'vitcap_engine_prefill': (C.c_int, [vp, C.c_int, C.POINTER(GenOpts), vp, C.c_size_t, vp]),
+    'vitcap_engine_decode': (C.c_int, [vp, C.c_int, C.POINTER(GenOpts), vp, C.c_size_t, vp, vp, vp, vp]),
+    'vitcap_engine_tags': (C.c_int, [vp, C.c_int, C.POINTER(GenOpts), vp, vp, vp, vp]),
+    'vitcap_engine_graph_count': (C.c_int, [vp]),
+    'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int, C.POINTER(GenOpts)]),
     'vitcap_repetition_penalty': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
-    'vitcap_engine_beam_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp, vp]),
-    'vitcap_engine_decode_multi': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]),
-    'vitcap_engine_decode': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
@@ -173,6 +180,20 @@ def _load():
 
 
 lib = _load()
+
+
+def gen_opts(**kw):
+    """vitcap_gen_opts with the reference's test-time defaults (..._bertemb.py:588-608), fields overridden by keyword."""
+    o = GenOpts()
+    lib.vitcap_gen_opts_init(C.byref(o))
+    for k, v in kw.items():
+        if k == 'sampling':
+            o.sampling = v
+        else:
+            if not hasattr(o, k):
+                raise AttributeError('vitcap_gen_opts has no field %r' % k)
+            setattr(o, k, v)
+    return o
 
 
 def check(rc, what=''):

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ vis_qkv,
                                                           bf16_t* __restrict__ text_kv, bf16_t* __restrict__ out,
                                                           int S_vis, int t, int max_len, int seq_per_image,
-                                                          float c_log2) {
+                                                          float c_log2, const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   __shared__ float sc[2][MAXKEYS];
   __shared__ float red[2][4];
   __shared__ float oacc[4][2][HD];
@@ -506,7 +507,7 @@ extern "C" int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv
   VC_REQUIRE(seq_per_image >= 1 && B % seq_per_image == 0, "attn_decode: bad seq_per_image");
   const float c = scale * 1.4426950408889634f;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(NH, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_step,
-                     (const bf16_t*)vis_qkv, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len, seq_per_image, c);
+                     (const bf16_t*)vis_qkv, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len, seq_per_image, c, vc_tls_live);
   VC_LAUNCH_CHECK("attn_decode");
   return VITCAP_OK;
 }

@@ -17,6 +17,16 @@ typedef unsigned short bf16_t;  // storage type
 
 void vitcap_set_error(const char* fmt, ...);
 
+// Engine-internal: while vitcap_engine_decode enqueues its step loop, this thread-local pointer names the device
+// counter of sequences (beam search: images) still unfinished; the decode-step launchers pass it to their kernels,
+// which return at entry once it reads 0 -- the reference's `if cur_unfinished.max() == 0: break`
+// (modeling_utils.py:866 / `if all(done): break`, :1072) without a host synchronisation.  NULL outside the engine.
+extern thread_local const int32_t* vc_tls_live;
+#define VC_LIVE_EXIT(live)                         \
+  do {                                             \
+    if ((live) != nullptr && *(live) == 0) return; \
+  } while (0)
+
 #define VC_REQUIRE(cond, ...)                 \
   do {                                        \
     if (!(cond)) {                            \

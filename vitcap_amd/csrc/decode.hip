@@ -24,8 +24,9 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
 }
 
 __global__ void greedy_init_kernel(int64_t* ids, int32_t* unf, float* sum_lp, float* cnt, int B, int max_len, int bos,
-                                   int pad) {
+                                   int pad, int32_t* live) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && live) *live = B;            // sequences still unfinished (decode kernels return at entry once it is 0)
   if (i < B * max_len) ids[i] = (i % max_len == 0) ? bos : pad;
   if (i < B) {
     unf[i] = 1;
@@ -40,12 +41,24 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
                                                            float* __restrict__ sum_lp, float* __restrict__ cnt,
                                                            float* __restrict__ logprob_out,
                                                            float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
-                                                           int t, int max_len, int eos, int pad) {
+                                                           int t, int max_len, int eos, int pad, int32_t* __restrict__ live) {
   __shared__ ArgMax s_am[16];
   __shared__ float s_second[16];
   __shared__ float s_sum[16];
   __shared__ ArgMax s_best;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (unf[b] == 0) {
+    // finished sequence: tokens_to_add = pad, the score is frozen (modeling_utils.py:855-858, 873-877); the logits are not
+    // read -- once every sequence has finished the step's other kernels have not even produced them
+    if (tid == 0) {
+      ids[(size_t)b * max_len + t] = pad;
+      if (t == max_len - 1) {
+        if (raw_last) raw_last[b] = pad;
+        logprob_out[b] = sum_lp[b] / cnt[b];
+      }
+    }
+    return;
+  }
   const float* row = logits + (size_t)b * ldl;
   ArgMax best{-INFINITY, 0x7fffffff};
   float second = -INFINITY;   // runner-up value (for the top-2 margin tap)
@@ -109,6 +122,7 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
     sum_lp[b] = s;
     cnt[b] = c;
     unf[b] = nu;
+    if (live && u && !nu) atomicSub(live, 1);
   }
 }
 
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
                                                            float* __restrict__ logprob_out,
                                                            float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
                                                            int t, int max_len, int eos, int pad, float temperature, int top_k,
-                                                           float top_p, uint32_t seed) {
+                                                           float top_p, uint32_t seed, int32_t* __restrict__ live) {
   __shared__ unsigned long long s_hist[256];
   __shared__ unsigned long long s_acc;
   __shared__ uint32_t s_sel;
@@ -175,6 +189,16 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
   __shared__ ArgMax s_am[16];
   __shared__ float s_second[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (unf[b] == 0) {                    // finished sequence: pad, frozen score (see greedy_step_kernel)
+    if (tid == 0) {
+      ids[(size_t)b * max_len + t] = pad;
+      if (t == max_len - 1) {
+        if (raw_last) raw_last[b] = pad;
+        logprob_out[b] = sum_lp[b] / cnt[b];
+      }
+    }
+    return;
+  }
   const float* row = logits + (size_t)b * ldl;
   float x[SM_NPT];
   uint32_t key[SM_NPT];      // 0 = absent (column >= V)
@@ -293,6 +317,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     sum_lp[b] = s;
     cnt[b] = c;
     unf[b] = nu;
+    if (live && u && !nu) atomicSub(live, 1);
   }
 }
 
@@ -379,7 +404,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long a)
 
 __global__ __launch_bounds__(1024) void row_topk_lse_kernel(const float* __restrict__ logits, int ldl, int V, int k,
                                                             float* __restrict__ out_val, int* __restrict__ out_idx,
-                                                            float* __restrict__ out_lse) {
+                                                            float* __restrict__ out_lse, const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   // Threshold selection -- three scans of the 32 register values per thread instead of 2 per extracted element (k rounds of
   // rescanning + removing made this kernel VALU-bound: 150-210 us for 1280 rows):
   //   1. every thread's maximum; the k largest of the 1024 thread maxima (cheap: one value per thread);
@@ -491,7 +517,8 @@ struct BeamState {
   int n_keep;           // BeamHypotheses.n_hyp = num_keep_best
 };
 
-__global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bos, int pad) {
+__global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bos, int pad, int32_t* live) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && live) *live = B;     // images whose search is still open
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * K * max_len) {
     st.ids_in[i] = (i % max_len == 0) ? bos : pad;
@@ -522,9 +549,11 @@ __global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bo
 //      new beams' prefixes.
 __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
                                                        const float* __restrict__ lse, BeamState st, int B, int K, int V, int t,
-                                                       int max_len, int eos, int pad, float length_penalty) {
+                                                       int max_len, int eos, int pad, float length_penalty, int32_t* __restrict__ live) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
+  // every image done (`if all(done): break`, modeling_utils.py:1072): beams, hypotheses and scores stay as they are
+  if (live && *live == 0) return;
   const int C = 2 * K, n = K * C, NH = st.n_keep;
   __shared__ float s_sc[MAXBEAM * 2 * MAXBEAM];
   __shared__ int s_fl[MAXBEAM * 2 * MAXBEAM];
@@ -552,10 +581,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   float* hsc = st.hyp_score + (size_t)b * NH;
   int* hln = st.hyp_len + (size_t)b * NH;
   int64_t* htk = st.hyp_tok + (size_t)b * NH * max_len;
-  // old hypothesis rows into registers (NH * max_len <= 8 * 20 = 160 values, <= 3 per lane)
-  int64_t old_tok[3];
+  // old hypothesis rows into registers (NH * max_len <= 8 * 40 = 320 values, <= 5 per lane)
+  int64_t old_tok[5];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < 5; ++u) {
     const int i = lane + u * 64;
     old_tok[u] = i < NH * max_len ? htk[i] : 0;
   }
@@ -564,6 +593,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
     int nh = st.has_hyp[b];
     for (int i = 0; i < nh; ++i) { s_hsc[i] = hsc[i]; s_hln[i] = hln[i]; s_hsrc[i] = i; }
     int done = st.done[b];
+    const int was_done = done;
     if (!done && nh >= NH) {
       // BeamHypotheses.is_done: the list is full and its worst score already beats what the best open beam can reach
       float worst = s_hsc[0];
@@ -604,17 +634,18 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
       for (int i = 0; i < K; ++i) { s_nsc[i] = 0.f; s_nword[i] = pad; s_npar[i] = b * K; }
     }
     s_nh = nh;
+    if (live && done && !was_done) atomicSub(live, 1);
     st.done[b] = done;
     st.has_hyp[b] = nh;
     for (int i = 0; i < nh; ++i) { hsc[i] = s_hsc[i]; hln[i] = s_hln[i]; }
   }
   __syncthreads();
   // hypothesis token rows: slot i <- old slot s_hsrc[i] (from the registers, via LDS exchange) or beam -(s_hsrc[i]+1)'s prefix
-  __shared__ int64_t s_old[MAXBEAM * 24];
+  __shared__ int64_t s_old[MAXBEAM * 40];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < 5; ++u) {
     const int i = lane + u * 64;
-    if (i < NH * max_len && i < MAXBEAM * 24) s_old[i] = old_tok[u];
+    if (i < NH * max_len && i < MAXBEAM * 40) s_old[i] = old_tok[u];
   }
   __syncthreads();
   const int nh = s_nh;
@@ -639,7 +670,9 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
 
 // dst[l][s][0..t) = src[l][parent[s]][0..t)   (rows of 2*768 bf16 = 3 KiB)
 __global__ __launch_bounds__(192) void beam_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
-                                                           const int* __restrict__ parent, int NS, int max_len, int t) {
+                                                           const int* __restrict__ parent, int NS, int max_len, int t,
+                                                           const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   const int s = blockIdx.x, l = blockIdx.y;
   const size_t rowv = 2 * 768 * 2 / 16;   // 192 uint4 per position
   const uint4* sp = src + ((size_t)l * NS + parent[s]) * max_len * rowv;
@@ -678,7 +711,8 @@ __global__ void beam_finalize_kernel(BeamState st, int64_t* out_ids, float* out_
 // One wave per row; lane j owns prefix position j and acts if no earlier position holds the same token.
 __global__ __launch_bounds__(256) void repetition_penalty_kernel(float* __restrict__ logits, int ldl, int V,
                                                                  const int64_t* __restrict__ ids, int ld_ids, int t,
-                                                                 float penalty, int rows) {
+                                                                 float penalty, int rows, const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows || lane >= t) return;
   const int64_t* r = ids + (size_t)row * ld_ids;
@@ -698,7 +732,7 @@ extern "C" int vitcap_repetition_penalty(float* logits, int ldl, int V, const in
   VC_REQUIRE(logits && ids && rows > 0 && V > 0 && ldl >= V && t >= 1 && t <= ld_ids && t <= 64 && penalty > 0.f,
              "repetition_penalty: bad arguments (t=%d, penalty=%g)", t, (double)penalty);
   hipLaunchKernelGGL(repetition_penalty_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, ids,
-                     ld_ids, t, penalty, rows);
+                     ld_ids, t, penalty, rows, vc_tls_live);
   VC_LAUNCH_CHECK("repetition_penalty");
   return VITCAP_OK;
 }
@@ -708,7 +742,7 @@ extern "C" int vitcap_greedy_init(int64_t* ids, int32_t* unfinished, float* sum_
   VC_REQUIRE(ids && unfinished && sum_lp && cnt && B > 0 && max_len > 1, "greedy_init: bad arguments");
   const int n = B * max_len;
   hipLaunchKernelGGL(greedy_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, unfinished,
-                     sum_lp, cnt, B, max_len, bos, pad);
+                     sum_lp, cnt, B, max_len, bos, pad, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("greedy_init");
   return VITCAP_OK;
 }
@@ -719,7 +753,7 @@ extern "C" int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* 
   VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out, "greedy_step: null pointer");
   VC_REQUIRE(B > 0 && V > 0 && ldl >= V && t >= 1 && t < max_len, "greedy_step: bad sizes (t=%d)", t);
   hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
-                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad);
+                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("greedy_step");
   return VITCAP_OK;
 }
@@ -740,7 +774,7 @@ extern "C" int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, f
   VC_REQUIRE(logits && out_val && out_idx && out_lse && rows > 0, "row_topk_lse: bad arguments");
   VC_REQUIRE(k >= 1 && k <= 16 && V <= TK_PER_THREAD * 1024 && ldl >= V, "row_topk_lse: k=%d V=%d unsupported", k, V);
   hipLaunchKernelGGL(row_topk_lse_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, k, out_val,
-                     out_idx, out_lse);
+                     out_idx, out_lse, vc_tls_live);
   VC_LAUNCH_CHECK("row_topk_lse");
   return VITCAP_OK;
 }
@@ -759,7 +793,7 @@ extern "C" int vitcap_beam_init(const vitcap_beam_state* s, int B, int K, int ma
   VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_init: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
   const int n = B * (K > s->n_keep ? K : s->n_keep) * max_len;
   hipLaunchKernelGGL(beam_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, make_state(s), B, K,
-                     max_len, bos, pad);
+                     max_len, bos, pad, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("beam_init");
   return VITCAP_OK;
 }
@@ -768,10 +802,10 @@ extern "C" int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, 
                                 const vitcap_beam_state* s, int B, int K, int V, int t, int max_len, int eos, int pad,
                                 float length_penalty, void* stream) {
   VC_REQUIRE(cand_val && cand_idx && lse && s && B > 0 && K >= 1 && K <= MAXBEAM, "beam_step: bad arguments");
-  VC_REQUIRE(t >= 1 && t < max_len && max_len <= 24, "beam_step: t=%d out of range (max_len %d <= 24)", t, max_len);
+  VC_REQUIRE(t >= 1 && t < max_len && max_len <= 40, "beam_step: t=%d out of range (max_len %d <= 40)", t, max_len);
   VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_step: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
-                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty);
+                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("beam_step");
   return VITCAP_OK;
 }
@@ -780,7 +814,7 @@ extern "C" int vitcap_beam_reorder_cache(const void* src, void* dst, const int32
                                          int max_len, int t, void* stream) {
   VC_REQUIRE(src && dst && parent && layers > 0 && NS > 0 && t >= 1 && t <= max_len, "beam_reorder: bad arguments");
   hipLaunchKernelGGL(beam_reorder_kernel, dim3(NS, layers), dim3(192), 0, (hipStream_t)stream, (const uint4*)src,
-                     (uint4*)dst, parent, NS, max_len, t);
+                     (uint4*)dst, parent, NS, max_len, t, vc_tls_live);
   VC_LAUNCH_CHECK("beam_reorder");
   return VITCAP_OK;
 }
@@ -806,7 +840,7 @@ extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* 
              (double)sp->top_p);
   hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
                      sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, sp->temperature, sp->top_k,
-                     sp->top_p, sp->seed);
+                     sp->top_p, sp->seed, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
 }

@@ -16,11 +16,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "../../include/vitcap_hip.h"
 
 void vitcap_set_error(const char* fmt, ...);
+extern thread_local const int32_t* vc_tls_live;   // csrc/common.h: early-exit counter handed to the decode-step launchers
 
 #include <vector>
 
@@ -33,20 +35,28 @@ struct GemmTiming {
   double flops;
 };
 
+struct GraphEntry {
+  int B;
+  void* ws;
+  vitcap_gen_opts opts;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
 struct vitcap_engine {
   vitcap_weights w;
   bool bound = false;
   bool timing = false;
-  vitcap_sample_params sampling = {0, 1.0f, 0, 1.0f, 0u};
+  // one enqueue at a time per engine: the side stream / fork-join events and the graph cache are shared by all callers
+  std::mutex mu;
   // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int keep_best = 1;            // num_keep_best of the beam search (BeamHypotheses.n_hyp)
-  float repetition_penalty = 1.0f;
   bool full_last_tag_block = false;   // VITCAP_FULL_TAG_BLOCK=1: compute all 577 rows of tag_blocks[3] (parity taps / measurements)
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
   size_t used = 0;
+  std::vector<GraphEntry> graphs;     // captured decode loops (vitcap_gen_opts.use_graph)
 };
 
 namespace {
@@ -54,11 +64,45 @@ namespace {
 constexpr int D = VITCAP_HID;
 constexpr int NV = VITCAP_NVIS;        // 577
 constexpr int SV = VITCAP_NVIS + 1;    // 578 decoder visual rows (tag CLS first)
-constexpr int L = VITCAP_MAXLEN;       // 20
 constexpr int VP = VITCAP_VOCAB_PAD;
 constexpr int TOPK = 50;
-constexpr int BOS = 101, EOS = 102, PAD = 0, MASK = 103;
 constexpr int SPLIT_AO = 6, SPLIT_FC2 = 12, SPLIT_MAX = 12;   // split-K of the K=768 / K=3072 decode GEMMs with N=768
+
+vitcap_gen_opts default_opts() {
+  vitcap_gen_opts o;
+  memset(&o, 0, sizeof(o));
+  o.num_beams = 1;
+  o.seqs_per_image = 1;
+  o.num_keep_best = 1;
+  o.max_length = VITCAP_MAXLEN;
+  o.bos_token_id = 101; o.eos_token_id = 102; o.pad_token_id = 0; o.mask_token_id = 103;
+  o.length_penalty = 1.0f;
+  o.repetition_penalty = 1.0f;
+  o.sampling.do_sample = 0; o.sampling.temperature = 1.0f; o.sampling.top_k = 0; o.sampling.top_p = 1.0f; o.sampling.seed = 0u;
+  o.gemm_mode = VITCAP_GEMM_AUTO;
+  o.early_exit = 1;
+  o.use_graph = 0;
+  return o;
+}
+
+int check_opts(const vitcap_gen_opts& o) {
+#define OPT_REQ(cond, ...) do { if (!(cond)) { vitcap_set_error(__VA_ARGS__); return VITCAP_EINVAL; } } while (0)
+  OPT_REQ(o.num_beams >= 1 && o.num_beams <= 8, "gen_opts: num_beams must be 1..8 (got %d)", o.num_beams);
+  OPT_REQ(o.seqs_per_image >= 1 && o.seqs_per_image <= 8, "gen_opts: seqs_per_image must be 1..8 (got %d)", o.seqs_per_image);
+  OPT_REQ(o.num_keep_best >= 1 && o.num_keep_best <= 8, "gen_opts: num_keep_best must be 1..8 (got %d)", o.num_keep_best);
+  OPT_REQ(!(o.num_beams > 1 && o.seqs_per_image > 1), "gen_opts: seqs_per_image > 1 needs num_beams == 1");
+  OPT_REQ(!(o.num_beams == 1 && o.num_keep_best > 1), "gen_opts: cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)");
+  OPT_REQ(!(o.num_beams > 1 && o.sampling.do_sample), "gen_opts: beam sampling (num_beams > 1 with do_sample) is not built");
+  OPT_REQ(o.max_length >= 2 && o.max_length <= VITCAP_MAXLEN_CAP, "gen_opts: max_length must be 2..%d (got %d)", VITCAP_MAXLEN_CAP, o.max_length);
+  const int32_t toks[4] = {o.bos_token_id, o.eos_token_id, o.pad_token_id, o.mask_token_id};
+  for (int i = 0; i < 4; ++i) OPT_REQ(toks[i] >= 0 && toks[i] < VITCAP_VOCAB, "gen_opts: token id %d out of the vocabulary", toks[i]);
+  OPT_REQ(o.repetition_penalty > 0.f, "gen_opts: repetition_penalty must be > 0 (got %g)", (double)o.repetition_penalty);
+  OPT_REQ(!o.sampling.do_sample || (o.sampling.temperature > 0.f && o.sampling.top_k >= 0 && o.sampling.top_p > 0.f),
+          "gen_opts: temperature %g / top_k %d / top_p %g out of range", (double)o.sampling.temperature, o.sampling.top_k, (double)o.sampling.top_p);
+  OPT_REQ(o.gemm_mode == VITCAP_GEMM_AUTO || o.gemm_mode == VITCAP_GEMM_TILES, "gen_opts: gemm_mode %d unknown", o.gemm_mode);
+#undef OPT_REQ
+  return VITCAP_OK;
+}
 
 struct Layout {
   size_t off = 0;
@@ -70,13 +114,20 @@ struct Layout {
   // image-sized buffers (B images) first, so their offsets do not depend on the number of decode sequences
   size_t patches, x, xt, h, qkv, mlp, th, tqkv, tmlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
-  // sequence-sized buffers (NS = B for greedy, B*beams for beam search)
+  // sequence-sized buffers (NS = B * seqs_per_image for greedy / sampling, B * beams for beam search)
   size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
   size_t hd_f, hd_b, logits;
-  size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok;
-  size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok;
-  Layout(int B, int NS, bool beam) {
-    const size_t b = (size_t)B, n = (size_t)NS;
+  size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok, live;
+  size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok, fin_ids, fin_lp;
+  int L, NS, K;
+  bool beam;
+  Layout(int B, const vitcap_gen_opts& o) {
+    L = o.max_length;
+    beam = o.num_beams > 1;
+    K = beam ? o.num_beams : o.seqs_per_image;
+    NS = B * K;
+    const bool two = K > 1;                       // layouts with several sequences per image carry the second cache / id buffer
+    const size_t b = (size_t)B, n = (size_t)NS, l = (size_t)L;
     patches = take(b * 576 * D * 2);
     x = take(b * NV * D * 4);
     xt = take(b * NV * D * 4);
@@ -88,7 +139,7 @@ struct Layout {
     tmlp = take(b * NV * 4 * D * 2);
     vis_f = take(b * SV * D * 4);
     vis_b = take(b * SV * D * 2);
-    for (int l = 0; l < 4; ++l) dqkv[l] = take(b * SV * 3 * D * 2);
+    for (int i = 0; i < 4; ++i) dqkv[i] = take(b * SV * 3 * D * 2);
     da_f = take(b * SV * D * 4);
     da_b = take(b * SV * D * 2);
     dtmp = take(b * SV * D * 4);
@@ -108,19 +159,21 @@ struct Layout {
     sa_f = take(n * 2 * D * 4);
     sa_b = take(n * 2 * D * 2);
     smlp = take(n * 2 * 4 * D * 2);
-    tcache = take(4 * n * L * 2 * D * 2);
-    tcache2 = beam ? take(4 * n * L * 2 * D * 2) : 0;
+    tcache = take(4 * n * l * 2 * D * 2);
+    tcache2 = two ? take(4 * n * l * 2 * D * 2) : 0;
     hd_f = take(n * D * 4);
     hd_b = take(n * D * 2);
     logits = take(n * VP * 4);
-    ids = take(n * L * 8);
-    ids2 = beam ? take(n * L * 8) : 0;
+    ids = take(n * l * 8);
+    ids2 = two ? take(n * l * 8) : 0;
     unf = take(n * 4);
     sum_lp = take(n * 4);
     cnt = take(n * 4);
-    margins = take(n * L * 4);
+    margins = take(n * l * 4);
     logprob = take(n * 4);
     last_tok = take(n * 8);
+    live = take(256);
+    cand_val = cand_idx = lse = beam_scores = parent = done = has_hyp = hyp_score = hyp_len = hyp_tok = fin_ids = fin_lp = 0;
     if (beam) {
       cand_val = take(n * 16 * 4);
       cand_idx = take(n * 16 * 4);
@@ -131,18 +184,39 @@ struct Layout {
       has_hyp = take(b * 4);
       hyp_score = take(b * 8 * 4);          // up to 8 kept hypotheses per image (num_keep_best)
       hyp_len = take(b * 8 * 4);
-      hyp_tok = take(b * 8 * L * 8);
+      hyp_tok = take(b * 8 * l * 8);
+      fin_ids = take(b * 8 * l * 8);
+      fin_lp = take(b * 8 * 4);
     }
   }
 };
 
 thread_local vitcap_engine* g_cur = nullptr;   // engine whose launches are being enqueued (timing hook)
+thread_local int g_gemm_mode = VITCAP_GEMM_AUTO; // vitcap_gen_opts.gemm_mode of the call being enqueued
+thread_local const int32_t* g_live = nullptr;    // live counter handed to the decode-step GEMMs (vitcap_gemm_desc.live)
 
-int gemm_desc(const void* A, const void* W, const float* bias, const float* res, void* C, const vitcap_gemm_desc& d,
-              void* s) {
+// sets the per-call context (timing hook, GEMM launch form, early-exit counter) for the duration of one engine call
+struct CallScope {
+  CallScope(vitcap_engine* e, int gemm_mode, const int32_t* live) {
+    g_cur = e;
+    g_gemm_mode = gemm_mode;
+    g_live = live;
+    vc_tls_live = live;
+  }
+  ~CallScope() {
+    g_live = nullptr;
+    vc_tls_live = nullptr;
+    g_gemm_mode = VITCAP_GEMM_AUTO;
+  }
+};
+
+int gemm_desc(const void* A, const void* W, const float* bias, const float* res, void* C, vitcap_gemm_desc d, void* s) {
   vitcap_engine* e = g_cur;
   const bool timed = e && e->timing && d.M > 256 && e->used < e->pool.size();
   GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
+  // one tile per workgroup for the large GEMMs when the caller overlaps a second stream (vitcap_gen_opts.gemm_mode)
+  if (d.tile_hint == 0 && g_gemm_mode == VITCAP_GEMM_TILES && d.M >= 2048 && d.act != VITCAP_ACT_TANH && d.split_k <= 1) d.tile_hint = 5;
+  if (d.M <= 4096) d.live = g_live;           // decode-step shapes only; the encoder / prefill GEMMs never carry it
   if (t) {
     t->variant = d.act * 4 + d.out_dtype * 2 + (res ? 1 : 0);
     t->flops = 2.0 * d.M * d.N * d.K;
@@ -179,8 +253,33 @@ int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int
     if (rc_ != 0) return rc_; \
   } while (0)
 
+#define HIPCK(call, what)                                                              \
+  do {                                                                                 \
+    hipError_t he_ = (call);                                                           \
+    if (he_ != hipSuccess) {                                                           \
+      vitcap_set_error("%s: %s", what, hipGetErrorString(he_));                        \
+      return VITCAP_ELAUNCH;                                                           \
+    }                                                                                  \
+  } while (0)
+
+void drop_graphs(vitcap_engine* e) {
+  for (auto& g : e->graphs) {
+    (void)hipGraphExecDestroy(g.exec);
+    (void)hipGraphDestroy(g.graph);
+  }
+  e->graphs.clear();
+}
+
 }  // namespace
 
+
+extern "C" void vitcap_gen_opts_init(vitcap_gen_opts* o) {
+  if (o) *o = default_opts();
+}
+extern "C" int vitcap_gen_opts_check(const vitcap_gen_opts* o) {
+  if (!o) return VITCAP_OK;
+  return check_opts(*o);
+}
 
 extern "C" int vitcap_engine_create(vitcap_engine** out) {
   if (!out) return VITCAP_EINVAL;
@@ -199,14 +298,17 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
+  drop_graphs(e);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
+extern "C" int vitcap_engine_graph_count(vitcap_engine* e) { return e ? (int)e->graphs.size() : 0; }
 
 extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
   if (!e || max_launches < 0) return VITCAP_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
   while ((int)e->pool.size() < max_launches) {
     GemmTiming t;
     if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
@@ -226,6 +328,7 @@ extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
 // Synchronises on the recorded events; call after the timed region.
 extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* flops, int* launches) {
   if (!e || !ms || !flops || !launches) return VITCAP_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
   for (int i = 0; i < 12; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   for (size_t i = 0; i < e->used; ++i) {
     GemmTiming& t = e->pool[i];
@@ -248,21 +351,24 @@ extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights
   const void* const* p = (const void* const*)w;
   for (size_t i = 0; i < sizeof(vitcap_weights) / sizeof(void*); ++i)
     if (!p[i]) { vitcap_set_error("bind_weights: pointer #%zu of vitcap_weights is NULL", i); return VITCAP_EINVAL; }
+  std::lock_guard<std::mutex> lk(e->mu);
   e->w = *w;
   e->bound = true;
+  drop_graphs(e);          // captured loops hold the old weight pointers
   return VITCAP_OK;
 }
 
-extern "C" size_t vitcap_engine_workspace_bytes(int B) { return B > 0 ? Layout(B, B, false).off : 0; }
-extern "C" size_t vitcap_engine_workspace_bytes_beam(int B, int beams) {
-  return (B > 0 && beams >= 1 && beams <= 8) ? Layout(B, B * beams, true).off : 0;
+extern "C" size_t vitcap_engine_workspace_bytes(int B, const vitcap_gen_opts* opts) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (B <= 0 || check_opts(o) != VITCAP_OK) return 0;
+  return Layout(B, o).off;
 }
 
-static int check(vitcap_engine* e, int B, void* ws, size_t ws_bytes, size_t need = 0) {
+static int check(vitcap_engine* e, int B, const vitcap_gen_opts& o, void* ws, size_t ws_bytes, size_t need) {
   if (!e || !e->bound) { vitcap_set_error("engine: weights not bound"); return VITCAP_ESTATE; }
   if (B <= 0 || !ws) { vitcap_set_error("engine: bad batch/workspace"); return VITCAP_EINVAL; }
   if (((uintptr_t)ws & 255) != 0) { vitcap_set_error("engine: workspace must be 256-byte aligned"); return VITCAP_EINVAL; }
-  if (need == 0 && B > 0) need = Layout(B, B, false).off;
+  CK(check_opts(o));
   if (ws_bytes < need) {
     vitcap_set_error("engine: workspace %zu < required %zu bytes", ws_bytes, need);
     return VITCAP_EWORKSPACE;
@@ -303,13 +409,10 @@ static int vit_block_cls_only(const vitcap_vit_block_w& w, float* x, void* h, vo
 
 static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s);
 
-extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
-                                    size_t workspace_bytes, void* s) {
-  CK(check(e, B, workspace, workspace_bytes));
-  g_cur = e;
+static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts& o, const Layout& lo,
+                         char* ws, void* s) {
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
-  const Layout lo(B, B, false);
-  char* ws = (char*)workspace;
+  CallScope scope(e, o.gemm_mode, nullptr);
   const vitcap_weights& w = e->w;
   float* x = (float*)(ws + lo.x);
   float* xt = (float*)(ws + lo.xt);
@@ -328,14 +431,10 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
   // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork.  Run the fork on a side stream when the large GEMMs are
   // in their one-tile-per-workgroup form (batch pipeline) and the batch is small enough for tile-quantisation gaps to
   // matter: B=64 pipelined +2.3 %; with persistent GEMMs or at B=512 it costs 1-2 % (measured), so it stays serial there.
-  const bool fork = e->fork_tag_branch && !vitcap_gemm_get_persistent() && B <= 128;
+  const bool fork = e->fork_tag_branch && o.gemm_mode == VITCAP_GEMM_TILES && B <= 128;
   for (int i = 0; i < 12; ++i) {
-    if (i == 8) {
-      if (hipMemcpyAsync(xt, x, (size_t)B * NV * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
-        vitcap_set_error("encode: fork copy failed");
-        return VITCAP_ELAUNCH;
-      }
-    }
+    if (i == 8)
+      HIPCK(hipMemcpyAsync(xt, x, (size_t)B * NV * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)s), "encode: fork copy");
     if (i == 8 && fork) {
       // fork: the tag branch depends only on the copy of x made above
       if (!e->side) {
@@ -346,21 +445,29 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
           return VITCAP_ELAUNCH;
         }
       }
-      if (hipEventRecord(e->ev_fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) {
-        vitcap_set_error("encode: fork failed");
-        return VITCAP_ELAUNCH;
-      }
+      HIPCK(hipEventRecord(e->ev_fork, (hipStream_t)s), "encode: fork record");
+      HIPCK(hipStreamWaitEvent(e->side, e->ev_fork, 0), "encode: fork wait");
       CK(tag_branch(e, lo, ws, B, e->side));
-      if (hipEventRecord(e->ev_join, e->side) != hipSuccess) { vitcap_set_error("encode: join record failed"); return VITCAP_ELAUNCH; }
+      HIPCK(hipEventRecord(e->ev_join, e->side), "encode: join record");
     }
     CK(vit_block(w.blocks[i], x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
   }
   if (fork) {
-    if (hipStreamWaitEvent((hipStream_t)s, e->ev_join, 0) != hipSuccess) { vitcap_set_error("encode: join failed"); return VITCAP_ELAUNCH; }
+    HIPCK(hipStreamWaitEvent((hipStream_t)s, e->ev_join, 0), "encode: join wait");
   } else {
     CK(tag_branch(e, lo, ws, B, s));
   }
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts* opts,
+                                    void* workspace, size_t workspace_bytes, void* s) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (B <= 0 || check_opts(o) != VITCAP_OK) { if (B <= 0) vitcap_set_error("engine: bad batch"); return VITCAP_EINVAL; }
+  const Layout lo(B, o);
+  CK(check(e, B, o, workspace, workspace_bytes, lo.off));
+  std::lock_guard<std::mutex> lk(e->mu);
+  return encode_locked(e, image, image_is_bf16, B, o, lo, (char*)workspace, s);
 }
 
 // a5 (tag fork) + a6: 4 tag blocks on the forked stream, then the tag head on the tag branch CLS row
@@ -386,11 +493,8 @@ static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void*
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, void* s) {
-  CK(check(e, B, workspace, workspace_bytes));
-  g_cur = e;
-  const Layout lo(B, B, false);
-  char* ws = (char*)workspace;
+static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
+  CallScope scope(e, o.gemm_mode, nullptr);
   const vitcap_weights& w = e->w;
   const int M = B * SV;
   float* vis_f = (float*)(ws + lo.vis_f);
@@ -418,14 +522,25 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, void* workspace, s
   return VITCAP_OK;
 }
 
+extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, size_t workspace_bytes,
+                                     void* s) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (B <= 0 || check_opts(o) != VITCAP_OK) { if (B <= 0) vitcap_set_error("engine: bad batch"); return VITCAP_EINVAL; }
+  const Layout lo(B, o);
+  CK(check(e, B, o, workspace, workspace_bytes, lo.off));
+  std::lock_guard<std::mutex> lk(e->mu);
+  return prefill_locked(e, B, o, lo, (char*)workspace, s);
+}
+
 // One decode step for NS sequences (K sequences share one image's visual K/V): embeddings of (token t-1, [MASK]) ->
 // 4 decoder layers against the caches -> LM head on the [MASK] rows -> fp32 logits [NS, VOCAB_PAD].
-static int step_forward(const vitcap_weights& w, const Layout& lo, char* ws, int NS, int K, int t, const int64_t* ids,
+static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_gen_opts& o, char* ws, int t, const int64_t* ids,
                         char* tcache, void* s) {
+  const int NS = lo.NS, K = lo.K, L = lo.L;
   float* xs_f = (float*)(ws + lo.xs_f);
   char* xs_b = ws + lo.xs_b;
   const int R = 2 * NS;
-  CK(vitcap_embed_step(ids, L, t, MASK, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
+  CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
                        NS, s));
   float* part = (float*)(ws + lo.spart);
   for (int l = 0; l < 4; ++l) {
@@ -454,85 +569,37 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, char* ws, int
   return VITCAP_OK;
 }
 
-// Greedy / sampled decode of NS = B * K sequences, K per image (K > 1: ViTCAP.generate with num_return_sequences = K expands
-// every input K times, modeling_bert.py:976-994; the K copies of an image share its encoder output and visual K/V here, as
-// the beams of a beam search do).  K > 1 uses the beam workspace layout (vitcap_engine_workspace_bytes_beam(B, K)).
-static int decode_sequences(vitcap_engine* e, int B, int K, void* workspace, size_t workspace_bytes, int64_t* out_ids,
-                            float* out_logprobs, int64_t* out_last_tok, void* s) {
-  const int NS = B * K;
-  const Layout lo(B, NS, K > 1);
-  CK(check(e, B, workspace, workspace_bytes, K > 1 ? lo.off : 0));
-  g_cur = e;
-  if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
-  char* ws = (char*)workspace;
+// Greedy / sampled decode loop of NS = B * K sequences, K per image (K > 1: ViTCAP.generate with num_return_sequences = K
+// expands every input K times, modeling_bert.py:976-994; the K copies of an image share its encoder output and visual K/V
+// here, as the beams of a beam search do).  Results stay in the workspace (lo.ids, lo.logprob, lo.last_tok).
+static int greedy_loop(vitcap_engine* e, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
   const vitcap_weights& w = e->w;
+  const int NS = lo.NS, L = lo.L;
   int64_t* ids = (int64_t*)(ws + lo.ids);
   int32_t* unf = (int32_t*)(ws + lo.unf);
   float* sum_lp = (float*)(ws + lo.sum_lp);
   float* cnt = (float*)(ws + lo.cnt);
-  CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, NS, L, BOS, PAD, s));
+  CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, NS, L, o.bos_token_id, o.pad_token_id, s));
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, ws, NS, K, t, ids, ws + lo.tcache, s));
-    if (e->repetition_penalty != 1.0f)
-      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, e->repetition_penalty, NS, s));
-    if (e->sampling.do_sample)
+    CK(step_forward(w, lo, o, ws, t, ids, ws + lo.tcache, s));
+    if (o.repetition_penalty != 1.0f)
+      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, o.repetition_penalty, NS, s));
+    if (o.sampling.do_sample)
       CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L, EOS,
-                            PAD, &e->sampling, s));
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L,
+                            o.eos_token_id, o.pad_token_id, &o.sampling, s));
     else
       CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L, EOS,
-                            PAD, s));
-  }
-  if (hipMemcpyAsync(out_ids, ids, (size_t)NS * L * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
-      hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)NS * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
-          hipSuccess) {
-    vitcap_set_error("decode: output copy failed");
-    return VITCAP_ELAUNCH;
-  }
-  // the token chosen at the last position before the forced [SEP] (its log-probability is what the score holds)
-  if (out_last_tok && hipMemcpyAsync(out_last_tok, ws + lo.last_tok, (size_t)NS * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
-    vitcap_set_error("decode: last-token copy failed");
-    return VITCAP_ELAUNCH;
+                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L,
+                            o.eos_token_id, o.pad_token_id, s));
   }
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, void* workspace, size_t workspace_bytes, int64_t* out_ids,
-                                    float* out_logprobs, void* s) {
-  return decode_sequences(e, B, 1, workspace, workspace_bytes, out_ids, out_logprobs, nullptr, s);
-}
-
-extern "C" int vitcap_engine_decode_multi(vitcap_engine* e, int B, int seqs_per_image, void* workspace, size_t workspace_bytes,
-                                          int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* s) {
-  if (seqs_per_image < 1 || seqs_per_image > 8) { vitcap_set_error("decode_multi: seqs_per_image must be 1..8 (got %d)", seqs_per_image); return VITCAP_EINVAL; }
-  return decode_sequences(e, B, seqs_per_image, workspace, workspace_bytes, out_ids, out_logprobs, out_last_tok, s);
-}
-
-// Beam search (a13): encoder + prefill once per image, B*beams sequences in the step loop, all bookkeeping on device.
-extern "C" int vitcap_engine_beam(vitcap_engine* e, const void* image, int image_is_bf16, int B, int beams,
-                                  float length_penalty, void* workspace, size_t workspace_bytes, int64_t* out_ids,
-                                  float* out_logprobs, void* s) {
-  if (beams < 1 || beams > 8) { vitcap_set_error("beam: num_beams must be 1..8 (got %d)", beams); return VITCAP_EINVAL; }
-  const int NS = B * beams;
-  const Layout lo(B, NS, true);
-  CK(check(e, B, workspace, workspace_bytes, lo.off));
-  if (!out_ids || !out_logprobs) { vitcap_set_error("beam: null outputs"); return VITCAP_EINVAL; }
-  CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
-  CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
-  return vitcap_engine_beam_decode(e, B, beams, length_penalty, workspace, workspace_bytes, out_ids, out_logprobs, s);
-}
-
-extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, float length_penalty, void* workspace,
-                                         size_t workspace_bytes, int64_t* out_ids, float* out_logprobs, void* s) {
-  if (beams < 1 || beams > 8) { vitcap_set_error("beam: num_beams must be 1..8 (got %d)", beams); return VITCAP_EINVAL; }
-  const int NS = B * beams;
-  const Layout lo(B, NS, true);
-  CK(check(e, B, workspace, workspace_bytes, lo.off));
-  if (!out_ids || !out_logprobs) { vitcap_set_error("beam: null outputs"); return VITCAP_EINVAL; }
-  g_cur = e;
-  char* ws = (char*)workspace;
+// Beam search loop (a13): B*beams sequences, all bookkeeping on device; the final n-best lists land in lo.fin_ids / lo.fin_lp.
+static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
   const vitcap_weights& w = e->w;
+  const int NS = lo.NS, L = lo.L, beams = o.num_beams;
   vitcap_beam_state st;
   st.ids_in = (int64_t*)(ws + lo.ids);
   st.ids_out = (int64_t*)(ws + lo.ids2);
@@ -543,80 +610,124 @@ extern "C" int vitcap_engine_beam_decode(vitcap_engine* e, int B, int beams, flo
   st.hyp_score = (float*)(ws + lo.hyp_score);
   st.hyp_len = (int32_t*)(ws + lo.hyp_len);
   st.hyp_tok = (int64_t*)(ws + lo.hyp_tok);
-  st.n_keep = e->keep_best;
-  CK(vitcap_beam_init(&st, B, beams, L, BOS, PAD, s));
+  st.n_keep = o.num_keep_best;
+  CK(vitcap_beam_init(&st, B, beams, L, o.bos_token_id, o.pad_token_id, s));
   char* tc_cur = ws + lo.tcache;
   char* tc_alt = ws + lo.tcache2;
   const int C = 2 * beams;
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, ws, NS, beams, t, st.ids_in, tc_cur, s));
-    if (e->repetition_penalty != 1.0f)
-      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, e->repetition_penalty, NS, s));
+    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, s));
+    if (o.repetition_penalty != 1.0f)
+      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, o.repetition_penalty, NS, s));
     CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),
                            (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), NS, s));
     CK(vitcap_beam_step((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
-                        (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, EOS, PAD, length_penalty, s));
+                        (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, o.eos_token_id, o.pad_token_id,
+                        o.length_penalty, s));
     if (t + 1 < L) {   // re-order the text K/V history (positions 0..t-1) by parent beam for the next step
       CK(vitcap_beam_reorder_cache(tc_cur, tc_alt, st.parent, 4, NS, L, t, s));
       char* tmp = tc_cur; tc_cur = tc_alt; tc_alt = tmp;
     }
     int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
   }
-  CK(vitcap_beam_finalize(&st, out_ids, out_logprobs, B, L, EOS, PAD, s));
+  // finalize reads hypotheses only; it runs whether or not the loop ended early
+  CK(vitcap_beam_finalize(&st, (int64_t*)(ws + lo.fin_ids), (float*)(ws + lo.fin_lp), B, L, o.eos_token_id, o.pad_token_id, s));
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_engine_set_repetition_penalty(vitcap_engine* e, float penalty) {
-  if (!e || !(penalty > 0.f)) { vitcap_set_error("set_repetition_penalty: need an engine and penalty > 0 (got %g)", (double)penalty); return VITCAP_EINVAL; }
-  e->repetition_penalty = penalty;
-  return VITCAP_OK;
+static int decode_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
+  CallScope scope(e, o.gemm_mode, o.early_exit ? (const int32_t*)(ws + lo.live) : nullptr);
+  return lo.beam ? beam_loop(e, B, lo, o, ws, s) : greedy_loop(e, lo, o, ws, s);
 }
 
-extern "C" int vitcap_engine_set_num_keep_best(vitcap_engine* e, int n) {
-  if (!e || n < 1 || n > 8) { vitcap_set_error("set_num_keep_best: need an engine and 1 <= n <= 8 (got %d)", n); return VITCAP_EINVAL; }
-  e->keep_best = n;
-  return VITCAP_OK;
-}
-
-extern "C" int vitcap_engine_set_sampling(vitcap_engine* e, const vitcap_sample_params* sp) {
-  if (!e || !sp) { vitcap_set_error("set_sampling: null pointer"); return VITCAP_EINVAL; }
-  if (sp->do_sample && !(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f)) {
-    vitcap_set_error("set_sampling: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature,
-                     sp->top_k, (double)sp->top_p);
-    return VITCAP_EINVAL;
+static int decode_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, int64_t* out_ids,
+                         float* out_logprobs, int64_t* out_last_tok, void* s) {
+  if (!out_ids || !out_logprobs) { vitcap_set_error("decode: null outputs"); return VITCAP_EINVAL; }
+  hipStream_t st = (hipStream_t)s;
+  const bool graph = o.use_graph && !o.sampling.do_sample;
+  if (!graph) {
+    CK(decode_loop(e, B, lo, o, ws, s));
+  } else {
+    GraphEntry* hit = nullptr;
+    for (auto& g : e->graphs)
+      if (g.B == B && g.ws == (void*)ws && memcmp(&g.opts, &o, sizeof(o)) == 0) { hit = &g; break; }
+    if (!hit) {
+      // capture the loop once: every launch below becomes a kernel node with its arguments frozen (workspace pointers,
+      // step index, option values), which is why the key holds all of them
+      GraphEntry g;
+      g.B = B; g.ws = (void*)ws; g.opts = o; g.graph = nullptr; g.exec = nullptr;
+      HIPCK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "decode: begin capture");
+      const int rc = decode_loop(e, B, lo, o, ws, s);
+      const hipError_t he = hipStreamEndCapture(st, &g.graph);
+      if (rc != VITCAP_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+      HIPCK(he, "decode: end capture");
+      HIPCK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0), "decode: graph instantiate");
+      if (e->graphs.size() >= 16) drop_graphs(e);        // bounded cache
+      e->graphs.push_back(g);
+      hit = &e->graphs.back();
+    }
+    HIPCK(hipGraphLaunch(hit->exec, st), "decode: graph launch");
   }
-  e->sampling = *sp;
+  const size_t L = (size_t)lo.L;
+  if (lo.beam) {
+    const size_t n = (size_t)B * o.num_keep_best;
+    HIPCK(hipMemcpyAsync(out_ids, ws + lo.fin_ids, n * L * 8, hipMemcpyDeviceToDevice, st), "decode: output copy");
+    HIPCK(hipMemcpyAsync(out_logprobs, ws + lo.fin_lp, n * 4, hipMemcpyDeviceToDevice, st), "decode: output copy");
+  } else {
+    HIPCK(hipMemcpyAsync(out_ids, ws + lo.ids, (size_t)lo.NS * L * 8, hipMemcpyDeviceToDevice, st), "decode: output copy");
+    HIPCK(hipMemcpyAsync(out_logprobs, ws + lo.logprob, (size_t)lo.NS * 4, hipMemcpyDeviceToDevice, st), "decode: output copy");
+    // the token chosen at the last position before the forced [SEP] (its log-probability is what the score holds)
+    if (out_last_tok)
+      HIPCK(hipMemcpyAsync(out_last_tok, ws + lo.last_tok, (size_t)lo.NS * 8, hipMemcpyDeviceToDevice, st), "decode: last-token copy");
+  }
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_engine_greedy(vitcap_engine* e, const void* image, int image_is_bf16, int B, void* workspace,
-                                    size_t workspace_bytes, int64_t* out_ids, float* out_logprobs,
-                                    float* tag_logits_out, int64_t* tag_topk_out, void* s) {
-  CK(vitcap_engine_encode(e, image, image_is_bf16, B, workspace, workspace_bytes, s));
-  CK(vitcap_engine_prefill(e, B, workspace, workspace_bytes, s));
-  CK(vitcap_engine_decode(e, B, workspace, workspace_bytes, out_ids, out_logprobs, s));
-  const Layout lo(B, B, false);
+extern "C" int vitcap_engine_decode(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, size_t workspace_bytes,
+                                    int64_t* out_ids, float* out_logprobs, int64_t* out_last_tok, void* s) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (B <= 0 || check_opts(o) != VITCAP_OK) { if (B <= 0) vitcap_set_error("engine: bad batch"); return VITCAP_EINVAL; }
+  const Layout lo(B, o);
+  CK(check(e, B, o, workspace, workspace_bytes, lo.off));
+  std::lock_guard<std::mutex> lk(e->mu);
+  return decode_locked(e, B, o, lo, (char*)workspace, out_ids, out_logprobs, out_last_tok, s);
+}
+
+static int tags_copy(const Layout& lo, int B, char* ws, float* tag_logits_out, int64_t* tag_topk_out, void* s) {
+  if (tag_logits_out)
+    HIPCK(hipMemcpy2DAsync(tag_logits_out, (size_t)VITCAP_VOCAB * 4, ws + lo.tag_logits, (size_t)VP * 4, (size_t)VITCAP_VOCAB * 4,
+                           B, hipMemcpyDeviceToDevice, (hipStream_t)s), "tags: logits copy");
+  if (tag_topk_out)
+    HIPCK(hipMemcpyAsync(tag_topk_out, ws + lo.tag_ids, (size_t)B * TOPK * 8, hipMemcpyDeviceToDevice, (hipStream_t)s), "tags: topk copy");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_tags(vitcap_engine* e, int B, const vitcap_gen_opts* opts, void* workspace, float* tag_logits_out,
+                                  int64_t* tag_topk_out, void* s) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (!e || B <= 0 || !workspace || check_opts(o) != VITCAP_OK) { vitcap_set_error("tags: bad arguments"); return VITCAP_EINVAL; }
+  return tags_copy(Layout(B, o), B, (char*)workspace, tag_logits_out, tag_topk_out, s);
+}
+
+extern "C" int vitcap_engine_generate(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts* opts,
+                                      void* workspace, size_t workspace_bytes, int64_t* out_ids, float* out_logprobs,
+                                      float* tag_logits_out, int64_t* tag_topk_out, void* s) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (B <= 0 || check_opts(o) != VITCAP_OK) { if (B <= 0) vitcap_set_error("engine: bad batch"); return VITCAP_EINVAL; }
+  const Layout lo(B, o);
+  CK(check(e, B, o, workspace, workspace_bytes, lo.off));
   char* ws = (char*)workspace;
-  if (tag_logits_out) {
-    if (hipMemcpy2DAsync(tag_logits_out, (size_t)VITCAP_VOCAB * 4, ws + lo.tag_logits, (size_t)VP * 4,
-                         (size_t)VITCAP_VOCAB * 4, B, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
-      vitcap_set_error("greedy: tag logits copy failed");
-      return VITCAP_ELAUNCH;
-    }
-  }
-  if (tag_topk_out) {
-    if (hipMemcpyAsync(tag_topk_out, ws + lo.tag_ids, (size_t)B * TOPK * 8, hipMemcpyDeviceToDevice, (hipStream_t)s) !=
-        hipSuccess) {
-      vitcap_set_error("greedy: tag topk copy failed");
-      return VITCAP_ELAUNCH;
-    }
-  }
-  return VITCAP_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  CK(encode_locked(e, image, image_is_bf16, B, o, lo, ws, s));
+  CK(prefill_locked(e, B, o, lo, ws, s));
+  CK(decode_locked(e, B, o, lo, ws, out_ids, out_logprobs, nullptr, s));
+  return tags_copy(lo, B, ws, tag_logits_out, tag_topk_out, s);
 }
 
-extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B) {
-  if (!e || !name || !workspace || B <= 0) return nullptr;
-  const Layout lo(B, B, false);
+extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspace, int B, const vitcap_gen_opts* opts) {
+  const vitcap_gen_opts o = opts ? *opts : default_opts();
+  if (!e || !name || !workspace || B <= 0 || check_opts(o) != VITCAP_OK) return nullptr;
+  const Layout lo(B, o);
   char* ws = (char*)workspace;
   if (!strcmp(name, "last_token")) return ws + lo.last_tok;
   if (!strcmp(name, "hidden")) return ws + lo.x;
@@ -628,5 +739,6 @@ extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, voi
   if (!strcmp(name, "tag_prob")) return ws + lo.tag_prob;
   if (!strcmp(name, "tag_len")) return ws + lo.tag_len;
   if (!strcmp(name, "ids")) return ws + lo.ids;
+  if (!strcmp(name, "live")) return ws + lo.live;
   return nullptr;
 }

@@ -1,9 +1,11 @@
 // Thread-local error text + version for libvitcap_hip.so
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdint.h>
 #include "../../include/vitcap_hip.h"
 
 static thread_local char g_err[512] = "";
+thread_local const int32_t* vc_tls_live = nullptr;   // see common.h
 
 void vitcap_set_error(const char* fmt, ...) {
   va_list ap;
@@ -13,4 +15,4 @@ void vitcap_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vitcap_last_error(void) { return g_err; }
-extern "C" int vitcap_version(void) { return 1; }
+extern "C" int vitcap_version(void) { return 2; }

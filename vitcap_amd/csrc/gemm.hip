@@ -41,6 +41,7 @@ struct GemmArgs {
   size_t slab;
   int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
   unsigned long long* trace;   // instrumentation (tools/gemm_trace.py): [workgroup][8 tiles][4] s_memtime stamps, else null
+  const int32_t* live;         // decode loop: return at entry once *live == 0 (vitcap_gemm_desc.live)
 };
 
 unsigned long long* g_gemm_trace = nullptr;
@@ -62,6 +63,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 
 template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  VC_LIVE_EXIT(p.live);
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1232,6 +1234,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs q) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int BM = 32 * WAVES_M, BN = 32 * WAVES_N;
   const GemmArgs& p = q.g;
+  VC_LIVE_EXIT(p.live);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w / WAVES_N, wn = w % WAVES_N;
@@ -1390,14 +1393,12 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
                               const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
                               void* stream);
 
-// Process-wide choice between the persistent and the one-tile-per-workgroup form of the 256x256 GEMM.  Alone on the
-// GPU the persistent form wins (+2..11 %); when another stream's small kernels should slip in between (the batch
-// pipeline of ImageCaptioning.generate_async) the non-persistent form wins, because a persistent grid owns every CU
-// for the whole GEMM (3277 vs 3133 img/s at B=64).
-static int g_gemm_persistent = 1;
+// Persistent vs one-tile-per-workgroup form of the 256x256 GEMM is a PER-CALL choice (vitcap_gemm_desc.tile_hint 12 / 5;
+// 0 = auto = persistent where it wins).  Alone on the GPU the persistent form wins (+2..11 %); when another stream's small
+// kernels should slip in between (the batch pipeline of ImageCaptioning.generate_async) the non-persistent form wins,
+// because a persistent grid owns every CU for the whole GEMM (3277 vs 3133 img/s at B=64) -- the engine asks for it through
+// vitcap_gen_opts.gemm_mode.  There is no process-wide switch.
 extern "C" void vitcap_gemm_set_trace(unsigned long long* buf) { g_gemm_trace = buf; }
-extern "C" void vitcap_gemm_set_persistent(int on) { g_gemm_persistent = on ? 1 : 0; }
-extern "C" int vitcap_gemm_get_persistent(void) { return g_gemm_persistent; }
 
 extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                                     void* C, const vitcap_gemm_desc* d, void* stream) {
@@ -1430,6 +1431,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.aux = (const bf16_t*)aux_bf16; a.ldaux = ldaux;
   a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
+  a.live = d->live;
   {
     static const int direct = [] { const char* e = getenv("VITCAP_GEMM_DIRECT_EPILOGUE"); return e ? atoi(e) : 1; }();
     a.direct_epilogue = direct;
@@ -1486,7 +1488,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %);
   // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
   static const int env_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : -1; }();
-  const int use_persistent = env_persistent >= 0 ? env_persistent : g_gemm_persistent;
+  const int use_persistent = env_persistent >= 0 ? env_persistent : 1;   // a caller that wants one tile per workgroup passes tile_hint 5
   // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
   if (hint == 0 && use_persistent && wide_ok && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(64) void sum_layernorm768_kernel(const float* __res
                                                               const float* __restrict__ res, int ldr, int act,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
-                                                              bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
+                                                              bf16_t* __restrict__ yb, float* __restrict__ yf, int M,
+                                                              const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   const int lane = threadIdx.x;
   const int row = blockIdx.x;
   const float* p0 = part + (size_t)row * D768 + lane * 4;
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restri
                                                          const bf16_t* __restrict__ type,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows) {
+                                                         float* __restrict__ xf, bf16_t* __restrict__ xb, int rows,
+                                                         const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -231,7 +235,7 @@ extern "C" int vitcap_sum_layernorm(const float* partials, int S, size_t slab_st
   VC_REQUIRE(D == D768 && S >= 1 && M > 0, "sum_layernorm: only D=768, S>=1 (got D=%d S=%d)", D, S);
   VC_REQUIRE(!(act_before_ln && residual), "sum_layernorm: activation and residual are mutually exclusive");
   hipLaunchKernelGGL(sum_layernorm768_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, partials, S,
-                     slab_stride, bias, residual, ldr, act_before_ln, gamma, beta, eps, (bf16_t*)y_bf16, y_f32, M);
+                     slab_stride, bias, residual, ldr, act_before_ln, gamma, beta, eps, (bf16_t*)y_bf16, y_f32, M, vc_tls_live);
   VC_LAUNCH_CHECK("sum_layernorm");
   return VITCAP_OK;
 }
@@ -244,7 +248,7 @@ extern "C" int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mas
   const int rows = 2 * B;
   hipLaunchKernelGGL(embed_step_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, max_len, t,
                      mask_token, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma,
-                     beta, eps, x_f32, (bf16_t*)x_bf16, rows);
+                     beta, eps, x_f32, (bf16_t*)x_bf16, rows, vc_tls_live);
   VC_LAUNCH_CHECK("embed_step");
   return VITCAP_OK;
 }

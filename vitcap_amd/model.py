@@ -207,87 +207,167 @@ class ImageCaptioning(nn.Module):
             pass
 
     # ---------------------------------------------------------------- forward
-    def _workspace(self, B, dev, slot=0, beams=0):
-        """One workspace per slot: concurrent generate() calls on different HIP streams use different slots."""
-        need = lib.vitcap_engine_workspace_bytes_beam(B, beams) if beams else lib.vitcap_engine_workspace_bytes(B)
+    def _workspace(self, B, dev, slot=0, opts=None, wait=None):
+        """One workspace per slot: concurrent generate() calls on different HIP streams use different slots.  `wait`: event of
+        the slot's in-flight work, waited for before a larger buffer replaces the old one (the caching allocator may hand the
+        old block to another stream at once)."""
+        need = lib.vitcap_engine_workspace_bytes(B, C.byref(opts) if opts is not None else None)
+        if need == 0:
+            check(lib.vitcap_gen_opts_check(C.byref(opts)), 'gen_opts')
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need or ws.device != dev:
+            if ws is not None and wait is not None:
+                wait.synchronize()
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._ws[slot] = ws
         return ws, need
 
-    def set_sampling(self, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, seed=0):
-        """Token choice of generate(): greedy, or one draw from the temperature / top-k / top-p filtered distribution
-        (modeling_utils.py:839-846).  Draws are a pure function of (seed, sequence, step, token)."""
-        from ._lib import SampleParams
-        sp = SampleParams(int(bool(do_sample)), float(temperature), int(top_k), float(top_p), int(seed) & 0xffffffff)
-        if self._packed is None:
-            raise RuntimeError('pack() the model before set_sampling()')
-        check(lib.vitcap_engine_set_sampling(self._engine, C.byref(sp)), 'set_sampling')
+    # ---- options: test_extra_input (the kwargs ViTCAP.generate receives, ..._bertemb.py:588-608) -> vitcap_gen_opts
+    def gen_options(self, gemm_mode=L.GEMM_AUTO, use_graph=None, **over):
+        """Validated vitcap_gen_opts for the current test_extra_input (+ overrides).  Raises for generate() options this build
+        does not implement instead of silently ignoring them; used by forward() AND by the pipeline's predict loop."""
+        te = dict(self.test_extra_input)
+        te.update(over)
+        if te.get('use_cbs', False):
+            raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
+        eos = te.get('eos_token_ids', [102])
+        eos = list(eos) if isinstance(eos, (list, tuple)) else [eos]
+        if len(eos) != 1:
+            raise NotImplementedError('eos_token_ids must hold exactly one id in this build (got %r)' % (eos,))
+        nb, keep = int(te.get('num_beams', 1) or 1), int(te.get('num_keep_best', 1) or 1)
+        nret = int(te.get('num_return_sequences', 1) or 1)
+        do_sample = bool(te.get('do_sample', False))
+        if keep != 1 and nb == 1:
+            # modeling_utils.py:790: "cannot generate >1 sentences in greedy search"
+            raise AssertionError('cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)')
+        if nret > 1 and (not do_sample or nb > 1):
+            raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
+        if nb > 1 and do_sample:
+            raise NotImplementedError('beam sampling (num_beams > 1 with do_sample, modeling_utils.py:966-985) is not built')
+        ml = int(te.get('max_length', L.MAXLEN))
+        if not 2 <= ml <= L.MAXLEN_CAP:
+            raise NotImplementedError('max_length must be 2..%d in this build (got %d)' % (L.MAXLEN_CAP, ml))
+        sp = L.SampleParams(int(do_sample), float(te.get('temperature', 1) or 1), int(te.get('top_k', 0) or 0),
+                            float(te.get('top_p', 1) or 1), int(te.get('seed', 0)) & 0xffffffff)
+        if use_graph is None:
+            use_graph = bool(te.get('use_graph', False))
+        o = L.gen_opts(num_beams=nb, seqs_per_image=min(nret, 8) if nret > 1 else 1, num_keep_best=keep, max_length=ml,
+                       bos_token_id=int(te.get('bos_token_id', 101)), eos_token_id=int(eos[0]),
+                       pad_token_id=int(te.get('pad_token_id', 0)), mask_token_id=int(te.get('mask_token_id', 103)),
+                       length_penalty=float(te.get('length_penalty', 1) or 1),
+                       repetition_penalty=float(te.get('repetition_penalty', 1) or 1), sampling=sp, gemm_mode=int(gemm_mode),
+                       early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)))
+        check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
+        return o
 
-    def generate(self, image, want_tags=False, slot=0):
-        """image: (B,3,384,384) fp32 or bf16 on the GPU, normalised with mean=.5/std=.5."""
+    def check_text_inputs(self, data, max_length=L.MAXLEN):
+        """The text side of the test-time batch (CaptionTensorizer.tensorize_ab at test time, dataset.py:218-219, 326, 377-390;
+        consumed by ImageCaptioning.construct_attn_mask ..._bertemb.py:57-85 and ViTCAP.generate modeling_bert.py:955-1001).
+        The engine hard-wires the mask STRUCTURE those tensors describe -- caption row i attends caption rows <= i and the 578
+        visual tokens, nothing attends the tag slots -- so what the caller hands over is verified against that structure and
+        anything else is refused: a different mask can no longer yield a silently wrong caption.
+
+        * attention_mask (B, T, T), T = max_length + od_len: lower-triangular ones on [0:max_length, 0:max_length], zeros
+          elsewhere (the 210 ones of SURVEY 8d for max_length 20);
+        * token_type_ids: zeros;  masked_pos: not read by generate() beyond slicing;
+        * input_ids (B, T): only the od-label slots [max_length:] are read by generate() (modeling_bert.py:959); their
+          embeddings are overwritten by the predicted tag tokens (1435-1489) and never attended, so any value is harmless."""
+        am = data.get('attention_mask')
+        if am is not None:
+            if am.dim() != 3 or am.shape[1] != am.shape[2] or am.shape[1] < max_length:
+                raise ValueError('attention_mask must be (B, T, T) with T >= max_length=%d, got %s' % (max_length, tuple(am.shape)))
+            want = torch.zeros(am.shape[1:], dtype=am.dtype, device=am.device)
+            want[:max_length, :max_length] = torch.tril(torch.ones(max_length, max_length, dtype=am.dtype, device=am.device))
+            if not bool((am == want.unsqueeze(0)).all()):
+                raise NotImplementedError(
+                    'attention_mask differs from the test-time seq2seq pattern (tril on the first %d caption slots, zeros elsewhere: '
+                    'dataset.py:377-390); the HIP engine implements that mask structure only (tag tokens visible to the caption are '
+                    'SURVEY 8f rank 4)' % max_length)
+        tt = data.get('token_type_ids')
+        if tt is not None and bool((tt != 0).any()):
+            raise NotImplementedError('token_type_ids must be all zero at test time (dataset.py:326); segment-1 text tokens are not built')
+        ii = data.get('input_ids')
+        if ii is not None and (ii.dim() != 2 or ii.shape[1] < max_length):
+            raise ValueError('input_ids must be (B, T) with T >= max_length=%d, got %s' % (max_length, tuple(ii.shape)))
+        for k in ('input_ids', 'attention_mask', 'token_type_ids', 'masked_pos'):
+            v = data.get(k)
+            if v is not None and v.shape[0] != data['image'].shape[0]:
+                raise ValueError('%s has batch %d but image has %d' % (k, v.shape[0], data['image'].shape[0]))
+
+    def _check_image(self, image):
         if self._packed is None:
             self.pack(image.device)
-        dev = self._packed[2]
         assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
         assert image.dtype in (torch.float32, torch.bfloat16)
+        return self._packed[2]
+
+    def _out_buffers(self, B, o, dev):
+        if o.num_beams > 1:
+            shape = (B, o.num_keep_best)
+        else:
+            shape = (B * o.seqs_per_image, 1)
+        return (torch.empty(shape + (o.max_length,), dtype=torch.int64, device=dev),
+                torch.empty(shape, dtype=torch.float32, device=dev))
+
+    def run(self, image, opts, want_tags=False, slot=0, want_last=False):
+        """One vitcap_engine_generate call on the current stream under `opts` (a vitcap_gen_opts from gen_options())."""
+        dev = self._check_image(image)
         B = image.shape[0]
-        ws, need = self._workspace(B, dev, slot)
-        ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
-        lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        ws, need = self._workspace(B, dev, slot, opts)
+        ids, lp = self._out_buffers(B, opts, dev)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wp = C.c_void_p(ws.data_ptr())
+        if want_last:
+            last = torch.empty((B * opts.seqs_per_image,), dtype=torch.int64, device=dev)
+            check(lib.vitcap_engine_encode(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B,
+                                           C.byref(opts), wp, need, s), 'engine_encode')
+            check(lib.vitcap_engine_prefill(self._engine, B, C.byref(opts), wp, need, s), 'engine_prefill')
+            check(lib.vitcap_engine_decode(self._engine, B, C.byref(opts), wp, need, C.c_void_p(ids.data_ptr()),
+                                           C.c_void_p(lp.data_ptr()), C.c_void_p(last.data_ptr()), s), 'engine_decode')
+            return ids, lp, last
         tag_logits = torch.empty((B, L.VOCAB), dtype=torch.float32, device=dev) if want_tags else None
         tag_topk = torch.empty((B, 50), dtype=torch.int64, device=dev) if want_tags else None
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        lib.vitcap_gemm_set_persistent(1)
-        check(lib.vitcap_engine_greedy(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16),
-                                       B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
-                                       C.c_void_p(lp.data_ptr()),
-                                       C.c_void_p(tag_logits.data_ptr()) if want_tags else None,
-                                       C.c_void_p(tag_topk.data_ptr()) if want_tags else None, s), 'engine_greedy')
+        check(lib.vitcap_engine_generate(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B,
+                                         C.byref(opts), wp, need, C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
+                                         C.c_void_p(tag_logits.data_ptr()) if want_tags else None,
+                                         C.c_void_p(tag_topk.data_ptr()) if want_tags else None, s), 'engine_generate')
         if want_tags:
             self.last_tags = (tag_logits, tag_topk)
+        self._last = (slot, opts, B)
         return ids, lp
 
-    def generate_multi(self, image, seqs_per_image, slot=0, want_last=False):
-        """`seqs_per_image` greedy / sampled sequences per image (num_return_sequences of ViTCAP.generate): the encoder and the
-        visual prefill run once per image, the sequences of an image share its visual K/V.  Returns (ids (B*n,1,20),
+    def generate(self, image, want_tags=False, slot=0, **over):
+        """Greedy captions.  image: (B,3,384,384) fp32 or bf16 on the GPU, normalised with mean=.5/std=.5."""
+        return self.run(image, self.gen_options(num_beams=1, do_sample=False, num_return_sequences=1, num_keep_best=1, **over),
+                        want_tags=want_tags, slot=slot)
+
+    def generate_multi(self, image, seqs_per_image, slot=0, want_last=False, **over):
+        """`seqs_per_image` sampled sequences per image (num_return_sequences of ViTCAP.generate): the encoder and the
+        visual prefill run once per image, the sequences of an image share its visual K/V.  Returns (ids (B*n,1,L),
         logprobs (B*n,1)) image-major -- the same sequences generate() gives on the n-times repeated batch -- and, with
         want_last, the token chosen at the last position (before the forced [SEP]) of every sequence."""
-        if self._packed is None:
-            self.pack(image.device)
-        dev = self._packed[2]
-        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
-        B, n = image.shape[0], int(seqs_per_image)
-        ws, need = self._workspace(B, dev, slot, beams=n)
-        ids = torch.empty((B * n, 1, L.MAXLEN), dtype=torch.int64, device=dev)
-        lp = torch.empty((B * n, 1), dtype=torch.float32, device=dev)
-        last = torch.empty((B * n,), dtype=torch.int64, device=dev) if want_last else None
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        lib.vitcap_gemm_set_persistent(1)
-        wp = C.c_void_p(ws.data_ptr())
-        check(lib.vitcap_engine_encode(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B, wp, need, s),
-              'engine_encode')
-        check(lib.vitcap_engine_prefill(self._engine, B, wp, need, s), 'engine_prefill')
-        check(lib.vitcap_engine_decode_multi(self._engine, B, n, wp, need, C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
-                                             C.c_void_p(last.data_ptr()) if want_last else None, s), 'engine_decode_multi')
-        return (ids, lp, last) if want_last else (ids, lp)
+        o = self.gen_options(num_beams=1, num_keep_best=1, num_return_sequences=int(seqs_per_image), do_sample=True, **over)
+        return self.run(image, o, slot=slot, want_last=want_last)
 
-    def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0):
-        """Greedy captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
-        HIP stream while the 19 decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of ~630
-        small latency-bound kernels that leaves most of the chip idle; the encoder is MFMA-bound and has a tail at every
-        GEMM -- interleaved they fill each other's gaps (B=64: 22.2 -> 19.8 ms per batch, tools/pipe_bench.py).
-        Returns a handle; `.result()` waits for this batch only and gives (ids (B,1,20), logprobs (B,1)).  Results are
-        identical to generate()."""
-        if self._packed is None:
-            self.pack(image.device)
-        dev = self._packed[2]
-        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
-        assert image.dtype in (torch.float32, torch.bfloat16)
-        pipes = getattr(self, '_pipes', None)
-        if pipes is None:
-            pipes = self._pipes = {}
+    def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0, num_keep_best=1, **over):
+        """Beam search -> (ids (B,num_keep_best,L), logprobs (B,num_keep_best)), best hypothesis first, like
+        ViTCAP._generate_beam_search (modeling_utils.py:888-1100)."""
+        o = self.gen_options(num_beams=int(num_beams), length_penalty=float(length_penalty), num_keep_best=int(num_keep_best),
+                             do_sample=False, num_return_sequences=1, **over)
+        return self.run(image, o, slot=slot)
+
+    def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0, opts=None):
+        """Captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
+        HIP stream while the decode steps of the PREVIOUS batch run on another.  The decode phase is a chain of small
+        latency-bound kernels that leaves most of the chip idle; the encoder is MFMA-bound and has a tail at every
+        GEMM -- interleaved they fill each other's gaps (tools/pipe_bench.py).  The large GEMMs run one tile per workgroup
+        here (vitcap_gen_opts.gemm_mode = TILES, a per-call option).
+        Returns a handle; `.result()` waits for this batch only and gives (ids, logprobs).  Results are identical to run()."""
+        dev = self._check_image(image)
+        if opts is None:
+            opts = self.gen_options(gemm_mode=L.GEMM_TILES, num_beams=int(num_beams), length_penalty=float(length_penalty),
+                                    num_keep_best=1, do_sample=False, num_return_sequences=1)
+        pipes = self.__dict__.setdefault('_pipes', {})
         pipe = pipes.get(lane)
         if pipe is None:
             import os
@@ -296,77 +376,60 @@ class ImageCaptioning(nn.Module):
                                   'done': [None, None], 'n': 0}
         slot = pipe['n'] % 2
         pipe['n'] += 1
-        lib.vitcap_gemm_set_persistent(0)       # let the other slot's decode kernels in between GEMM tiles
         B = image.shape[0]
-        ws, need = self._workspace(B, dev, slot='pipe%d_%d' % (lane, slot), beams=num_beams if num_beams > 1 else 0)
+        ws, need = self._workspace(B, dev, slot='pipe%d_%d' % (lane, slot), opts=opts, wait=pipe['done'][slot])
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)
         image.record_stream(pipe['enc'])
+        wp = C.c_void_p(ws.data_ptr())
         with torch.cuda.stream(pipe['enc']):
             pipe['enc'].wait_event(ready)
             if pipe['done'][slot] is not None:
                 pipe['enc'].wait_event(pipe['done'][slot])         # the slot's previous decode has drained
             h = C.c_void_p(pipe['enc'].cuda_stream)
             check(lib.vitcap_engine_encode(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16),
-                                           B, C.c_void_p(ws.data_ptr()), need, h), 'engine_encode')
-            check(lib.vitcap_engine_prefill(self._engine, B, C.c_void_p(ws.data_ptr()), need, h), 'engine_prefill')
+                                           B, C.byref(opts), wp, need, h), 'engine_encode')
+            check(lib.vitcap_engine_prefill(self._engine, B, C.byref(opts), wp, need, h), 'engine_prefill')
             filled = torch.cuda.Event()
             filled.record(pipe['enc'])
         with torch.cuda.stream(pipe['dec']):
             pipe['dec'].wait_event(filled)
-            ids = torch.empty((B, 1, L.MAXLEN), dtype=torch.int64, device=dev)
-            lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
-            if num_beams > 1:
-                check(lib.vitcap_engine_set_num_keep_best(self._engine, 1), 'set_num_keep_best')
-                check(lib.vitcap_engine_beam_decode(self._engine, B, num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
-                                                    C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()),
-                                                    C.c_void_p(pipe['dec'].cuda_stream)), 'engine_beam_decode')
-            else:
-                check(lib.vitcap_engine_decode(self._engine, B, C.c_void_p(ws.data_ptr()), need, C.c_void_p(ids.data_ptr()),
-                                               C.c_void_p(lp.data_ptr()), C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
+            ids, lp = self._out_buffers(B, opts, dev)
+            check(lib.vitcap_engine_decode(self._engine, B, C.byref(opts), wp, need, C.c_void_p(ids.data_ptr()),
+                                           C.c_void_p(lp.data_ptr()), None, C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
             done = torch.cuda.Event()
             done.record(pipe['dec'])
         pipe['done'][slot] = done
         return _Pending(ids, lp, done, image)
 
-    def prime_pipeline(self, B, device, num_beams=1, lane=0):
+    def prime_pipeline(self, B, device, num_beams=1, lane=0, opts=None):
         """Allocate (and touch) both workspaces of generate_async's two-slot pipeline for batches of B images, so that no
         allocation lands inside a caller's timed or latency-critical region.  No kernels of the captioning path run."""
         if self._packed is None:
             self.pack(device)
+        if opts is None:
+            opts = self.gen_options(gemm_mode=L.GEMM_TILES, num_beams=int(num_beams), num_keep_best=1, do_sample=False,
+                                    num_return_sequences=1)
         for slot in range(2):
-            ws, _ = self._workspace(B, self._packed[2], slot='pipe%d_%d' % (lane, slot), beams=num_beams if num_beams > 1 else 0)
+            ws, _ = self._workspace(B, self._packed[2], slot='pipe%d_%d' % (lane, slot), opts=opts)
             ws.zero_()
 
-    def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0, num_keep_best=1):
-        """Beam search -> (ids (B,num_keep_best,20), logprobs (B,num_keep_best)), best hypothesis first, like
-        ViTCAP._generate_beam_search (modeling_utils.py:888-1100)."""
-        if self._packed is None:
-            self.pack(image.device)
-        dev = self._packed[2]
-        assert image.is_cuda and image.is_contiguous() and tuple(image.shape[1:]) == (3, 384, 384)
-        B = image.shape[0]
-        ws, need = self._workspace(B, dev, slot, beams=num_beams)
-        keep = int(num_keep_best)
-        ids = torch.empty((B, keep, L.MAXLEN), dtype=torch.int64, device=dev)
-        lp = torch.empty((B, keep), dtype=torch.float32, device=dev)
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.vitcap_engine_set_num_keep_best(self._engine, keep), 'set_num_keep_best')
-        check(lib.vitcap_engine_beam(self._engine, C.c_void_p(image.data_ptr()), int(image.dtype == torch.bfloat16), B,
-                                     num_beams, length_penalty, C.c_void_p(ws.data_ptr()), need,
-                                     C.c_void_p(ids.data_ptr()), C.c_void_p(lp.data_ptr()), s), 'engine_beam')
-        return ids, lp
-
-    def tap(self, name, B, shape, dtype=torch.float32):
-        """Copy of an engine workspace buffer after the last generate() (parity taps)."""
-        ws, _ = self._workspace(B, self._packed[2])
-        p = lib.vitcap_engine_tap(self._engine, name.encode(), C.c_void_p(ws.data_ptr()), B)
+    def tap(self, name, B, shape, dtype=torch.float32, slot=0, opts=None):
+        """Copy of an engine workspace buffer after the last run() on `slot` (parity taps)."""
+        if opts is None:
+            last = getattr(self, '_last', None)
+            opts = last[1] if last is not None and last[0] == slot and last[2] == B else self.gen_options()
+        ws, _ = self._workspace(B, self._packed[2], slot, opts)
+        p = lib.vitcap_engine_tap(self._engine, name.encode(), C.c_void_p(ws.data_ptr()), B, C.byref(opts))
         if not p:
             raise KeyError(name)
         off = p - ws.data_ptr()
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return ws[off:off + n].view(dtype).view(shape).clone()
+
+    def graph_count(self):
+        return int(lib.vitcap_engine_graph_count(self._engine)) if self._engine is not None else 0
 
     def forward(self, data):
         """Test-time contract of the reference wrapper (..._bertemb.py:87-184)."""
@@ -381,49 +444,17 @@ class ImageCaptioning(nn.Module):
                 raise RuntimeError('training-mode forward needs a vitcap_amd.train.TrainEngine(model, ...) attached')
             return eng.loss_dict(data)
         te = self.test_extra_input
-        keep = int(te.get('num_keep_best', 1))
-        if keep != 1 and te.get('num_beams', 1) == 1:
-            # modeling_utils.py:790: "cannot generate >1 sentences in greedy search"
-            raise AssertionError('cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)')
-        nret = int(te.get('num_return_sequences', 1))
-        if nret > 1:
-            # ViTCAP.generate expands every input num_return_sequences times (modeling_bert.py:976-979, 994,
-            # _expand_for_beams) and returns (B * n, 1, 20): n independent draws per image, image-major
-            if not te.get('do_sample', False) or te.get('num_beams', 1) > 1:
-                raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
-            if nret > 8:       # beyond the engine's sequences-per-image limit: expand the inputs like the reference does
-                data = dict(data)
-                data['image'] = data['image'].repeat_interleave(nret, 0).contiguous()
-                nret = 1
-        if te.get('max_length', 20) != L.MAXLEN:
-            raise NotImplementedError('max_length is fixed to 20 in this build')
-        # fail loudly on generate() options this build does not implement instead of silently ignoring them
-        fixed = {'bos_token_id': 101, 'pad_token_id': 0, 'mask_token_id': 103, 'eos_token_ids': [102]}
-        for k, v in fixed.items():
-            got = te.get(k, v)
-            if (list(got) if isinstance(got, (list, tuple)) else got) != v:
-                raise NotImplementedError('%s is fixed to %r in this build (got %r)' % (k, v, got))
-        if te.get('num_beams', 1) > 1 and te.get('do_sample', False):
-            raise NotImplementedError('beam sampling (num_beams > 1 with do_sample, modeling_utils.py:966-985) is not built')
-        if te.get('use_cbs', False):
-            raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
-        rp = float(te.get('repetition_penalty', 1) or 1)
-        if rp != getattr(self, '_rep_penalty', 1.0):
-            if self._packed is None:
-                self.pack(data['image'].device)
-            check(lib.vitcap_engine_set_repetition_penalty(self._engine, rp), 'set_repetition_penalty')
-            self._rep_penalty = rp
-        if te.get('num_beams', 1) > 1:
-            return self.generate_beam(data['image'], te['num_beams'], float(te.get('length_penalty', 1)), num_keep_best=keep)
+        over = {}
         if te.get('do_sample', False):
             # every forward() call advances the stream of draws, like consecutive torch.multinomial calls would
             self._sample_calls = getattr(self, '_sample_calls', 0) + 1
-            if self._packed is None:
-                self.pack(data['image'].device)
-            self.set_sampling(True, te.get('temperature', 1), te.get('top_k', 0), te.get('top_p', 1),
-                              int(te.get('seed', 0)) + 0x632be5ab * (self._sample_calls - 1))
-            try:
-                return self.generate_multi(data['image'], nret) if nret > 1 else self.generate(data['image'])
-            finally:
-                self.set_sampling(False)
-        return self.generate(data['image'])
+            over['seed'] = int(te.get('seed', 0)) + 0x632be5ab * (self._sample_calls - 1)
+        nret = int(te.get('num_return_sequences', 1) or 1)
+        image = data['image']
+        if nret > 8 and te.get('do_sample', False) and int(te.get('num_beams', 1) or 1) == 1:
+            # beyond the engine's sequences-per-image limit: expand the inputs like the reference does (modeling_bert.py:976-994)
+            image = image.repeat_interleave(nret, 0).contiguous()
+            over['num_return_sequences'] = 1
+        opts = self.gen_options(**over)
+        self.check_text_inputs(data, opts.max_length)
+        return self.run(image, opts)

@@ -44,13 +44,26 @@ _CAPTION_DEFAULT = {   # CaptionUniPipeline._default.update (..._bertemb.py:195-
 
 
 class _EngineState(object):
-    """state_dict() view of the training engine for Checkpointer.save (same keys as the reference checkpoint)."""
+    """state_dict() / load_state_dict() views of the training engine for Checkpointer (same keys as the reference
+    checkpoint: 'model' / 'optimizer' / 'scheduler', src/tools/opt/checkpoint.py:60-102)."""
 
-    def __init__(self, eng):
-        self.eng = eng
+    def __init__(self, eng, what='model'):
+        self.eng, self.what = eng, what
 
     def state_dict(self):
+        if self.what == 'optimizer':
+            return self.eng.optimizer_state_dict()
+        if self.what == 'scheduler':
+            return self.eng.scheduler_state_dict()
         return {k: v.cpu() for k, v in self.eng.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=False):
+        if self.what == 'optimizer':
+            return self.eng.load_optimizer_state_dict(sd)
+        if self.what == 'scheduler':
+            return self.eng.load_scheduler_state_dict(sd)
+        self.eng.load_model_state_dict(sd)
+        return torch.nn.modules.module._IncompatibleKeys([], [])
 
 
 class CaptionUniPipeline(object):
@@ -76,14 +89,17 @@ class CaptionUniPipeline(object):
         return op.join(self.output_folder, 'snapshot')
 
     def get_checkpoint_file(self, iteration=None):
+        """uni_pipeline.py:614-622: `model_file` if given (and no iteration asked for), else snapshot/model_iter_<max_iter>.pt.
+        `basemodel` is the training INIT only (..._bertemb.py:259-267) and never the file that is evaluated."""
+        if iteration is None and self.cfg.model_file is not None:
+            return self.cfg.model_file
         it = self.cfg.max_iter if iteration is None else iteration
         if isinstance(it, str):
             raise ValueError("max_iter given in epochs ('%s') needs the training set; use an integer" % it)
         return op.join(self.get_snapshot_dir(), 'model_iter_{:07d}.pt'.format(int(it)))
 
     def is_train_finished(self):
-        f = self.get_checkpoint_file()
-        return op.isfile(f) or bool(self.cfg.basemodel and op.isfile(self.cfg.basemodel))
+        return op.isfile(self.get_checkpoint_file())
 
     def get_predict_file(self, model_file):
         cc = [model_file, self.cfg.test_data or 'synthetic', self.cfg.test_split or 'test']
@@ -120,6 +136,10 @@ class CaptionUniPipeline(object):
         extra = {'max_length': self.cfg.max_gen_length, 'num_beams': self.cfg.num_beams,
                  'temperature': self.cfg.temperature, 'top_k': self.cfg.top_k, 'top_p': self.cfg.top_p,
                  'add_od_labels': self.cfg.add_od_labels, 'od_labels_start_posid': self.cfg.max_seq_a_length}
+        for k in ('repetition_penalty', 'length_penalty', 'num_keep_best', 'do_sample', 'num_return_sequences', 'use_cbs',
+                  'use_graph'):          # optional YAML keys forwarded to generate() when present
+            if getattr(self.cfg, k) is not None:
+                extra[k] = getattr(self.cfg, k)
         return ImageCaptioning(tie_weights=bool(self.cfg.tie_weights), tagemb=self.cfg.tagemb or 'bert',
                                test_extra_input=extra, cfg=self.cfg).eval()
 
@@ -134,19 +154,23 @@ class CaptionUniPipeline(object):
         return model
 
     # ------------------------------------------------------------------ entry points used by run.py
-    def iter_train_batches(self, per_gpu):
-        """`data: synthetic` -> endless seeded batches with the training collate's layout (per-rank seeds)."""
+    def iter_train_batches(self, per_gpu, start_iter=0):
+        """`data: synthetic` -> endless seeded batches with the training collate's layout (per-rank seeds).  `start_iter`
+        batches are skipped so that a resumed job sees the batches the uninterrupted one would have seen."""
         if self.cfg.train_batches is not None:
+            n = 0
             while True:
                 for b in self.cfg.train_batches:
-                    yield b
+                    n += 1
+                    if n > start_iter:
+                        yield b
         if self.cfg.data and self.cfg.data != 'synthetic':
-            for b in self.real_train_batches(per_gpu):
+            for b in self.real_train_batches(per_gpu, start_iter):
                 yield b
             return
         from . import weights as W
         from .synthetic import synthetic_train_inputs
-        it = 0
+        it = start_iter
         while True:
             seed = D.shard_seed(int(self.cfg.synthetic_seed or 1234), self.rank) + 1000 * it
             batch = synthetic_train_inputs(per_gpu, seed=seed)
@@ -157,7 +181,7 @@ class CaptionUniPipeline(object):
             yield batch
             it += 1
 
-    def real_train_batches(self, per_gpu):
+    def real_train_batches(self, per_gpu, start_iter=0):
         """`data: <name>` -> data/<name>/train.tsv (+ .caption.tsv, optional .label / .num_caption): the reference's training
         transform chain (get_transform(is_train=True), ..._bertemb.py:373-518) via vitcap_amd/dataset.py; images are cropped,
         resized, jittered, flipped and normalised on this rank's GPU."""
@@ -186,7 +210,7 @@ class CaptionUniPipeline(object):
                              augmentation=TrainAugmentation(seed=seed, small_scale=c.input_small_scale))
         tf = TrainImagePreprocessor(torch.device('cuda', self.local_rank), train_crop_size=int(c.train_crop_size))
         return TrainBatchLoader(ds, per_gpu, tf, rank=self.rank, world=self.world, seed=seed, workers=int(c.num_workers),
-                                want_captions=bool(c.scst))
+                                want_captions=bool(c.scst), start_iter=start_iter)
 
     def ensure_train(self):
         """do_train_dict (trainer.py:33-213) on the HIP training engine: per-GPU batch = effective_batch_size // world,
@@ -230,15 +254,24 @@ class CaptionUniPipeline(object):
                           max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist,
                           attn_dropout=attn_drop, dropout_seed=int(self.cfg.random_seed or 0))
         per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
-        ckpt = Checkpointer(model=_EngineState(eng), save_dir=self.get_snapshot_dir(), save_to_disk=self.rank == 0)
+        ckpt = Checkpointer(model=_EngineState(eng), optimizer=_EngineState(eng, 'optimizer'),
+                            scheduler=_EngineState(eng, 'scheduler'), save_dir=self.get_snapshot_dir(),
+                            save_to_disk=self.rank == 0)
+        # resume (checkpoint.py recover_or_load + trainer.py:95 start_iter): an interrupted job continues from the latest
+        # snapshot named by snapshot/last_checkpoint -- parameters, AdamW moments, step count and LR schedule
+        start_iter = 0
+        if ckpt.has_checkpoint() and not self.cfg.force_train:
+            extra = ckpt.load()
+            start_iter = int(extra.get('iteration', 0))
+            logging.info('resuming from %s at iteration %d', ckpt.get_checkpoint_file(), start_iter)
         t0, log_step = time.time(), int(self.cfg.log_step)
-        batches = self.iter_train_batches(per_gpu)
+        batches = self.iter_train_batches(per_gpu, start_iter=start_iter)
         scst = None
         if self.cfg.scst:          # BASELINE config 5 (..._expanding.py:404-478): self-critical step instead of cross-entropy
             from .scst import ScstTrainer
             scst = ScstTrainer(model, eng, self.tokenizer, num_return=int(self.cfg.scst_num_return or 5),
                                seed=int(self.cfg.random_seed or 0) + self.rank)
-        for it in range(1, max_iter + 1):
+        for it in range(start_iter + 1, max_iter + 1):
             b = next(batches)
             b = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
             if scst is not None:
@@ -255,7 +288,9 @@ class CaptionUniPipeline(object):
                 t0 = time.time()
             if it % int(self.cfg.snapshot_steps) == 0 or it == max_iter:
                 ckpt.save('model_iter_{:07d}'.format(it), iteration=it)
-        return self.get_checkpoint_file()
+        if dist is not None:
+            dist.barrier()      # uni_pipeline.py:376 synchronize(): no rank may reach ensure_predict before rank 0's final snapshot exists
+        return self.get_checkpoint_file(iteration=max_iter)
 
     def iter_test_batches(self):
         """Per-rank shard of the test set.  `data: synthetic` -> seeded images, keys '<rank>_<i>'."""
@@ -320,15 +355,19 @@ class CaptionUniPipeline(object):
 
         te = model.test_extra_input
         overlap = not te.get('do_sample', False)
-        nb, lpn = int(te.get('num_beams', 1)), float(te.get('length_penalty', 1))
+        # the same option validation ImageCaptioning.forward applies (max_length, repetition_penalty, num_keep_best, use_cbs,
+        # token ids ...): an option this build does not implement raises here instead of being decoded with defaults
+        popts = model.gen_options(gemm_mode=1) if overlap else None
 
         def gen_rows():
-            pending = []                          # greedy: batch i decodes while batch i+1 is encoded (generate_async)
+            pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
             with torch.no_grad():
                 for batch in self.iter_test_batches():
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
-                    pending.append((batch, model.generate_async(batch['image'], nb, lpn) if overlap else model(batch)))
+                    if overlap:
+                        model.check_text_inputs(batch, popts.max_length)
+                    pending.append((batch, model.generate_async(batch['image'], opts=popts) if overlap else model(batch)))
                     while len(pending) > (1 if overlap else 0):
                         b, out = pending.pop(0)
                         out = out.result() if overlap else out
@@ -360,8 +399,7 @@ class CaptionUniPipeline(object):
             return None
         self._ensure_initialized()
         if model_file is None:
-            model_file = self.cfg.basemodel if (self.cfg.basemodel and op.isfile(self.cfg.basemodel)) \
-                else self.get_checkpoint_file()
+            model_file = self.get_checkpoint_file()        # uni_pipeline.py:680-683; never `basemodel`
         predict_result_file = self.get_predict_file(model_file)
         if not op.isfile(model_file) and self.cfg.init_recipe_seed is None:
             logging.info('ignore to run predict since %s does not exist', model_file)

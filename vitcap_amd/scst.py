@@ -140,15 +140,12 @@ class ScstTrainer(object):
         g_ids = g_ids.clone()
         # the K samples of an image share its encoder pass and visual K/V (generation) and its encoder forward / backward
         # (training): what the reference computes on K-times expanded inputs, without the K-fold repetition of the ViT
-        self.model.set_sampling(True, 1.0, 0, 1.0, self.seed + 0x9e3779b1 * self.iter)
-        try:
-            if K <= 8:
-                s_ids, _, raw_last = self.model.generate_multi(images, K, want_last=True)
-            else:
-                s_ids, _ = self.model.generate(images.repeat_interleave(K, 0).contiguous())
-                raw_last = self.model.tap('last_token', B * K, (B * K,), torch.int64)
-        finally:
-            self.model.set_sampling(False)
+        seed = (self.seed + 0x9e3779b1 * self.iter) & 0xffffffff
+        samp = dict(temperature=1.0, top_k=0, top_p=1.0, seed=seed)
+        if K <= 8:
+            s_ids, _, raw_last = self.model.generate_multi(images, K, want_last=True, **samp)
+        else:
+            s_ids, _, raw_last = self.model.generate_multi(images.repeat_interleave(K, 0).contiguous(), 1, want_last=True, **samp)
         s_ids = s_ids[:, 0].clone()
         reward, score = scst_rewards(gt_captions, self._decode(g_ids[:, 0].cpu()), self._decode(s_ids.cpu()), self.scorer)
         fed = s_ids.clone()

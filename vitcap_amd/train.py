@@ -184,8 +184,12 @@ class _FusedLoss(torch.autograd.Function):
         if not eng._pending:
             raise RuntimeError('backward() called twice on the loss of one fused training forward')
         eng._pending = False
-        eng.G.mul_(g.to(eng.G.dtype))          # d(sum of losses)/d(masked_loss), 1 in do_train_dict
+        # forward_backward() already launched the per-bucket all-reduce (+ 1/world scaling) of this same flat buffer on the
+        # communication stream: join it BEFORE touching G on the compute stream, or the multiply races with the reduce and the
+        # ranks end up with different gradients
         eng.all_reduce_grads()
+        if float(g) != 1.0:                     # d(sum of losses)/d(masked_loss), 1 in do_train_dict (trainer.py:117-119)
+            eng.G.mul_(g.to(eng.G.dtype))
         return None, None, None
 
 
@@ -247,6 +251,33 @@ class TrainEngine(object):
 
     def state_dict(self):
         return {k: self.p(k).detach().clone() for k in W.state_dict_spec()}
+
+    # optimizer / scheduler payloads of the reference checkpoint (src/tools/opt/checkpoint.py:60-75 saves
+    # optimizer.state_dict() and scheduler.state_dict() next to the model; trainer.py:95 resumes from 'iteration')
+    def optimizer_state_dict(self):
+        return {'format': 'vitcap_amd.flat_adamw.v1', 'nflat': self.nflat, 'step': self.step_no,
+                'exp_avg': self.M.detach().cpu(), 'exp_avg_sq': self.V.detach().cpu()}
+
+    def load_optimizer_state_dict(self, sd):
+        if sd.get('format') != 'vitcap_amd.flat_adamw.v1' or int(sd.get('nflat', -1)) != self.nflat:
+            raise ValueError('optimizer state of another layout (%r, %r elements; this engine holds %d)'
+                             % (sd.get('format'), sd.get('nflat'), self.nflat))
+        self.M.copy_(sd['exp_avg'])
+        self.V.copy_(sd['exp_avg_sq'])
+        self.step_no = int(sd['step'])
+
+    def scheduler_state_dict(self):
+        return {'last_epoch': self.step_no, 'lr_scale': self.lr_scale, 't_total': self.max_iter}
+
+    def load_scheduler_state_dict(self, sd):
+        self.lr_scale = float(sd['lr_scale'])
+
+    def load_model_state_dict(self, sd):
+        """Parameters from a checkpoint's 'model' dict (resume): flat fp32 master copy + the bf16 GEMM operands."""
+        for k in W.state_dict_spec():
+            if k in sd:
+                self.p(k).copy_(sd[k])
+        self.refresh_weights()
 
     # ------------------------------------------------------------------ bf16 operands of the GEMMs
     def _matrices(self):

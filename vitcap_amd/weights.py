@@ -14,6 +14,19 @@ The key names and shapes are the reference's checkpoint layout (SURVEY.md sectio
 Unlike the reference's own init (zeros for biases, ones for LayerNorm gains --
 src/layers/bert/modeling_bert.py:578-589, timm vision_transformer.py:391-398) every tensor gets
 non-trivial values here so that a dropped bias or gain shows up in the parity tests.
+
+Recipe version 2 (round 2), made so that token-exact comparison of the bf16 device path with the fp32
+reference is well conditioned (SURVEY.md section 7 "hard parts", measured in DESIGN.md section 5):
+
+* every matrix / embedding table ('w' kind) is rounded to the nearest bfloat16 value, so the fp32
+  reference and the bf16 device path hold IDENTICAL weights and only activation rounding separates them
+  (logit noise 3.0e-3 -> 1.8e-3 rms);
+* the two vocabulary biases (``*.predictions.bias``, kind 'vbias') follow a unigram-like prior: a
+  sum of 12 uniforms (Irwin-Hall, std 1 nat, exact in fp32 adds) instead of uniform(+-0.035) -- trained
+  heads have such a prior, and it is noise-free on both sides (biases stay fp32), which widens the typical
+  top-2 margin without touching the data-dependent part of the logits;
+* the [SEP] bias equals the largest bias of the table, so [SEP] is a live candidate at every step
+  (beam hypotheses finish at many lengths) without winning the greedy argmax outright.
 """
 import hashlib
 import zlib
@@ -66,7 +79,7 @@ def _bert_embeddings(prefix):
 
 def _lm_head(prefix):
     d = OrderedDict()
-    d[prefix + '.predictions.bias'] = ((VOCAB,), 'bias')
+    d[prefix + '.predictions.bias'] = ((VOCAB,), 'vbias')
     d[prefix + '.predictions.transform.dense.weight'] = ((HIDDEN, HIDDEN), 'w')
     d[prefix + '.predictions.transform.dense.bias'] = ((HIDDEN,), 'bias')
     d[prefix + '.predictions.transform.LayerNorm.weight'] = ((HIDDEN,), 'ln_w')
@@ -142,18 +155,43 @@ def _hash_u32(key, n):
     return x
 
 
-def gen_tensor(name, shape, kind, seed=0):
-    """One tensor of the recipe as a float32 numpy array (bit-reproducible)."""
-    n = int(np.prod(shape))
+RECIPE_VERSION = 2
+VBIAS_STD = np.float32(1.0)      # nats; Irwin-Hall(12) has unit variance
+SEP_ID = 102
+
+
+def bf16_round(a):
+    """float32 array -> nearest-even bfloat16 value, still stored as float32 (pure integer arithmetic)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).reshape(-1).view(np.uint32).astype(np.uint64)
+    u = (u + np.uint64(0x7fff) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xffff0000)
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def _uniform01(name, n, seed):
     key = zlib.crc32(('%d|%s' % (seed, name)).encode()) & 0xffffffff
     with np.errstate(over='ignore'):
         x = _hash_u32(key, n)
-    u = (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)      # [0, 1), exact
+    return (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)      # [0, 1), exact
+
+
+def gen_tensor(name, shape, kind, seed=0):
+    """One tensor of the recipe as a float32 numpy array (bit-reproducible)."""
+    n = int(np.prod(shape))
+    if kind == 'vbias':
+        acc = np.zeros(n, dtype=np.float32)
+        for j in range(12):                       # fixed order: every add is one IEEE fp32 operation
+            acc = acc + _uniform01('%s|g%d' % (name, j), n, seed)
+        out = (acc - np.float32(6.0)) * VBIAS_STD
+        out[SEP_ID] = out.max()
+        return out.reshape(shape)
+    u = _uniform01(name, n, seed)
     v = u * np.float32(2.0) - np.float32(1.0)                              # [-1, 1), exact
     a = np.float32(_STD[kind]) * _SQRT3
     out = v * a
     if kind == 'ln_w':
         out = out + np.float32(1.0)
+    if kind == 'w':
+        out = bf16_round(out)
     return out.reshape(shape)
 
 
