@@ -54,13 +54,29 @@ def comparable_prefix(margins_row, floor):
     return int(below[0]) if len(below) else len(margins_row)
 
 
-def assert_tokens_match_reference(got_ids, want_ids, margins, floor, min_full=1, what=''):
+def relevant_margins(want_row, margins_row, eos):
+    """Margins of the decisions that can change the returned ids: the reference records one per step for every row, also after
+    the row has finished (those tokens are replaced by PAD, modeling_utils.py:855-858) and at the last position, where an
+    unfinished row gets the forced EOS whatever was chosen (modeling_utils.py:870-871)."""
+    import numpy as np
+    m = np.array(margins_row, dtype=np.float64)
+    L = len(want_row)
+    hits = [k for k in range(1, L) if want_row[k] == eos]
+    end = hits[0] if hits else L - 1           # position of the terminating EOS (chosen or forced)
+    m[end:] = np.inf                           # decisions for positions > end
+    if not hits or hits[0] == L - 1:
+        m[L - 2] = np.inf                      # the last position's choice does not reach the ids
+    return m
+
+
+def assert_tokens_match_reference(got_ids, want_ids, margins, floor, min_full=1, what='', eos=102):
     """got_ids / want_ids: (B, n_best, 20) with n_best == 1 for the comparison; margins (B, 19), decision t-1 picks the
     token at position t.  Asserts got == want on every sequence's comparable prefix (positions 0..p where p = number of
     leading above-floor decisions) and on the WHOLE sequence when all its decisions are above the floor; at least `min_full`
     sequences must be whole-sequence comparable so that the test cannot pass vacuously.  Returns the per-sequence status."""
     import numpy as np
     got, want = np.asarray(got_ids)[:, 0], np.asarray(want_ids)[:, 0]
+    margins = np.stack([relevant_margins(want[b], margins[b], eos) for b in range(want.shape[0])])
     full, report = 0, []
     for b in range(want.shape[0]):
         p = comparable_prefix(margins[b], floor)

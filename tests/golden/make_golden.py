@@ -299,6 +299,16 @@ def main():
     out['greedy_sel_logprobs'] = lp.numpy().copy()
     out['greedy_sel_margins'] = m
     print('greedy selected', ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    # the alternative EOS on the well-conditioned images too: whole captions of different lengths are comparable
+    cap = out['greedy_sel_ids'][:, 0]
+    cands = [t for t in np.unique(cap[:, 2:19]) if t not in (0, 101, 102)]
+    alt2 = int(max(cands, key=lambda t: (len(set(first_pos(t))), -min(first_pos(t)))))
+    ids, lp, m = ref_generate(model, enc, cand[sel], eos_token_ids=[alt2])
+    out['alt_eos_sel_id'] = np.array([alt2])
+    out['greedy_alteos_sel_ids'] = ids.numpy().copy()
+    out['greedy_alteos_sel_logprobs'] = lp.numpy().copy()
+    out['greedy_alteos_sel_margins'] = m
+    print('greedy selected, alt eos %d' % alt2, ids.tolist(), lp.tolist())
     # also store the reference's own step-1 logits row for a direct float comparison
     with torch.no_grad():
         input_ids, am = O.test_text_inputs(1)

@@ -92,7 +92,7 @@ def test_run_py_eval_on_image_tsv(tmp_path, monkeypatch):
     ck = tmp_path / 'base.pt'
     torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'iteration': 0}, ck)
     cfg = {'type': 'pipeline_eval_multi', 'all_test_data': [{'test_data': 'toy', 'test_split': 'test'}],
-           'param': {'full_expid': 'E', 'max_iter': 10, 'basemodel': str(ck), 'text_encoder_type': str(enc), 'tagemb': 'cls',
+           'param': {'full_expid': 'E', 'max_iter': 10, 'model_file': str(ck), 'text_encoder_type': str(enc), 'tagemb': 'cls',
                      'test_batch_size': 2, 'force_predict': True, 'crop_pct': 1.0, 'test_crop_size': 384,
                      'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
     yf = tmp_path / 'exp.yaml'

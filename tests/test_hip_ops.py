@@ -108,6 +108,35 @@ def test_gemm_skinny_splitk(ops, M, N, K, split):
         _close(got, want + bias.cpu(), 1e-4, 1e-4, 'skinny')
 
 
+@pytest.mark.parametrize('M,N,K,hint,act', [(128, 2304, 768, 20, 'none'), (128, 3072, 768, 20, 'gelu'), (128, 768, 768, 21, 'none'),
+                                            (128, 768, 3072, 20, 'slabs'), (64, 768, 768, 21, 'none'), (2, 2304, 768, 20, 'none'),
+                                            (130, 768, 3072, 22, 'slabs'), (256, 2304, 768, 22, 'none')])
+def test_gemm_resident_whole_k(ops, M, N, K, hint, act):
+    """Resident form of the decode-step GEMMs (tile_hint 20/21/22): the whole 768-long k range of a tile is requested at once;
+    K = 3072 is cut into 4 partial slabs."""
+    from vitcap_amd import _lib as L
+    a = _bf(_rand((M, K), 50)).cuda()
+    w = _bf(_rand((N, K), 51, 0.05)).cuda()
+    bias = _rand((N,), 52, 0.1).cuda()
+    z = a.float().cpu() @ w.float().cpu().t()
+    if act == 'slabs':
+        out = torch.empty((K // 768, M, N), device='cuda', dtype=torch.float32)
+        ops.gemm_bias_act(a, w, None, out=out, tile_hint=hint)
+        for i in range(K // 768):
+            zi = a.float().cpu()[:, i * 768:(i + 1) * 768] @ w.float().cpu()[:, i * 768:(i + 1) * 768].t()
+            _close(out[i], zi, 1e-4, 1e-4, 'resident slab %d' % i)
+        _close(out.sum(0), z, 1e-4, 1e-4, 'resident slab sum')
+    elif act == 'gelu':
+        got = ops.gemm_bias_act(a, w, bias, act=L.ACT_GELU_ERF, tile_hint=hint)
+        _close(got, torch.nn.functional.gelu(z + bias.cpu()), 2 ** -7, 2e-3, 'resident gelu')
+    else:
+        got = ops.gemm_bias_act(a, w, bias, out_dtype=torch.float32, tile_hint=hint)
+        _close(got, z + bias.cpu(), 1e-4, 1e-4, 'resident f32')
+        x = _rand((M, N), 53).cuda()
+        got = ops.gemm_bias_act(a, w, bias, residual=x, out_dtype=torch.float32, tile_hint=hint)
+        _close(got, z + bias.cpu() + x.cpu(), 1e-4, 1e-4, 'resident f32 + residual')
+
+
 @pytest.mark.parametrize('act', [False, True])
 def test_sum_layernorm(ops, act):
     S, M = 6, 130

@@ -133,6 +133,12 @@ def test_greedy_alternative_eos_matches_reference(golden, sd_t):
     np.testing.assert_allclose(lp.numpy(), vec['greedy_alteos_b4_logprobs'], rtol=1e-5, atol=1e-5)
     lens = [(r != 0).sum() for r in vec['greedy_alteos_b4_ids'][:, 0]]
     assert len(set(lens)) >= 2, 'the alternative-EOS golden is meant to exercise different caption lengths'
+    eos = int(vec['alt_eos_sel_id'][0])
+    cand = torch.from_numpy(W.gen_image_batch(16, int(vec['sel_image_seed'][0])))[torch.from_numpy(vec['sel_index'])]
+    with torch.no_grad():
+        ids, lp = O.greedy_incremental(sd_t, cand, emulate_bf16=False, eos=eos)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_alteos_sel_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_alteos_sel_logprobs'], rtol=1e-5, atol=1e-5)
 
 
 def test_greedy_selected_images_match_reference(golden, sd_t):

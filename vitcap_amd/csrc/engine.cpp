@@ -51,6 +51,8 @@ struct vitcap_engine {
   std::mutex mu;
   // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
   hipStream_t side = nullptr;
+  hipStream_t cap = nullptr;          // the decode loop is CAPTURED on this engine-owned stream (capture executes nothing), so the
+                                      // caller's stream may be any stream, the legacy default stream included
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool full_last_tag_block = false;   // VITCAP_FULL_TAG_BLOCK=1: compute all 577 rows of tag_blocks[3] (parity taps / measurements)
   bool fork_tag_branch = true;
@@ -247,6 +249,20 @@ int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int
   return gemm_desc(A, W, nullptr, nullptr, partials, d, s);
 }
 
+// Decode-step GEMMs with few rows (M <= 256): the "resident" kernel form requests the whole 768-long k range of a tile at
+// once (one memory round trip instead of four dependent ones: 9.3 -> ~5.5 us per launch at M = 128).  Returns the number of
+// fp32 partial slabs written (K / 768) when `partials` is used, 0 for a finished output.
+int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M, int N, int K, int act, int out,
+               int hint, void* s) {
+  vitcap_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K;
+  d.lda = lda; d.ldw = K; d.ldc = ldc;
+  d.act = act; d.out_dtype = out;
+  d.tile_hint = hint;
+  return gemm_desc(A, W, bias, nullptr, C, d, s);
+}
+
 #define CK(call)             \
   do {                       \
     int rc_ = (call);        \
@@ -302,6 +318,7 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->cap) (void)hipStreamDestroy(e->cap);
   delete e;
 }
 extern "C" int vitcap_engine_graph_count(vitcap_engine* e) { return e ? (int)e->graphs.size() : 0; }
@@ -543,29 +560,62 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
   CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
                        NS, s));
   float* part = (float*)(ws + lo.spart);
+  static const int force_old = [] { const char* e = getenv("VITCAP_DECODE_SPLITK"); return e ? atoi(e) : 0; }();   // A/B measurements
+  const bool small = R <= 256 && !force_old;      // resident whole-K kernels (greedy / sampling batches); beams keep the split-K path
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
     char* tc = tcache + (size_t)l * NS * L * 2 * D * 2;
-    CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE,
-            VITCAP_OUT_BF16, s));
+    if (small)
+      CK(gemm_small(xs_b, D, lw.qkv_w, lw.qkv_b, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, 20, s));
+    else
+      CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
     CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, NS, SV, t, L, K, 0.125f, s));
-    // attention.output.dense and output.dense: split-K partial slabs, reduced inside the fused
-    // bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
-    CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
-    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
+    // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),
+    // reduced inside the fused bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
+    int s_ao = SPLIT_AO, s_fc2 = SPLIT_FC2;
+    if (small) {
+      CK(gemm_small(ws + lo.sctx, D, lw.ao_w, nullptr, part, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
+      s_ao = 1;
+    } else {
+      CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
+    }
+    CK(vitcap_sum_layernorm(part, s_ao, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
                             ws + lo.sa_b, (float*)(ws + lo.sa_f), R, D, s));
-    CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
-            VITCAP_OUT_BF16, s));
-    CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
-    CK(vitcap_sum_layernorm(part, SPLIT_FC2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
+    if (small)
+      CK(gemm_small(ws + lo.sa_b, D, lw.i_w, lw.i_b, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, 20, s));
+    else
+      CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
+              VITCAP_OUT_BF16, s));
+    if (small) {
+      CK(gemm_small(ws + lo.smlp, 4 * D, lw.o_w, nullptr, part, D, R, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 20, s));
+      s_fc2 = 4;
+    } else {
+      CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
+    }
+    CK(vitcap_sum_layernorm(part, s_fc2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
                             lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
   }
   // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
-  CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, NS, D, D, SPLIT_AO, s));
-  CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
-                          ws + lo.hd_b, nullptr, NS, D, s));
-  CK(gemm(ws + lo.hd_b, D, w.cls.dec_w, w.cls.dec_b, nullptr, 0, ws + lo.logits, VP, NS, VP, D, VITCAP_ACT_NONE,
-          VITCAP_OUT_F32, s));
+  if (small) {
+    CK(gemm_small(xs_b + D * 2, 2 * D, w.cls.dense_w, nullptr, part, D, NS, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
+    CK(vitcap_sum_layernorm(part, 1, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
+                            ws + lo.hd_b, nullptr, NS, D, s));
+  } else {
+    CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, NS, D, D, SPLIT_AO, s));
+    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
+                            ws + lo.hd_b, nullptr, NS, D, s));
+  }
+  {
+    // vocabulary GEMM: 47 MB of weights streamed once per step.  With few rows (greedy: NS <= 128) the 64x64-tile kernel
+    // moves them at 3.8 TB/s against 2.3 TB/s for the 32x32 tiles the small-M dispatch would pick (12.5 vs 20.8 us at NS = 64)
+    vitcap_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = NS; d.N = VP; d.K = D;
+    d.lda = D; d.ldw = D; d.ldc = VP;
+    d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
+    d.tile_hint = NS <= 128 ? 1 : 0;
+    CK(gemm_desc(ws + lo.hd_b, w.cls.dec_w, w.cls.dec_b, nullptr, ws + lo.logits, d, s));
+  }
   return VITCAP_OK;
 }
 
@@ -656,9 +706,10 @@ static int decode_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, cons
       // step index, option values), which is why the key holds all of them
       GraphEntry g;
       g.B = B; g.ws = (void*)ws; g.opts = o; g.graph = nullptr; g.exec = nullptr;
-      HIPCK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "decode: begin capture");
-      const int rc = decode_loop(e, B, lo, o, ws, s);
-      const hipError_t he = hipStreamEndCapture(st, &g.graph);
+      if (!e->cap) HIPCK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking), "decode: capture stream");
+      HIPCK(hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal), "decode: begin capture");
+      const int rc = decode_loop(e, B, lo, o, ws, (void*)e->cap);
+      const hipError_t he = hipStreamEndCapture(e->cap, &g.graph);
       if (rc != VITCAP_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
       HIPCK(he, "decode: end capture");
       HIPCK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0), "decode: graph instantiate");

@@ -1370,6 +1370,48 @@ int launch(const GemmArgs& a, hipStream_t s) {
   return VITCAP_OK;
 }
 
+// "Resident" form for the decode-step shapes (M <= 256 rows, K a multiple of 768): NST = 12 stages = the WHOLE 768-long k
+// range of the workgroup is requested by LDS-DMA in the prologue (one HBM/L2 round trip instead of 12 / (NST-1) dependent
+// ones), then multiplied.  K > 768 is cut into K / 768 splits (blockIdx.y) that write fp32 partial slabs, summed by
+// vitcap_sum_layernorm.  LDS: 12 * (BM + BN) * 128 B <= 160 KiB, i.e. BM + BN <= 96.
+template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES>
+int launch_resident(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NST = 12;
+  constexpr int smem = NST * (BM + BN) * 64 * 2;
+  static_assert(smem <= 160 * 1024, "resident tile does not fit the LDS");
+  auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES, NST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
+  const int splits = a.K / 768;
+  if (splits > 1) {
+    p.split_k = splits;
+    p.kt_per_split = 12;
+    p.slab = (size_t)a.M * a.ldc;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, splits), dim3(256), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt(resident)");
+  return VITCAP_OK;
+}
+
+template <int WM, int WN>
+int dispatch_resident(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+  const bool res = a.res != nullptr;
+  if (a.K > 768) return launch_resident<WM, WN, VITCAP_ACT_NONE, 1, false>(a, s);      // partial slabs only
+  if (act == VITCAP_ACT_NONE && !out_f32 && !res) return launch_resident<WM, WN, VITCAP_ACT_NONE, 0, false>(a, s);
+  if (act == VITCAP_ACT_NONE && out_f32 && !res) return launch_resident<WM, WN, VITCAP_ACT_NONE, 1, false>(a, s);
+  if (act == VITCAP_ACT_NONE && out_f32 && res) return launch_resident<WM, WN, VITCAP_ACT_NONE, 1, true>(a, s);
+  if (act == VITCAP_ACT_GELU_ERF && !out_f32 && !res) return launch_resident<WM, WN, VITCAP_ACT_GELU_ERF, 0, false>(a, s);
+  if (act == VITCAP_ACT_GELU_ERF && out_f32 && !res) return launch_resident<WM, WN, VITCAP_ACT_GELU_ERF, 1, false>(a, s);
+  vitcap_set_error("gemm(resident): unsupported epilogue act=%d out=%d res=%d", act, out_f32, (int)res);
+  return VITCAP_EINVAL;
+}
+
 template <int WM, int WN>
 int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   const bool res = a.res != nullptr;
@@ -1443,6 +1485,15 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   const int hint = d->tile_hint;
   const int split_k = d->split_k > 1 ? d->split_k : 1;
   const bool plain_rows = d->row_group == 0;
+  if (hint == 20 || hint == 21 || hint == 22) {
+    // resident whole-K form (decode-step shapes); K > 768 -> K/768 fp32 partial slabs in C = [K/768][M][ldc]
+    VC_REQUIRE(d->K % 768 == 0 && plain_rows && !aux_bf16 && !zout_bf16, "gemm(resident): needs K %% 768 == 0, plain rows, no training extras");
+    VC_REQUIRE(d->K == 768 || (d->out_dtype == VITCAP_OUT_F32 && !bias && !residual && d->act == VITCAP_ACT_NONE),
+               "gemm(resident): K > 768 writes raw fp32 partial slabs");
+    if (hint == 20) return dispatch_resident<2, 1>(a, d->act, d->out_dtype, s);     // 64 x 32 tiles
+    if (hint == 21) return dispatch_resident<1, 1>(a, d->act, d->out_dtype, s);     // 32 x 32
+    return dispatch_resident<1, 2>(a, d->act, d->out_dtype, s);                     // 32 x 64
+  }
   if (split_k > 1 && d->M > 256) {
     // weight-gradient shape: few output tiles, very long K -> 128x128 tiles with ragged split-K into fp32 slabs
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && plain_rows && !aux_bf16 && !zout_bf16, "gemm: split-K writes fp32 partial slabs only");
