@@ -75,6 +75,10 @@ typedef struct {
   const int32_t* live; /* optional device counter: the kernel returns at entry when *live == 0 (decode loop after every
                           sequence has finished -- the reference's `if cur_unfinished.max() == 0: break`,
                           modeling_utils.py:866; NULL = always run).  Honoured by the small-M (decode) kernels. */
+  float* rowstat;      /* optional, fp32 [M][2*ceil(N/64)][4]: per row and 32-column piece {max, column of the max (int bits,
+                          lowest on ties), sum exp(x - max), 0} of the finished values -- what argmax / log_softmax over the
+                          row are assembled from (vitcap_greedy_select_embed) without reading C back.  Needs fp32 output,
+                          no activation / residual; 64x64 tiles. */
 } vitcap_gemm_desc;
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
@@ -198,6 +202,15 @@ int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_
 /* raw_last (optional, int64 [B]): at t == max_len-1 the token actually chosen at the last position, before it is
  * overwritten by [SEP] for unfinished rows -- the returned log-prob is that of the chosen token (modeling_utils.py:
  * 850-877), which a teacher-forced re-computation of the sequence probability needs. */
+
+/* The same step taken from the vocabulary GEMM's row statistics (vitcap_gemm_desc.rowstat, `pieces` = 2*ceil(V_pad/64) per row)
+ * instead of the logits, fused with BertEmbeddings.forward for step t+1 (vitcap_embed_step): token choice, log-prob and
+ * bookkeeping exactly as vitcap_greedy_step; then x rows (b,0) = LN(word[ids[b][t]] + pos[t] + type[0]),
+ * (b,1) = LN(word[mask] + pos[t+1] + type[0]) unless t == max_len-1.  One launch instead of three per decode step. */
+int vitcap_greedy_select_embed(const float* rowstat, int pieces, int64_t* ids, int32_t* unfinished, float* sum_lp, float* cnt,
+                               float* logprob_out, int64_t* raw_last, int B, int t, int max_len, int eos, int pad,
+                               int mask_token, const void* word_emb, const void* pos_emb, const void* type_emb,
+                               const float* gamma, const float* beta, float eps, float* x_f32, void* x_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling variant of the step above (do_sample=True, modeling_utils.py:839-846 + top_k_top_p_filtering

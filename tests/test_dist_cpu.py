@@ -88,7 +88,7 @@ def test_grad_buckets_cover_exactly_the_tensors_that_get_gradients():
         assert max(sizes) < 128 and sum(s > 32 for s in sizes) >= 10      # MB: few large messages
 
 
-def _reduce_worker(rank, world, port, out):
+def _reduce_worker(rank, world, port, out, algo='all_reduce'):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     from vitcap_amd import dist_util as D
@@ -97,8 +97,8 @@ def _reduce_worker(rank, world, port, out):
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(n, generator=g)
     mine = flat.clone()
-    buckets = {'last': [(3000, 4000)], 'mid': [(1024, 2048), (2100, 2900)], 'first': [(0, 1000)]}
-    red = D.BucketedAllReduce(flat, buckets, ['last', 'mid', 'first'], dist)
+    buckets = {'last': [(3000, 4000)], 'mid': [(1024, 2048), (2100, 2901)], 'first': [(0, 1000)]}    # 801: odd, exercises the tail
+    red = D.BucketedAllReduce(flat, buckets, ['last', 'mid', 'first'], dist, algo=algo)
     red.begin()
     err = None
     try:
@@ -123,11 +123,14 @@ def _reduce_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucketed_all_reduce_two_ranks_gloo():
+@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag'])
+def test_bucketed_all_reduce_two_ranks_gloo(algo):
+    """Both gradient-exchange algorithms (one all-reduce per range / reduce-scatter + scale own slice + all-gather) give every
+    rank the mean of the ranks' buckets and leave everything outside the buckets untouched."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
@@ -138,7 +141,7 @@ def test_bucketed_all_reduce_two_ranks_gloo():
     assert e0 and 'out of order' in e0 and e1 and c0 and c1
     mean = (m0 + m1) / 2                        # after step 1 both hold the mean; step 2 averages two equal copies
     inside = torch.zeros(4096, dtype=torch.bool)
-    for a, b in ((3000, 4000), (1024, 2048), (2100, 2900), (0, 1000)):
+    for a, b in ((3000, 4000), (1024, 2048), (2100, 2901), (0, 1000)):
         inside[a:b] = True
     assert torch.allclose(f0[inside], mean[inside]) and torch.equal(f0[inside], f1[inside])
     assert torch.equal(f0[~inside], m0[~inside]) and torch.equal(f1[~inside], m1[~inside])   # untouched outside buckets

@@ -137,6 +137,55 @@ def test_gemm_resident_whole_k(ops, M, N, K, hint, act):
         _close(got, z + bias.cpu() + x.cpu(), 1e-4, 1e-4, 'resident f32 + residual')
 
 
+def test_greedy_select_embed_equals_step_plus_embed(ops):
+    """The fused greedy step (vocabulary GEMM row statistics -> token, log-prob, bookkeeping, next step's embedding) against
+    the three separate kernels it replaces, over a whole 19-step loop with early finishers: ids, unfinished flags and
+    embeddings bit-identical, log-probs to fp32 summation order; ties resolve to the lowest column."""
+    from vitcap_amd import _lib as L
+    B, V, VP = 37, 30522, 30592
+    g = torch.Generator().manual_seed(5)
+    wl = torch.zeros(VP, 768)
+    wl[:V] = torch.randn(V, 768, generator=g) * 0.05
+    wl = _bf(wl).cuda()
+    bias = torch.full((VP,), -1e30)
+    bias[:V] = torch.randn(V, generator=g)
+    bias = bias.cuda()
+    word = _bf(torch.randn(VP, 768, generator=g) * 0.05).cuda()
+    pos = _bf(torch.randn(512, 768, generator=g) * 0.05).cuda()
+    typ = _bf(torch.randn(2, 768, generator=g) * 0.05).cuda()
+    gam = (1 + torch.randn(768, generator=g) * 0.1).cuda()
+    bet = (torch.randn(768, generator=g) * 0.1).cuda()
+    st_a, st_b = ops.greedy_init(B), ops.greedy_init(B)
+    for st in (st_a, st_b):
+        st['raw_last'] = torch.zeros(B, dtype=torch.int64, device='cuda')
+    eos = 102
+    for t in range(1, 20):
+        h = _bf(torch.randn(B, 768, generator=g)).cuda()
+        bias_t = bias.clone()
+        if t in (3, 9):
+            bias_t[eos] = 50.0 if t == 9 else bias_t[eos]          # step 9: every row picks [SEP] -> all finished afterwards
+        if t == 3:
+            h[5] = 0                                                 # row 5: logits = bias only ...
+            bias_t[700] = 40.0
+            bias_t[12345] = 40.0                                     # ... with an exact tie: the lower column must win
+        logits, rs = ops.gemm_rowstat(h, wl, bias_t)
+        ref = h.float().cpu() @ wl.float().cpu().t() + bias_t.cpu()
+        _close(logits[:, :V], ref[:, :V], 1e-4, 1e-4, 'rowstat logits')
+        ops.greedy_step(logits, st_a, t, eos=eos)
+        xf, xb = ops.greedy_select_embed(rs, st_b, t, word, pos, typ, gam, bet, eos=eos)
+        assert torch.equal(st_a['ids'], st_b['ids']), t
+        assert torch.equal(st_a['unf'], st_b['unf']) and torch.equal(st_a['cnt'], st_b['cnt'])
+        np.testing.assert_allclose(st_a['sum_lp'].cpu().numpy(), st_b['sum_lp'].cpu().numpy(), rtol=0, atol=2e-5)
+        if t == 3:
+            assert int(st_b['ids'][5, 3]) == 700
+        if t < 19:
+            want_f, want_b = ops.embed_step(st_a['ids'], t + 1, word, pos, typ, gam, bet)
+            assert torch.equal(xf, want_f) and torch.equal(xb, want_b)
+    assert int(st_b['unf'].sum()) == 0 and torch.equal(st_a['raw_last'], st_b['raw_last'])
+    np.testing.assert_allclose(st_a['logprob'].cpu().numpy(), st_b['logprob'].cpu().numpy(), rtol=0, atol=2e-6)
+    assert (st_b['ids'][:, 10:] == 0).all()
+
+
 @pytest.mark.parametrize('act', [False, True])
 def test_sum_layernorm(ops, act):
     S, M = 6, 130

@@ -215,9 +215,67 @@ def test_pipeline_train_then_eval(tmp_path, monkeypatch, scst):
     assert ck['iteration'] == 2 and len(ck['model']) == 288
     assert (snap / 'last_checkpoint').read_text().endswith('model_iter_0000002.pt')
     assert list(snap.glob('*.predict.tsv')), 'eval after training wrote no predictions'
+    assert 'optimizer' in ck and 'scheduler' in ck and int(ck['optimizer']['step']) == 2
 
 
-def _dp_worker(rank, world, port, out, tmp):
+def test_pipeline_basemodel_is_the_init_and_training_resumes(tmp_path, monkeypatch):
+    """The shipped YAML is `pipeline_train_eval_multi` WITH `basemodel:` set.  (1) basemodel is the training init only: the
+    model that is evaluated afterwards is snapshot/model_iter_<max_iter>.pt (uni_pipeline.py:614-622, 680-683), the predict
+    TSV sits next to the snapshot and is_train_finished() is False before training.  (2) An interrupted job resumes from
+    snapshot/last_checkpoint -- parameters, AdamW moments, step count, LR schedule, batch position -- and ends bit-identical
+    to the uninterrupted job (checkpoint.py recover_or_load, trainer.py:95)."""
+    import run
+    import yaml
+    from vitcap_amd.model import ImageCaptioning
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
+    base = tmp_path / 'base.pt'
+    torch.save({'model': {'module.' + k: v for k, v in ImageCaptioning().load_recipe(0).state_dict().items()}}, base)
+
+    def cfg(expid, max_iter, **kw):
+        p = {'full_expid': expid, 'max_iter': max_iter, 'effective_batch_size': 2, 'basemodel': str(base), 'log_step': 1,
+             'snapshot_steps': 1, 'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'test_batch_size': 2,
+             'synthetic_num_images': 2, 'force_predict': True, 'base_lr': 1e-3,
+             'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}
+        p.update(kw)
+        return {'type': 'pipeline_train_eval_multi', 'all_test_data': [{'test_data': 'synthetic', 'test_split': 'test'}], 'param': p}
+
+    def launch(c):
+        yf = tmp_path / 'exp.yaml'
+        yf.write_text(yaml.safe_dump(c))
+        kw = run.parse_general_args(['-c', str(yf)])
+        getattr(run, kw.pop('type'))(**kw)
+
+    pip = run.load_pipeline(**cfg('A', 3)['param'])
+    assert not pip.is_train_finished(), 'a basemodel on disk does not make training finished'
+    assert pip.get_checkpoint_file().endswith('output/A/snapshot/model_iter_0000003.pt')
+    launch(cfg('A', 3))                                    # uninterrupted: 3 steps
+    snapA = tmp_path / 'output' / 'A' / 'snapshot'
+    assert (snapA / 'model_iter_0000003.pt').is_file()
+    pred = list(snapA.glob('model_iter_0000003.pt.*predict.tsv'))
+    assert pred, 'the predict file belongs to the trained snapshot, not to the basemodel'
+    assert not list(tmp_path.glob('base.pt.*predict.tsv'))
+    a = torch.load(snapA / 'model_iter_0000003.pt', weights_only=False)
+    b0 = torch.load(base, weights_only=False)['model']
+    k = 'module.bert.decoder.layer.0.intermediate.dense.weight'
+    assert not torch.equal(a['model'][k], b0['module.' + k]), 'training did not move the weights that were evaluated'
+    # interrupted after 2 of 3 steps (same schedule: max_iter 3), then resumed
+    launch(cfg('B', 3, stop_after_iter=2, ignore_predict=True))
+    snapB = tmp_path / 'output' / 'B' / 'snapshot'
+    assert (snapB / 'model_iter_0000002.pt').is_file() and not (snapB / 'model_iter_0000003.pt').exists()
+    launch(cfg('B', 3))                                    # picks up snapshot/last_checkpoint at iteration 2
+    b = torch.load(snapB / 'model_iter_0000003.pt', weights_only=False)
+    assert b['iteration'] == 3
+    for key in a['model']:
+        assert torch.equal(a['model'][key], b['model'][key]), 'resumed run differs from the uninterrupted one: ' + key
+    assert torch.equal(a['optimizer']['exp_avg'], b['optimizer']['exp_avg'])
+
+
+def _dp_worker(rank, world, port, out, tmp, path='train_step'):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -235,7 +293,19 @@ def _dp_worker(rank, world, port, out, tmp):
     sl = slice(rank * 2, rank * 2 + 2)
     b = {k: v[sl].contiguous().cuda() for k, v in full.items()}
     b['image'] = img[sl].contiguous().cuda()
-    res = eng.train_step(b)
+    if path == 'train_step':
+        res = eng.train_step(b)
+    else:
+        # the documented trainer contract (do_train_dict, trainer.py:112-131): loss_dict = model(data); losses.backward();
+        # optimizer.step() -- backward() must join the bucketed all-reduce before anything else touches the gradients
+        m = eng.model
+        m.train()
+        b['key'] = list(range(2))
+        loss_dict = m(b)
+        losses = sum(loss_dict.values())
+        losses.backward()
+        eng.optimizer_step()
+        res = {'masked_loss': loss_dict['masked_loss'].detach()}
     torch.cuda.synchronize()
     torch.save(eng.P.cpu(), '%s/p%d.pt' % (tmp, rank))        # 0.87 GB: by file, not through the queue
     out.put((rank, float(res['masked_loss']), eng.grad_norm(), eng.reducer.launched_bytes))
@@ -243,10 +313,12 @@ def _dp_worker(rank, world, port, out, tmp):
     dist.destroy_process_group()
 
 
-def test_two_process_data_parallel_step(tmp_path):
+@pytest.mark.parametrize('path', ['train_step', 'loss_dict'])
+def test_two_process_data_parallel_step(tmp_path, path):
     """The DP path as the driver launches it (one process per rank, bucketed all-reduce on the side stream behind the
     backward pass), here with 2 ranks on ONE GPU over gloo: after one step both ranks hold the same parameters, equal
-    to a single-process step on the concatenated batch."""
+    to a single-process step on the concatenated batch -- through TrainEngine.train_step and through the trainer contract
+    `model(data)['masked_loss'].backward()` + optimizer_step()."""
     import socket
     import torch.multiprocessing as mp
     from vitcap_amd import weights as W
@@ -259,7 +331,7 @@ def test_two_process_data_parallel_step(tmp_path):
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, str(tmp_path), path)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
@@ -360,6 +432,135 @@ def test_scst_trainer_iteration():
     for _ in range(3):
         out = tr.step(img, gts)
     assert torch.isfinite(out['scst_loss'])
+
+
+def _toy_tokenizer():
+    from vitcap_amd.tokenizer import CaptionDetokenizer
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    return CaptionDetokenizer(tokens=toks)
+
+
+def test_scst_step_at_config_size():
+    """BASELINE configs[4] per-GPU size: scst_num_return = 5, 16 images (80 sampled sequences + 16 greedy baselines per step).
+    Size-independent properties of the step: (a) the 5 samples of an image share ONE encoder pass yet equal the sequences the
+    generator draws on the 5-times repeated batch (same per-sequence random streams); (b) loss and gradients of the
+    shared-encoder gradient pass equal the reference formulation on expanded inputs; (c) a full ScstTrainer.step is finite,
+    deterministic for a fixed seed and moves only optimizer-owned parameters."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.scst import ScstTrainer
+    from vitcap_amd.train import TrainEngine
+    B, K = 16, 5
+    img = torch.from_numpy(W.gen_image_batch(B, 505)).cuda().to(torch.bfloat16)
+    model = ImageCaptioning().load_recipe(0).eval()
+    model.pack('cuda')
+    samp = dict(temperature=1.0, top_k=0, top_p=1.0, seed=99)
+    rep = img.repeat_interleave(K, 0).contiguous()
+    a_ids, a_lp, a_last = [t.clone() for t in model.generate_multi(rep, 1, want_last=True, **samp)]
+    b_ids, b_lp, b_last = model.generate_multi(img, K, want_last=True, **samp)
+    assert b_ids.shape == (B * K, 1, 20)
+    # 80 sequences = 160 rows on both sides: the same decode kernels, bit-identical draws
+    assert torch.equal(a_ids, b_ids) and torch.equal(a_last, b_last)
+    np.testing.assert_allclose(a_lp.cpu().numpy(), b_lp.cpu().numpy(), atol=1e-6)
+    per_image = [len({tuple(r) for r in b_ids[i * K:(i + 1) * K, 0].tolist()}) for i in range(B)]
+    assert min(per_image) > 1, 'the samples of one image should differ'
+    fed = b_ids[:, 0].clone()
+    fed[:, -1] = b_last
+    g = torch.Generator().manual_seed(3)
+    w = (torch.rand(B * K, generator=g) - 0.5).cuda() / (B * K)
+    res = []
+    for shared in (False, True):
+        eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.1, dropout_seed=2)
+        batch = {'sample_ids': fed, 'sample_weight': w}
+        batch.update({'image': img, 'seq_per_image': K} if shared else {'image': rep})
+        loss, _ = eng.forward_backward(batch)
+        res.append((float(loss), eng.G.clone()))
+        del eng
+        torch.cuda.empty_cache()
+    (l0, g0), (l1, g1) = res
+    rel = float((g0 - g1).norm() / g0.norm())
+    print('scst (16 x 5) loss expanded %.6f shared %.6f, gradient rel diff %.2e' % (l0, l1, rel))
+    assert abs(l0 - l1) < 2e-5 * max(1.0, abs(l0)) and rel < 2e-3
+    del res, g0, g1
+    torch.cuda.empty_cache()
+    tok = _toy_tokenizer()
+    outs = []
+    for _ in range(2):
+        m = ImageCaptioning().load_recipe(0)
+        eng = TrainEngine(m, 'cuda', max_iter=100, base_lr=2e-5, attn_dropout=0.1, dropout_seed=4)
+        m.eval()
+        g_ids, _ = m.generate(img)
+        gts = [[tok.decode(r.tolist(), skip_special_tokens=True) + ' w7 w8', 'w11 w12 w13'] for r in g_ids[:, 0].cpu()]
+        tr = ScstTrainer(m, eng, tok, num_return=K, seed=5)
+        p0 = eng.P.clone()
+        out = tr.step(img, gts)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out['scst_loss']) and out['score'] >= 0
+        moved = (eng.P - p0).abs()
+        assert 0 < float(moved.max()) < 1e-3
+        cls_off = eng.off['module.cls.predictions.bias']
+        assert float(moved[cls_off:cls_off + 30522].max()) == 0.0
+        outs.append((float(out['scst_loss']), eng.P.clone()))
+        del eng, tr, m
+        torch.cuda.empty_cache()
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]), 'the SCST step is not reproducible for a fixed seed'
+
+
+def _scst_dp_worker(rank, world, port, out, tmp):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch
+    from vitcap_amd import dist_util as D
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.scst import ScstTrainer
+    from vitcap_amd.train import TrainEngine
+    dist = D.init('gloo')
+    m = ImageCaptioning().load_recipe(0)
+    eng = TrainEngine(m, 'cuda:0', max_iter=10, attn_dropout=0.0, dist=dist)
+    assert eng.reducer.world == world
+    tok = _toy_tokenizer()
+    img = torch.from_numpy(W.gen_image_batch(2, 700 + rank)).cuda().to(torch.bfloat16)       # every rank its own shard
+    gts = [['w%d w%d w%d' % (11 + i, 12 + i, 13 + i)] for i in range(2)]
+    tr = ScstTrainer(m, eng, tok, num_return=2, seed=rank)                                   # per-rank sampling streams
+    res = tr.step(img, gts)
+    torch.cuda.synchronize()
+    torch.save(eng.P.cpu(), '%s/sp%d.pt' % (tmp, rank))
+    torch.save(eng.G.cpu(), '%s/sg%d.pt' % (tmp, rank))
+    out.put((rank, float(res['scst_loss']), eng.grad_norm(), eng.reducer.launched_bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_scst_step(tmp_path):
+    """e2: the SCST step under data parallelism -- ScstTrainer.step on 2 ranks (one GPU, gloo), each with its own images,
+    sampling stream and rewards; the gradient mean goes through the same BucketedAllReduce as the cross-entropy step: both
+    ranks end with identical all-reduced gradients and identical parameters, every gradient bucket travelled."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_scst_dp_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, l0, n0, nb), (_, l1, n1, _) = res
+    g0, g1 = torch.load(str(tmp_path / 'sg0.pt')), torch.load(str(tmp_path / 'sg1.pt'))
+    p0, p1 = torch.load(str(tmp_path / 'sp0.pt')), torch.load(str(tmp_path / 'sp1.pt'))
+    assert torch.equal(g0, g1), 'ranks hold different gradients after the all-reduce'
+    assert torch.equal(p0, p1), 'ranks diverged after the SCST step'
+    assert abs(n0 - n1) < 1e-6 * max(n0, 1e-12) and nb > 600e6
+    assert l0 != l1, 'the ranks were meant to see different shards / samples'
+    print('scst dp: losses %.5f %.5f, grad norm %.5f' % (l0, l1, n0))
 
 
 def test_inference_engine_bound_to_training_buffers():

@@ -118,7 +118,7 @@ struct Layout {
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
   // sequence-sized buffers (NS = B * seqs_per_image for greedy / sampling, B * beams for beam search)
   size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
-  size_t hd_f, hd_b, logits;
+  size_t hd_f, hd_b, logits, rowstat;
   size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok, live;
   size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok, fin_ids, fin_lp;
   int L, NS, K;
@@ -166,6 +166,7 @@ struct Layout {
     hd_f = take(n * D * 4);
     hd_b = take(n * D * 2);
     logits = take(n * VP * 4);
+    rowstat = take(n * (size_t)(2 * (VP / 64)) * 16);    // {max, argmax, sum exp, -} per row and 32-column piece of the logits
     ids = take(n * l * 8);
     ids2 = two ? take(n * l * 8) : 0;
     unf = take(n * 4);
@@ -552,13 +553,14 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, const vitcap_gen_o
 // One decode step for NS sequences (K sequences share one image's visual K/V): embeddings of (token t-1, [MASK]) ->
 // 4 decoder layers against the caches -> LM head on the [MASK] rows -> fp32 logits [NS, VOCAB_PAD].
 static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_gen_opts& o, char* ws, int t, const int64_t* ids,
-                        char* tcache, void* s) {
+                        char* tcache, bool embed, bool rowstat, void* s) {
   const int NS = lo.NS, K = lo.K, L = lo.L;
   float* xs_f = (float*)(ws + lo.xs_f);
   char* xs_b = ws + lo.xs_b;
   const int R = 2 * NS;
-  CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
-                       NS, s));
+  if (embed)          // otherwise the previous step's vitcap_greedy_select_embed already wrote this step's x
+    CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
+                         NS, s));
   float* part = (float*)(ws + lo.spart);
   static const int force_old = [] { const char* e = getenv("VITCAP_DECODE_SPLITK"); return e ? atoi(e) : 0; }();   // A/B measurements
   const bool small = R <= 256 && !force_old;      // resident whole-K kernels (greedy / sampling batches); beams keep the split-K path
@@ -614,6 +616,7 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
     d.lda = D; d.ldw = D; d.ldc = VP;
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
     d.tile_hint = NS <= 128 ? 1 : 0;
+    d.rowstat = rowstat ? (float*)(ws + lo.rowstat) : nullptr;     // greedy: argmax / log-softmax pieces next to the logits
     CK(gemm_desc(ws + lo.hd_b, w.cls.dec_w, w.cls.dec_b, nullptr, ws + lo.logits, d, s));
   }
   return VITCAP_OK;
@@ -630,8 +633,20 @@ static int greedy_loop(vitcap_engine* e, const Layout& lo, const vitcap_gen_opts
   float* sum_lp = (float*)(ws + lo.sum_lp);
   float* cnt = (float*)(ws + lo.cnt);
   CK(vitcap_greedy_init(ids, unf, sum_lp, cnt, NS, L, o.bos_token_id, o.pad_token_id, s));
+  // Plain greedy decoding of a small batch: the vocabulary GEMM also emits per-piece (max, argmax, sum exp) of its rows, and ONE
+  // kernel turns them into the token, its log-prob, the bookkeeping and the NEXT step's embedded rows -- instead of reading the
+  // 30522-wide fp32 rows back (greedy_step 18.7 us) and a separate embedding launch per step.
+  static const int no_fuse = [] { const char* e = getenv("VITCAP_DECODE_NOFUSE"); return e ? atoi(e) : 0; }();
+  const bool fused = !o.sampling.do_sample && o.repetition_penalty == 1.0f && NS <= 128 && !no_fuse;
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, o, ws, t, ids, ws + lo.tcache, s));
+    CK(step_forward(w, lo, o, ws, t, ids, ws + lo.tcache, !fused || t == 1, fused, s));
+    if (fused) {
+      CK(vitcap_greedy_select_embed((const float*)(ws + lo.rowstat), 2 * (VP / 64), ids, unf, sum_lp, cnt, (float*)(ws + lo.logprob),
+                                    (int64_t*)(ws + lo.last_tok), NS, t, L, o.eos_token_id, o.pad_token_id, o.mask_token_id,
+                                    w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, (float*)(ws + lo.xs_f),
+                                    ws + lo.xs_b, s));
+      continue;
+    }
     if (o.repetition_penalty != 1.0f)
       CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, o.repetition_penalty, NS, s));
     if (o.sampling.do_sample)
@@ -666,7 +681,7 @@ static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen
   char* tc_alt = ws + lo.tcache2;
   const int C = 2 * beams;
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, s));
+    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, true, false, s));
     if (o.repetition_penalty != 1.0f)
       CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, o.repetition_penalty, NS, s));
     CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),

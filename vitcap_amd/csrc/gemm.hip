@@ -42,6 +42,7 @@ struct GemmArgs {
   int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
   unsigned long long* trace;   // instrumentation (tools/gemm_trace.py): [workgroup][8 tiles][4] s_memtime stamps, else null
   const int32_t* live;         // decode loop: return at entry once *live == 0 (vitcap_gemm_desc.live)
+  float* rowstat;              // ROWSTAT kernels: per (row, 32-column piece) {max, argmax column, sum exp(x - max), 0}
 };
 
 unsigned long long* g_gemm_trace = nullptr;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES, int NST>
+template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES, int NST, bool ROWSTAT = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   VC_LIVE_EXIT(p.live);
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 64;
@@ -217,6 +218,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         o.y = pack2bf(v[2], v[3]);
         *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
       }
+      if (ROWSTAT) acc[i][j] = v;          // keep the finished values (bias added) for the row statistics below
+    }
+  }
+  if (ROWSTAT) {
+    // Vocabulary GEMM of the greedy decode step: next to the logits, every wave emits for each of its rows the maximum of
+    // its WN*16 columns, the column of that maximum (lowest on ties, torch.argmax's rule) and sum exp(x - max) -- the
+    // pieces `argmax` and `log_softmax` (modeling_utils.py:846-851) are assembled from by vitcap_greedy_select_embed, so the
+    // 30522-wide rows are never read back.  Piece index = tn * 2 + wn; columns >= N never win (skipped here, and the padded
+    // vocabulary columns carry a -1e30 bias).
+    const int pieces = p.tiles_n * 2;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int m = m0 + wm * WM * 16 + i * 16 + frow;
+      float bm = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[i][j][e];
+          if (n + e < p.N && (x > bm || (x == bm && n + e < bi))) { bm = x; bi = n + e; }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {             // the row's columns are spread over the 4 lane groups fk = lane >> 4
+        const float om = __shfl_xor(bm, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) se += expf(acc[i][j][e] - bm);
+      }
+      se += __shfl_xor(se, 16, 64);
+      se += __shfl_xor(se, 32, 64);
+      if (fk == 0 && m < p.M)
+        *(f32x4*)(p.rowstat + ((size_t)m * pieces + tn * 2 + wn) * 4) = f32x4{bm, __int_as_float(bi), se, 0.f};
     }
   }
 }
@@ -1412,6 +1455,23 @@ int dispatch_resident(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   return VITCAP_EINVAL;
 }
 
+// 64 x 64 tiles + row statistics (vitcap_gemm_desc.rowstat): the vocabulary GEMM of the greedy decode step
+int launch_rowstat(const GemmArgs& a, hipStream_t s) {
+  constexpr int NST = 4, smem = NST * (64 + 64) * 64 * 2;
+  auto kern = gemm_nt_kernel<2, 2, VITCAP_ACT_NONE, 1, false, NST, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (a.M + 63) / 64;
+  p.tiles_n = (a.N + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(256), smem, s, p);
+  VC_LAUNCH_CHECK("gemm_nt(rowstat)");
+  return VITCAP_OK;
+}
+
 template <int WM, int WN>
 int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   const bool res = a.res != nullptr;
@@ -1474,6 +1534,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
   a.live = d->live;
+  a.rowstat = (float*)d->rowstat;
   {
     static const int direct = [] { const char* e = getenv("VITCAP_GEMM_DIRECT_EPILOGUE"); return e ? atoi(e) : 1; }();
     a.direct_epilogue = direct;
@@ -1485,6 +1546,11 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   const int hint = d->tile_hint;
   const int split_k = d->split_k > 1 ? d->split_k : 1;
   const bool plain_rows = d->row_group == 0;
+  if (d->rowstat) {
+    VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && !residual && plain_rows && split_k == 1 && !aux_bf16 && !zout_bf16,
+               "gemm(rowstat): fp32 output, no activation / residual / split-K");
+    return launch_rowstat(a, s);
+  }
   if (hint == 20 || hint == 21 || hint == 22) {
     // resident whole-K form (decode-step shapes); K > 768 -> K/768 fp32 partial slabs in C = [K/768][M][ldc]
     VC_REQUIRE(d->K % 768 == 0 && plain_rows && !aux_bf16 && !zout_bf16, "gemm(resident): needs K %% 768 == 0, plain rows, no training extras");

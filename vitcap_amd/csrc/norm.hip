@@ -133,6 +133,96 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restri
   ln_row(v, gamma, beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
 }
 
+// Greedy token choice + bookkeeping for step t from the vocabulary GEMM's row statistics, fused with the text embedding of
+// step t+1.  One 128-thread workgroup per sequence.
+//   rowstat [B][pieces][4] = {max, argmax column (int bits), sum exp(x - max), -} per 32-column piece of the logits row:
+//   tok = column of the overall maximum, lowest column on ties (torch.argmax);  lp = log_softmax(row)[tok] =
+//   -log(sum_pieces s_p * exp(m_p - M));  then exactly greedy_step_kernel's bookkeeping (modeling_utils.py:850-877);
+//   rows (b,0) = word[ids[b][t]] + pos[t] + type[0], (b,1) = word[MASK] + pos[t+1] + type[0], LayerNorm -> x of step t+1.
+__global__ __launch_bounds__(128) void greedy_select_embed_kernel(const float* __restrict__ rowstat, int pieces,
+                                                                  int64_t* __restrict__ ids, int32_t* __restrict__ unf,
+                                                                  float* __restrict__ sum_lp, float* __restrict__ cnt,
+                                                                  float* __restrict__ logprob_out, int64_t* __restrict__ raw_last,
+                                                                  int t, int max_len, int eos, int pad, int32_t* __restrict__ live,
+                                                                  int mask_token, const bf16_t* __restrict__ word,
+                                                                  const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float eps, float* __restrict__ xf, bf16_t* __restrict__ xb) {
+  const bool last = t == max_len - 1;
+  if (live != nullptr && *live == 0 && !last) return;       // every sequence finished: ids stay PAD, x is not needed any more
+  __shared__ float s_m[2], s_s[2];
+  __shared__ int s_i[2];
+  __shared__ long long s_tok;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int u = unf[b];
+  float M = 0.f, lp = 0.f;
+  int I = pad;
+  if (u) {
+    const f32x4* rs = (const f32x4*)rowstat + (size_t)b * pieces;
+    float bm = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < pieces; i += 128) {
+      const f32x4 r = rs[i];
+      const int idx = __float_as_int(r[1]);
+      if (r[0] > bm || (r[0] == bm && idx < bi)) { bm = r[0]; bi = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(bm, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+    }
+    if (lane == 0) { s_m[w] = bm; s_i[w] = bi; }
+    __syncthreads();
+    M = s_m[0];
+    I = s_i[0];
+    if (s_m[1] > M || (s_m[1] == M && s_i[1] < I)) { M = s_m[1]; I = s_i[1]; }
+    float se = 0.f;
+    for (int i = tid; i < pieces; i += 128) {
+      const f32x4 r = rs[i];
+      se += r[2] * expf(r[0] - M);
+    }
+    se = wave_sum(se);
+    if (lane == 0) s_s[w] = se;
+    __syncthreads();
+    lp = -logf(s_s[0] + s_s[1]);                              // logit[tok] - M - log(sum exp(x - M)), tok is the maximum
+  }
+  if (tid == 0) {
+    const int add = u ? I : pad;
+    const float s = sum_lp[b] + lp * (float)u;
+    const float c = cnt[b] + (float)u;
+    const int nu = u * (add != eos ? 1 : 0);
+    long long outtok = add;
+    if (last) {
+      if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
+      if (nu) outtok = eos;                          // modeling_utils.py:870-871
+      logprob_out[b] = s / c;                        // modeling_utils.py:873-877
+    }
+    ids[(size_t)b * max_len + t] = outtok;
+    sum_lp[b] = s;
+    cnt[b] = c;
+    unf[b] = nu;
+    if (live && u && !nu) atomicSub(live, 1);
+    s_tok = outtok;
+  }
+  if (last) return;
+  __syncthreads();
+  // embedding of step t+1 (BertEmbeddings.forward, modeling_bert.py:222-237): wave 0 -> row (b,0), wave 1 -> row (b,1)
+  const long long tok = w ? (long long)mask_token : s_tok;
+  const int p = w ? t + 1 : t;
+  const int row = b * 2 + w;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 a = ld_bf4(word + (size_t)tok * D768 + c);
+    const f32x4 q = ld_bf4(pos + (size_t)p * D768 + c);
+    const f32x4 ty = ld_bf4(type + c);
+    v[i] = (a + q) + ty;   // same association as `words + position + token_type` (modeling_bert.py:234)
+  }
+  ln_row(v, gamma, beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
+}
+
 // teacher-forced text rows: row r = word[ids[r]] + pos[r % rows_per_seq] + type[0] -> (pre-LN sum fp32, LN fp32, LN bf16)
 __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restrict__ ids, int rows_per_seq,
                                                          const bf16_t* __restrict__ word, const bf16_t* __restrict__ pos,
@@ -250,6 +340,23 @@ extern "C" int vitcap_embed_step(const int64_t* ids, int max_len, int t, int mas
                      mask_token, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma,
                      beta, eps, x_f32, (bf16_t*)x_bf16, rows, vc_tls_live);
   VC_LAUNCH_CHECK("embed_step");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_greedy_select_embed(const float* rowstat, int pieces, int64_t* ids, int32_t* unfinished, float* sum_lp,
+                                          float* cnt, float* logprob_out, int64_t* raw_last, int B, int t, int max_len, int eos,
+                                          int pad, int mask_token, const void* word_emb, const void* pos_emb,
+                                          const void* type_emb, const float* gamma, const float* beta, float eps, float* x_f32,
+                                          void* x_bf16, void* stream) {
+  VC_REQUIRE(rowstat && ids && unfinished && sum_lp && cnt && logprob_out, "greedy_select_embed: null pointer");
+  VC_REQUIRE(B > 0 && pieces > 0 && t >= 1 && t < max_len, "greedy_select_embed: bad sizes (t=%d, pieces=%d)", t, pieces);
+  VC_REQUIRE(t == max_len - 1 || (word_emb && pos_emb && type_emb && gamma && beta && x_f32 && x_bf16),
+             "greedy_select_embed: the embedding of step t+1 needs the tables and outputs");
+  hipLaunchKernelGGL(greedy_select_embed_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, rowstat, pieces, ids, unfinished,
+                     sum_lp, cnt, logprob_out, raw_last, t, max_len, eos, pad, (int32_t*)vc_tls_live, mask_token,
+                     (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta, eps, x_f32,
+                     (bf16_t*)x_bf16);
+  VC_LAUNCH_CHECK("greedy_select_embed");
   return VITCAP_OK;
 }
 

@@ -52,16 +52,29 @@ class BucketedAllReduce(object):
     `flat` is the flat gradient buffer; `buckets[stage]` lists the (start, end) ranges whose gradients are final once
     backward stage `stage` has run; `stages` is the order in which stages complete.  `stage_done(stage)` -- called by
     the training engine right after it enqueued the stage's last kernel -- records an event on the compute stream and
-    starts the bucket's all-reduce (+ 1/world scaling) on a side stream, so the ring all-reduce of stage k travels over
+    starts the bucket's exchange (+ 1/world scaling) on a side stream, so the collective of stage k travels over
     xGMI while the GPU computes stage k+1.  `finish()` makes the compute stream wait for the side stream.  Buckets are
     tens of MB (two layers each): xGMI rings are per-link bound, so few large messages beat many small ones.
-    On CPU tensors (gloo tests) the same calls run without streams."""
+    On CPU tensors (gloo tests) the same calls run without streams.
 
-    def __init__(self, flat, buckets, stages, dist):
+    Two exchange algorithms behind the same interface (`algo`, default from VITCAP_DP_REDUCE):
+      'all_reduce'  one in-place all-reduce per range, then the 1/world scaling of the whole range;
+      'rs_ag'       reduce-scatter (every rank ends with the sum of ITS 1/world slice of the range), scaling of that slice
+                    only, all-gather of the slices (what a ring all-reduce does internally, made explicit so that
+                    the two halves of consecutive buckets overlap on xGMI's point-to-point links and the scaling touches
+                    1/world of the bytes).  Range tails that do not divide by world go through a small all-reduce.
+    Both give the same mean (bit-identical on 2 ranks; summation order may differ with more)."""
+
+    def __init__(self, flat, buckets, stages, dist, algo=None):
         self.flat, self.buckets, self.stages, self.dist = flat, buckets, list(stages), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
         self.cuda = flat.is_cuda
         self.comm = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
+        self.algo = algo or os.environ.get('VITCAP_DP_REDUCE', 'all_reduce')
+        if self.algo not in ('all_reduce', 'rs_ag'):
+            raise ValueError('unknown gradient exchange %r (all_reduce | rs_ag)' % self.algo)
+        self._native_rs = self.world > 1 and dist.get_backend() == 'nccl'     # gloo has no reduce_scatter: emulate per slice
         self._works = []
         self._done = set()
         self.launched_bytes = 0
@@ -71,6 +84,35 @@ class BucketedAllReduce(object):
             raise RuntimeError('begin() before the previous step\'s finish()')
         self._done = set()
         self.launched_bytes = 0
+
+    # ---- one range [a, b) of the flat buffer, synchronous with respect to the calling (side) stream
+    def _exchange(self, a, b):
+        t = self.flat[a:b]
+        scale = 1.0 / self.world
+        if self.algo == 'all_reduce':
+            self.dist.all_reduce(t)
+            t.mul_(scale)
+            return
+        n = b - a
+        per = n // self.world
+        m = per * self.world
+        if per:
+            body = t[:m]
+            mine = body[self.rank * per:(self.rank + 1) * per]
+            if self._native_rs:
+                self.dist.reduce_scatter_tensor(mine, body)          # in place: the output is this rank's slice of the input
+                mine.mul_(scale)
+                self.dist.all_gather_into_tensor(body, mine)
+            else:
+                for r in range(self.world):                            # gloo: one reduce per slice = a reduce-scatter
+                    self.dist.reduce(body[r * per:(r + 1) * per], dst=r)
+                mine.mul_(scale)
+                parts = [body[r * per:(r + 1) * per] for r in range(self.world)]
+                self.dist.all_gather(parts, mine.clone())
+        if m < n:
+            tail = t[m:]
+            self.dist.all_reduce(tail)
+            tail.mul_(scale)
 
     def stage_done(self, stage):
         if stage not in self.buckets:
@@ -90,16 +132,17 @@ class BucketedAllReduce(object):
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
                 for a, b in self.buckets[stage]:
-                    t = self.flat[a:b]
-                    work = self.dist.all_reduce(t, async_op=True)
-                    work.wait()                     # the side stream (not the host) waits for the collective
-                    t.mul_(scale)
-                    self.launched_bytes += (b - a) * t.element_size()
-        else:
+                    self._exchange(a, b)             # collectives are enqueued on the side stream; the host does not wait
+                    self.launched_bytes += (b - a) * self.flat.element_size()
+        elif self.algo == 'all_reduce':
             for a, b in self.buckets[stage]:
                 t = self.flat[a:b]
                 self._works.append((self.dist.all_reduce(t, async_op=True), t))
                 self.launched_bytes += (b - a) * t.element_size()
+        else:
+            for a, b in self.buckets[stage]:
+                self._exchange(a, b)
+                self.launched_bytes += (b - a) * self.flat.element_size()
 
     def finish(self):
         if len(self._done) != len(self.stages) and self.world > 1:

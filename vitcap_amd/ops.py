@@ -156,6 +156,33 @@ def greedy_step(logits, st, t, V=L.VOCAB, eos=102, pad=0):
                                  pad, _stream()), 'greedy_step')
 
 
+def gemm_rowstat(a, w, bias):
+    """Vocabulary GEMM with row statistics: (logits fp32 [M][N], rowstat fp32 [M][2*ceil(N/64)][4])."""
+    _dev_bf16(a)
+    _dev_bf16(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    pieces = 2 * ((N + 63) // 64)
+    rs = torch.zeros((M, pieces, 4), device=a.device, dtype=torch.float32)
+    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0), act=L.ACT_NONE, out_dtype=L.OUT_F32,
+                   rowstat=rs.data_ptr())
+    check(lib.vitcap_gemm_bias_act(_p(a), _p(w), _p(bias), None, _p(out), C.byref(d), _stream()), 'gemm(rowstat)')
+    return out, rs
+
+
+def greedy_select_embed(rowstat, st, t, word, pos, typ, gamma, beta, eps=1e-12, mask_token=103, eos=102, pad=0):
+    """greedy_step from row statistics + embed_step for t+1 in one launch; returns (x_f32, x_bf16) of step t+1 (None at the end)."""
+    B, max_len = st['ids'].shape
+    lastp = t == max_len - 1
+    xf = None if lastp else torch.empty((2 * B, 768), device=rowstat.device, dtype=torch.float32)
+    xb = None if lastp else torch.empty((2 * B, 768), device=rowstat.device, dtype=torch.bfloat16)
+    check(lib.vitcap_greedy_select_embed(_p(rowstat), rowstat.shape[1], _p(st['ids']), _p(st['unf']), _p(st['sum_lp']), _p(st['cnt']),
+                                         _p(st['logprob']), _p(st.get('raw_last')), B, t, max_len, eos, pad, mask_token, _p(word),
+                                         _p(pos), _p(typ), _p(gamma), _p(beta), eps, _p(xf), _p(xb), _stream()), 'greedy_select_embed')
+    return xf, xb
+
+
 def sample_step(logits, st, t, temperature=1.0, top_k=0, top_p=1.0, seed=0, V=L.VOCAB, eos=102, pad=0):
     """do_sample variant of greedy_step (modeling_utils.py:839-851): same state dict, one draw per sequence."""
     from ._lib import SampleParams

@@ -288,6 +288,9 @@ class CaptionUniPipeline(object):
                 t0 = time.time()
             if it % int(self.cfg.snapshot_steps) == 0 or it == max_iter:
                 ckpt.save('model_iter_{:07d}'.format(it), iteration=it)
+            if self.cfg.stop_after_iter is not None and it >= int(self.cfg.stop_after_iter):
+                logging.info('stop_after_iter=%s: leaving the training loop early (resume test / pre-emption drill)', self.cfg.stop_after_iter)
+                break
         if dist is not None:
             dist.barrier()      # uni_pipeline.py:376 synchronize(): no rank may reach ensure_predict before rank 0's final snapshot exists
         return self.get_checkpoint_file(iteration=max_iter)
