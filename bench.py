@@ -181,6 +181,7 @@ def main():
     ap.add_argument('--beams', type=int, default=1, help='num_beams (1 = greedy, the headline metric; 5 = BASELINE configs[2])')
     ap.add_argument('--graph', type=int, default=0,
                     help='1: the decode loop is captured once into a hipGraph inside the engine (vitcap_gen_opts.use_graph) and replayed')
+    ap.add_argument('--gemm-tiles', type=int, default=0, help='one-stream runs: large GEMMs one tile per workgroup (+ forked tag branch)')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1: two-slot batch pipeline (encode+prefill of step i+1 overlaps the decode of step i on a second '
                          'stream; same results); 0: one stream, steps strictly back to back')
@@ -206,7 +207,7 @@ def main():
     img = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
     from vitcap_amd import _lib as L
     gen_kw = dict(num_beams=args.beams, num_keep_best=1, do_sample=False, num_return_sequences=1, use_graph=bool(args.graph))
-    opts = model.gen_options(**gen_kw)                               # one stream: persistent GEMMs
+    opts = model.gen_options(gemm_mode=L.GEMM_TILES if args.gemm_tiles else L.GEMM_AUTO, **gen_kw)   # one stream
     popts = model.gen_options(gemm_mode=L.GEMM_TILES, **gen_kw)      # batch pipeline: one tile per workgroup
 
     def barrier():

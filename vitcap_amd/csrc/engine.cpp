@@ -114,7 +114,7 @@ struct Layout {
     return o;
   }
   // image-sized buffers (B images) first, so their offsets do not depend on the number of decode sequences
-  size_t patches, x, xt, h, qkv, mlp, th, tqkv, tmlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
+  size_t patches, x, x2, xt, h, qkv, mlp, th, tqkv, tmlp, vis_f, vis_b, dqkv[4], da_f, da_b, dtmp;
   size_t pool_in, pooled, tg_f, tg_b, tag_logits, tag_ids, tag_prob, tag_len;
   // sequence-sized buffers (NS = B * seqs_per_image for greedy / sampling, B * beams for beam search)
   size_t xs_f, xs_b, sqkv, sctx, spart, sa_f, sa_b, smlp, tcache, tcache2;
@@ -132,6 +132,7 @@ struct Layout {
     const size_t b = (size_t)B, n = (size_t)NS, l = (size_t)L;
     patches = take(b * 576 * D * 2);
     x = take(b * NV * D * 4);
+    x2 = take(b * NV * D * 4);          // caption branch after the fork (blocks 8-11); x keeps the fork state, read by both branches
     xt = take(b * NV * D * 4);
     h = take(b * SV * D * 2);
     qkv = take(b * NV * 3 * D * 2);
@@ -394,12 +395,15 @@ static int check(vitcap_engine* e, int B, const vitcap_gen_opts& o, void* ws, si
   return VITCAP_OK;
 }
 
-static int vit_block(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, void* mlp, int B, void* s) {
+// x_in: the block's input (read by LN1 and as the residual of proj); x: its output buffer, updated in place from proj on.
+// x_in != x only at the fork (block 8 and tag block 0 both read the output of block 7 and write their own stream), which
+// replaces a 113 MB device-to-device copy of the fork state per batch.
+static int vit_block(const vitcap_vit_block_w& w, const float* x_in, float* x, void* h, void* qkv, void* mlp, int B, void* s) {
   const int M = B * NV;
-  CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  CK(vitcap_layernorm_fwd(x_in, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
   CK(gemm(h, D, w.qkv_w, w.qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
   CK(vitcap_attn_dense_fwd(qkv, h, B, NV, 0.125f, s));
-  CK(gemm(h, D, w.proj_w, w.proj_b, x, D, x, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  CK(gemm(h, D, w.proj_w, w.proj_b, x_in, D, x, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
   CK(vitcap_layernorm_fwd(x, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, M, D, s));
   CK(gemm(h, D, w.fc1_w, w.fc1_b, nullptr, 0, mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
   CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
@@ -433,7 +437,6 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
   CallScope scope(e, o.gemm_mode, nullptr);
   const vitcap_weights& w = e->w;
   float* x = (float*)(ws + lo.x);
-  float* xt = (float*)(ws + lo.xt);
   // a1: patch embed as GEMM (+bias +pos_embed[1+p]) into rows b*577+1+p; cls rows separately
   CK(vitcap_patch_gather(image, image_is_bf16, ws + lo.patches, B, s));
   {
@@ -450,11 +453,10 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
   // in their one-tile-per-workgroup form (batch pipeline) and the batch is small enough for tile-quantisation gaps to
   // matter: B=64 pipelined +2.3 %; with persistent GEMMs or at B=512 it costs 1-2 % (measured), so it stays serial there.
   const bool fork = e->fork_tag_branch && o.gemm_mode == VITCAP_GEMM_TILES && B <= 128;
+  float* x2 = (float*)(ws + lo.x2);
   for (int i = 0; i < 12; ++i) {
-    if (i == 8)
-      HIPCK(hipMemcpyAsync(xt, x, (size_t)B * NV * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)s), "encode: fork copy");
     if (i == 8 && fork) {
-      // fork: the tag branch depends only on the copy of x made above
+      // fork: the tag branch depends only on x (the output of block 7), which nobody writes from here on
       if (!e->side) {
         if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -468,7 +470,8 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
       CK(tag_branch(e, lo, ws, B, e->side));
       HIPCK(hipEventRecord(e->ev_join, e->side), "encode: join record");
     }
-    CK(vit_block(w.blocks[i], x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
+    if (i < 8) CK(vit_block(w.blocks[i], x, x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
+    else CK(vit_block(w.blocks[i], i == 8 ? x : x2, x2, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
   }
   if (fork) {
     HIPCK(hipStreamWaitEvent((hipStream_t)s, e->ev_join, 0), "encode: join wait");
@@ -492,9 +495,10 @@ extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int ima
 static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s) {
   const vitcap_weights& w = e->w;
   float* xt = (float*)(ws + lo.xt);
-  for (int i = 0; i < 3; ++i) CK(vit_block(w.tag_blocks[i], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+  const float* xf = (const float*)(ws + lo.x);       // fork state (output of block 7)
+  for (int i = 0; i < 3; ++i) CK(vit_block(w.tag_blocks[i], i == 0 ? xf : xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
   if (e->full_last_tag_block)
-    CK(vit_block(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+    CK(vit_block(w.tag_blocks[3], xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
   else
     CK(vit_block_cls_only(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, ws + lo.pool_in, B, s));
   CK(vitcap_gather_rows_bf16(xt, NV, ws + lo.pool_in, B, D, s));
@@ -517,7 +521,7 @@ static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, con
   const int M = B * SV;
   float* vis_f = (float*)(ws + lo.vis_f);
   void* vis_b = ws + lo.vis_b;
-  CK(vitcap_assemble_visual((const float*)(ws + lo.x), (const float*)(ws + lo.xt), vis_f, vis_b, B, NV, s));
+  CK(vitcap_assemble_visual((const float*)(ws + lo.x2), (const float*)(ws + lo.xt), vis_f, vis_b, B, NV, s));
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
     void* dq = ws + lo.dqkv[l];
@@ -796,7 +800,7 @@ extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, voi
   const Layout lo(B, o);
   char* ws = (char*)workspace;
   if (!strcmp(name, "last_token")) return ws + lo.last_tok;
-  if (!strcmp(name, "hidden")) return ws + lo.x;
+  if (!strcmp(name, "hidden")) return ws + lo.x2;
   if (!strcmp(name, "tag_hidden")) return ws + lo.xt;
   if (!strcmp(name, "vis")) return ws + lo.vis_f;
   if (!strcmp(name, "logits_last")) return ws + lo.logits;

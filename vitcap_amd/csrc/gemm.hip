@@ -1605,7 +1605,10 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // measured (tools/gemm_bench.py 5,12): the persistent variant wins without a residual operand (qkv +11 %, fc1 +6 %);
   // with one, its residual rows are requested a pass ahead and before the next tile's DMA.
   static const int env_persistent = [] { const char* e = getenv("VITCAP_GEMM_PERSISTENT"); return e ? atoi(e) : -1; }();
-  const int use_persistent = env_persistent >= 0 ? env_persistent : 1;   // a caller that wants one tile per workgroup passes tile_hint 5
+  // auto = one tile per workgroup: since the direct (LDS-free) epilogue and the column-group tile order the persistent form no
+  // longer wins (tools/gemm_bench.py 0,5 at M = 36928 / 295424: qkv 148 / 1072 us persistent vs 145 / 1041, fc1 201 / 1645 vs
+  // 192 / 1537, fc2 and proj equal; end to end +1.0 % at B = 64, +2.4 % at B = 512).  tile_hint 12 still selects it.
+  const int use_persistent = env_persistent >= 0 ? env_persistent : 0;
   // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
   if (hint == 0 && use_persistent && wide_ok && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);
