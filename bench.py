@@ -29,15 +29,15 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r01_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 # What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
 # visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row
 # attention block 0.23.  Reported next to the algorithmic figure; `value` (images/s) does not depend on either.
 FLOP_EXECUTED_PER_IMAGE = FLOP_PER_IMAGE - (9.19e9 - 1.36e9 - 0.23e9)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4>', 0: 'void gemm_nt_256p_kernel<0, 0, false>',
-              4: 'void gemm_nt_256p_kernel<1, 0, false>'}
+PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4>', 0: 'void gemm_nt_256_kernel<0, 0, false, 4>',
+              4: 'void gemm_nt_256_kernel<1, 0, false, 4>'}
 VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
                  2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
                  4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}
@@ -91,27 +91,48 @@ def bench_train(args, rank, world, local, dist, D):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    from vitcap_amd import ops
     for _ in range(max(args.warmup, 1)):
         out = eng.train_step(batch)
     barrier()
+    ops.TIMING = []                      # events on the launch stream around every large GEMM of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = eng.train_step(batch)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dist, device='cuda')
+    timing, ops.TIMING = ops.TIMING, None
+    kinds = {}
+    for kind, fl, e0, e1 in timing:
+        k = kinds.setdefault(kind, [0.0, 0.0, 0])
+        k[0] += e0.elapsed_time(e1)
+        k[1] += fl
+        k[2] += 1
     if rank == 0:
         value = D.whole_job_rate(B, args.steps, world, elapsed)
+        dom = max(kinds, key=lambda k: kinds[k][0]) if kinds else None
+        roof = None
+        if dom:
+            ms_, fl_, n_ = kinds[dom]
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(fl_ / (ms_ * 1e-3) / 1e12, 2), 'peak': PEAK_BF16_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(fl_ / (ms_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'launches': n_, 'avg_launch_ms': round(ms_ / n_, 4), 'avg_launch_gflop': round(fl_ / n_ / 1e9, 3),
+                    'share_of_step_time': round(ms_ / args.steps / (elapsed / args.steps * 1e3), 4),
+                    'per_kind': {k: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+                                 for k, v in kinds.items()}}
         print(json.dumps({
             'metric': 'images/sec cross-entropy training step, ViT-B/16-384 + 4-layer caption decoder',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[3]: cross-entropy training step, %d samples per GPU (global %d), '
-                                   'decoder attention dropout 0.1 on, fp32 master weights + AdamW, gradient all-reduce over RCCL' % (B, B * world),
+                                   'decoder attention dropout 0.1 on, fp32 master weights + AdamW, gradient exchange over RCCL (%s)'
+                                   % (B, B * world, eng.reducer.algo),
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
             'end_to_end_tflops_algorithmic': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12, 2),
             'end_to_end_tflops_executed': round(value / world * TRAIN_FLOP_EXECUTED_PER_SAMPLE / 1e12, 2),
             'end_to_end_frac_of_bf16_peak': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_TFLOPS, 4),
+            'roofline': roof,
             'masked_loss': float(out['masked_loss']), 'tag_loss': float(out['tag_loss'])}), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,13 +1,27 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): parity tests, smoke, bench, rocprof summary.  Usage: scripts_gpu_round.sh [tag]
+# Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of BASELINE configs[1..4], rocprof summaries, PMC traffic.
+# Usage: bash scripts_gpu_round.sh [tag] [notests]
 TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -80 > gpurun_out/tests_$TAG.log
+if [ "$2" != "notests" ]; then
+python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/tests_$TAG.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
-python bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline > gpurun_out/bench_seq_$TAG.json 2>> gpurun_out/bench_$TAG.err
-python tools/decode_bench.py 64 > gpurun_out/decode_bench_$TAG.log 2>&1
+fi
+python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+python bench.py --steps 50 --warmup 3 --pipeline 0 --no-cpu-baseline > gpurun_out/bench_seq_$TAG.json 2>> gpurun_out/bench_$TAG.err
+python bench.py --steps 20 --warmup 2 --beams 5 --batch 256 --graph 1 --no-cpu-baseline > gpurun_out/bench_beam5_$TAG.json 2>> gpurun_out/bench_$TAG.err
+python bench.py --steps 30 --warmup 3 --mode train > gpurun_out/bench_train_$TAG.json 2>> gpurun_out/bench_$TAG.err
+python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.json 2>> gpurun_out/bench_$TAG.err
+python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
+python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
+bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o seq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --pipeline 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG.log 2>&1
-cd $GRAFT_REPO_ROOT
-DB=$(find gpurun_out/prof_$TAG -name "*.db" | head -1); python tools/rocprof_summary.py "$DB" "bench.py --pipeline 0 --steps 3 (one stream, B=64)" > gpurun_out/prof_${TAG}_summary.md 2>&1 || true
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 5 --warmup 1 --pipeline 0 --no-cpu-baseline >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o train -- python3 $R/bench.py --steps 3 --warmup 1 --mode train >> $R/gpurun_out/prof_$TAG.log 2>&1
+cd $R
+for k in pipe seq train; do
+DB=$(find gpurun_out/prof_$TAG -name "${k}_results.db" | head -1)
+python tools/rocprof_summary.py "$DB" "bench.py ($k), B=64" > gpurun_out/prof_${TAG}_${k}.md 2>&1 || true
+done

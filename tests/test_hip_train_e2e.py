@@ -270,9 +270,19 @@ def test_pipeline_basemodel_is_the_init_and_training_resumes(tmp_path, monkeypat
     launch(cfg('B', 3))                                    # picks up snapshot/last_checkpoint at iteration 2
     b = torch.load(snapB / 'model_iter_0000003.pt', weights_only=False)
     assert b['iteration'] == 3
+    # the backward pass accumulates a few reductions with float atomics (embedding scatter-add, LayerNorm gamma/beta), so two runs
+    # agree to rounding, not bit for bit; a resume that lost the AdamW moments, the step count or the schedule would move most
+    # elements by ~base_lr = 1e-3 (Adam's first steps are sign-like)
+    worst = 0.0
     for key in a['model']:
-        assert torch.equal(a['model'][key], b['model'][key]), 'resumed run differs from the uninterrupted one: ' + key
-    assert torch.equal(a['optimizer']['exp_avg'], b['optimizer']['exp_avg'])
+        d = (a['model'][key].float() - b['model'][key].float()).abs()
+        worst = max(worst, float(d.mean()))
+        assert float(d.mean()) < 2e-5 and float((d > 2e-4).float().mean()) < 1e-3, 'resumed run differs from the uninterrupted one: ' + key
+    dm = (a['optimizer']['exp_avg'] - b['optimizer']['exp_avg']).abs()
+    assert float(dm.max()) < 1e-3 * float(a['optimizer']['exp_avg'].abs().max()) + 1e-7
+    assert int(a['optimizer']['step']) == int(b['optimizer']['step']) == 3
+    assert a['scheduler'] == b['scheduler']
+    print('resume: worst mean |dp| %.2e' % worst)
 
 
 def _dp_worker(rank, world, port, out, tmp, path='train_step'):
@@ -504,7 +514,10 @@ def test_scst_step_at_config_size():
         outs.append((float(out['scst_loss']), eng.P.clone()))
         del eng, tr, m
         torch.cuda.empty_cache()
-    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]), 'the SCST step is not reproducible for a fixed seed'
+    # same seed -> same samples and rewards; the loss sum and a few backward reductions use float atomics, so two runs agree to
+    # rounding (1e-6 relative), not bit for bit
+    assert abs(outs[0][0] - outs[1][0]) < 1e-5 * max(1.0, abs(outs[0][0])), 'the SCST step is not reproducible for a fixed seed'
+    assert float((outs[0][1] - outs[1][1]).abs().mean()) < 1e-7
 
 
 def _scst_dp_worker(rank, world, port, out, tmp):
@@ -523,8 +536,11 @@ def _scst_dp_worker(rank, world, port, out, tmp):
     assert eng.reducer.world == world
     tok = _toy_tokenizer()
     img = torch.from_numpy(W.gen_image_batch(2, 700 + rank)).cuda().to(torch.bfloat16)       # every rank its own shard
-    gts = [['w%d w%d w%d' % (11 + i, 12 + i, 13 + i)] for i in range(2)]
-    tr = ScstTrainer(m, eng, tok, num_return=2, seed=rank)                                   # per-rank sampling streams
+    m.eval()
+    g_ids, _ = m.generate(img)
+    # references that share n-grams with what the model generates: non-zero CIDEr-D advantages, hence a non-zero gradient
+    gts = [[tok.decode(r.tolist()[:8 + 3 * rank], skip_special_tokens=True) + ' w7 w8'] for r in g_ids[:, 0].cpu()]
+    tr = ScstTrainer(m, eng, tok, num_return=3, seed=rank)                                   # per-rank sampling streams
     res = tr.step(img, gts)
     torch.cuda.synchronize()
     torch.save(eng.P.cpu(), '%s/sp%d.pt' % (tmp, rank))
@@ -559,7 +575,7 @@ def test_two_process_scst_step(tmp_path):
     assert torch.equal(g0, g1), 'ranks hold different gradients after the all-reduce'
     assert torch.equal(p0, p1), 'ranks diverged after the SCST step'
     assert abs(n0 - n1) < 1e-6 * max(n0, 1e-12) and nb > 600e6
-    assert l0 != l1, 'the ranks were meant to see different shards / samples'
+    assert l0 != l1 and n0 > 0, 'the ranks were meant to see different shards / samples and a non-zero gradient'
     print('scst dp: losses %.5f %.5f, grad norm %.5f' % (l0, l1, n0))
 
 

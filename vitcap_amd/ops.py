@@ -11,6 +11,29 @@ from . import _lib as L
 from ._lib import lib, check
 
 
+# Optional live timing of the large GEMM launches of the TRAINING path (bench.py --mode train roofline): when TIMING is a list,
+# every gemm_ex / gemm_tn launch with M > 256 is bracketed by events recorded on the launch stream (the current torch stream is
+# the stream the kernel is launched on) and appended as (kind, flops, start, stop).
+TIMING = None
+
+
+class _Timed(object):
+    def __init__(self, kind, flops, big):
+        self.on = TIMING is not None and big
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            TIMING.append((self.kind, self.flops, self.e0, self.e1))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -220,9 +243,10 @@ def gemm_ex(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_dtype=
     d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(-2),
                    ldr=residual.stride(0) if residual is not None else 0, act=act,
                    out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16, tile_hint=tile_hint, split_k=split_k)
-    check(lib.vitcap_gemm_ex(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _p(aux),
-                             aux.stride(0) if aux is not None else 0, _p(zout), zout.stride(0) if zout is not None else 0,
-                             _stream()), 'gemm_ex')
+    with _Timed('gemm_nt (forward / input gradients)', 2.0 * M * N * K, M > 256):
+        check(lib.vitcap_gemm_ex(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _p(aux),
+                                 aux.stride(0) if aux is not None else 0, _p(zout), zout.stride(0) if zout is not None else 0,
+                                 _stream()), 'gemm_ex')
     return out
 
 
@@ -270,7 +294,8 @@ def gemm_tn(y, x, splits, slabs=None):
     assert x.shape[0] == M
     if slabs is None:
         slabs = torch.empty((splits, N, K), device=y.device, dtype=torch.float32)
-    check(lib.vitcap_gemm_tn(_p(y), y.stride(0), _p(x), x.stride(0), _p(slabs), M, N, K, splits, _stream()), 'gemm_tn')
+    with _Timed('gemm_tn (weight gradients)', 2.0 * M * N * K, True):
+        check(lib.vitcap_gemm_tn(_p(y), y.stride(0), _p(x), x.stride(0), _p(slabs), M, N, K, splits, _stream()), 'gemm_tn')
     return slabs
 
 
