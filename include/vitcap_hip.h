@@ -230,6 +230,11 @@ typedef struct vitcap_sample_params {
 int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
                        float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last, int B, int t,
                        int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream);
+/* the same for rows that are sequences seq_offset .. seq_offset + B - 1 of a larger call (row b draws from the random stream of
+ * sequence seq_offset + b): a batch processed in slices draws what the whole batch would */
+int vitcap_sample_step_offset(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                              float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last, int B, int t,
+                              int max_len, int eos, int pad, const vitcap_sample_params* sp, int seq_offset, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tag head tail: prob = sigmoid(logit); top-k (largest, sorted, lowest index first on ties);
@@ -362,6 +367,9 @@ typedef struct vitcap_gen_opts {
   int32_t use_graph;          /* 1: the decode loop is captured once per (B, workspace, options) into a hipGraph owned
                                  by the engine and replayed by later calls (greedy and beam search; not sampling, whose
                                  seed changes per call)                                                                 */
+  int32_t decode_streams;     /* greedy / sampling loop: 2 = the batch is cut into two slices that decode on two streams (the
+                                 second one engine-owned, forked from and joined to the caller's); 1 = one chain; 0 = auto
+                                 (= 1: measured, the second chain does not hide the per-kernel latency).  Same results.   */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */

@@ -364,6 +364,33 @@ def test_decode_loop_hipgraph_replay(model):
     assert model.graph_count() == n0 + 2, 'one graph per (batch, workspace, options), reused by later calls'
 
 
+def test_split_decode_loop_equals_single_chain(model):
+    """vitcap_gen_opts.decode_streams: the greedy / sampling loop cut into two slices on two streams gives bit-identical ids,
+    scores and last tokens -- eager and graph-replayed, even and odd batch sizes, several sequences per image."""
+    for B in (16, 33):
+        img = _images(B, 900 + B).cuda().to(torch.bfloat16)
+        one = [t.clone() for t in model.generate(img, decode_streams=1)]
+        two = [t.clone() for t in model.generate(img, decode_streams=2)]
+        auto = [t.clone() for t in model.generate(img)]
+        gr = [t.clone() for t in model.generate(img, decode_streams=2, use_graph=True)]
+        gr2 = [t.clone() for t in model.generate(img, decode_streams=2, use_graph=True)]
+        for other in (two, auto, gr, gr2):
+            assert torch.equal(one[0], other[0]) and torch.equal(one[1], other[1]), B
+    img = _images(6, 77).cuda().to(torch.bfloat16)
+    samp = dict(temperature=0.9, top_k=50, top_p=0.9, seed=21)
+    a = [t.clone() for t in model.generate_multi(img, 3, want_last=True, decode_streams=1, **samp)]
+    b = [t.clone() for t in model.generate_multi(img, 3, want_last=True, decode_streams=2, **samp)]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # an alternative EOS ends sequences early in both slices; the shared live counter still reaches 0
+    full = model.generate(img)[0].cpu()[:, 0]
+    common = [t for t in full[0, 1:8].tolist() if all(t in r[1:8].tolist() for r in full)]
+    c = [t.clone() for t in model.generate(img, eos_token_ids=[common[0]], decode_streams=1)]
+    d = [t.clone() for t in model.generate(img, eos_token_ids=[common[0]], decode_streams=2)]
+    assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
+    assert int(model.tap('live', 6, (1,), torch.int32)[0]) == 0
+
+
 def test_text_inputs_are_validated(model):
     """a8 / a16: forward() checks the caller's text tensors against the mask structure the kernels implement."""
     from oracle import vitcap_oracle as O

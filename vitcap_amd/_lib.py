@@ -45,7 +45,7 @@ class GenOpts(C.Structure):
                 ('max_length', C.c_int32), ('bos_token_id', C.c_int32), ('eos_token_id', C.c_int32),
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
-                ('early_exit', C.c_int32), ('use_graph', C.c_int32)]
+                ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('decode_streams', C.c_int32)]
 
 
 class Image(C.Structure):
@@ -134,6 +134,8 @@ _SIGS = {
                                              C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]),
     'vitcap_sample_step': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp, vp]),
+    'vitcap_sample_step_offset': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, vp, C.c_int, vp]),
     'vitcap_sigmoid_topk': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
     'vitcap_row_topk_lse': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_beam_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

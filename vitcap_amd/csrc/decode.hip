@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
                                                            float* __restrict__ logprob_out,
                                                            float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
                                                            int t, int max_len, int eos, int pad, float temperature, int top_k,
-                                                           float top_p, uint32_t seed, int32_t* __restrict__ live) {
+                                                           float top_p, uint32_t seed, int seq_off, int32_t* __restrict__ live) {
   __shared__ unsigned long long s_hist[256];
   __shared__ unsigned long long s_acc;
   __shared__ uint32_t s_sel;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     }
   }
   // ---- one draw: argmax(x + Gumbel noise) over the surviving set == multinomial(softmax(filtered)) ----------
-  const uint32_t hrow = vc_mix(vc_mix(seed, (uint32_t)b), (uint32_t)t);
+  const uint32_t hrow = vc_mix(vc_mix(seed, (uint32_t)(b + seq_off)), (uint32_t)t);   // stream of sequence b + seq_off of the call
   ArgMax best{-INFINITY, 0x7fffffff};
   float bx = 0.f, second = -INFINITY;
 #pragma unroll
@@ -829,18 +829,26 @@ extern "C" int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
-                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last,
-                                  int B, int t, int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
+extern "C" int vitcap_sample_step_offset(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                                         float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last,
+                                         int B, int t, int max_len, int eos, int pad, const vitcap_sample_params* sp, int seq_offset,
+                                         void* stream) {
   VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out && sp, "sample_step: null pointer");
-  VC_REQUIRE(B > 0 && V > 0 && V <= SM_NPT * 1024 && ldl >= V && t >= 1 && t < max_len,
+  VC_REQUIRE(B > 0 && V > 0 && V <= SM_NPT * 1024 && ldl >= V && t >= 1 && t < max_len && seq_offset >= 0,
              "sample_step: bad sizes (V=%d t=%d)", V, t);
   VC_REQUIRE(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f,
              "sample_step: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature, sp->top_k,
              (double)sp->top_p);
   hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
                      sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, sp->temperature, sp->top_k,
-                     sp->top_p, sp->seed, (int32_t*)vc_tls_live);
+                     sp->top_p, sp->seed, seq_offset, (int32_t*)vc_tls_live);
   VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* ids, int32_t* unfinished,
+                                  float* sum_lp, float* cnt, float* logprob_out, float* margin_out, int64_t* raw_last,
+                                  int B, int t, int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
+  return vitcap_sample_step_offset(logits, ldl, V, ids, unfinished, sum_lp, cnt, logprob_out, margin_out, raw_last, B, t, max_len, eos,
+                                   pad, sp, 0, stream);
 }

@@ -54,6 +54,8 @@ struct vitcap_engine {
   hipStream_t cap = nullptr;          // the decode loop is CAPTURED on this engine-owned stream (capture executes nothing), so the
                                       // caller's stream may be any stream, the legacy default stream included
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t dec2 = nullptr;         // second stream of the split decode loop (vitcap_gen_opts.decode_streams = 2)
+  hipEvent_t ev_dfork = nullptr, ev_djoin = nullptr;
   bool full_last_tag_block = false;   // VITCAP_FULL_TAG_BLOCK=1: compute all 577 rows of tag_blocks[3] (parity taps / measurements)
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
@@ -84,6 +86,7 @@ vitcap_gen_opts default_opts() {
   o.gemm_mode = VITCAP_GEMM_AUTO;
   o.early_exit = 1;
   o.use_graph = 0;
+  o.decode_streams = 0;
   return o;
 }
 
@@ -102,6 +105,7 @@ int check_opts(const vitcap_gen_opts& o) {
   OPT_REQ(!o.sampling.do_sample || (o.sampling.temperature > 0.f && o.sampling.top_k >= 0 && o.sampling.top_p > 0.f),
           "gen_opts: temperature %g / top_k %d / top_p %g out of range", (double)o.sampling.temperature, o.sampling.top_k, (double)o.sampling.top_p);
   OPT_REQ(o.gemm_mode == VITCAP_GEMM_AUTO || o.gemm_mode == VITCAP_GEMM_TILES, "gen_opts: gemm_mode %d unknown", o.gemm_mode);
+  OPT_REQ(o.decode_streams >= 0 && o.decode_streams <= 2, "gen_opts: decode_streams must be 0 (auto), 1 or 2 (got %d)", o.decode_streams);
 #undef OPT_REQ
   return VITCAP_OK;
 }
@@ -321,6 +325,9 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->cap) (void)hipStreamDestroy(e->cap);
+  if (e->dec2) (void)hipStreamDestroy(e->dec2);
+  if (e->ev_dfork) (void)hipEventDestroy(e->ev_dfork);
+  if (e->ev_djoin) (void)hipEventDestroy(e->ev_djoin);
   delete e;
 }
 extern "C" int vitcap_engine_graph_count(vitcap_engine* e) { return e ? (int)e->graphs.size() : 0; }
@@ -554,74 +561,90 @@ extern "C" int vitcap_engine_prefill(vitcap_engine* e, int B, const vitcap_gen_o
   return prefill_locked(e, B, o, lo, (char*)workspace, s);
 }
 
-// One decode step for NS sequences (K sequences share one image's visual K/V): embeddings of (token t-1, [MASK]) ->
-// 4 decoder layers against the caches -> LM head on the [MASK] rows -> fp32 logits [NS, VOCAB_PAD].
-static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_gen_opts& o, char* ws, int t, const int64_t* ids,
-                        char* tcache, bool embed, bool rowstat, void* s) {
+// A contiguous slice of the decode batch: sequences [s0, s0 + ns) = images [i0, i0 + ns / K).  The greedy loop can be cut into
+// two such slices that run on two streams (vitcap_gen_opts.decode_streams = 2).  Every decode-step kernel costs ~4.5 us of
+// dispatch-to-drain latency whatever its size (31 of them per step: 140 us of a 295 us step at 64 sequences); the experiment
+// showed that a second chain does NOT hide it (see greedy_loop).  Results are bit-identical to the unsplit loop.
+struct Part {
+  int s0, ns, i0;
+};
+
+// One decode step for the sequences of `pt` (K sequences share one image's visual K/V): embeddings of (token t-1, [MASK]) ->
+// 4 decoder layers against the caches -> LM head on the [MASK] rows -> fp32 logits [ns, VOCAB_PAD] (+ row statistics).
+static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_gen_opts& o, char* ws, int t, const int64_t* ids_all,
+                        char* tcache, bool embed, bool rowstat, const Part& pt, void* s) {
   const int NS = lo.NS, K = lo.K, L = lo.L;
-  float* xs_f = (float*)(ws + lo.xs_f);
-  char* xs_b = ws + lo.xs_b;
-  const int R = 2 * NS;
+  const int ns = pt.ns, R = 2 * ns;
+  const size_t r0 = (size_t)pt.s0 * 2;                       // first step-buffer row of the slice
+  const int64_t* ids = ids_all + (size_t)pt.s0 * L;
+  float* xs_f = (float*)(ws + lo.xs_f) + r0 * D;
+  char* xs_b = ws + lo.xs_b + r0 * D * 2;
+  char* sqkv = ws + lo.sqkv + r0 * 3 * D * 2;
+  char* sctx = ws + lo.sctx + r0 * D * 2;
+  float* sa_f = (float*)(ws + lo.sa_f) + r0 * D;
+  char* sa_b = ws + lo.sa_b + r0 * D * 2;
+  char* smlp = ws + lo.smlp + r0 * 4 * D * 2;
+  char* hd_b = ws + lo.hd_b + (size_t)pt.s0 * D * 2;
+  float* part = (float*)(ws + lo.spart) + (size_t)SPLIT_MAX * r0 * D;      // the slice's own slab region
   if (embed)          // otherwise the previous step's vitcap_greedy_select_embed already wrote this step's x
     CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
-                         NS, s));
-  float* part = (float*)(ws + lo.spart);
+                         ns, s));
   static const int force_old = [] { const char* e = getenv("VITCAP_DECODE_SPLITK"); return e ? atoi(e) : 0; }();   // A/B measurements
-  const bool small = R <= 256 && !force_old;      // resident whole-K kernels (greedy / sampling batches); beams keep the split-K path
+  // resident whole-K kernels for greedy / sampling batches; beams keep the split-K path.  The choice follows the WHOLE batch, so
+  // that a sequence's arithmetic does not depend on how the batch is sliced.
+  const bool small = 2 * NS <= 256 && !force_old;
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
-    char* tc = tcache + (size_t)l * NS * L * 2 * D * 2;
+    char* tc = tcache + ((size_t)l * NS + pt.s0) * L * 2 * D * 2;
+    const char* vis = ws + lo.dqkv[l] + (size_t)pt.i0 * SV * 3 * D * 2;
     if (small)
-      CK(gemm_small(xs_b, D, lw.qkv_w, lw.qkv_b, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, 20, s));
+      CK(gemm_small(xs_b, D, lw.qkv_w, lw.qkv_b, sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, 20, s));
     else
-      CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, ws + lo.sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
-    CK(vitcap_attn_decode_step(ws + lo.sqkv, ws + lo.dqkv[l], tc, ws + lo.sctx, NS, SV, t, L, K, 0.125f, s));
+      CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+    CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
     // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),
     // reduced inside the fused bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
     int s_ao = SPLIT_AO, s_fc2 = SPLIT_FC2;
     if (small) {
-      CK(gemm_small(ws + lo.sctx, D, lw.ao_w, nullptr, part, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
+      CK(gemm_small(sctx, D, lw.ao_w, nullptr, part, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
       s_ao = 1;
     } else {
-      CK(gemm_split(ws + lo.sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
+      CK(gemm_split(sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
     }
-    CK(vitcap_sum_layernorm(part, s_ao, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f,
-                            ws + lo.sa_b, (float*)(ws + lo.sa_f), R, D, s));
+    CK(vitcap_sum_layernorm(part, s_ao, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f, sa_b, sa_f, R, D, s));
     if (small)
-      CK(gemm_small(ws + lo.sa_b, D, lw.i_w, lw.i_b, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, 20, s));
+      CK(gemm_small(sa_b, D, lw.i_w, lw.i_b, smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, 20, s));
     else
-      CK(gemm(ws + lo.sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF,
-              VITCAP_OUT_BF16, s));
+      CK(gemm(sa_b, D, lw.i_w, lw.i_b, nullptr, 0, smlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
     if (small) {
-      CK(gemm_small(ws + lo.smlp, 4 * D, lw.o_w, nullptr, part, D, R, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 20, s));
+      CK(gemm_small(smlp, 4 * D, lw.o_w, nullptr, part, D, R, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 20, s));
       s_fc2 = 4;
     } else {
-      CK(gemm_split(ws + lo.smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
+      CK(gemm_split(smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
     }
-    CK(vitcap_sum_layernorm(part, s_fc2, (size_t)R * D, lw.o_b, (const float*)(ws + lo.sa_f), D, 0, lw.o_g,
-                            lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
+    CK(vitcap_sum_layernorm(part, s_fc2, (size_t)R * D, lw.o_b, sa_f, D, 0, lw.o_g, lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
   }
   // LM head on the [MASK] rows (row 1 of every pair): A = xs_b + 768, lda = 1536
   if (small) {
-    CK(gemm_small(xs_b + D * 2, 2 * D, w.cls.dense_w, nullptr, part, D, NS, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
-    CK(vitcap_sum_layernorm(part, 1, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
-                            ws + lo.hd_b, nullptr, NS, D, s));
+    CK(gemm_small(xs_b + D * 2, 2 * D, w.cls.dense_w, nullptr, part, D, ns, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
+    CK(vitcap_sum_layernorm(part, 1, (size_t)ns * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f, hd_b, nullptr, ns, D, s));
   } else {
-    CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, NS, D, D, SPLIT_AO, s));
-    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)NS * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f,
-                            ws + lo.hd_b, nullptr, NS, D, s));
+    CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, ns, D, D, SPLIT_AO, s));
+    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)ns * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f, hd_b, nullptr,
+                            ns, D, s));
   }
   {
     // vocabulary GEMM: 47 MB of weights streamed once per step.  With few rows (greedy: NS <= 128) the 64x64-tile kernel
     // moves them at 3.8 TB/s against 2.3 TB/s for the 32x32 tiles the small-M dispatch would pick (12.5 vs 20.8 us at NS = 64)
     vitcap_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.M = NS; d.N = VP; d.K = D;
+    d.M = ns; d.N = VP; d.K = D;
     d.lda = D; d.ldw = D; d.ldc = VP;
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
     d.tile_hint = NS <= 128 ? 1 : 0;
-    d.rowstat = rowstat ? (float*)(ws + lo.rowstat) : nullptr;     // greedy: argmax / log-softmax pieces next to the logits
-    CK(gemm_desc(ws + lo.hd_b, w.cls.dec_w, w.cls.dec_b, nullptr, ws + lo.logits, d, s));
+    // greedy: argmax / log-softmax pieces next to the logits
+    d.rowstat = rowstat ? (float*)(ws + lo.rowstat) + (size_t)pt.s0 * (2 * (VP / 64)) * 4 : nullptr;
+    CK(gemm_desc(hd_b, w.cls.dec_w, w.cls.dec_b, nullptr, ws + lo.logits + (size_t)pt.s0 * VP * 4, d, s));
   }
   return VITCAP_OK;
 }
@@ -631,7 +654,7 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
 // here, as the beams of a beam search do).  Results stay in the workspace (lo.ids, lo.logprob, lo.last_tok).
 static int greedy_loop(vitcap_engine* e, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
   const vitcap_weights& w = e->w;
-  const int NS = lo.NS, L = lo.L;
+  const int NS = lo.NS, L = lo.L, K = lo.K, B = NS / K;
   int64_t* ids = (int64_t*)(ws + lo.ids);
   int32_t* unf = (int32_t*)(ws + lo.unf);
   float* sum_lp = (float*)(ws + lo.sum_lp);
@@ -642,25 +665,62 @@ static int greedy_loop(vitcap_engine* e, const Layout& lo, const vitcap_gen_opts
   // 30522-wide fp32 rows back (greedy_step 18.7 us) and a separate embedding launch per step.
   static const int no_fuse = [] { const char* e = getenv("VITCAP_DECODE_NOFUSE"); return e ? atoi(e) : 0; }();
   const bool fused = !o.sampling.do_sample && o.repetition_penalty == 1.0f && NS <= 128 && !no_fuse;
-  for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, o, ws, t, ids, ws + lo.tcache, !fused || t == 1, fused, s));
-    if (fused) {
-      CK(vitcap_greedy_select_embed((const float*)(ws + lo.rowstat), 2 * (VP / 64), ids, unf, sum_lp, cnt, (float*)(ws + lo.logprob),
-                                    (int64_t*)(ws + lo.last_tok), NS, t, L, o.eos_token_id, o.pad_token_id, o.mask_token_id,
-                                    w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, (float*)(ws + lo.xs_f),
-                                    ws + lo.xs_b, s));
-      continue;
+  // two slices on two streams (decode_streams = 2): measured at 64 sequences, eager and graph-replayed: 5.96 ms per batch against
+  // 5.66 ms for one chain -- the ~4.5 us per dependent small kernel is not hidden by a second chain (the dispatch path is the
+  // shared resource), so auto = 1; the option stays for experiments and is covered by tests (bit-identical results)
+  int nparts = o.decode_streams;
+  if (nparts == 0) nparts = 1;
+  if (B < 2) nparts = 1;
+  Part parts[2] = {{0, NS, 0}, {0, 0, 0}};
+  void* st[2] = {s, s};
+  if (nparts == 2) {
+    const int b0 = B / 2;
+    parts[0] = Part{0, b0 * K, 0};
+    parts[1] = Part{b0 * K, (B - b0) * K, b0};
+    if (!e->dec2) {
+      if (hipStreamCreateWithFlags(&e->dec2, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_dfork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_djoin, hipEventDisableTiming) != hipSuccess) {
+        vitcap_set_error("decode: second stream creation failed");
+        return VITCAP_ELAUNCH;
+      }
     }
-    if (o.repetition_penalty != 1.0f)
-      CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, L, t, o.repetition_penalty, NS, s));
-    if (o.sampling.do_sample)
-      CK(vitcap_sample_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L,
-                            o.eos_token_id, o.pad_token_id, &o.sampling, s));
-    else
-      CK(vitcap_greedy_step((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, ids, unf, sum_lp, cnt,
-                            (float*)(ws + lo.logprob), (float*)(ws + lo.margins), (int64_t*)(ws + lo.last_tok), NS, t, L,
-                            o.eos_token_id, o.pad_token_id, s));
+    HIPCK(hipEventRecord(e->ev_dfork, (hipStream_t)s), "decode: fork record");
+    HIPCK(hipStreamWaitEvent(e->dec2, e->ev_dfork, 0), "decode: fork wait");
+    st[1] = (void*)e->dec2;
+  }
+  for (int t = 1; t < L; ++t) {
+    for (int p = 0; p < nparts; ++p) {            // the slices' launches alternate so that both streams are fed evenly
+      const Part& pt = parts[p];
+      void* ps = st[p];
+      const size_t s0 = (size_t)pt.s0;
+      CK(step_forward(w, lo, o, ws, t, ids, ws + lo.tcache, !fused || t == 1, fused, pt, ps));
+      float* logits = (float*)(ws + lo.logits) + s0 * VP;
+      if (fused) {
+        CK(vitcap_greedy_select_embed((const float*)(ws + lo.rowstat) + s0 * (2 * (VP / 64)) * 4, 2 * (VP / 64), ids + s0 * L, unf + s0,
+                                      sum_lp + s0, cnt + s0, (float*)(ws + lo.logprob) + s0, (int64_t*)(ws + lo.last_tok) + s0, pt.ns, t,
+                                      L, o.eos_token_id, o.pad_token_id, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb,
+                                      w.emb_ln_g, w.emb_ln_b, 1e-12f, (float*)(ws + lo.xs_f) + s0 * 2 * D, ws + lo.xs_b + s0 * 2 * D * 2, ps));
+        continue;
+      }
+      if (o.repetition_penalty != 1.0f)
+        CK(vitcap_repetition_penalty(logits, VP, VITCAP_VOCAB, ids + s0 * L, L, t, o.repetition_penalty, pt.ns, ps));
+      if (o.sampling.do_sample) {
+        // the draws are keyed by (seed, sequence index within the call): a slice passes its first sequence as the stream offset
+        vitcap_sample_params sp = o.sampling;
+        CK(vitcap_sample_step_offset(logits, VP, VITCAP_VOCAB, ids + s0 * L, unf + s0, sum_lp + s0, cnt + s0,
+                                     (float*)(ws + lo.logprob) + s0, (float*)(ws + lo.margins) + s0 * L, (int64_t*)(ws + lo.last_tok) + s0,
+                                     pt.ns, t, L, o.eos_token_id, o.pad_token_id, &sp, pt.s0, ps));
+      } else {
+        CK(vitcap_greedy_step(logits, VP, VITCAP_VOCAB, ids + s0 * L, unf + s0, sum_lp + s0, cnt + s0, (float*)(ws + lo.logprob) + s0,
+                              (float*)(ws + lo.margins) + s0 * L, (int64_t*)(ws + lo.last_tok) + s0, pt.ns, t, L, o.eos_token_id,
+                              o.pad_token_id, ps));
+      }
+    }
+  }
+  if (nparts == 2) {
+    HIPCK(hipEventRecord(e->ev_djoin, e->dec2), "decode: join record");
+    HIPCK(hipStreamWaitEvent((hipStream_t)s, e->ev_djoin, 0), "decode: join wait");
   }
   return VITCAP_OK;
 }
@@ -685,7 +745,7 @@ static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen
   char* tc_alt = ws + lo.tcache2;
   const int C = 2 * beams;
   for (int t = 1; t < L; ++t) {
-    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, true, false, s));
+    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, true, false, Part{0, NS, 0}, s));
     if (o.repetition_penalty != 1.0f)
       CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, o.repetition_penalty, NS, s));
     CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),

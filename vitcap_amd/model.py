@@ -256,7 +256,8 @@ class ImageCaptioning(nn.Module):
                        pad_token_id=int(te.get('pad_token_id', 0)), mask_token_id=int(te.get('mask_token_id', 103)),
                        length_penalty=float(te.get('length_penalty', 1) or 1),
                        repetition_penalty=float(te.get('repetition_penalty', 1) or 1), sampling=sp, gemm_mode=int(gemm_mode),
-                       early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)))
+                       early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)),
+                       decode_streams=int(te.get('decode_streams', 0) or 0))
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
