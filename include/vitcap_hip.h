@@ -174,6 +174,14 @@ int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, const void* dou
 int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out,
                             int B, int S_vis, int t, int max_len, int seq_per_image, float scale,
                             void* stream);
+/* The same with the predicted tag tokens visible to the caption rows (the mask CaptionTensorizer builds when
+ * a text_b of n_tag tag tokens is attached, dataset.py:240-252, 387-390): n_tag more keys per image between the visual and the
+ * text keys.  tag_qkv_a / tag_qkv_b: bf16 [B/seq_per_image][n_tag][2304] packed like vis_qkv, the tag rows' K/V under the two
+ * embedding branches of modeling_bert.py:1435-1489; the step uses branch A iff tag_len[0] + 20 <= t + 51 -- the reference's own
+ * test `topk_len[0] + 20 <= input_ids.shape[1]` (tag_len: int64 device array, element 0 is read). */
+int vitcap_attn_decode_step_tags(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B, int S_vis, int t,
+                                 int max_len, int seq_per_image, float scale, const void* tag_qkv_a, const void* tag_qkv_b,
+                                 int n_tag, const int64_t* tag_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Text embedding for step t: rows (b,0)=word[ids[b][t-1]]+pos[t-1]+type[0], (b,1)=word[MASK]+pos[t]+type[0],
@@ -202,6 +210,20 @@ int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_
 /* raw_last (optional, int64 [B]): at t == max_len-1 the token actually chosen at the last position, before it is
  * overwritten by [SEP] for unfinished rows -- the returned log-prob is that of the chosen token (modeling_utils.py:
  * 850-877), which a teacher-forced re-computation of the sequence probability needs. */
+
+/* Embeddings of the predicted tag tokens written over the last 50 text slots (ViTSplitCLSEmbModel.forward,
+ * modeling_bert.py:1435-1489, encode_tag_to_embedding 1381-1406): rows (b, j < n), token = tag_ids[b][j] (int64 [B][50]; slot 49
+ * forced to 102).  branch_a / tagemb_cls select the four forms: raw rows of the caption head's decoder matrix (A, 'cls'),
+ * LN(word + pos[20+j] + type) (A, other), LN(cls_w + pos[20+j] + type) (B, 'cls'), bert.extra_embeddings (B, other; the x* tables).
+ * Outputs fp32 and bf16 [B*n][768]. */
+int vitcap_tag_embed(const int64_t* tag_ids, int n, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
+                     const void* pos_emb, const void* type_emb, const float* gamma, const float* beta, const void* xword_emb,
+                     const void* xpos_emb, const void* xtype_emb, const float* xgamma, const float* xbeta, float eps, float* x_f32,
+                     void* x_bf16, int B, void* stream);
+/* bf16 row blocks between per-image layouts: dst[(b*dst_img_rows + dst_row0 + r)*ld_dst + dst_col0 + c] =
+ * src[(b*src_img_rows + src_row0 + r)*ld_src + src_col0 + c], r < rows, c < cols (multiples of 8 elements). */
+int vitcap_copy_row_blocks(const void* src, int src_img_rows, int src_row0, int ld_src, int src_col0, void* dst, int dst_img_rows,
+                           int dst_row0, int ld_dst, int dst_col0, int rows, int cols, int B, void* stream);
 
 /* The same step taken from the vocabulary GEMM's row statistics (vitcap_gemm_desc.rowstat, `pieces` = 2*ceil(V_pad/64) per row)
  * instead of the logits, fused with BertEmbeddings.forward for step t+1 (vitcap_embed_step): token choice, log-prob and
@@ -335,6 +357,10 @@ typedef struct {
   const float* emb_ln_g; const float* emb_ln_b;
   vitcap_bert_layer_w dec[4];
   vitcap_lm_head_w cls;
+  /* bert.extra_embeddings (tag rows under branch B when tagemb != 'cls', modeling_bert.py:1484-1485): OPTIONAL, may be NULL
+   * unless vitcap_gen_opts.tag_visible > 0 with tagemb_cls == 0 */
+  const void* xword_emb; const void* xpos_emb; const void* xtype_emb;
+  const float* xemb_ln_g; const float* xemb_ln_b;
 } vitcap_weights;
 
 typedef struct vitcap_engine vitcap_engine;
@@ -367,6 +393,11 @@ typedef struct vitcap_gen_opts {
   int32_t use_graph;          /* 1: the decode loop is captured once per (B, workspace, options) into a hipGraph owned
                                  by the engine and replayed by later calls (greedy and beam search; not sampling, whose
                                  seed changes per call)                                                                 */
+  int32_t tag_visible;        /* n in 0..50: the first n predicted tag tokens are VISIBLE to the caption rows and to each other
+                                 (the mask tensorize_ab builds for a text_b of n tokens, dataset.py:240-252, 387-390; SURVEY 8f
+                                 rank 4).  0 = the shipped test mask (nothing attends the tag slots).  Needs max_length == 20.   */
+  int32_t tagemb_cls;         /* model config `tagemb == 'cls'` (YAML tagemb: cls): which embedding the tag rows take
+                                 (modeling_bert.py:1454-1489); only read when tag_visible > 0                                   */
   int32_t decode_streams;     /* greedy / sampling loop: 2 = the batch is cut into two slices that decode on two streams (the
                                  second one engine-owned, forked from and joined to the caller's); 1 = one chain; 0 = auto
                                  (= 1: measured, the second chain does not hide the per-kernel latency).  Same results.   */

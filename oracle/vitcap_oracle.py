@@ -188,8 +188,12 @@ def bert_layer(sd, p, x, ext_mask, keep=None, p_drop=0.0):
 # --------------------------------------------------------------------------------------------
 # a8  masks   (tagger_caption_uni_pipeline_expanding_bertemb.py:57-85; dataset.py:377-390 test mode)
 # --------------------------------------------------------------------------------------------
-def test_text_inputs(batch, max_len=MAX_LEN, od_len=OD_LEN):
-    """What CaptionTensorizer emits at test time (dataset.py:218-219, 326, 377-390; notebook cell 15)."""
+def test_text_inputs(batch, max_len=MAX_LEN, od_len=OD_LEN, n_tag_visible=0):
+    """What CaptionTensorizer emits at test time (dataset.py:218-219, 326, 377-390; notebook cell 15).
+
+    ``n_tag_visible`` > 0: the mask ``tensorize_ab`` builds when a ``text_b`` of n tag tokens is attached (add_od_labels,
+    dataset.py:240-252, 387-390): the n tag slots see each other, every caption row sees them (the shipped
+    pipeline hard-codes text_b away, ..._bertemb.py:424)."""
     T = max_len + od_len
     input_ids = torch.zeros(batch, T, dtype=torch.long)
     input_ids[:, 0] = BOS
@@ -197,6 +201,10 @@ def test_text_inputs(batch, max_len=MAX_LEN, od_len=OD_LEN):
     input_ids[:, max_len - 1] = EOS
     am = torch.zeros(T, T)
     am[:max_len, :max_len] = torch.tril(torch.ones(max_len, max_len))
+    if n_tag_visible:
+        n = int(n_tag_visible)
+        am[max_len:max_len + n, max_len:max_len + n] = 1          # L-L
+        am[:max_len, max_len:max_len + n] = 1                      # C-L
     attention_mask = am.unsqueeze(0).expand(batch, T, T).clone()
     return input_ids, attention_mask
 
@@ -283,12 +291,12 @@ def apply_repetition_penalty(logits, prefix_ids, penalty):
 
 
 def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_start_posid=20,
-                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0, eos=EOS):
+                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0, eos=EOS, n_tag_visible=0):
     """Reference greedy decode.  ``reuse_encoder=True`` computes the (step-invariant) ViT encoder
     once instead of 19 times -- same numbers, used only to keep CPU tests fast."""
     B = image.shape[0]
     img_feats = patch_embed(sd, image)
-    input_ids0, am = test_text_inputs(B, max_length)
+    input_ids0, am = test_text_inputs(B, max_length, n_tag_visible=n_tag_visible)
     full_mask = construct_attn_mask(am, img_feats.shape[1])
     od_label_ids = input_ids0[:, max_length:]
     od_len = od_label_ids.shape[1]

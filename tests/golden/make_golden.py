@@ -174,13 +174,13 @@ class _MarginRecorder(object):
         return m.numpy().copy()
 
 
-def ref_generate(model, enc, image, num_beams=1, **over):
+def ref_generate(model, enc, image, num_beams=1, n_tag_visible=0, **over):
     """Notebook cell 15/16 flow == ImageCaptioning.forward test branch (..._bertemb.py:87-184).
     Returns (ids, logprobs, margins (B,19))."""
     sys.path.insert(0, os.path.join(REPO))
     from oracle import vitcap_oracle as O
     B = image.shape[0]
-    input_ids, am = O.test_text_inputs(B)
+    input_ids, am = O.test_text_inputs(B, n_tag_visible=n_tag_visible)
     img_feats = enc(image)
     full = O.construct_attn_mask(am, img_feats.shape[1])      # restated 30-line mask (pipeline needs cv2)
     kw = dict(is_decode=True, do_sample=False, bos_token_id=101, pad_token_id=0, eos_token_ids=[102],
@@ -349,6 +349,24 @@ def main():
     out['beam_sel_index'] = bsel.numpy().copy()
     beam_case('beam5_sel', cand[bsel], 5, {})
 
+    # ---- the predicted tag tokens VISIBLE to the caption (the mask tensorize_ab builds when a text_b of n tag
+    # tokens is attached): all 50 slots, and a partial set of 7; pipeline flow (tagemb 'cls': branch B for steps 1..18, branch A at
+    # the last step with the recipe's topk_len = 50, modeling_bert.py:1435-1489)
+    for n in (50, 7):
+        ids, lp, m = ref_generate(model, enc, img4[:2], n_tag_visible=n)
+        out['greedy_tags%d_b2_ids' % n] = ids.numpy().copy()
+        out['greedy_tags%d_b2_logprobs' % n] = lp.numpy().copy()
+        out['greedy_tags%d_b2_margins' % n] = m
+        print('tags visible %d' % n, ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    ids, lp, m = ref_generate(model, enc, cand[sel], n_tag_visible=50)
+    out['greedy_tags50_sel_ids'] = ids.numpy().copy()
+    out['greedy_tags50_sel_logprobs'] = lp.numpy().copy()
+    out['greedy_tags50_sel_margins'] = m
+    print('tags visible 50, selected images', ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    with torch.no_grad():
+        _, _, pred_l, tl = O.tag_head(sd_t, O.split_encoder(sd_t, O.patch_embed(sd_t, img4[:2]))[1])
+    out['tags_topk_len_b2'] = tl.numpy().copy()
+
     # ---- notebook flow (BASELINE configs[0]): tagemb None, untied
     sd2 = W.make_state_dict(seed=0, tie_weights=False)
     model2, enc2 = build_reference(None, False)
@@ -359,6 +377,11 @@ def main():
         out['greedy_untied_nocls_b%d_logprobs' % B] = lp.numpy().copy()
         out['greedy_untied_nocls_b%d_margins' % B] = m
         print('untied B=%d' % B, ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    ids, lp, m = ref_generate(model2, enc2, img4[:2], n_tag_visible=50)          # tagemb None: extra_embeddings / word embeddings
+    out['greedy_untied_tags50_b2_ids'] = ids.numpy().copy()
+    out['greedy_untied_tags50_b2_logprobs'] = lp.numpy().copy()
+    out['greedy_untied_tags50_b2_margins'] = m
+    print('untied, tags visible 50', ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
     meta['recipe_version'] = W.RECIPE_VERSION
 
     np.savez_compressed(os.path.join(HERE, 'reference_vectors.npz'), **out)

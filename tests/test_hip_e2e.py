@@ -391,6 +391,52 @@ def test_split_decode_loop_equals_single_chain(model):
     assert int(model.tap('live', 6, (1,), torch.int32)[0]) == 0
 
 
+@pytest.mark.parametrize('flow', ['cls', 'untied'])
+def test_tag_tokens_visible_to_caption(golden, flow):
+    """with the mask tensorize_ab builds for a text_b of n tag tokens (dataset.py:240-252, 387-390) every
+    caption row attends the first n predicted tag tokens, whose embeddings follow the two branches of modeling_bert.py:1435-1489
+    (re-selected at every step by `topk_len[0] + 20 <= L`).  Device captions against the reference's own output for n = 50 and
+    n = 7 (pipeline flow, tagemb 'cls') and n = 50 in the notebook flow (tagemb None: bert.extra_embeddings / word embeddings),
+    driven through ImageCaptioning.forward with the caller's attention_mask; the tags really change the captions."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd.model import ImageCaptioning
+    vec, _ = golden
+    if flow == 'cls':
+        m = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+        cases = [('greedy_tags50_b2', 50, _images(2), 0), ('greedy_tags7_b2', 7, _images(2), 0), ('greedy_tags50_sel', 50, _selected(vec), 0)]
+        plain = vec['greedy_b2_ids']
+    else:
+        m = ImageCaptioning(tie_weights=False, tagemb=None).load_recipe(0).eval()
+        cases = [('greedy_untied_tags50_b2', 50, _images(2), 0)]
+        plain = vec['greedy_untied_nocls_b2_ids']
+    m.pack('cuda')
+    key0 = cases[0][0]
+    plain_lp = vec['greedy_b2_logprobs' if flow == 'cls' else 'greedy_untied_nocls_b2_logprobs']
+    assert not np.array_equal(vec[key0 + '_ids'], plain) or float(np.abs(vec[key0 + '_logprobs'] - plain_lp).max()) > 5e-3, \
+        'golden: visible tags were meant to change the caption or at least its score'
+    for name, n, img, min_full in cases:
+        B = img.shape[0]
+        input_ids, am = O.test_text_inputs(B, n_tag_visible=n)
+        data = {'image': img.cuda(), 'key': list(range(B)), 'input_ids': input_ids.cuda(), 'attention_mask': am.cuda(),
+                'token_type_ids': torch.zeros(B, 70, dtype=torch.long).cuda(), 'masked_pos': torch.ones(B, 70, dtype=torch.int32).cuda()}
+        ids, lp = m(data)
+        rep = assert_tokens_match_reference(ids.cpu().numpy(), vec[name + '_ids'], vec[name + '_margins'], GREEDY_MARGIN_FLOOR,
+                                            min_full=min_full, what=name)
+        print(name, rep, lp.flatten().tolist(), vec[name + '_logprobs'].flatten().tolist())
+        same = np.array([r[4] for r in rep])          # a sequence that left the reference's path at a sub-floor decision has another score
+        assert same.any()
+        np.testing.assert_allclose(lp.cpu().numpy()[same], vec[name + '_logprobs'][same], rtol=0, atol=1e-2)
+        # the same through the option instead of the mask, and a beam search over the same keys runs and is well formed
+        ids2, _ = m.generate(img.cuda(), tag_visible=n)
+        assert torch.equal(ids, ids2)
+    bi, bl = m.generate_beam(cases[0][2].cuda(), 3, tag_visible=50)
+    assert bi.shape == (cases[0][2].shape[0], 1, 20) and torch.isfinite(bl).all() and (bi[:, 0, 0] == 101).all()
+    # the shipped mask is untouched by the option's existence
+    ids0, _ = m.generate(_images(2).cuda())
+    assert_tokens_match_reference(ids0.cpu().numpy(), plain, vec['greedy_b2_margins' if flow == 'cls' else 'greedy_untied_nocls_b2_margins'],
+                                  GREEDY_MARGIN_FLOOR, min_full=0, what='plain after tags')
+
+
 def test_text_inputs_are_validated(model):
     """a8 / a16: forward() checks the caller's text tensors against the mask structure the kernels implement."""
     from oracle import vitcap_oracle as O

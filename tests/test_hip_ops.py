@@ -137,6 +137,39 @@ def test_gemm_resident_whole_k(ops, M, N, K, hint, act):
         _close(got, z + bias.cpu() + x.cpu(), 1e-4, 1e-4, 'resident f32 + residual')
 
 
+@pytest.mark.parametrize('branch_a,cls', [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_tag_embed_four_forms(ops, branch_a, cls):
+    """vitcap_tag_embed: the four tag-row embeddings of modeling_bert.py:1435-1489 against their torch definition."""
+    import ctypes as C
+    from vitcap_amd._lib import lib, check
+    B, n, VP = 3, 50, 30592
+    g = torch.Generator().manual_seed(8)
+    mk = lambda *sh: _bf(torch.randn(*sh, generator=g) * 0.05).cuda()
+    cls_w, word, pos, typ = mk(VP, 768), mk(VP, 768), mk(512, 768), mk(2, 768)
+    xword, xpos, xtyp = mk(VP, 768), mk(512, 768), mk(2, 768)
+    gam, bet = (1 + torch.randn(768, generator=g) * 0.1).cuda(), (torch.randn(768, generator=g) * 0.1).cuda()
+    xgam, xbet = (1 + torch.randn(768, generator=g) * 0.1).cuda(), (torch.randn(768, generator=g) * 0.1).cuda()
+    tags = torch.randint(0, 30522, (B, 50), generator=g).cuda()
+    xf = torch.empty(B * n, 768, device='cuda')
+    xb = torch.empty(B * n, 768, device='cuda', dtype=torch.bfloat16)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.vitcap_tag_embed(p(tags), n, branch_a, cls, p(cls_w), p(word), p(pos), p(typ), p(gam), p(bet), p(xword), p(xpos), p(xtyp),
+                               p(xgam), p(xbet), 1e-12, p(xf), p(xb), B, None), 'tag_embed')
+    t = tags.clone()
+    t[:, -1] = 102
+    j = torch.arange(50, device='cuda') + 20
+    if branch_a and cls:
+        want = cls_w[t].float()
+    elif branch_a:
+        want = torch.nn.functional.layer_norm(word[t].float() + pos[j].float() + typ[0].float(), (768,), gam, bet, 1e-12)
+    elif cls:
+        want = torch.nn.functional.layer_norm(cls_w[t].float() + pos[j].float() + typ[0].float(), (768,), gam, bet, 1e-12)
+    else:
+        want = torch.nn.functional.layer_norm(xword[t].float() + xpos[j].float() + xtyp[0].float(), (768,), xgam, xbet, 1e-12)
+    _close(xf.view(B, 50, 768), want.cpu(), 2e-5, 2e-5, 'tag_embed')
+    assert torch.equal(xb.cpu(), xf.cpu().to(torch.bfloat16))
+
+
 def test_greedy_select_embed_equals_step_plus_embed(ops):
     """The fused greedy step (vocabulary GEMM row statistics -> token, log-prob, bookkeeping, next step's embedding) against
     the three separate kernels it replaces, over a whole 19-step loop with early finishers: ids, unfinished flags and

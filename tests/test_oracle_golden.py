@@ -173,6 +173,19 @@ def test_greedy_untied_incremental_matches_reference(golden):
     np.testing.assert_allclose(lp.numpy(), vec['greedy_untied_nocls_b2_logprobs'], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.slow
+def test_tags_visible_as_written_matches_reference(golden, sd_t, img):
+    """the mask with the first n tag slots visible to the caption (dataset.py:240-252, 387-390) through the
+    oracle's restatement of ViTSplitCLSEmbModel.forward (both embedding branches) against the reference's own captions."""
+    vec, _ = golden
+    with torch.no_grad():
+        ids, lp = O.greedy_as_written(sd_t, img, reuse_encoder=True, n_tag_visible=50)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_tags50_b2_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_tags50_b2_logprobs'], rtol=1e-5, atol=1e-5)
+    assert not np.array_equal(vec['greedy_tags50_b2_ids'], vec['greedy_b2_ids'])
+    assert int(vec['tags_topk_len_b2'][0]) == 50            # recipe: branch B at steps 1..18, branch A at step 19
+
+
 def test_beam2_as_written_matches_reference(golden, sd_t, img):
     """a13: the beam driver + BeamHypotheses restatement against the reference's own beam=2 output."""
     vec, _ = golden

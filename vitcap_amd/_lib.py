@@ -45,7 +45,8 @@ class GenOpts(C.Structure):
                 ('max_length', C.c_int32), ('bos_token_id', C.c_int32), ('eos_token_id', C.c_int32),
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
-                ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('decode_streams', C.c_int32)]
+                ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('tag_visible', C.c_int32), ('tagemb_cls', C.c_int32),
+                ('decode_streams', C.c_int32)]
 
 
 class Image(C.Structure):
@@ -78,7 +79,8 @@ class Weights(C.Structure):
                 ('blocks', VitBlockW * 12), ('tag_blocks', VitBlockW * 4),
                 ('pooler_w', vp), ('pooler_b', vp), ('tag_logit', LmHeadW),
                 ('word_emb', vp), ('pos_emb', vp), ('type_emb', vp), ('emb_ln_g', vp), ('emb_ln_b', vp),
-                ('dec', BertLayerW * 4), ('cls', LmHeadW)]
+                ('dec', BertLayerW * 4), ('cls', LmHeadW),
+                ('xword_emb', vp), ('xpos_emb', vp), ('xtype_emb', vp), ('xemb_ln_g', vp), ('xemb_ln_b', vp)]
 
 
 _SIGS = {
@@ -125,6 +127,12 @@ _SIGS = {
                                              C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_attn_decode_step': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, vp]),
+    'vitcap_attn_decode_step_tags': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp,
+                                               C.c_int, vp, vp]),
+    'vitcap_tag_embed': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp,
+                                   C.c_int, vp]),
+    'vitcap_copy_row_blocks': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, vp]),
     'vitcap_embed_step': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp,
                                     C.c_int, vp]),
     'vitcap_greedy_init': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -307,13 +307,15 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
 // Two passes over the scores: they are staged in LDS (<= 640 keys x 2 rows fp32) so the softmax uses
 // the exact row max like the oracle.
 // ------------------------------------------------------------------------------------------------
-constexpr int MAXKEYS = 640;
+constexpr int MAXKEYS = 704;     // 578 visual + 50 tag + 41 text + pad
 
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv_step,
                                                           const bf16_t* __restrict__ vis_qkv,
                                                           bf16_t* __restrict__ text_kv, bf16_t* __restrict__ out,
                                                           int S_vis, int t, int max_len, int seq_per_image,
-                                                          float c_log2, const int32_t* __restrict__ live) {
+                                                          float c_log2, const int32_t* __restrict__ live,
+                                                          const bf16_t* __restrict__ tag_a, const bf16_t* __restrict__ tag_b,
+                                                          int n_tag, const int64_t* __restrict__ tag_len) {
   VC_LIVE_EXIT(live);
   __shared__ float sc[2][MAXKEYS];
   __shared__ float red[2][4];
@@ -323,7 +325,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   const int img = b / seq_per_image;
   const int sub = lane & 7;          // which 8-wide d slice
   const int kslot = tid >> 3;        // 0..31: key slot within a 32-key sweep
-  const int nkeys = S_vis + t + 1;   // visual | text 0..t-1 | mask row
+  // Optional tag keys (the predicted tag tokens visible to the caption): n_tag rows per image between the
+  // visual and the text keys, packed like the visual rows ([image][n_tag][2304]).  Which of the two embedding branches of
+  // modeling_bert.py:1435-1489 the step sees is the reference's own data-dependent test, `topk_len[0] + 20 <= L`, with
+  // L = t + 1 + 50 text slots at step t.
+  const bf16_t* tag_kv = nullptr;
+  if (n_tag > 0) tag_kv = ((int)tag_len[0] + 20 <= t + 51) ? tag_a : tag_b;
+  const int S_pre = S_vis + n_tag;   // keys before the text rows
+  const int nkeys = S_pre + t + 1;   // visual | tags | text 0..t-1 | mask row
 
   const bf16_t* q0p = qkv_step + ((size_t)b * 2) * QKV_LD + h * HD + sub * 8;
   const bf16_t* q1p = q0p + QKV_LD;
@@ -343,7 +352,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   }
   auto key_ptr = [&](int k, int which) -> const bf16_t* {   // which: 0 K, 1 V
     if (k < S_vis) return vis_qkv + ((size_t)img * S_vis + k) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
-    const int tp = k - S_vis;
+    if (k < S_pre) return tag_kv + ((size_t)img * n_tag + (k - S_vis)) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
+    const int tp = k - S_pre;
     if (tp < t - 1) return tkv + ((size_t)tp * 2 + which) * 768 + h * HD + sub * 8;
     return qkv_step + ((size_t)b * 2 + (tp - (t - 1))) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
   };
@@ -500,14 +510,23 @@ extern "C" int vitcap_attn_dense_fwd_train(const void* qkv, void* out, float* ls
                                           stream);
 }
 
-extern "C" int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B,
-                                       int S_vis, int t, int max_len, int seq_per_image, float scale, void* stream) {
+extern "C" int vitcap_attn_decode_step_tags(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B,
+                                            int S_vis, int t, int max_len, int seq_per_image, float scale, const void* tag_qkv_a,
+                                            const void* tag_qkv_b, int n_tag, const int64_t* tag_len, void* stream) {
   VC_REQUIRE(qkv_step && vis_qkv && text_kv && out && B > 0, "attn_decode: bad arguments");
-  VC_REQUIRE(t >= 1 && t < max_len && S_vis + t + 1 <= MAXKEYS, "attn_decode: t=%d S_vis=%d out of range", t, S_vis);
+  VC_REQUIRE(n_tag >= 0 && n_tag <= 50 && (n_tag == 0 || (tag_qkv_a && tag_qkv_b && tag_len)), "attn_decode: bad tag keys (n_tag=%d)", n_tag);
+  VC_REQUIRE(t >= 1 && t < max_len && S_vis + n_tag + t + 1 <= MAXKEYS, "attn_decode: t=%d S_vis=%d out of range", t, S_vis);
   VC_REQUIRE(seq_per_image >= 1 && B % seq_per_image == 0, "attn_decode: bad seq_per_image");
   const float c = scale * 1.4426950408889634f;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(NH, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_step,
-                     (const bf16_t*)vis_qkv, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len, seq_per_image, c, vc_tls_live);
+                     (const bf16_t*)vis_qkv, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len, seq_per_image, c, vc_tls_live,
+                     (const bf16_t*)tag_qkv_a, (const bf16_t*)tag_qkv_b, n_tag, tag_len);
   VC_LAUNCH_CHECK("attn_decode");
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_decode_step(const void* qkv_step, const void* vis_qkv, void* text_kv, void* out, int B,
+                                       int S_vis, int t, int max_len, int seq_per_image, float scale, void* stream) {
+  return vitcap_attn_decode_step_tags(qkv_step, vis_qkv, text_kv, out, B, S_vis, t, max_len, seq_per_image, scale, nullptr, nullptr,
+                                      0, nullptr, stream);
 }

@@ -14,6 +14,7 @@
 // (SURVEY.md headline 5), so they are not materialised; the tag head itself is still computed and exposed.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <mutex>
@@ -70,6 +71,7 @@ constexpr int NV = VITCAP_NVIS;        // 577
 constexpr int SV = VITCAP_NVIS + 1;    // 578 decoder visual rows (tag CLS first)
 constexpr int VP = VITCAP_VOCAB_PAD;
 constexpr int TOPK = 50;
+constexpr int JROWS = 640;           // rows per image of the joint [visual | tag] buffer (578 + 50, padded to 5 x 128)
 constexpr int SPLIT_AO = 6, SPLIT_FC2 = 12, SPLIT_MAX = 12;   // split-K of the K=768 / K=3072 decode GEMMs with N=768
 
 vitcap_gen_opts default_opts() {
@@ -86,6 +88,8 @@ vitcap_gen_opts default_opts() {
   o.gemm_mode = VITCAP_GEMM_AUTO;
   o.early_exit = 1;
   o.use_graph = 0;
+  o.tag_visible = 0;
+  o.tagemb_cls = 1;
   o.decode_streams = 0;
   return o;
 }
@@ -105,6 +109,8 @@ int check_opts(const vitcap_gen_opts& o) {
   OPT_REQ(!o.sampling.do_sample || (o.sampling.temperature > 0.f && o.sampling.top_k >= 0 && o.sampling.top_p > 0.f),
           "gen_opts: temperature %g / top_k %d / top_p %g out of range", (double)o.sampling.temperature, o.sampling.top_k, (double)o.sampling.top_p);
   OPT_REQ(o.gemm_mode == VITCAP_GEMM_AUTO || o.gemm_mode == VITCAP_GEMM_TILES, "gen_opts: gemm_mode %d unknown", o.gemm_mode);
+  OPT_REQ(o.tag_visible >= 0 && o.tag_visible <= 50, "gen_opts: tag_visible must be 0..50 (got %d)", o.tag_visible);
+  OPT_REQ(o.tag_visible == 0 || o.max_length == VITCAP_MAXLEN, "gen_opts: tag_visible > 0 needs max_length == %d", VITCAP_MAXLEN);
   OPT_REQ(o.decode_streams >= 0 && o.decode_streams <= 2, "gen_opts: decode_streams must be 0 (auto), 1 or 2 (got %d)", o.decode_streams);
 #undef OPT_REQ
   return VITCAP_OK;
@@ -125,6 +131,9 @@ struct Layout {
   size_t hd_f, hd_b, logits, rowstat;
   size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok, live;
   size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok, fin_ids, fin_lp;
+  // tag rows visible to the caption (vitcap_gen_opts.tag_visible = n > 0): per embedding branch v in {A, B}
+  size_t tagx_f[2], tagx_b[2], tqkv_c[2][4], jqkv, jout, jlse, tg_ctx, tg_sa_f, tg_sa_b, tg_mlp, tg_tmp;
+  int NT;
   int L, NS, K;
   bool beam;
   Layout(int B, const vitcap_gen_opts& o) {
@@ -181,6 +190,28 @@ struct Layout {
     logprob = take(n * 4);
     last_tok = take(n * 8);
     live = take(256);
+    NT = o.tag_visible;
+    for (int v = 0; v < 2; ++v) {
+      tagx_f[v] = tagx_b[v] = 0;
+      for (int i = 0; i < 4; ++i) tqkv_c[v][i] = 0;
+    }
+    jqkv = jout = jlse = tg_ctx = tg_sa_f = tg_sa_b = tg_mlp = tg_tmp = 0;
+    if (NT > 0) {
+      const size_t r = b * (size_t)NT;            // tag rows of the batch
+      for (int v = 0; v < 2; ++v) {
+        tagx_f[v] = take(r * D * 4);
+        tagx_b[v] = take(r * D * 2);
+        for (int i = 0; i < 4; ++i) tqkv_c[v][i] = take(r * 3 * D * 2);      // the tag rows' packed q|k|v = their K/V cache
+      }
+      jqkv = take(b * JROWS * 3 * D * 2);         // per image [578 visual K/V | n tag rows] for the tag rows' attention
+      jout = take(b * JROWS * D * 2);
+      jlse = take(b * 12 * JROWS * 4);
+      tg_ctx = take(r * D * 2);
+      tg_sa_f = take(r * D * 4);
+      tg_sa_b = take(r * D * 2);
+      tg_mlp = take(r * 4 * D * 2);
+      tg_tmp = take(r * D * 4);
+    }
     cand_val = cand_idx = lse = beam_scores = parent = done = has_hyp = hyp_score = hyp_len = hyp_tok = fin_ids = fin_lp = 0;
     if (beam) {
       cand_val = take(n * 16 * 4);
@@ -375,7 +406,8 @@ extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* fl
 extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w) {
   if (!e || !w) { vitcap_set_error("bind_weights: null"); return VITCAP_EINVAL; }
   const void* const* p = (const void* const*)w;
-  for (size_t i = 0; i < sizeof(vitcap_weights) / sizeof(void*); ++i)
+  const size_t required = offsetof(vitcap_weights, xword_emb) / sizeof(void*);      // bert.extra_embeddings is optional
+  for (size_t i = 0; i < required; ++i)
     if (!p[i]) { vitcap_set_error("bind_weights: pointer #%zu of vitcap_weights is NULL", i); return VITCAP_EINVAL; }
   std::lock_guard<std::mutex> lk(e->mu);
   e->w = *w;
@@ -522,6 +554,52 @@ static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void*
   return VITCAP_OK;
 }
 
+// the predicted tag tokens as real rows of the joint sequence.  With the mask tensorize_ab builds for a
+// text_b of n tokens (dataset.py:240-252, 387-390) the n tag rows attend each other and the 578 visual rows, and every caption
+// row attends them; nothing they attend depends on the caption, so their hidden states -- hence their K/V in every decoder
+// layer -- are computed ONCE here, for BOTH embedding branches of modeling_bert.py:1435-1489 (the reference re-evaluates
+// `topk_len[0] + 20 <= L` at every step: the decode attention picks the branch per step, vitcap_attn_decode_step_tags).
+// Per layer: tag q|k|v (compact rows = the cache) -> joint buffer [visual K/V | tag rows] per image -> dense MFMA attention on
+// the query range that covers the tag rows -> BertSelfOutput / BertIntermediate / BertOutput on the tag rows.
+static int prefill_tags(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
+  const vitcap_weights& w = e->w;
+  const int n = lo.NT, R = B * n, S2 = SV + n;
+  if (!o.tagemb_cls && !(w.xword_emb && w.xpos_emb && w.xtype_emb && w.xemb_ln_g && w.xemb_ln_b)) {
+    vitcap_set_error("prefill: tag_visible with tagemb != 'cls' needs bert.extra_embeddings bound (vitcap_weights.x*)");
+    return VITCAP_ESTATE;
+  }
+  for (int v = 0; v < 2; ++v)
+    CK(vitcap_tag_embed((const int64_t*)(ws + lo.tag_ids), n, v == 0, o.tagemb_cls, w.cls.dec_w, w.word_emb, w.pos_emb, w.type_emb,
+                        w.emb_ln_g, w.emb_ln_b, w.xword_emb, w.xpos_emb, w.xtype_emb, w.xemb_ln_g, w.xemb_ln_b, 1e-12f,
+                        (float*)(ws + lo.tagx_f[v]), ws + lo.tagx_b[v], B, s));
+  for (int l = 0; l < 4; ++l) {
+    const vitcap_bert_layer_w& lw = w.dec[l];
+    if (l < 3)        // visual K | V of this layer into the joint buffer (the Q columns of those rows are never read as queries we keep)
+      CK(vitcap_copy_row_blocks(ws + lo.dqkv[l], SV, 0, 3 * D, D, ws + lo.jqkv, JROWS, 0, 3 * D, D, SV, 2 * D, B, s));
+    for (int v = 0; v < 2; ++v) {
+      char* tq = ws + lo.tqkv_c[v][l];
+      float* xf = (float*)(ws + lo.tagx_f[v]);
+      char* xb = ws + lo.tagx_b[v];
+      if (l == 3) {   // the last layer's tag-row outputs feed nothing: K | V only
+        CK(gemm(xb, D, (const char*)lw.qkv_w + (size_t)D * D * 2, lw.qkv_b + D, nullptr, 0, tq + (size_t)D * 2, 3 * D, R, 2 * D, D,
+                VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+        continue;
+      }
+      CK(gemm(xb, D, lw.qkv_w, lw.qkv_b, nullptr, 0, tq, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+      CK(vitcap_copy_row_blocks(tq, n, 0, 3 * D, 0, ws + lo.jqkv, JROWS, SV, 3 * D, 0, n, 3 * D, B, s));
+      CK(vitcap_attn_dense_fwd_train_rows(ws + lo.jqkv, ws + lo.jout, (float*)(ws + lo.jlse), B, S2, JROWS, 0.125f, 0.f, 0u, 0, 0, 512, S2, s));
+      CK(vitcap_copy_row_blocks(ws + lo.jout, JROWS, SV, D, 0, ws + lo.tg_ctx, n, 0, D, 0, n, D, B, s));
+      CK(gemm(ws + lo.tg_ctx, D, lw.ao_w, lw.ao_b, xf, D, ws + lo.tg_tmp, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+      CK(vitcap_layernorm_fwd((const float*)(ws + lo.tg_tmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.tg_sa_b, (float*)(ws + lo.tg_sa_f), R, D, s));
+      CK(gemm(ws + lo.tg_sa_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.tg_mlp, 4 * D, R, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
+      CK(gemm(ws + lo.tg_mlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.tg_sa_f), D, ws + lo.tg_tmp, D, R, D, 4 * D, VITCAP_ACT_NONE,
+              VITCAP_OUT_F32, s));
+      CK(vitcap_layernorm_fwd((const float*)(ws + lo.tg_tmp), D, lw.o_g, lw.o_beta, 1e-12f, xb, xf, R, D, s));
+    }
+  }
+  return VITCAP_OK;
+}
+
 static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
   CallScope scope(e, o.gemm_mode, nullptr);
   const vitcap_weights& w = e->w;
@@ -548,6 +626,7 @@ static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, con
             VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
     CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.o_g, lw.o_beta, 1e-12f, vis_b, vis_f, M, D, s));
   }
+  if (lo.NT > 0) CK(prefill_tags(e, B, o, lo, ws, s));
   return VITCAP_OK;
 }
 
@@ -601,7 +680,12 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
       CK(gemm_small(xs_b, D, lw.qkv_w, lw.qkv_b, sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, 20, s));
     else
       CK(gemm(xs_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, sqkv, 3 * D, R, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
-    CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
+    if (lo.NT > 0)
+      CK(vitcap_attn_decode_step_tags(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f,
+                                      ws + lo.tqkv_c[0][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2, ws + lo.tqkv_c[1][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2,
+                                      lo.NT, (const int64_t*)(ws + lo.tag_len), s));
+    else
+      CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
     // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),
     // reduced inside the fused bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
     int s_ao = SPLIT_AO, s_fc2 = SPLIT_FC2;

@@ -223,6 +223,71 @@ __global__ __launch_bounds__(128) void greedy_select_embed_kernel(const float* _
   ln_row(v, gamma, beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
 }
 
+// Embeddings of the predicted tag tokens that ViTSplitCLSEmbModel.forward writes over the last 50 text slots
+// (modeling_bert.py:1435-1489); one wave per (image, slot j < n).  tok = pred_topk[b][j], slot 49 forced to 102 (:1452, :1477).
+//   branch A (topk_len[0] + 20 <= L), tagemb == 'cls': the raw row of the caption head's decoder matrix (F.embedding, :1456-1462)
+//   branch A, otherwise        : LN_emb(word[tok] + pos[20 + j] + type[0])                       (encode_tag_to_embedding, :1381-1406)
+//   branch B, tagemb == 'cls'  : LN_emb(cls_w[tok] + pos[20 + j] + type[0])                      (:1481)
+//   branch B, otherwise        : LN_x(xword[tok] + xpos[20 + j] + xtype[0])   (bert.extra_embeddings, :1484-1485)
+__global__ __launch_bounds__(256) void tag_embed_kernel(const int64_t* __restrict__ tag_ids, int n, int branch_a, int tagemb_cls,
+                                                        const bf16_t* __restrict__ cls_w, const bf16_t* __restrict__ word,
+                                                        const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const bf16_t* __restrict__ xword, const bf16_t* __restrict__ xpos,
+                                                        const bf16_t* __restrict__ xtype, const float* __restrict__ xgamma,
+                                                        const float* __restrict__ xbeta, float eps, float* __restrict__ xf,
+                                                        bf16_t* __restrict__ xb, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / n, j = row - b * n;
+  const int64_t tok = j == 49 ? (int64_t)102 : tag_ids[(size_t)b * 50 + j];
+  const bool extra = !branch_a && !tagemb_cls;
+  const bf16_t* tab = tagemb_cls ? cls_w : (extra ? xword : word);
+  const bf16_t* ptab = extra ? xpos : pos;
+  const bf16_t* ttab = extra ? xtype : type;
+  f32x4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 a = ld_bf4(tab + (size_t)tok * D768 + c);
+    if (branch_a && tagemb_cls) {
+      v[i] = a;
+    } else {
+      const f32x4 q = ld_bf4(ptab + (size_t)(20 + j) * D768 + c);
+      const f32x4 ty = ld_bf4(ttab + c);
+      v[i] = (a + q) + ty;
+    }
+  }
+  if (branch_a && tagemb_cls) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      *(f32x4*)(xf + (size_t)row * D768 + c) = v[i];
+      uint2 o;
+      o.x = pack2bf(v[i][0], v[i][1]);
+      o.y = pack2bf(v[i][2], v[i][3]);
+      *(uint2*)(xb + (size_t)row * D768 + c) = o;
+    }
+    return;
+  }
+  ln_row(v, extra ? xgamma : gamma, extra ? xbeta : beta, eps, lane, xb + (size_t)row * D768, xf + (size_t)row * D768);
+}
+
+// dst[(b * dst_img_rows + dst_row0 + r) * ld_dst + dst_col0 + c] = src[(b * src_img_rows + src_row0 + r) * ld_src + src_col0 + c]
+// for r < rows, c < cols (bf16 elements, cols and all offsets multiples of 8): moves row blocks between per-image layouts
+__global__ __launch_bounds__(256) void copy_row_blocks_kernel(const bf16_t* __restrict__ src, int src_img_rows, int src_row0, int ld_src,
+                                                              int src_col0, bf16_t* __restrict__ dst, int dst_img_rows, int dst_row0,
+                                                              int ld_dst, int dst_col0, int rows, int cols8) {
+  const int b = blockIdx.y;
+  const int per = rows * cols8;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+    const int r = i / cols8, c = (i - r * cols8) * 8;
+    const uint4 v = *(const uint4*)(src + ((size_t)b * src_img_rows + src_row0 + r) * ld_src + src_col0 + c);
+    *(uint4*)(dst + ((size_t)b * dst_img_rows + dst_row0 + r) * ld_dst + dst_col0 + c) = v;
+  }
+}
+
 // teacher-forced text rows: row r = word[ids[r]] + pos[r % rows_per_seq] + type[0] -> (pre-LN sum fp32, LN fp32, LN bf16)
 __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restrict__ ids, int rows_per_seq,
                                                          const bf16_t* __restrict__ word, const bf16_t* __restrict__ pos,
@@ -357,6 +422,40 @@ extern "C" int vitcap_greedy_select_embed(const float* rowstat, int pieces, int6
                      (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta, eps, x_f32,
                      (bf16_t*)x_bf16);
   VC_LAUNCH_CHECK("greedy_select_embed");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_tag_embed(const int64_t* tag_ids, int n, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
+                                const void* pos_emb, const void* type_emb, const float* gamma, const float* beta,
+                                const void* xword_emb, const void* xpos_emb, const void* xtype_emb, const float* xgamma,
+                                const float* xbeta, float eps, float* x_f32, void* x_bf16, int B, void* stream) {
+  VC_REQUIRE(tag_ids && x_f32 && x_bf16 && B > 0 && n >= 1 && n <= 50, "tag_embed: bad arguments (n=%d)", n);
+  const bool need_extra = !tagemb_cls && !branch_a, raw = tagemb_cls && branch_a;
+  VC_REQUIRE(!tagemb_cls || cls_w, "tag_embed: tagemb == 'cls' needs the caption head's decoder matrix");
+  VC_REQUIRE(tagemb_cls || need_extra || word_emb, "tag_embed: missing word embedding table");
+  VC_REQUIRE(raw || need_extra || (pos_emb && type_emb && gamma && beta), "tag_embed: missing position / type tables or LayerNorm");
+  VC_REQUIRE(!need_extra || (xword_emb && xpos_emb && xtype_emb && xgamma && xbeta), "tag_embed: bert.extra_embeddings tables missing");
+  const int rows = B * n;
+  hipLaunchKernelGGL(tag_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, tag_ids, n, branch_a, tagemb_cls,
+                     (const bf16_t*)cls_w, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta,
+                     (const bf16_t*)xword_emb, (const bf16_t*)xpos_emb, (const bf16_t*)xtype_emb, xgamma, xbeta, eps, x_f32,
+                     (bf16_t*)x_bf16, rows);
+  VC_LAUNCH_CHECK("tag_embed");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_copy_row_blocks(const void* src, int src_img_rows, int src_row0, int ld_src, int src_col0, void* dst,
+                                      int dst_img_rows, int dst_row0, int ld_dst, int dst_col0, int rows, int cols, int B,
+                                      void* stream) {
+  VC_REQUIRE(src && dst && B > 0 && rows > 0 && cols > 0, "copy_row_blocks: bad arguments");
+  VC_REQUIRE(((cols | ld_src | ld_dst | src_col0 | dst_col0) & 7) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+             "copy_row_blocks: columns / leading dimensions must be multiples of 8 bf16 elements");
+  const int per = rows * (cols / 8);
+  int gx = (per + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(copy_row_blocks_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_img_rows,
+                     src_row0, ld_src, src_col0, (bf16_t*)dst, dst_img_rows, dst_row0, ld_dst, dst_col0, rows, cols / 8);
+  VC_LAUNCH_CHECK("copy_row_blocks");
   return VITCAP_OK;
 }
 

@@ -190,6 +190,15 @@ class ImageCaptioning(nn.Module):
             d.o_beta = ptr(f32(self._t(p + '.output.LayerNorm.bias')))
         tied = self._params[W.TIED_DST] is self._params[W.TIED_SRC]
         lm_head(w.cls, 'module.cls', dec_w_packed=word if tied else None)
+        if self.tagemb != 'cls':
+            # bert.extra_embeddings: the tag rows' embedding under branch B of modeling_bert.py:1484-1485 (only read when the tag
+            # tokens are visible to the caption, vitcap_gen_opts.tag_visible > 0)
+            x = 'module.bert.extra_embeddings'
+            w.xword_emb = ptr(bf(pad_vocab(self._t(x + '.word_embeddings.weight'))))
+            w.xpos_emb = ptr(bf(self._t(x + '.position_embeddings.weight')))
+            w.xtype_emb = ptr(bf(self._t(x + '.token_type_embeddings.weight')))
+            w.xemb_ln_g = ptr(f32(self._t(x + '.LayerNorm.weight')))
+            w.xemb_ln_b = ptr(f32(self._t(x + '.LayerNorm.bias')))
 
         if self._engine is None:
             h = C.c_void_p()
@@ -257,6 +266,7 @@ class ImageCaptioning(nn.Module):
                        length_penalty=float(te.get('length_penalty', 1) or 1),
                        repetition_penalty=float(te.get('repetition_penalty', 1) or 1), sampling=sp, gemm_mode=int(gemm_mode),
                        early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)),
+                       tag_visible=int(te.get('tag_visible', 0) or 0), tagemb_cls=int(self.tagemb == 'cls'),
                        decode_streams=int(te.get('decode_streams', 0) or 0))
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
@@ -269,21 +279,32 @@ class ImageCaptioning(nn.Module):
         anything else is refused: a different mask can no longer yield a silently wrong caption.
 
         * attention_mask (B, T, T), T = max_length + od_len: lower-triangular ones on [0:max_length, 0:max_length], zeros
-          elsewhere (the 210 ones of SURVEY 8d for max_length 20);
+          elsewhere (the 210 ones of SURVEY 8d for max_length 20) -- or, additionally, the first n tag slots visible to every
+          caption row and to each other (what tensorize_ab builds for a text_b of n tokens): returns n;
         * token_type_ids: zeros;  masked_pos: not read by generate() beyond slicing;
         * input_ids (B, T): only the od-label slots [max_length:] are read by generate() (modeling_bert.py:959); their
           embeddings are overwritten by the predicted tag tokens (1435-1489) and never attended, so any value is harmless."""
         am = data.get('attention_mask')
+        n_tag = 0
         if am is not None:
             if am.dim() != 3 or am.shape[1] != am.shape[2] or am.shape[1] < max_length:
                 raise ValueError('attention_mask must be (B, T, T) with T >= max_length=%d, got %s' % (max_length, tuple(am.shape)))
-            want = torch.zeros(am.shape[1:], dtype=am.dtype, device=am.device)
+            T = am.shape[1]
+            # tags visible to the caption (a text_b of n tokens, dataset.py:240-252, 387-390): ones on [L0:L0+n, L0:L0+n] and on
+            # [0:L0, L0:L0+n]; n is read off the first caption row of the first sample and must describe the whole batch
+            n_tag = int((am[0, 0, max_length:] != 0).sum())
+            want = torch.zeros((T, T), dtype=am.dtype, device=am.device)
             want[:max_length, :max_length] = torch.tril(torch.ones(max_length, max_length, dtype=am.dtype, device=am.device))
+            if n_tag:
+                want[max_length:max_length + n_tag, max_length:max_length + n_tag] = 1
+                want[:max_length, max_length:max_length + n_tag] = 1
             if not bool((am == want.unsqueeze(0)).all()):
                 raise NotImplementedError(
-                    'attention_mask differs from the test-time seq2seq pattern (tril on the first %d caption slots, zeros elsewhere: '
-                    'dataset.py:377-390); the HIP engine implements that mask structure only (tag tokens visible to the caption are '
-                    'SURVEY 8f rank 4)' % max_length)
+                    'attention_mask is neither the test-time seq2seq pattern (tril on the first %d caption slots, zeros elsewhere: '
+                    'dataset.py:377-390) nor that pattern with the first n tag slots visible to the caption and to each other '
+                    '(dataset.py:387-390); the HIP engine implements these two mask structures only' % max_length)
+            if n_tag > 50 or (n_tag and max_length != L.MAXLEN):
+                raise NotImplementedError('tag tokens visible to the caption need max_length == 20 and at most 50 tag slots')
         tt = data.get('token_type_ids')
         if tt is not None and bool((tt != 0).any()):
             raise NotImplementedError('token_type_ids must be all zero at test time (dataset.py:326); segment-1 text tokens are not built')
@@ -294,6 +315,7 @@ class ImageCaptioning(nn.Module):
             v = data.get(k)
             if v is not None and v.shape[0] != data['image'].shape[0]:
                 raise ValueError('%s has batch %d but image has %d' % (k, v.shape[0], data['image'].shape[0]))
+        return n_tag
 
     def _check_image(self, image):
         if self._packed is None:
@@ -457,5 +479,9 @@ class ImageCaptioning(nn.Module):
             image = image.repeat_interleave(nret, 0).contiguous()
             over['num_return_sequences'] = 1
         opts = self.gen_options(**over)
-        self.check_text_inputs(data, opts.max_length)
+        n_tag = self.check_text_inputs(data, opts.max_length)
+        if n_tag != opts.tag_visible:
+            if opts.tag_visible:
+                raise ValueError('test_extra_input tag_visible=%d but the attention_mask shows %d tag slots' % (opts.tag_visible, n_tag))
+            opts = self.gen_options(tag_visible=n_tag, **over)      # the caller's mask decides
         return self.run(image, opts)
