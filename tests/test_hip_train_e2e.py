@@ -275,6 +275,8 @@ def test_pipeline_basemodel_is_the_init_and_training_resumes(tmp_path, monkeypat
     # elements by ~base_lr = 1e-3 (Adam's first steps are sign-like)
     worst = 0.0
     for key in a['model']:
+        if key.endswith('attention.self.key.bias'):
+            continue        # mathematically zero gradient (softmax is shift-invariant): Adam normalises pure rounding noise to +-lr
         d = (a['model'][key].float() - b['model'][key].float()).abs()
         worst = max(worst, float(d.mean()))
         # (weights with tiny gradients -- the decoder's query / key matrices -- are the most sign-sensitive: 1e-5 mean, 0.13 % beyond 2e-4)

@@ -116,6 +116,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242); register-staged tiles (global_load -> VGPR ->
   // ds_write_b128) instead of LDS-DMA: 195 -> 499 us.  SQ counters: no LDS bank conflicts, 67 % of wave cycles in
   // s_waitcnt/barriers, MFMA pipe 33 % busy.
+  // Round 2, measured and reverted: the bias gradient (column sums of Y) as extra MFMAs against an all-ones fragment inside this
+  // kernel (8 per 32-row step on the wk = 0 waves of the k-tile-0 workgroups, or 2 per wave) instead of the separate colsum pass:
+  // the colsum launches disappear (-1.7 ms per training step) but this kernel slows from 13.15 to 14.6 / 14.9 ms per step -- the
+  // MFMA issue slots are not free although the pipe is a third busy.  No net gain.
   if (nst > 0) STAGE(0, s_begin);
   for (int t = 0; t < nst; ++t) {
     const int buf = t & 1;
