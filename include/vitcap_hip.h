@@ -401,6 +401,9 @@ typedef struct vitcap_gen_opts {
   int32_t decode_streams;     /* greedy / sampling loop: 2 = the batch is cut into two slices that decode on two streams (the
                                  second one engine-owned, forked from and joined to the caller's); 1 = one chain; 0 = auto
                                  (= 1: measured, the second chain does not hide the per-kernel latency).  Same results.   */
+  int32_t encode_parts;       /* encoder + prefill of the batch as 1..4 independent chains of batch parts on separate streams
+                                 (engine-owned, forked from / joined to the caller's): one part's GEMM tails are filled by
+                                 the other's kernels (2 parts: +1..2 % images/s at 32..128 images); 0 = auto = 1.  Same results.  */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */
@@ -508,6 +511,9 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */
 int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches);
 int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, int* launches12);
+/* the same plus busy_ms12: per variant the length of the union of its launches' [start, stop] intervals (launches of one kernel
+ * overlap when several chains are in flight; their summed durations count that time twice) */
+int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms12, double* flops12, int* launches12, double* busy_ms12);
 
 /* ------------------------------------------------------------------------------------------------
  * Input side of the path: the reference's test-time image transform, get_transform_vit_default

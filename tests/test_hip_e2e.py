@@ -437,6 +437,24 @@ def test_tag_tokens_visible_to_caption(golden, flow):
                                   GREEDY_MARGIN_FLOOR, min_full=0, what='plain after tags')
 
 
+def test_encoder_parts_equal_single_chain(model):
+    """vitcap_gen_opts.encode_parts: encoder + prefill of the batch as 2..4 independent chains of batch parts on separate streams
+    give bit-identical captions, scores, tag outputs and hidden states (even and odd batch sizes, greedy and beam)."""
+    for B in (9, 64):
+        img = _images(B, 1300 + B).cuda().to(torch.bfloat16)
+        one = [t.clone() for t in model.generate(img, encode_parts=1, want_tags=True)]
+        tags1 = [t.clone() for t in model.last_tags]
+        hid1 = model.tap('hidden', B, (B, 577, 768))
+        for parts in (2, 3, 4):
+            got = [t.clone() for t in model.generate(img, encode_parts=parts, want_tags=True)]
+            assert torch.equal(one[0], got[0]) and torch.equal(one[1], got[1]), (B, parts)
+            assert torch.equal(tags1[0], model.last_tags[0]) and torch.equal(tags1[1], model.last_tags[1])
+            assert torch.equal(hid1, model.tap('hidden', B, (B, 577, 768)))
+        b1 = [t.clone() for t in model.generate_beam(img[:9].contiguous(), 3, encode_parts=1)]
+        b2 = model.generate_beam(img[:9].contiguous(), 3, encode_parts=2)
+        assert torch.equal(b1[0], b2[0]) and torch.equal(b1[1], b2[1])
+
+
 def test_text_inputs_are_validated(model):
     """a8 / a16: forward() checks the caller's text tensors against the mask structure the kernels implement."""
     from oracle import vitcap_oracle as O

@@ -46,7 +46,7 @@ class GenOpts(C.Structure):
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
                 ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('tag_visible', C.c_int32), ('tagemb_cls', C.c_int32),
-                ('decode_streams', C.c_int32)]
+                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32)]
 
 
 class Image(C.Structure):
@@ -169,6 +169,8 @@ _SIGS = {
     'vitcap_repetition_penalty': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'vitcap_engine_timing_end_ex': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_double)]),
 }
 
 EXPORTS = tuple(_SIGS)

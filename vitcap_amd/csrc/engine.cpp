@@ -17,7 +17,9 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
+#include <utility>
 #include <new>
 
 #include "../../include/vitcap_hip.h"
@@ -57,6 +59,8 @@ struct vitcap_engine {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t dec2 = nullptr;         // second stream of the split decode loop (vitcap_gen_opts.decode_streams = 2)
   hipEvent_t ev_dfork = nullptr, ev_djoin = nullptr;
+  hipStream_t part[3] = {nullptr, nullptr, nullptr};   // streams of encoder parts 1..3 (part 0 runs on the caller's stream)
+  hipEvent_t ev_pfork = nullptr, ev_pjoin[3] = {nullptr, nullptr, nullptr};
   bool full_last_tag_block = false;   // VITCAP_FULL_TAG_BLOCK=1: compute all 577 rows of tag_blocks[3] (parity taps / measurements)
   bool fork_tag_branch = true;
   std::vector<GemmTiming> pool;
@@ -91,6 +95,7 @@ vitcap_gen_opts default_opts() {
   o.tag_visible = 0;
   o.tagemb_cls = 1;
   o.decode_streams = 0;
+  o.encode_parts = 0;
   return o;
 }
 
@@ -111,6 +116,7 @@ int check_opts(const vitcap_gen_opts& o) {
   OPT_REQ(o.gemm_mode == VITCAP_GEMM_AUTO || o.gemm_mode == VITCAP_GEMM_TILES, "gen_opts: gemm_mode %d unknown", o.gemm_mode);
   OPT_REQ(o.tag_visible >= 0 && o.tag_visible <= 50, "gen_opts: tag_visible must be 0..50 (got %d)", o.tag_visible);
   OPT_REQ(o.tag_visible == 0 || o.max_length == VITCAP_MAXLEN, "gen_opts: tag_visible > 0 needs max_length == %d", VITCAP_MAXLEN);
+  OPT_REQ(o.encode_parts >= 0 && o.encode_parts <= 4, "gen_opts: encode_parts must be 0 (auto) .. 4 (got %d)", o.encode_parts);
   OPT_REQ(o.decode_streams >= 0 && o.decode_streams <= 2, "gen_opts: decode_streams must be 0 (auto), 1 or 2 (got %d)", o.decode_streams);
 #undef OPT_REQ
   return VITCAP_OK;
@@ -136,6 +142,21 @@ struct Layout {
   int NT;
   int L, NS, K;
   bool beam;
+  // the same layout seen from image i0 on: every image-major buffer of the encoder / prefill advanced by i0 images
+  Layout from_image(int i0) const {
+    Layout v = *this;
+    const size_t i = (size_t)i0;
+    v.patches += i * 576 * D * 2;
+    v.x += i * NV * D * 4; v.x2 += i * NV * D * 4; v.xt += i * NV * D * 4;
+    v.h += i * SV * D * 2; v.qkv += i * NV * 3 * D * 2; v.mlp += i * SV * 4 * D * 2;
+    v.th += i * NV * D * 2; v.tqkv += i * NV * 3 * D * 2; v.tmlp += i * NV * 4 * D * 2;
+    v.vis_f += i * SV * D * 4; v.vis_b += i * SV * D * 2;
+    for (int l = 0; l < 4; ++l) v.dqkv[l] += i * SV * 3 * D * 2;
+    v.da_f += i * SV * D * 4; v.da_b += i * SV * D * 2; v.dtmp += i * SV * D * 4;
+    v.pool_in += i * D * 2; v.pooled += i * D * 2; v.tg_f += i * D * 4; v.tg_b += i * D * 2;
+    v.tag_logits += i * VP * 4; v.tag_ids += i * TOPK * 8; v.tag_prob += i * TOPK * 4; v.tag_len += i * 8;
+    return v;
+  }
   Layout(int B, const vitcap_gen_opts& o) {
     L = o.max_length;
     beam = o.num_beams > 1;
@@ -359,6 +380,11 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
   if (e->dec2) (void)hipStreamDestroy(e->dec2);
   if (e->ev_dfork) (void)hipEventDestroy(e->ev_dfork);
   if (e->ev_djoin) (void)hipEventDestroy(e->ev_djoin);
+  for (int i = 0; i < 3; ++i) {
+    if (e->part[i]) (void)hipStreamDestroy(e->part[i]);
+    if (e->ev_pjoin[i]) (void)hipEventDestroy(e->ev_pjoin[i]);
+  }
+  if (e->ev_pfork) (void)hipEventDestroy(e->ev_pfork);
   delete e;
 }
 extern "C" int vitcap_engine_graph_count(vitcap_engine* e) { return e ? (int)e->graphs.size() : 0; }
@@ -382,11 +408,14 @@ extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
 }
 
 // Sums per GEMM epilogue variant (index = act*4 + out_f32*2 + has_res, 12 slots): milliseconds, flops, launches.
-// Synchronises on the recorded events; call after the timed region.
-extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* flops, int* launches) {
+// Synchronises on the recorded events; call after the timed region.  busy_ms (optional): per variant, the length of the UNION of
+// its launches' [start, stop] intervals -- with several chains in flight (batch pipeline, encoder parts) launches of one kernel
+// overlap each other and their summed durations count that time twice.
+extern "C" int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms, double* flops, int* launches, double* busy_ms) {
   if (!e || !ms || !flops || !launches) return VITCAP_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
-  for (int i = 0; i < 12; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (int i = 0; i < 12; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; if (busy_ms) busy_ms[i] = 0; }
+  std::vector<std::pair<float, float>> iv[12];
   for (size_t i = 0; i < e->used; ++i) {
     GemmTiming& t = e->pool[i];
     float el = 0.f;
@@ -397,10 +426,29 @@ extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* fl
     ms[t.variant] += el;
     flops[t.variant] += t.flops;
     launches[t.variant] += 1;
+    if (busy_ms) {
+      float a = 0.f;
+      if (hipEventElapsedTime(&a, e->pool[0].start, t.start) != hipSuccess) a = 0.f;     // timestamp relative to the first launch
+      iv[t.variant].push_back({a, a + el});
+    }
   }
+  if (busy_ms)
+    for (int v = 0; v < 12; ++v) {
+      std::sort(iv[v].begin(), iv[v].end());
+      float end = -1e30f;
+      double tot = 0;
+      for (auto& p : iv[v]) {
+        if (p.first > end) { tot += p.second - p.first; end = p.second; }
+        else if (p.second > end) { tot += p.second - end; end = p.second; }
+      }
+      busy_ms[v] = tot;
+    }
   e->timing = false;
   e->used = 0;
   return VITCAP_OK;
+}
+extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* flops, int* launches) {
+  return vitcap_engine_timing_end_ex(e, ms, flops, launches, nullptr);
 }
 
 extern "C" int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w) {
@@ -470,10 +518,8 @@ static int vit_block_cls_only(const vitcap_vit_block_w& w, float* x, void* h, vo
 
 static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void* s);
 
-static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts& o, const Layout& lo,
-                         char* ws, void* s) {
-  if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
-  CallScope scope(e, o.gemm_mode, nullptr);
+static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts& o, const Layout& lo,
+                       char* ws, bool allow_fork, void* s) {
   const vitcap_weights& w = e->w;
   float* x = (float*)(ws + lo.x);
   // a1: patch embed as GEMM (+bias +pos_embed[1+p]) into rows b*577+1+p; cls rows separately
@@ -491,7 +537,7 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
   // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork.  Run the fork on a side stream when the large GEMMs are
   // in their one-tile-per-workgroup form (batch pipeline) and the batch is small enough for tile-quantisation gaps to
   // matter: B=64 pipelined +2.3 %; with persistent GEMMs or at B=512 it costs 1-2 % (measured), so it stays serial there.
-  const bool fork = e->fork_tag_branch && o.gemm_mode == VITCAP_GEMM_TILES && B <= 128;
+  const bool fork = allow_fork && e->fork_tag_branch && o.gemm_mode == VITCAP_GEMM_TILES && B <= 128;
   float* x2 = (float*)(ws + lo.x2);
   for (int i = 0; i < 12; ++i) {
     if (i == 8 && fork) {
@@ -518,6 +564,72 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
     CK(tag_branch(e, lo, ws, B, s));
   }
   return VITCAP_OK;
+}
+
+static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s);
+
+// vitcap_gen_opts.encode_parts: the batch is cut into parts whose encoder + prefill run as independent chains on separate
+// streams (part 0 on the caller's), so that the tile-quantisation tail of one part's GEMM (qkv: 5.1 rounds of 256 CUs cost 6 at
+// B = 64) is filled by the other part's kernels; every row's arithmetic is unchanged (bit-identical results).  Measured,
+// 2-slot pipeline, images/s without / with 2 parts: B = 16 2039 / 2034, 32 2825 / 2854, 64 3560 / 3635, 128 3724 / 3808,
+// 512 3975 / 3990; 3 and 4 parts lose (B = 64: 3318 / 3460).  auto = 1 part: the gain is 1-2 %, and with two GEMM chains in
+// flight every launch of the dominant kernel shares the chip with the other chain (its per-launch rate, the bench's roofline
+// figure, drops from 0.24 to 0.17 of peak although throughput rises).  VITCAP_ENCODE_SPLIT overrides for experiments.
+static int encode_parts(const vitcap_gen_opts& o, int B, const Layout& lo) {
+  static const int env = [] { const char* e = getenv("VITCAP_ENCODE_SPLIT"); return e ? atoi(e) : -1; }();
+  int p = env >= 0 ? env : o.encode_parts;
+  if (p == 0) p = 1;
+  if (p > 4) p = 4;
+  if (B < 8 || lo.NT > 0) p = 1;
+  return p;
+}
+
+static int ensure_dec2(vitcap_engine* e) {
+  if (!e->dec2) {
+    if (hipStreamCreateWithFlags(&e->dec2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_dfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_djoin, hipEventDisableTiming) != hipSuccess) {
+      vitcap_set_error("engine: second stream creation failed");
+      return VITCAP_ELAUNCH;
+    }
+  }
+  return VITCAP_OK;
+}
+
+static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts& o, const Layout& lo,
+                         char* ws, void* s) {
+  if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
+  CallScope scope(e, o.gemm_mode, nullptr);
+  const int np = encode_parts(o, B, lo);
+  if (np >= 2) {
+    if (!e->ev_pfork) HIPCK(hipEventCreateWithFlags(&e->ev_pfork, hipEventDisableTiming), "encode: event");
+    for (int i = 0; i < np - 1; ++i)
+      if (!e->part[i]) {
+        HIPCK(hipStreamCreateWithFlags(&e->part[i], hipStreamNonBlocking), "encode: part stream");
+        HIPCK(hipEventCreateWithFlags(&e->ev_pjoin[i], hipEventDisableTiming), "encode: event");
+      }
+    HIPCK(hipEventRecord(e->ev_pfork, (hipStream_t)s), "encode: split fork record");
+    const size_t img_bytes = (size_t)3 * 384 * 384 * (image_is_bf16 ? 2 : 4);
+    int i0[5];
+    for (int i = 0; i <= np; ++i) i0[i] = (int)((long long)B * i / np);
+    for (int i = 0; i < np; ++i) {
+      void* ps = i == 0 ? s : (void*)e->part[i - 1];
+      if (i > 0) HIPCK(hipStreamWaitEvent((hipStream_t)ps, e->ev_pfork, 0), "encode: split fork wait");
+      const Layout lv = lo.from_image(i0[i]);
+      CK(encode_part(e, (const char*)image + (size_t)i0[i] * img_bytes, image_is_bf16, i0[i + 1] - i0[i], o, lv, ws, false, ps));
+    }
+    // the prefill of each part follows on its own stream (prefill_locked then has nothing left to do)
+    for (int i = 0; i < np; ++i) {
+      void* ps = i == 0 ? s : (void*)e->part[i - 1];
+      CK(prefill_part(e, i0[i + 1] - i0[i], o, lo.from_image(i0[i]), ws, ps));
+      if (i > 0) {
+        HIPCK(hipEventRecord(e->ev_pjoin[i - 1], (hipStream_t)ps), "encode: split join record");
+        HIPCK(hipStreamWaitEvent((hipStream_t)s, e->ev_pjoin[i - 1], 0), "encode: split join wait");
+      }
+    }
+    return VITCAP_OK;
+  }
+  return encode_part(e, image, image_is_bf16, B, o, lo, ws, true, s);
 }
 
 extern "C" int vitcap_engine_encode(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts* opts,
@@ -602,6 +714,11 @@ static int prefill_tags(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
 
 static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
   CallScope scope(e, o.gemm_mode, nullptr);
+  if (encode_parts(o, B, lo) >= 2) return VITCAP_OK;       // done by encode_locked, per part
+  return prefill_part(e, B, o, lo, ws, s);
+}
+
+static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
   const vitcap_weights& w = e->w;
   const int M = B * SV;
   float* vis_f = (float*)(ws + lo.vis_f);

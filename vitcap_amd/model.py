@@ -267,7 +267,7 @@ class ImageCaptioning(nn.Module):
                        repetition_penalty=float(te.get('repetition_penalty', 1) or 1), sampling=sp, gemm_mode=int(gemm_mode),
                        early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)),
                        tag_visible=int(te.get('tag_visible', 0) or 0), tagemb_cls=int(self.tagemb == 'cls'),
-                       decode_streams=int(te.get('decode_streams', 0) or 0))
+                       decode_streams=int(te.get('decode_streams', 0) or 0), encode_parts=int(te.get('encode_parts', 0) or 0))
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
