@@ -281,8 +281,10 @@ def test_pipeline_basemodel_is_the_init_and_training_resumes(tmp_path, monkeypat
         worst = max(worst, float(d.mean()))
         # (weights with tiny gradients -- the decoder's query / key matrices -- are the most sign-sensitive: 1e-5 mean, 0.13 % beyond 2e-4)
         assert float(d.mean()) < 5e-5 and float((d > 2e-4).float().mean()) < 1e-2, 'resumed run differs from the uninterrupted one: ' + key
-    dm = (a['optimizer']['exp_avg'] - b['optimizer']['exp_avg']).abs()
-    assert float(dm.max()) < 1e-3 * float(a['optimizer']['exp_avg'].abs().max()) + 1e-7
+    # first moments: relative L2 (a resume that restarted them from zero would be off by O(1); rounding-level drift measures ~1e-3)
+    ea, eb = a['optimizer']['exp_avg'].double(), b['optimizer']['exp_avg'].double()
+    rel = float((ea - eb).norm() / ea.norm())
+    assert rel < 2e-2, rel
     assert int(a['optimizer']['step']) == int(b['optimizer']['step']) == 3
     assert a['scheduler'] == b['scheduler']
     print('resume: worst mean |dp| %.2e' % worst)
