@@ -298,6 +298,18 @@ int vitcap_beam_init(const vitcap_beam_state* s, int B, int beams, int max_len, 
 int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, const float* lse, const vitcap_beam_state* s,
                      int B, int beams, int V, int t, int max_len, int eos, int pad, float length_penalty,
                      void* stream);
+/* Beam search WITH sampling (num_beams > 1 and do_sample, modeling_utils.py:966-985).  vitcap_beam_sample_candidates: per row
+ * (= beam) temperature, top_k_top_p_filtering with min_tokens_to_keep = 2 (k = max(top_k, 2); ranks 0..2 survive top-p), then TWO
+ * words drawn without replacement from the softmax of what is left -- the two largest of (logit + Gumbel noise), the draw
+ * torch.multinomial(p, 2) makes, on the counter-based stream (seed, row + row_offset, t).  out_val / out_idx: [rows][2] (the words'
+ * temperature-scaled logits), out_lse: [rows] log-sum-exp of the surviving set.  vitcap_beam_step_sampled: vitcap_beam_step on
+ * those candidates, consumed in position order with the reference's own beam attribution (position p of the (B, 2*beams) view is
+ * scored with beam p / 2 but continues beam p % beams -- as written at modeling_utils.py:979-984). */
+int vitcap_beam_sample_candidates(const float* logits, int ldl, int V, int rows, int t, const vitcap_sample_params* sp,
+                                  int row_offset, float* out_val, int32_t* out_idx, float* out_lse, void* stream);
+int vitcap_beam_step_sampled(const float* cand_val, const int32_t* cand_idx, const float* lse, const vitcap_beam_state* s,
+                             int B, int beams, int V, int t, int max_len, int eos, int pad, float length_penalty,
+                             void* stream);
 int vitcap_beam_reorder_cache(const void* src, void* dst, const int32_t* parent, int layers, int n_seq, int max_len,
                               int t, void* stream);
 int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B, int max_len,
@@ -385,7 +397,7 @@ typedef struct vitcap_gen_opts {
   int32_t bos_token_id, eos_token_id, pad_token_id, mask_token_id;   /* 101 / 102 / 0 / 103; eos_token_ids has one entry */
   float length_penalty;       /* beam search                                                                            */
   float repetition_penalty;   /* CTRL penalty, 1 = off (modeling_utils.py:828-836, 955-963)                             */
-  vitcap_sample_params sampling;   /* do_sample / temperature / top_k / top_p / seed; needs num_beams == 1             */
+  vitcap_sample_params sampling;   /* do_sample / temperature / top_k / top_p / seed (with num_beams > 1: beam sampling) */
   int32_t gemm_mode;          /* VITCAP_GEMM_AUTO | VITCAP_GEMM_TILES                                                   */
   int32_t early_exit;         /* 1 (default): once every sequence (beam search: image) has finished, the remaining
                                  steps' kernels return at entry -- `if cur_unfinished.max() == 0: break`

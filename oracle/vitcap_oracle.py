@@ -538,17 +538,18 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
 
 # --------------------------------------------------------------------------------------------
 # a12  sampling branch   (modeling_utils.py:839-851, top_k_top_p_filtering 1103-1135)
-def top_k_top_p_filter(logits, top_k=0, top_p=1.0):
+def top_k_top_p_filter(logits, top_k=0, top_p=1.0, min_tokens_to_keep=1):
     """Returns a copy of ``logits`` (B,V) with every filtered entry set to -inf.
 
-    top-k: everything strictly below the k-th largest value goes (ties with it stay).
+    top-k: k = max(top_k, min_tokens_to_keep); everything strictly below the k-th largest value goes (ties with it stay).
     top-p: rank descending, p = softmax over the row as it stands after top-k; entry of rank i goes iff the
     cumulative probability of ranks 0..i-1 exceeds top_p (so the entry that crosses the threshold stays and rank 0
-    always stays)."""
+    always stays).  With min_tokens_to_keep = n > 1 (the beam-sampling call, modeling_utils.py:970-972) the reference clears
+    the removal flags of ranks 0..n-1 BEFORE shifting them right by one (1125-1130), so ranks 0..n always stay: n + 1 tokens."""
     x = logits.clone()
     V = x.shape[-1]
     if top_k > 0:
-        k = min(max(int(top_k), 1), V)
+        k = min(max(int(top_k), int(min_tokens_to_keep), 1), V)
         kth = torch.topk(x, k, dim=-1).values[..., -1:]
         x = torch.where(x < kth, torch.full_like(x, float('-inf')), x)
     if top_p < 1.0:
@@ -558,6 +559,8 @@ def top_k_top_p_filter(logits, top_k=0, top_p=1.0):
         before = torch.cat([torch.zeros_like(cum[..., :1]), cum[..., :-1]], dim=-1)   # mass of the better ranks
         drop_ranked = before > top_p
         drop_ranked[..., 0] = False
+        if min_tokens_to_keep > 1:
+            drop_ranked[..., :min_tokens_to_keep + 1] = False
         drop = torch.zeros_like(drop_ranked).scatter(-1, order, drop_ranked)
         x = torch.where(drop, torch.full_like(x, float('-inf')), x)
     return x
@@ -653,8 +656,32 @@ class BeamHypotheses:
         return self.worst_score >= bound
 
 
+def gumbel_top2(x, seed, t, row0=0):
+    """Two draws WITHOUT replacement from softmax(x) per row (what torch.multinomial(p, num_samples=2) returns, first draw
+    first) in Gumbel-top-k form: the two largest of x + G, G the counter-based noise of row (row0 + r), step t."""
+    R, V = x.shape
+    g = torch.from_numpy(np.stack([gumbel_noise(seed, row0 + r, t, V) for r in range(R)]))
+    return (x + g).topk(2, dim=-1).indices
+
+
+def beam_sample_candidates(logits, beam_scores, B, K, t, temperature=1.0, top_k=0, top_p=1.0, seed=0, draw=None):
+    """The do_sample branch of _generate_beam_search (modeling_utils.py:966-985): per beam row temperature, the top-k /
+    top-p filter with min_tokens_to_keep = 2, TWO words drawn without replacement, score = log_softmax(filtered)[word] + the
+    row's beam score.  "Match shape of greedy beam search" then views the (B*K, 2) draws as (B, 2K) -- position p holds draw
+    p % 2 of beam p // 2 -- but adds `arange(K) * V` REPEATED twice as the beam offset, so position p is attributed to beam
+    p % K.  Restated as written: the hypothesis that continues with the word at position p is beam p % K's prefix, its score
+    comes from beam p // 2.  The candidates are consumed in position order (nothing sorts them)."""
+    x = logits / temperature if temperature != 1.0 else logits
+    x = top_k_top_p_filter(x, top_k, top_p, min_tokens_to_keep=2)
+    words = draw(x, t) if draw is not None else gumbel_top2(x, seed, t)          # (B*K, 2)
+    Vn = x.shape[1]
+    sc = torch.gather(F.log_softmax(x, dim=-1), -1, words) + beam_scores[:, None]
+    off = (torch.arange(K) * Vn).repeat(B, 2)
+    return sc.reshape(B, 2 * K), words.reshape(B, 2 * K) + off
+
+
 def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
-                     repetition_penalty=1.0, eos=EOS, return_margins=False):
+                     repetition_penalty=1.0, eos=EOS, return_margins=False, sample=None):
     """The reference's beam driver around an abstract model: ``step_logits_fn(input_ids (B*beams, cur_len), beam_idx)``
     returns the next-token logits (B*beams, V) for the current prefixes (``beam_idx`` = the re-ordering applied since
     the previous call, None at the first).  Returns (decoded (B,keep,max_length), logprobs (B,keep)).
@@ -676,11 +703,15 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     margins = torch.full((B, max_length - 1), float('inf'))
     while cur_len < max_length:
         logits = apply_repetition_penalty(step_logits_fn(input_ids, beam_idx).clone(), input_ids, repetition_penalty)
-        scores = F.log_softmax(logits, dim=-1)
-        Vn = scores.shape[1]
-        _scores = (scores + beam_scores[:, None]).view(B, K * Vn)
-        next_scores, next_words = torch.topk(_scores, 2 * K, dim=1, largest=True, sorted=True)
-        ext = torch.topk(_scores, 2 * K + 1, dim=1, largest=True, sorted=True).values if return_margins else None
+        Vn = logits.shape[1]
+        if sample is not None:           # do_sample with beams: ``sample`` = kwargs of beam_sample_candidates
+            assert not return_margins
+            next_scores, next_words = beam_sample_candidates(logits, beam_scores, B, K, cur_len, **sample)
+        else:
+            scores = F.log_softmax(logits, dim=-1)
+            _scores = (scores + beam_scores[:, None]).view(B, K * Vn)
+            next_scores, next_words = torch.topk(_scores, 2 * K, dim=1, largest=True, sorted=True)
+            ext = torch.topk(_scores, 2 * K + 1, dim=1, largest=True, sorted=True).values if return_margins else None
         nb = []
         for b in range(B):
             hyps[b].margin = float('inf')
@@ -735,7 +766,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
 
 
 def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
-                    repetition_penalty=1.0, eos=EOS):
+                    repetition_penalty=1.0, eos=EOS, sample=None):
     """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
     B = image.shape[0]
     K = num_beams
@@ -758,11 +789,11 @@ def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, leng
         tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
         logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
         return logits[:, cur, :]
-    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos)
+    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos, sample=sample)
 
 
 def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
-                     num_keep_best=1, repetition_penalty=1.0, eos=EOS, return_margins=False):
+                     num_keep_best=1, repetition_penalty=1.0, eos=EOS, return_margins=False, sample=None):
     """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
     image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
     r = _R(emulate_bf16)
@@ -821,7 +852,7 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
             trace.append(logits.clone())
         return logits
     out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos,
-                           return_margins=return_margins)
+                           return_margins=return_margins, sample=sample)
     return out + (trace,) if return_trace else out
 
 

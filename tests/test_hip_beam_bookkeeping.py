@@ -14,7 +14,7 @@ from oracle import vitcap_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _run_device(table, B, K, V, keep, lp, max_len=20):
+def _run_device(table, B, K, V, keep, lp, max_len=20, sample=None):
     from vitcap_amd import _lib as L
     from vitcap_amd._lib import lib, check
     dev = 'cuda'
@@ -47,8 +47,14 @@ def _run_device(table, B, K, V, keep, lp, max_len=20):
         cur = bufs['ids_in'] if st.ids_in == bufs['ids_in'].data_ptr() else bufs['ids_out']
         last = cur[:, t - 1]
         logits = table[t, (last + rows) % table.shape[1]].contiguous()
-        check(lib.vitcap_row_topk_lse(p(logits), V, V, 2 * K, p(cv), p(ci), p(lse), NS, s), 'topk')
-        check(lib.vitcap_beam_step(p(cv), p(ci), p(lse), C.byref(st), B, K, V, t, max_len, 102, 0, C.c_float(lp), s), 'step')
+        if sample is not None:
+            sp = L.SampleParams(1, sample['temperature'], sample['top_k'], sample['top_p'], sample['seed'])
+            check(lib.vitcap_beam_sample_candidates(p(logits), V, V, NS, t, C.byref(sp), 0, p(cv), p(ci), p(lse), s), 'draw')
+            check(lib.vitcap_beam_step_sampled(p(cv), p(ci), p(lse), C.byref(st), B, K, V, t, max_len, 102, 0, C.c_float(lp), s),
+                  'step')
+        else:
+            check(lib.vitcap_row_topk_lse(p(logits), V, V, 2 * K, p(cv), p(ci), p(lse), NS, s), 'topk')
+            check(lib.vitcap_beam_step(p(cv), p(ci), p(lse), C.byref(st), B, K, V, t, max_len, 102, 0, C.c_float(lp), s), 'step')
         st.ids_in, st.ids_out = st.ids_out, st.ids_in
     ids = torch.empty(B, keep, max_len, dtype=torch.int64, device=dev)
     logp = torch.empty(B, keep, dtype=torch.float32, device=dev)
@@ -84,3 +90,54 @@ def test_nbest_bookkeeping_matches_oracle(B, K, keep, lp, boost):
         gt = sorted(map(tuple, got_ids[b].tolist()))
         assert w == gt and float((want_lp[b][:-1] - want_lp[b][1:]).abs().min()) < 1e-5, (b, want_ids[b], got_ids[b])
     assert bool((got_lp[:, :-1] >= got_lp[:, 1:]).all())          # best first
+
+
+@pytest.mark.parametrize('B,K,keep,lp,boost,temperature,top_k,top_p', [
+    (6, 3, 1, 1.0, 3.0, 1.0, 0, 1.0), (5, 2, 2, 1.0, 4.0, 0.8, 50, 0.9), (4, 4, 3, 0.7, 5.0, 1.3, 0, 0.6), (3, 8, 8, 1.0, 6.0, 1.0, 1, 1.0),
+    (4, 5, 2, 1.0, 2.0, 1.0, 0, 0.02), (4, 3, 1, 1.0, -50.0, 1.0, 7, 1.0)])
+def test_beam_sampling_matches_oracle(B, K, keep, lp, boost, temperature, top_k, top_p):
+    """num_beams > 1 with do_sample (modeling_utils.py:966-985): vitcap_beam_sample_candidates + vitcap_beam_step_sampled against
+    the oracle's restatement (pinned to the reference's own output by tests/test_oracle_sample.py) on the same fp32 logit tables
+    and the same counter-based noise: filter with min_tokens_to_keep 2, two draws without replacement per beam, position-order
+    consumption with the reference's beam attribution, n-best list.  Cases: no filter, top-k + top-p, top-p with a length
+    penalty, top_k = 1 (min_tokens_to_keep lifts it to 2: the draws are the two best), a nucleus so small that only the three
+    always-kept ranks survive, and [SEP] impossible.  Images whose draw or nucleus boundary is undecidable at fp32 are skipped."""
+    V, R = 3000, 64
+    g = torch.Generator().manual_seed(1000 * B + 10 * K + keep)
+    table = torch.randn(20, R, V, generator=g) * 2.0
+    table[:, :, 102] += boost
+    NS = B * K
+    rows = torch.arange(NS)
+    seed = 31 + K
+
+    def run_oracle(dp):
+        risky = torch.zeros(B, dtype=torch.bool)
+
+        def step(input_ids, beam_idx):
+            t = input_ids.shape[1]
+            return table[t, (input_ids[:, t - 1] + rows) % R]
+
+        def draw(x, t):
+            sc = x + torch.from_numpy(np.stack([O.gumbel_noise(seed, r, t, V) for r in range(NS)]))
+            top3 = sc.topk(3, dim=-1)
+            near = (top3.values[:, :-1] - top3.values[:, 1:]).min(1).values < 1e-4      # logf of device and numpy differ by an ulp
+            risky.__ior__(near.view(B, K).any(1))
+            return top3.indices[:, :2]
+        out = O.beam_bookkeeping(step, B, K, 20, lp, keep,
+                                 sample=dict(temperature=temperature, top_k=top_k, top_p=top_p + dp, seed=seed, draw=draw))
+        return out, risky
+    (want_ids, want_lp), risky = run_oracle(0.0)
+    if top_p < 1:
+        for dp in (-1e-5, 1e-5):        # the nucleus boundary compares an fp32 cumulative sum with top_p (as test_sample_step_vs_oracle)
+            (ids_n, _), _ = run_oracle(dp)
+            risky |= (ids_n != want_ids).flatten(1).any(1)
+    got_ids, got_lp = _run_device(table.cuda(), B, K, V, keep, lp,
+                                  sample=dict(temperature=temperature, top_k=top_k, top_p=top_p, seed=seed))
+    ok = ~risky
+    assert int(ok.sum()) >= B - 1, risky
+    fin = want_lp > -1e4
+    assert bool(((got_lp > -1e4) == fin)[ok].all())
+    m = fin & ok[:, None]
+    np.testing.assert_allclose(got_lp[m].numpy(), want_lp[m].numpy(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(got_ids[ok], want_ids[ok]), (got_ids, want_ids)
+    assert bool((want_ids[:, 0, 0] == 101).all())

@@ -130,3 +130,41 @@ def test_num_return_sequences():
     m.test_extra_input.update(do_sample=False)
     with pytest.raises(NotImplementedError):
         m({'image': img, 'key': [0, 1]})
+
+
+def test_model_beam_sampling_vs_oracle(sd_t):
+    """generate(num_beams = 3, do_sample = True) end to end: the engine's beam loop with sampled candidates against the oracle's
+    incremental model + bookkeeping (bf16 emulation, same counter-based noise).  A sampled decision flips only when two
+    noise-perturbed scores are closer than the bf16 logits noise, which is rare (the perturbed gaps are O(0.1)); images are
+    compared when the oracle's own fp32 and bf16-emulated runs agree (a conditioning check that needs no device), and at least
+    one must be.  Also: a second call draws a different stream, the same seed replays, and the result differs from plain beam
+    search."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    m = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+    m.pack('cuda')
+    B, K = 3, 3
+    img = torch.from_numpy(W.gen_image_batch(B, 1234))
+    kw = dict(temperature=0.9, top_k=100, top_p=0.95, seed=5)
+    with torch.no_grad():
+        ids_e, lp_e = O.beam_incremental(sd_t, img, num_beams=K, emulate_bf16=True, sample=dict(kw))
+        ids_f, lp_f = O.beam_incremental(sd_t, img, num_beams=K, emulate_bf16=False, sample=dict(kw))
+    ok = (ids_e == ids_f).flatten(1).all(1)
+    ids, lp = m.generate_beam(img.cuda(), K, do_sample=True, **kw)
+    ids_again, _ = m.generate_beam(img.cuda(), K, do_sample=True, **kw)
+    ids_other, _ = m.generate_beam(img.cuda(), K, do_sample=True, **dict(kw, seed=6))
+    ids_beam, _ = m.generate_beam(img.cuda(), K)
+    print('hip   ', ids.cpu()[:, 0].tolist(), lp.cpu().flatten().tolist())
+    print('oracle', ids_e[:, 0].tolist(), lp_e.flatten().tolist(), 'comparable', ok.tolist())
+    assert ids.shape == (B, 1, 20) and bool((ids[:, 0, 0] == 101).all())
+    assert int(ok.sum()) >= 1
+    assert torch.equal(ids.cpu()[ok], ids_e[ok])
+    np.testing.assert_allclose(lp.cpu().numpy()[ok.numpy()], lp_e.numpy()[ok.numpy()], atol=1e-2)
+    assert torch.equal(ids, ids_again), 'the same seed must replay the same draws'
+    assert not torch.equal(ids, ids_other) and not torch.equal(ids, ids_beam)
+    # through forward(): the reference's kwargs, a fresh stream per call
+    m.test_extra_input.update(num_beams=K, do_sample=True, **kw)
+    a, _ = m({'image': img.cuda(), 'key': [0, 1, 2]})
+    b, _ = m({'image': img.cuda(), 'key': [0, 1, 2]})
+    assert torch.equal(a, ids) and not torch.equal(a, b)

@@ -53,3 +53,61 @@ def test_gumbel_max_follows_softmax():
     e = p[p > 0] * N
     chi2 = float(((counts[p > 0] - e) ** 2 / e).sum())
     assert chi2 < 30.0, chi2            # dof <= 7; P(chi2 > 30) < 1e-4
+
+
+BS_GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_beamsample.npz')
+
+
+def test_filter_min_tokens_to_keep_equals_reference_golden():
+    """The beam-sampling call of the filter (min_tokens_to_keep = 2, modeling_utils.py:970-972): k = max(top_k, 2) and ranks
+    0..2 always survive top-p (the reference clears the flags of ranks 0..1 before its shift-by-one)."""
+    from tests.golden.make_golden_beamsample import FILTER_CASES
+    z = np.load(BS_GOLD)
+    x = make_logits(2024)
+    for n, (k, p) in enumerate(FILTER_CASES):
+        assert z['filter%d_kp' % n].tolist() == [k, p]
+        keep = torch.isfinite(O.top_k_top_p_filter(x, k, p, min_tokens_to_keep=2)).numpy()
+        want = np.unpackbits(z['filter%d_keep' % n], axis=1)[:, :x.shape[1]].astype(bool)
+        assert np.array_equal(keep, want), (k, p, keep.sum(1), want.sum(1))
+
+
+def test_gumbel_top2_is_sampling_without_replacement():
+    """Two largest of x + G == two draws without replacement from softmax(x): first-draw frequencies follow p, and the
+    second draw given the first follows p renormalised without it (chi-square on the pair table)."""
+    x = torch.tensor([[1.5, 0.5, 0.0, -0.5, 1.0]])
+    p = torch.softmax(x, -1)[0].double().numpy()
+    V, N = 5, 60000
+    pair = np.zeros((V, V))
+    big = x.expand(1000, V).contiguous()
+    for t in range(N // 1000):
+        idx = O.gumbel_top2(big, seed=3, t=t).numpy()
+        assert (idx[:, 0] != idx[:, 1]).all()
+        np.add.at(pair, (idx[:, 0], idx[:, 1]), 1)
+    e = np.array([[0 if i == j else p[i] * p[j] / (1 - p[i]) for j in range(V)] for i in range(V)]) * N
+    m = e > 0
+    chi2 = float(((pair[m] - e[m]) ** 2 / e[m]).sum())
+    assert chi2 < 55.0, chi2            # dof 19; P(chi2 > 55) < 1e-4
+
+
+def test_beam_sampling_bookkeeping_matches_reference(sd_t):
+    """num_beams > 1 with do_sample (modeling_utils.py:966-985) against the reference's own output with torch.multinomial
+    replaced by the counter-based Gumbel top-2 draw (tests/golden/make_golden_beamsample.py): pins temperature -> filter with
+    min_tokens_to_keep 2 -> log-softmax scores, the positional candidate order, the beam attribution `p % num_beams` of the
+    reference's "match shape of greedy beam search" step, repetition penalty and the n-best list."""
+    from vitcap_amd import weights as W
+    z = np.load(BS_GOLD)
+    assert int(z['recipe_version']) == W.RECIPE_VERSION
+    n = 0
+    while 'case%d_cfg' % n in z:
+        beams, keep, B, temp, top_k, top_p, rep, seed = z['case%d_cfg' % n]
+        im = torch.from_numpy(W.gen_image_batch(int(B), int(z['image_seed'])))
+        sd_ = int(seed)
+        draw = lambda x, t: O.gumbel_top2(torch.log(torch.softmax(x, dim=-1)), sd_, t)
+        with torch.no_grad():
+            ids, lp = O.beam_incremental(sd_t, im, num_beams=int(beams), num_keep_best=int(keep), repetition_penalty=float(rep),
+                                         sample=dict(temperature=float(temp), top_k=int(top_k), top_p=float(top_p), seed=sd_,
+                                                     draw=draw))
+        np.testing.assert_array_equal(ids.numpy(), z['case%d_ids' % n])
+        np.testing.assert_allclose(lp.numpy(), z['case%d_logprobs' % n], rtol=2e-5, atol=2e-5)
+        n += 1
+    assert n == 3

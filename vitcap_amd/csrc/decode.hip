@@ -174,13 +174,20 @@ __device__ __forceinline__ uint32_t order_key(float v) {
     THR = prefix_;                                                                             \
   }
 
+// BEAM = true: the do_sample branch of beam search (modeling_utils.py:966-985).  Same temperature / filter, with
+// min_tokens_to_keep = `min_keep` (k = max(top_k, min_keep); ranks 0..min_keep always survive top-p, 1125-1130), then TWO draws
+// without replacement (the two largest of x + Gumbel noise == torch.multinomial(p, 2)); written per row: the two words, their
+// temperature-scaled logits and the log-sum-exp of the surviving set (so log_softmax(filtered)[word] = value - lse).
+template <bool BEAM>
 __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int ldl, int V,
                                                            int64_t* __restrict__ ids, int32_t* __restrict__ unf,
                                                            float* __restrict__ sum_lp, float* __restrict__ cnt,
                                                            float* __restrict__ logprob_out,
                                                            float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
                                                            int t, int max_len, int eos, int pad, float temperature, int top_k,
-                                                           float top_p, uint32_t seed, int seq_off, int32_t* __restrict__ live) {
+                                                           float top_p, uint32_t seed, int seq_off, int32_t* __restrict__ live,
+                                                           int min_keep, float* __restrict__ cand_val,
+                                                           int32_t* __restrict__ cand_idx, float* __restrict__ cand_lse) {
   __shared__ unsigned long long s_hist[256];
   __shared__ unsigned long long s_acc;
   __shared__ uint32_t s_sel;
@@ -189,7 +196,9 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
   __shared__ ArgMax s_am[16];
   __shared__ float s_second[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (unf[b] == 0) {                    // finished sequence: pad, frozen score (see greedy_step_kernel)
+  if (BEAM) {
+    if (live && *live == 0) return;     // every image's search has closed
+  } else if (unf[b] == 0) {             // finished sequence: pad, frozen score (see greedy_step_kernel)
     if (tid == 0) {
       ids[(size_t)b * max_len + t] = pad;
       if (t == max_len - 1) {
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
   // ---- top-k -------------------------------------------------------------------------------------------------
   uint32_t thr = 1u;                                       // keep every present element
   if (top_k > 0) {
+    if (top_k < min_keep) top_k = min_keep;
     const unsigned long long kk = (unsigned long long)(top_k < V ? top_k : V) - 1ull;
     uint32_t tk;
     SM_RADIX_SELECT(tk, 1ull, kk);
@@ -246,6 +256,11 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     uint32_t tp;
     const uint32_t thr_k = thr;
     SM_RADIX_SELECT(tp, (key[j] >= thr_k ? (unsigned long long)(expf(x[j] - m) * scale) : 0ull), P);
+    if (min_keep > 1) {                                    // ranks 0..min_keep stay whatever their mass
+      uint32_t tm;
+      SM_RADIX_SELECT(tm, (key[j] >= thr_k ? 1ull : 0ull), (unsigned long long)min_keep);
+      tp = tm < tp ? tm : tp;
+    }
     if (tp > thr) {
       thr = tp;
       z = 0.f;                                             // renormalise over the nucleus
@@ -259,8 +274,54 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
       z = s_bcast;
     }
   }
-  // ---- one draw: argmax(x + Gumbel noise) over the surviving set == multinomial(softmax(filtered)) ----------
   const uint32_t hrow = vc_mix(vc_mix(seed, (uint32_t)(b + seq_off)), (uint32_t)t);   // stream of sequence b + seq_off of the call
+  if (BEAM) {
+    // ---- two draws without replacement: the largest, then the largest of the rest, of x + Gumbel noise ----------------
+    float sc[SM_NPT];
+#pragma unroll
+    for (int j = 0; j < SM_NPT; ++j) {
+      const int i = tid + j * 1024;
+      sc[j] = key[j] >= thr ? x[j] - logf(-logf(vc_uniform(vc_mix(hrow, (uint32_t)i)))) : -INFINITY;
+    }
+    int excl = -1;
+    for (int d = 0; d < 2; ++d) {
+      ArgMax best{-INFINITY, 0x7fffffff};
+      float bx = 0.f;
+#pragma unroll
+      for (int j = 0; j < SM_NPT; ++j) {
+        const int i = tid + j * 1024;
+        if (key[j] >= thr && i != excl && (sc[j] > best.v || (sc[j] == best.v && i < best.i))) { best.v = sc[j]; best.i = i; bx = x[j]; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ArgMax ob;
+        ob.v = __shfl_xor(best.v, o, 64);
+        ob.i = __shfl_xor(best.i, o, 64);
+        const float obx = __shfl_xor(bx, o, 64);
+        const ArgMax nb = am_better(best, ob);
+        bx = (nb.i == best.i) ? bx : obx;
+        best = nb;
+      }
+      __syncthreads();
+      if (lane == 0) { s_am[w] = best; s_f[w] = bx; }
+      __syncthreads();
+      ArgMax bb = s_am[0];
+      float xx = s_f[0];
+      for (int k = 1; k < 16; ++k) {
+        const ArgMax nb = am_better(bb, s_am[k]);
+        xx = (nb.i == bb.i) ? xx : s_f[k];
+        bb = nb;
+      }
+      excl = bb.i;
+      if (tid == 0) {
+        cand_val[(size_t)b * 2 + d] = xx;
+        cand_idx[(size_t)b * 2 + d] = bb.i;
+      }
+    }
+    if (tid == 0) cand_lse[b] = m + logf(z);
+    return;
+  }
+  // ---- one draw: argmax(x + Gumbel noise) over the surviving set == multinomial(softmax(filtered)) ----------
   ArgMax best{-INFINITY, 0x7fffffff};
   float bx = 0.f, second = -INFINITY;
 #pragma unroll
@@ -549,12 +610,13 @@ __global__ void beam_init_kernel(BeamState st, int B, int K, int max_len, int bo
 //      new beams' prefixes.
 __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
                                                        const float* __restrict__ lse, BeamState st, int B, int K, int V, int t,
-                                                       int max_len, int eos, int pad, float length_penalty, int32_t* __restrict__ live) {
+                                                       int max_len, int eos, int pad, float length_penalty, int32_t* __restrict__ live,
+                                                       int sampled) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   // every image done (`if all(done): break`, modeling_utils.py:1072): beams, hypotheses and scores stay as they are
   if (live && *live == 0) return;
-  const int C = 2 * K, n = K * C, NH = st.n_keep;
+  const int C = 2 * K, n = sampled ? C : K * C, NH = st.n_keep;
   __shared__ float s_sc[MAXBEAM * 2 * MAXBEAM];
   __shared__ int s_fl[MAXBEAM * 2 * MAXBEAM];
   __shared__ float s_top_sc[2 * MAXBEAM];
@@ -565,18 +627,38 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   __shared__ int s_nh;
   __shared__ float s_nsc[MAXBEAM];
   __shared__ int s_nword[MAXBEAM], s_npar[MAXBEAM];
-  for (int i = lane; i < n; i += 64) {
-    const int k = i / C, row = b * K + k;
-    s_sc[i] = cval[(size_t)row * C + (i - k * C)] + (st.beam_scores[row] - lse[row]);   // log_softmax + beam score
-    s_fl[i] = k * V + cidx[(size_t)row * C + (i - k * C)];                              // index into the (beams*V) view
-  }
-  __syncthreads();
-  for (int i = lane; i < n; i += 64) {
-    const float v = s_sc[i];
-    const int f = s_fl[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (s_sc[j] > v || (s_sc[j] == v && s_fl[j] < f)) ? 1 : 0;
-    if (rank < C) { s_top_sc[rank] = v; s_top_fl[rank] = f; }
+  __shared__ float s_best_sc;
+  if (sampled) {
+    // do_sample (modeling_utils.py:966-985): the candidates are the 2 draws of each beam IN POSITION ORDER, not ranked.
+    // Position p holds draw p % 2 of beam p / 2 (score = its log-prob + THAT beam's score), but the reference's "match shape of
+    // greedy beam search" step adds `arange(K) * V` repeated twice as beam offsets, so position p is ATTRIBUTED to beam p % K:
+    // the prefix continued (or finished) with the word is beam p % K's.  Reproduced as written.
+    for (int i = lane; i < n; i += 64) {
+      const int row = b * K + (i >> 1);
+      s_top_sc[i] = cval[(size_t)row * 2 + (i & 1)] + (st.beam_scores[row] - lse[row]);
+      s_top_fl[i] = (i % K) * V + cidx[(size_t)row * 2 + (i & 1)];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      float mx = s_top_sc[0];
+      for (int i = 1; i < n; ++i) mx = fmaxf(mx, s_top_sc[i]);
+      s_best_sc = mx;                                          // is_done(next_scores.max())
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) {
+      const int k = i / C, row = b * K + k;
+      s_sc[i] = cval[(size_t)row * C + (i - k * C)] + (st.beam_scores[row] - lse[row]);   // log_softmax + beam score
+      s_fl[i] = k * V + cidx[(size_t)row * C + (i - k * C)];                              // index into the (beams*V) view
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+      const float v = s_sc[i];
+      const int f = s_fl[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (s_sc[j] > v || (s_sc[j] == v && s_fl[j] < f)) ? 1 : 0;
+      if (rank < C) { s_top_sc[rank] = v; s_top_fl[rank] = f; }
+      if (rank == 0) s_best_sc = v;
+    }
   }
   float* hsc = st.hyp_score + (size_t)b * NH;
   int* hln = st.hyp_len + (size_t)b * NH;
@@ -598,7 +680,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
       // BeamHypotheses.is_done: the list is full and its worst score already beats what the best open beam can reach
       float worst = s_hsc[0];
       for (int i = 1; i < nh; ++i) worst = fminf(worst, s_hsc[i]);
-      if (worst >= s_top_sc[0] / powf((float)(max_len - 1), length_penalty)) done = 1;
+      if (worst >= s_best_sc / powf((float)(max_len - 1), length_penalty)) done = 1;
     }
     int cnt = 0;
     if (!done) {
@@ -805,8 +887,22 @@ extern "C" int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, 
   VC_REQUIRE(t >= 1 && t < max_len && max_len <= 40, "beam_step: t=%d out of range (max_len %d <= 40)", t, max_len);
   VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_step: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
-                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty, (int32_t*)vc_tls_live);
+                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty, (int32_t*)vc_tls_live, 0);
   VC_LAUNCH_CHECK("beam_step");
+  return VITCAP_OK;
+}
+
+// The same step on SAMPLED candidates (vitcap_beam_sample_candidates: cand_val / cand_idx [B*K][2], lse [B*K]): consumed in
+// position order with the reference's beam attribution (see beam_step_kernel).
+extern "C" int vitcap_beam_step_sampled(const float* cand_val, const int32_t* cand_idx, const float* lse,
+                                        const vitcap_beam_state* s, int B, int K, int V, int t, int max_len, int eos, int pad,
+                                        float length_penalty, void* stream) {
+  VC_REQUIRE(cand_val && cand_idx && lse && s && B > 0 && K >= 2 && K <= MAXBEAM, "beam_step_sampled: bad arguments");
+  VC_REQUIRE(t >= 1 && t < max_len && max_len <= 40, "beam_step_sampled: t=%d out of range (max_len %d <= 40)", t, max_len);
+  VC_REQUIRE(s->n_keep >= 1 && s->n_keep <= MAXBEAM, "beam_step_sampled: n_keep must be 1..%d (got %d)", MAXBEAM, s->n_keep);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse,
+                     make_state(s), B, K, V, t, max_len, eos, pad, length_penalty, (int32_t*)vc_tls_live, 1);
+  VC_LAUNCH_CHECK("beam_step_sampled");
   return VITCAP_OK;
 }
 
@@ -839,9 +935,10 @@ extern "C" int vitcap_sample_step_offset(const float* logits, int ldl, int V, in
   VC_REQUIRE(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f,
              "sample_step: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature, sp->top_k,
              (double)sp->top_p);
-  hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
+  hipLaunchKernelGGL(sample_step_kernel<false>, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
                      sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, sp->temperature, sp->top_k,
-                     sp->top_p, sp->seed, seq_offset, (int32_t*)vc_tls_live);
+                     sp->top_p, sp->seed, seq_offset, (int32_t*)vc_tls_live, 1, (float*)nullptr, (int32_t*)nullptr,
+                     (float*)nullptr);
   VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
 }
@@ -851,4 +948,24 @@ extern "C" int vitcap_sample_step(const float* logits, int ldl, int V, int64_t* 
                                   int B, int t, int max_len, int eos, int pad, const vitcap_sample_params* sp, void* stream) {
   return vitcap_sample_step_offset(logits, ldl, V, ids, unfinished, sum_lp, cnt, logprob_out, margin_out, raw_last, B, t, max_len, eos,
                                    pad, sp, 0, stream);
+}
+
+// Candidates of one beam-search step WITH sampling (modeling_utils.py:966-985): per row (= beam) two words drawn without
+// replacement from softmax(filter(logits / temperature)), filter with min_tokens_to_keep = 2.  out_val / out_idx: [rows][2],
+// out_lse: [rows]; vitcap_beam_step_sampled consumes them.  The noise stream of row r is (seed, r + row_offset, t).
+extern "C" int vitcap_beam_sample_candidates(const float* logits, int ldl, int V, int rows, int t,
+                                             const vitcap_sample_params* sp, int row_offset, float* out_val, int32_t* out_idx,
+                                             float* out_lse, void* stream) {
+  VC_REQUIRE(logits && sp && out_val && out_idx && out_lse, "beam_sample_candidates: null pointer");
+  VC_REQUIRE(rows > 0 && V > 2 && V <= SM_NPT * 1024 && ldl >= V && t >= 1 && row_offset >= 0,
+             "beam_sample_candidates: bad sizes (V=%d t=%d)", V, t);
+  VC_REQUIRE(sp->temperature > 0.f && sp->top_k >= 0 && sp->top_p > 0.f,
+             "beam_sample_candidates: temperature %g / top_k %d / top_p %g out of range", (double)sp->temperature, sp->top_k,
+             (double)sp->top_p);
+  hipLaunchKernelGGL(sample_step_kernel<true>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V,
+                     (int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (int64_t*)nullptr, t, 0, 0, 0, sp->temperature, sp->top_k, sp->top_p, sp->seed, row_offset,
+                     (int32_t*)vc_tls_live, 2, out_val, out_idx, out_lse);
+  VC_LAUNCH_CHECK("beam_sample_candidates");
+  return VITCAP_OK;
 }

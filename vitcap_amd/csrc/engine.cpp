@@ -106,7 +106,6 @@ int check_opts(const vitcap_gen_opts& o) {
   OPT_REQ(o.num_keep_best >= 1 && o.num_keep_best <= 8, "gen_opts: num_keep_best must be 1..8 (got %d)", o.num_keep_best);
   OPT_REQ(!(o.num_beams > 1 && o.seqs_per_image > 1), "gen_opts: seqs_per_image > 1 needs num_beams == 1");
   OPT_REQ(!(o.num_beams == 1 && o.num_keep_best > 1), "gen_opts: cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)");
-  OPT_REQ(!(o.num_beams > 1 && o.sampling.do_sample), "gen_opts: beam sampling (num_beams > 1 with do_sample) is not built");
   OPT_REQ(o.max_length >= 2 && o.max_length <= VITCAP_MAXLEN_CAP, "gen_opts: max_length must be 2..%d (got %d)", VITCAP_MAXLEN_CAP, o.max_length);
   const int32_t toks[4] = {o.bos_token_id, o.eos_token_id, o.pad_token_id, o.mask_token_id};
   for (int i = 0; i < 4; ++i) OPT_REQ(toks[i] >= 0 && toks[i] < VITCAP_VOCAB, "gen_opts: token id %d out of the vocabulary", toks[i]);
@@ -949,11 +948,19 @@ static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen
     CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, true, false, Part{0, NS, 0}, s));
     if (o.repetition_penalty != 1.0f)
       CK(vitcap_repetition_penalty((float*)(ws + lo.logits), VP, VITCAP_VOCAB, st.ids_in, L, t, o.repetition_penalty, NS, s));
-    CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),
-                           (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), NS, s));
-    CK(vitcap_beam_step((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
-                        (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, o.eos_token_id, o.pad_token_id,
-                        o.length_penalty, s));
+    if (o.sampling.do_sample) {   // modeling_utils.py:966-985: two sampled words per beam instead of the 2*beams best
+      CK(vitcap_beam_sample_candidates((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, NS, t, &o.sampling, 0,
+                                       (float*)(ws + lo.cand_val), (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), s));
+      CK(vitcap_beam_step_sampled((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
+                                  (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, o.eos_token_id,
+                                  o.pad_token_id, o.length_penalty, s));
+    } else {
+      CK(vitcap_row_topk_lse((const float*)(ws + lo.logits), VP, VITCAP_VOCAB, C, (float*)(ws + lo.cand_val),
+                             (int32_t*)(ws + lo.cand_idx), (float*)(ws + lo.lse), NS, s));
+      CK(vitcap_beam_step((const float*)(ws + lo.cand_val), (const int32_t*)(ws + lo.cand_idx),
+                          (const float*)(ws + lo.lse), &st, B, beams, VITCAP_VOCAB, t, L, o.eos_token_id, o.pad_token_id,
+                          o.length_penalty, s));
+    }
     if (t + 1 < L) {   // re-order the text K/V history (positions 0..t-1) by parent beam for the next step
       CK(vitcap_beam_reorder_cache(tc_cur, tc_alt, st.parent, 4, NS, L, t, s));
       char* tmp = tc_cur; tc_cur = tc_alt; tc_alt = tmp;

@@ -251,8 +251,6 @@ class ImageCaptioning(nn.Module):
             raise AssertionError('cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)')
         if nret > 1 and (not do_sample or nb > 1):
             raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
-        if nb > 1 and do_sample:
-            raise NotImplementedError('beam sampling (num_beams > 1 with do_sample, modeling_utils.py:966-985) is not built')
         ml = int(te.get('max_length', L.MAXLEN))
         if not 2 <= ml <= L.MAXLEN_CAP:
             raise NotImplementedError('max_length must be 2..%d in this build (got %d)' % (L.MAXLEN_CAP, ml))
@@ -375,8 +373,9 @@ class ImageCaptioning(nn.Module):
     def generate_beam(self, image, num_beams, length_penalty=1.0, slot=0, num_keep_best=1, **over):
         """Beam search -> (ids (B,num_keep_best,L), logprobs (B,num_keep_best)), best hypothesis first, like
         ViTCAP._generate_beam_search (modeling_utils.py:888-1100)."""
+        over.setdefault('do_sample', False)      # do_sample=True: beam sampling (modeling_utils.py:966-985), temperature / top_k / top_p / seed
         o = self.gen_options(num_beams=int(num_beams), length_penalty=float(length_penalty), num_keep_best=int(num_keep_best),
-                             do_sample=False, num_return_sequences=1, **over)
+                             num_return_sequences=1, **over)
         return self.run(image, o, slot=slot)
 
     def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0, opts=None):
