@@ -1588,6 +1588,19 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // 64x64 / 64x32 / 32x32 tiles (tools/cold_gemm.py), against a ~4.5 us launch floor
   if (hint == 0 && d->M <= 128) return dispatch<1, 1>(a, d->act, d->out_dtype, s);
   if (hint == 1 || (hint == 0 && d->M <= 256)) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
+  if (hint == 0 && d->act != VITCAP_ACT_TANH) {
+    // Auto tile choice for 256 < M: the tile whose grid costs least under a linear model fitted to tools/gemm_bench.py on the
+    // hot shapes (M = 577 .. 36928; N = 768 / 2304 / 3072; K = 768 / 3072; us).  64x64: 4 + W * c; 128x128: max(one tile, 9 + W * c);
+    // 256x256: ceil(W / 256) * one tile.  A 256x256 grid of 30 workgroups (N = 768 at 1..8 images) leaves 7/8 of the chip idle
+    // for a whole tile time (fc2 at 4 images: 65 us, against 28 us on 64x64 tiles); one image's encoder 3.3 -> 2.6 ms.
+    const float kf = d->K > 768 ? (float)(d->K - 768) / 2304.f : 0.f;
+    const auto grid = [&](int t) { return (float)(((d->M + t - 1) / t) * ((d->N + t - 1) / t)); };
+    const float t64 = 4.f + grid(64) * (0.0165f + kf * 0.0385f);
+    const float t128 = fmaxf(16.f + kf * 26.f, 9.f + grid(128) * (0.0375f + kf * 0.0745f));
+    const float t256 = d->M >= 2048 ? ceilf(grid(256) / 256.f) * (23.f + kf * 57.f) : 1e30f;
+    if (t64 < t128 && t64 < t256) return dispatch<2, 2>(a, d->act, d->out_dtype, s);
+    if (t128 < t256) return dispatch<4, 4>(a, d->act, d->out_dtype, s);
+  }
   if (hint == 2 || (hint == 0 && (d->M < 2048 || d->act == VITCAP_ACT_TANH)))
     return dispatch<4, 4>(a, d->act, d->out_dtype, s);
   if (hint == 3) return dispatch_big(a, d->act, d->out_dtype, s);
