@@ -203,6 +203,7 @@ def main():
     ap.add_argument('--graph', type=int, default=0,
                     help='1: the decode loop is captured once into a hipGraph inside the engine (vitcap_gen_opts.use_graph) and replayed')
     ap.add_argument('--gemm-tiles', type=int, default=0, help='one-stream runs: large GEMMs one tile per workgroup (+ forked tag branch)')
+    ap.add_argument('--isolated', type=int, default=1, help='1: after the timed region, an untimed one-stream pass measures the dominant kernel with the chip to itself (roofline.isolated); 0 skips it (profiling runs: keeps the rocprofv3 per-kernel averages those of the timed configuration)')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1: two-slot batch pipeline (encode+prefill of step i+1 overlaps the decode of step i on a second '
                          'stream; same results); 0: one stream, steps strictly back to back')
@@ -268,21 +269,23 @@ def main():
         fl = (C.c_double * 12)()
         ln = (C.c_int * 12)()
         busy = (C.c_double * 12)()
-        check(lib.vitcap_engine_timing_end_ex(model._engine, ms, fl, ln, busy), 'timing_end')
+        kms = (C.c_double * 12)()
+        kbusy = (C.c_double * 12)()
+        check(lib.vitcap_engine_timing_end_kernel(model._engine, ms, fl, ln, busy, kms, kbusy), 'timing_end')
         # With the batch pipeline the GEMMs of the timed region share the chip with the other slot's decode kernels, so
         # their launch durations are longer than the kernel alone needs.  A second, untimed pass of (at most 20 of) the same
         # steps on ONE stream gives the kernel's own rate (reported next to, not instead of, the timed-region figure).
         iso = None
-        if piped:
+        if piped and args.isolated:
             n_iso = min(args.steps, 20)
-            ms2, fl2, ln2 = (C.c_double * 12)(), (C.c_double * 12)(), (C.c_int * 12)()
+            ms2, fl2, ln2, km2 = (C.c_double * 12)(), (C.c_double * 12)(), (C.c_int * 12)(), (C.c_double * 12)()
             check(lib.vitcap_engine_timing_begin(model._engine, n_iso * 160), 'timing_begin')
             iso_opts = model.gen_options(gemm_mode=L.GEMM_TILES if args.gemm_tiles else L.GEMM_AUTO, encode_parts=1, **gen_kw)
             for _ in range(n_iso):
                 model.run(img, iso_opts)            # ONE chain: no other kernel shares the chip with the GEMM launches
             stream.synchronize()
-            check(lib.vitcap_engine_timing_end(model._engine, ms2, fl2, ln2), 'timing_end')
-            iso = (list(ms2), list(fl2), list(ln2))
+            check(lib.vitcap_engine_timing_end_kernel(model._engine, ms2, fl2, ln2, None, km2, None), 'timing_end')
+            iso = (list(km2), list(fl2), list(ln2))
         # decode phase alone (one stream, after an encode + prefill): GPU time of the step loop per batch
         dec_ms = None
         if args.beams >= 1:
@@ -308,11 +311,14 @@ def main():
         return
 
     value = D.whole_job_rate(B, args.steps, world, elapsed)
-    tot_ms = sum(ms)
+    # kms: durations from HIP events bound to the kernel dispatches (kernel begins executing -> complete: what rocprofv3
+    # --kernel-trace reports); ms: stream-marker brackets around the launches (also hold the dispatch's wait behind the other stream)
+    tot_ms = sum(kms)
     tot_fl = sum(fl)
-    dom = max(range(12), key=lambda i: ms[i])
+    dom = max(range(12), key=lambda i: kms[i])
     gemm_all = (tot_fl / (tot_ms * 1e-3)) / 1e12 if tot_ms > 0 else 0.0
-    dom_tf = (fl[dom] / (ms[dom] * 1e-3)) / 1e12 if ms[dom] > 0 else 0.0
+    dom_tf = (fl[dom] / (kms[dom] * 1e-3)) / 1e12 if kms[dom] > 0 else 0.0
+    mark_tf = (fl[dom] / (ms[dom] * 1e-3)) / 1e12 if ms[dom] > 0 else 0.0
     traffic = None
     try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh);
         # FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), KiB -> bytes
@@ -345,23 +351,31 @@ def main():
             'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'traffic_note': ('HBM bytes per launch from a COMMITTED rocprofv3 PMC pass, not measured in this run: (2*FETCH_SIZE+WRITE_SIZE)*1024 '
                              'in %s (tools/pmc_traffic.sh regenerates it)' % os.path.relpath(TRAFFIC_FILE, REPO)) if traffic else None,
-            'launches': int(ln[dom]), 'avg_launch_ms': round(ms[dom] / max(1, ln[dom]), 4),
+            'launches': int(ln[dom]), 'avg_launch_ms': round(kms[dom] / max(1, ln[dom]), 4),
             'avg_launch_gflop': round(fl[dom] / max(1, ln[dom]) / 1e9, 3),
+            'timing': 'HIP events bound to each kernel dispatch (hipExtLaunchKernelGGL start / stop events on the launch stream: kernel '
+                      'begins executing -> kernel complete, the interval rocprofv3 --kernel-trace reports), every large-GEMM launch of '
+                      'the timed region',
             'all_large_gemm_tflops': round(gemm_all, 2),
-            'concurrency_note': 'the timed region runs several chains at once (2-slot batch pipeline, encoder in 2 batch parts): launches '
-                                'of this kernel overlap each other and other kernels, so `achieved` (flops / summed launch durations) counts '
-                                'shared time more than once; `achieved_busy` divides by the UNION of the launches\' intervals instead; '
-                                '`isolated` is the kernel with the chip to itself',
-            'achieved_busy': round(fl[dom] / (busy[dom] * 1e-3) / 1e12, 2) if busy[dom] > 0 else None,
-            'frac_busy': round(fl[dom] / (busy[dom] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if busy[dom] > 0 else None,
+            'stream_markers': {
+                'note': 'the same launches bracketed by hipEventRecord markers on the launch stream: the interval also holds the time '
+                        'the dispatch waited behind the other stream\'s (higher-priority) decode kernels, so with the 2-slot pipeline '
+                        'it is longer than the kernel ran',
+                'achieved': round(mark_tf, 2), 'frac': round(mark_tf / PEAK_BF16_TFLOPS, 4),
+                'avg_launch_ms': round(ms[dom] / max(1, ln[dom]), 4)},
+            'achieved_busy': round(fl[dom] / (kbusy[dom] * 1e-3) / 1e12, 2) if kbusy[dom] > 0 else None,
+            'frac_busy': round(fl[dom] / (kbusy[dom] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if kbusy[dom] > 0 else None,
+            'busy_note': 'flops / length of the UNION of this kernel\'s execution intervals; differs from `achieved` (flops / summed '
+                         'durations) because launches of the kernel overlap each other: the 4 tag blocks run on an engine side stream '
+                         'next to caption blocks 8-11, and with encode_parts > 1 the batch parts run as separate chains',
             'isolated': None if iso is None or iso[0][dom] <= 0 else {
                 'note': 'up to 20 of the same steps as ONE chain on one stream (no co-running kernels), untimed second pass',
                 'achieved': round(iso[1][dom] / (iso[0][dom] * 1e-3) / 1e12, 2),
                 'frac': round(iso[1][dom] / (iso[0][dom] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 'all_large_gemm_tflops': round(sum(iso[1]) / (sum(iso[0]) * 1e-3) / 1e12, 2)},
             'large_gemm_share_of_step_time': round(tot_ms / args.steps / (elapsed / args.steps * 1e3), 4),
-            'per_variant': {VARIANT_NAMES.get(i, str(i)): {'launches': int(ln[i]), 'ms': round(ms[i], 3),
-                                                            'tflops': round(fl[i] / (ms[i] * 1e-3) / 1e12, 2)}
+            'per_variant': {VARIANT_NAMES.get(i, str(i)): {'launches': int(ln[i]), 'ms': round(kms[i], 3),
+                                                            'tflops': round(fl[i] / (kms[i] * 1e-3) / 1e12, 2)}
                             for i in range(12) if ln[i] > 0},
         },
     }

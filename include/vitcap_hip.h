@@ -526,6 +526,11 @@ int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, in
 /* the same plus busy_ms12: per variant the length of the union of its launches' [start, stop] intervals (launches of one kernel
  * overlap when several chains are in flight; their summed durations count that time twice) */
 int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms12, double* flops12, int* launches12, double* busy_ms12);
+/* the same plus kernel_ms12 / kernel_busy_ms12: sums and union from HIP events bound to the KERNEL DISPATCHES themselves
+ * (hipExtLaunchKernelGGL start / stop: the kernel begins executing -> has completed, the interval rocprofv3 --kernel-trace
+ * reports); the stream-marker brackets above additionally hold the time a dispatch waited behind another stream's kernels */
+int vitcap_engine_timing_end_kernel(vitcap_engine* e, double* ms12, double* flops12, int* launches12, double* busy_ms12,
+                                    double* kernel_ms12, double* kernel_busy_ms12);
 
 /* ------------------------------------------------------------------------------------------------
  * Input side of the path: the reference's test-time image transform, get_transform_vit_default

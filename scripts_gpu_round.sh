@@ -17,8 +17,8 @@ python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
 bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 5 --warmup 1 --pipeline 0 --no-cpu-baseline >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline >> $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o train -- python3 $R/bench.py --steps 3 --warmup 1 --mode train >> $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 for k in pipe seq train; do

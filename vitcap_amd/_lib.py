@@ -174,6 +174,8 @@ _SIGS = {
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'vitcap_engine_timing_end_ex': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                               C.POINTER(C.c_double)]),
+    'vitcap_engine_timing_end_kernel': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -27,6 +27,13 @@ extern thread_local const int32_t* vc_tls_live;
     if ((live) != nullptr && *(live) == 0) return; \
   } while (0)
 
+// Engine-internal, timing runs only (vitcap_engine_timing_begin): when set, the large-GEMM launchers hand these two events to
+// hipExtLaunchKernelGGL, which binds them to THE KERNEL DISPATCH (start = the kernel begins executing, stop = it has completed:
+// the timestamps rocprofv3 --kernel-trace reports), instead of bracketing the launch with stream markers whose interval also holds
+// the time the dispatch waited for the chip behind another stream's kernels.  vc_tls_kev_used tells the engine that a launcher took them.
+extern thread_local hipEvent_t vc_tls_kev_start, vc_tls_kev_stop;
+extern thread_local bool vc_tls_kev_used;
+
 #define VC_REQUIRE(cond, ...)                 \
   do {                                        \
     if (!(cond)) {                            \

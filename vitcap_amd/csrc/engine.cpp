@@ -26,6 +26,8 @@
 
 void vitcap_set_error(const char* fmt, ...);
 extern thread_local const int32_t* vc_tls_live;   // csrc/common.h: early-exit counter handed to the decode-step launchers
+extern thread_local hipEvent_t vc_tls_kev_start, vc_tls_kev_stop;   // csrc/common.h: kernel-bound timing events (timing runs only)
+extern thread_local bool vc_tls_kev_used;
 
 #include <vector>
 
@@ -33,7 +35,9 @@ extern thread_local const int32_t* vc_tls_live;   // csrc/common.h: early-exit c
 // hipEvents are recorded on the SAME stream right before/after each launch; the pool is grown outside
 // the timed region by vitcap_engine_timing_begin().
 struct GemmTiming {
-  hipEvent_t start, stop;
+  hipEvent_t start, stop;     // stream markers right before / after the launch
+  hipEvent_t kstart, kstop;   // bound to the kernel dispatch itself (hipExtLaunchKernelGGL): what rocprofv3 --kernel-trace reports
+  bool kernel_bound;          // the launcher took kstart / kstop
   int variant;      // act*4 + out_f32*2 + has_res
   double flops;
 };
@@ -280,9 +284,16 @@ int gemm_desc(const void* A, const void* W, const float* bias, const float* res,
     t->variant = d.act * 4 + d.out_dtype * 2 + (res ? 1 : 0);
     t->flops = 2.0 * d.M * d.N * d.K;
     (void)hipEventRecord(t->start, (hipStream_t)s);
+    vc_tls_kev_start = t->kstart;
+    vc_tls_kev_stop = t->kstop;
+    vc_tls_kev_used = false;
   }
   const int rc = vitcap_gemm_bias_act(A, W, bias, res, C, &d, s);
-  if (t) (void)hipEventRecord(t->stop, (hipStream_t)s);
+  if (t) {
+    t->kernel_bound = vc_tls_kev_used;
+    vc_tls_kev_start = vc_tls_kev_stop = nullptr;
+    (void)hipEventRecord(t->stop, (hipStream_t)s);
+  }
   return rc;
 }
 
@@ -393,12 +404,14 @@ extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
   std::lock_guard<std::mutex> lk(e->mu);
   while ((int)e->pool.size() < max_launches) {
     GemmTiming t;
-    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
+    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess ||
+        hipEventCreate(&t.kstart) != hipSuccess || hipEventCreate(&t.kstop) != hipSuccess) {
       vitcap_set_error("timing_begin: hipEventCreate failed");
       return VITCAP_ELAUNCH;
     }
     t.variant = 0;
     t.flops = 0;
+    t.kernel_bound = false;
     e->pool.push_back(t);
   }
   e->used = 0;
@@ -410,11 +423,35 @@ extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
 // Synchronises on the recorded events; call after the timed region.  busy_ms (optional): per variant, the length of the UNION of
 // its launches' [start, stop] intervals -- with several chains in flight (batch pipeline, encoder parts) launches of one kernel
 // overlap each other and their summed durations count that time twice.
-extern "C" int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms, double* flops, int* launches, double* busy_ms) {
+static double union_ms(std::vector<std::pair<float, float>>& iv) {
+  std::sort(iv.begin(), iv.end());
+  float end = -1e30f;
+  double tot = 0;
+  for (auto& p : iv) {
+    if (p.first > end) { tot += p.second - p.first; end = p.second; }
+    else if (p.second > end) { tot += p.second - end; end = p.second; }
+  }
+  return tot;
+}
+
+// kernel_ms / kernel_busy_ms (optional): the same sums from the events BOUND TO THE KERNEL DISPATCHES (hipExtLaunchKernelGGL start /
+// stop events: kernel begins executing -> kernel complete, the interval rocprofv3 --kernel-trace reports).  The stream-marker
+// brackets (ms / busy_ms) also hold the time a dispatch waited behind another stream's kernels, so with two streams in flight they
+// are longer than the kernel ran.  Launches whose launcher does not take kernel events fall back to their bracket.
+extern "C" int vitcap_engine_timing_end_kernel(vitcap_engine* e, double* ms, double* flops, int* launches, double* busy_ms,
+                                               double* kernel_ms, double* kernel_busy_ms) {
   if (!e || !ms || !flops || !launches) return VITCAP_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
-  for (int i = 0; i < 12; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; if (busy_ms) busy_ms[i] = 0; }
-  std::vector<std::pair<float, float>> iv[12];
+  for (int i = 0; i < 12; ++i) {
+    ms[i] = 0; flops[i] = 0; launches[i] = 0;
+    if (busy_ms) busy_ms[i] = 0;
+    if (kernel_ms) kernel_ms[i] = 0;
+    if (kernel_busy_ms) kernel_busy_ms[i] = 0;
+  }
+  std::vector<std::pair<float, float>> iv[12], kiv[12];
+  hipEvent_t korigin = nullptr;     // time axis of the kernel-bound intervals: the first kernel-bound launch's start event
+  for (size_t i = 0; i < e->used && !korigin; ++i)
+    if (e->pool[i].kernel_bound) korigin = e->pool[i].kstart;
   for (size_t i = 0; i < e->used; ++i) {
     GemmTiming& t = e->pool[i];
     float el = 0.f;
@@ -425,26 +462,38 @@ extern "C" int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms, double*
     ms[t.variant] += el;
     flops[t.variant] += t.flops;
     launches[t.variant] += 1;
-    if (busy_ms) {
-      float a = 0.f;
-      if (hipEventElapsedTime(&a, e->pool[0].start, t.start) != hipSuccess) a = 0.f;     // timestamp relative to the first launch
-      iv[t.variant].push_back({a, a + el});
+    float a = 0.f;
+    if ((busy_ms || kernel_busy_ms) && hipEventElapsedTime(&a, e->pool[0].start, t.start) != hipSuccess) a = 0.f;   // relative to the first launch
+    if (busy_ms) iv[t.variant].push_back({a, a + el});
+    if (kernel_ms || kernel_busy_ms) {
+      float kel = el, ka = a;
+      if (t.kernel_bound) {
+        float x = 0.f, y = 0.f;
+        if (hipEventSynchronize(t.kstop) == hipSuccess && hipEventElapsedTime(&x, t.kstart, t.kstop) == hipSuccess &&
+            hipEventElapsedTime(&y, korigin, t.kstart) == hipSuccess) {
+          kel = x;
+          ka = y;
+        }
+      }
+      if (kernel_ms) kernel_ms[t.variant] += kel;
+      if (kernel_busy_ms) kiv[t.variant].push_back({ka, ka + kel});
     }
   }
-  if (busy_ms)
-    for (int v = 0; v < 12; ++v) {
-      std::sort(iv[v].begin(), iv[v].end());
-      float end = -1e30f;
-      double tot = 0;
-      for (auto& p : iv[v]) {
-        if (p.first > end) { tot += p.second - p.first; end = p.second; }
-        else if (p.second > end) { tot += p.second - end; end = p.second; }
-      }
-      busy_ms[v] = tot;
-    }
+  for (int v = 0; v < 12; ++v) {
+    if (busy_ms) busy_ms[v] = union_ms(iv[v]);
+    if (kernel_busy_ms) kernel_busy_ms[v] = union_ms(kiv[v]);
+  }
   e->timing = false;
   e->used = 0;
   return VITCAP_OK;
+}
+
+// Sums per GEMM epilogue variant (index = act*4 + out_f32*2 + has_res, 12 slots): milliseconds, flops, launches.
+// Synchronises on the recorded events; call after the timed region.  busy_ms (optional): per variant, the length of the UNION of
+// its launches' [start, stop] intervals -- with several chains in flight (batch pipeline, encoder parts) launches of one kernel
+// overlap each other and their summed durations count that time twice.
+extern "C" int vitcap_engine_timing_end_ex(vitcap_engine* e, double* ms, double* flops, int* launches, double* busy_ms) {
+  return vitcap_engine_timing_end_kernel(e, ms, flops, launches, busy_ms, nullptr, nullptr);
 }
 extern "C" int vitcap_engine_timing_end(vitcap_engine* e, double* ms, double* flops, int* launches) {
   return vitcap_engine_timing_end_ex(e, ms, flops, launches, nullptr);

@@ -1,4 +1,5 @@
 // Thread-local error text + version for libvitcap_hip.so
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -6,6 +7,8 @@
 
 static thread_local char g_err[512] = "";
 thread_local const int32_t* vc_tls_live = nullptr;   // see common.h
+thread_local hipEvent_t vc_tls_kev_start = nullptr, vc_tls_kev_stop = nullptr;
+thread_local bool vc_tls_kev_used = false;
 
 void vitcap_set_error(const char* fmt, ...) {
   va_list ap;

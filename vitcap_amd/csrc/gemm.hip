@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -46,6 +47,17 @@ struct GemmArgs {
 };
 
 unsigned long long* g_gemm_trace = nullptr;
+
+// launch of a large-tile GEMM: with kernel-bound timing events when the engine's timing run asked for them (common.h)
+#define VC_LAUNCH_GEMM(kern, grid, block, smem, s, p)                                                              \
+  do {                                                                                                             \
+    if (vc_tls_kev_start) {                                                                                        \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, s, vc_tls_kev_start, vc_tls_kev_stop, 0, p);                 \
+      vc_tls_kev_used = true;                                                                                      \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL(kern, grid, block, smem, s, p);                                                           \
+    }                                                                                                              \
+  } while (0)
 
 // width (in 256-column tiles) of the column groups the 256x256 kernels walk; VITCAP_GEMM_GROUP_N overrides (experiments)
 int tile_group_n(int tiles_n) {
@@ -908,7 +920,7 @@ int launch_256(const GemmArgs& a, hipStream_t s) {
   p.tiles_m = (a.M + 255) / 256;
   p.tiles_n = (a.N + 255) / 256;
   p.group_n = tile_group_n(p.tiles_n);
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+  VC_LAUNCH_GEMM(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256");
   return VITCAP_OK;
 }
@@ -1236,7 +1248,7 @@ int launch_256p(const GemmArgs& a, hipStream_t s) {
   const int nwg = p.tiles_m * p.tiles_n;
   p.trace = g_gemm_trace;
   p.group_n = tile_group_n(p.tiles_n);
-  hipLaunchKernelGGL(kern, dim3(nwg < n_cu ? nwg : n_cu), dim3(512), smem, s, p);
+  VC_LAUNCH_GEMM(kern, dim3(nwg < n_cu ? nwg : n_cu), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256p");
   return VITCAP_OK;
 }
