@@ -396,17 +396,6 @@ class ImageCaptioning(nn.Module):
             prio = int(os.environ.get('VITCAP_DECODE_PRIORITY', '-1'))     # -1 = high: the latency-bound chain goes first
             pipe = pipes[lane] = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
                                   'done': [None, None], 'n': 0}
-            ncu = int(os.environ.get('VITCAP_DECODE_CUMASK', '0'))       # experiment: decode chain on N CUs (low N mask bits = spread over XCDs / SEs)
-            if ncu > 0:
-                hip = C.CDLL('libamdhip64.so')
-                words = (C.c_uint32 * 8)()
-                for cu in range(ncu):
-                    words[cu // 32] |= 1 << (cu % 32)
-                h = C.c_void_p()
-                rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, words)
-                if rc != 0:
-                    raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
-                pipe['dec'] = torch.cuda.ExternalStream(h.value, dev)
         slot = pipe['n'] % 2
         pipe['n'] += 1
         B = image.shape[0]
