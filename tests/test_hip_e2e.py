@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (BEAM_MARGIN_FLOOR, GREEDY_MARGIN_FLOOR, assert_tokens_match_reference)
+from conftest import (BEAM_MARGIN_FLOOR, GREEDY_MARGIN_FLOOR, assert_tokens_match_reference, relevant_margins)
 
 pytestmark = pytest.mark.gpu
 
@@ -291,6 +291,82 @@ def test_max_length_other_than_20(model, sd_t, max_length):
     np.testing.assert_allclose(bl.cpu().numpy(), bl_o.numpy(), atol=1e-2)
     # the default length is untouched by the per-call override
     assert model.generate(img.cuda())[0].shape == (B, 1, 20)
+
+
+COMBOS = [
+    # generate() kwargs in combination (each is also tested alone above): the decode loop's branches interact -- penalty before
+    # filter before draw, EOS bookkeeping at other lengths, length penalty with n-best lists, the cap of 40 tokens
+    dict(max_length=12, eos=18218, repetition_penalty=1.2),
+    dict(max_length=40, repetition_penalty=0.9),
+    dict(max_length=25, eos=18218, repetition_penalty=1.1, sample=dict(temperature=0.8, top_k=30, top_p=0.9, seed=21)),
+    dict(num_beams=3, num_keep_best=2, length_penalty=0.7, repetition_penalty=1.3, max_length=15),
+    dict(num_beams=4, num_keep_best=4, length_penalty=1.4, eos=18218, max_length=24),
+    dict(num_beams=2, num_keep_best=2, max_length=16, repetition_penalty=1.2, sample=dict(temperature=1.1, top_k=0, top_p=0.8, seed=22)),
+]
+
+
+@pytest.mark.parametrize('combo', range(len(COMBOS)))
+def test_option_combinations_vs_oracle(model, sd_t, combo):
+    """Differential test of COMBINED generate() options against the oracle's incremental model (bf16 emulation; the oracle's
+    option handling is pinned to the reference one option at a time by tests/test_oracle_golden.py / test_oracle_sample.py).
+    An image is compared when the oracle's own fp32 and bf16-emulated runs give the same tokens (its decisions then clear the
+    rounding noise without reference to the device); its device tokens must be identical, log-probs within 1e-2."""
+    from oracle import vitcap_oracle as O
+    c = dict(COMBOS[combo])
+    B = 3
+    img = _images(B, seed=4000 + combo)
+    K, keep = c.get('num_beams', 1), c.get('num_keep_best', 1)
+    L, eos, rp, lpen = c.get('max_length', 20), c.get('eos', 102), c.get('repetition_penalty', 1.0), c.get('length_penalty', 1.0)
+    smp = c.get('sample')
+
+    steps = {}
+
+    def run_oracle(emulate):
+        """-> ids (B, keep, L), log-probs (B, keep), smallest decision margin per image (inf where the oracle does not track it)"""
+        with torch.no_grad():
+            if K == 1:
+                sampler = O.make_sampler(smp['temperature'], smp['top_k'], smp['top_p'], smp['seed']) if smp else None
+                ids, lp, tr = O.greedy_incremental(sd_t, img, emulate_bf16=emulate, max_length=L, sampler=sampler,
+                                                   repetition_penalty=rp, eos=eos, return_trace=True)
+                steps[emulate] = torch.stack([st['margin'] for st in tr['steps']], 1)
+                mg = torch.tensor([min(relevant_margins(ids[b].reshape(-1).tolist(), steps[emulate][b].tolist(), eos)) for b in range(B)])
+                return ids.view(B, 1, L), lp.view(B, 1), mg
+            if smp:
+                ids, lp = O.beam_incremental(sd_t, img, num_beams=K, emulate_bf16=emulate, max_length=L, length_penalty=lpen,
+                                             num_keep_best=keep, repetition_penalty=rp, eos=eos, sample=dict(smp))
+                return ids, lp, torch.full((B,), float('inf'))
+            ids, lp, gaps = O.beam_incremental(sd_t, img, num_beams=K, emulate_bf16=emulate, max_length=L, length_penalty=lpen,
+                                               num_keep_best=keep, repetition_penalty=rp, eos=eos, return_margins=True)
+            return ids, lp, gaps.min(1).values
+    ids_e, lp_e, mg_e = run_oracle(True)
+    ids_f, _, mg_f = run_oracle(False)
+    # comparable: the oracle's fp32 and bf16-emulated runs agree AND (where the oracle tracks decision margins: greedy argmax /
+    # Gumbel-perturbed draw, beam bookkeeping) every decision clears the noise floor in both
+    floor = MARGIN_TOL if K == 1 else BEAM_GAP_TOL
+    ok = (ids_e == ids_f).flatten(1).all(1) & (mg_e > floor) & (mg_f > floor)
+    kw = dict(num_beams=K, num_keep_best=keep, max_length=L, eos_token_ids=[eos], repetition_penalty=rp, length_penalty=lpen,
+              do_sample=bool(smp), num_return_sequences=1)
+    if smp:
+        kw.update(smp)
+    ids, lp = model.run(img.cuda(), model.gen_options(**kw))
+    ids, lp = ids.cpu(), lp.cpu()
+    print('combo', c, 'comparable', ok.tolist(), 'equal', (ids == ids_e).flatten(1).all(1).tolist())
+    assert ids.shape == (B, keep, L) and lp.shape == (B, keep)
+    print('margins', mg_e.tolist(), 'hip lp', lp.tolist(), 'oracle lp', lp_e.tolist())
+    if K == 1:        # token by token: identical up to each caption's first decision below the floor (in the emulation's own margins)
+        assert_tokens_match_reference(ids.numpy(), ids_e.numpy(), steps[True].numpy(), MARGIN_TOL, min_full=0, what=str(c), eos=eos)
+    if smp:
+        assert int(ok.sum()) >= 1, 'no image of this combination is well conditioned: pick another seed'
+    assert torch.equal(ids[ok], ids_e[ok]), (ids[ok].tolist(), ids_e[ok].tolist())
+    # every image, comparable or not: the kept scores agree (a near-tie resolved the other way moves them by less than the floor)
+    fin = lp_e > -1e4
+    assert bool(((lp > -1e4) == fin).all())
+    np.testing.assert_allclose(lp[fin].numpy(), lp_e[fin].numpy(), atol=3e-2 if K > 1 else 1e-2)
+    # well-formedness everywhere: starts with [CLS]; after the first EOS only padding
+    for row in ids.flatten(0, 1).tolist():
+        assert row[0] == 101
+        if eos in row[1:]:
+            assert all(t == 0 for t in row[row.index(eos, 1) + 1:])
 
 
 # ------------------------------------------------------------------------------------------------ properties / behaviour
