@@ -276,6 +276,12 @@ def _remove_rows_cols(t, rs, re, cs, ce):
     return torch.cat([torch.cat([t00, t01], dim=2), torch.cat([t10, t11], dim=2)], dim=1)
 
 
+def _eos_list(eos):
+    """`eos_token_ids` of generate(): one id or a list; every entry ends a sequence, entry 0 is the one written when a sequence
+    is closed by force (greedy: modeling_utils.py:862-871; beam: 1024-1026, 1096-1097)."""
+    return [int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)]
+
+
 def apply_repetition_penalty(logits, prefix_ids, penalty):
     """CTRL penalty as generate() applies it (modeling_utils.py:828-836, 955-963): for every distinct token of the
     sequence so far, logit < 0 ? logit * penalty : logit / penalty.  In place on (rows, V) logits."""
@@ -328,12 +334,13 @@ def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_sta
         unf_hist.append(unfinished)
         add = nxt * unfinished + PAD * (1 - unfinished)
         ids = torch.cat([ids, add.unsqueeze(-1)], dim=-1)
-        unfinished = unfinished * add.ne(eos).long()
+        for eid in _eos_list(eos):
+            unfinished = unfinished * add.ne(eid).long()
         cur_len += 1
         if unfinished.max() == 0:
             break
     if cur_len == max_length:
-        ids[:, -1].masked_fill_(unfinished.bool(), eos)
+        ids[:, -1].masked_fill_(unfinished.bool(), _eos_list(eos)[0])
     lp = torch.cat(logprobs, dim=1)
     uh = torch.stack(unf_hist, dim=1).float()
     lp = (lp * uh).sum(dim=1) / uh.sum(dim=1)
@@ -527,8 +534,9 @@ def greedy_incremental(sd, image, emulate_bf16=False, max_length=MAX_LEN, return
         cnt += unf
         add = nxt * unf + PAD * (1 - unf)
         ids[:, t] = add
-        unf = unf * add.ne(eos).long()
-    ids[:, -1].masked_fill_(unf.bool(), eos)
+        for eid in _eos_list(eos):
+            unf = unf * add.ne(eid).long()
+    ids[:, -1].masked_fill_(unf.bool(), _eos_list(eos)[0])
     out = (ids.unsqueeze(1), (sum_lp / cnt).unsqueeze(1))
     if return_trace:
         return out + ({'steps': trace, 'hidden': hidden, 'tag_hidden': tag_hidden, 'tags': tags},)
@@ -692,6 +700,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     the end the gaps between the kept hypotheses' final scores.  Order WITHIN the consumed candidates does not matter (the
     surviving set and the hypothesis scores are the same).  inf for steps of images that were already done."""
     K = num_beams
+    eos_ids = _eos_list(eos)
     input_ids = torch.full((B * K, 1), BOS, dtype=torch.long)
     hyps = [BeamHypotheses(num_keep_best, max_length, length_penalty) for _ in range(B)]
     beam_scores = torch.zeros(B, K)
@@ -726,7 +735,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
                 beam_id = int(idx) // Vn
                 word_id = int(idx) % Vn
                 used += 1
-                if word_id == eos or cur_len + 1 == max_length:
+                if word_id in eos_ids or cur_len + 1 == max_length:
                     hyps[b].add(input_ids[b * K + beam_id, :cur_len].clone(), sc.item())
                 else:
                     sent.append((sc, word_id, b * K + beam_id))
@@ -756,7 +765,7 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
             conf, hyp = h.hyp[int(hi)]
             logprobs[i, bi] = conf
             decoded[i, bi, :len(hyp)] = hyp
-            decoded[i, bi, len(hyp)] = eos
+            decoded[i, bi, len(hyp)] = eos_ids[0]
         if len(hs) > 1:
             srt = torch.sort(hs, descending=True).values
             margins[i, -1] = min(float(margins[i, -1]), float((srt[:-1] - srt[1:]).min()))
