@@ -75,7 +75,7 @@ typedef struct {
   const int32_t* live; /* optional device counter: the kernel returns at entry when *live == 0 (decode loop after every
                           sequence has finished -- the reference's `if cur_unfinished.max() == 0: break`,
                           modeling_utils.py:866; NULL = always run).  Honoured by the small-M (decode) kernels. */
-  float* rowstat;      /* optional, fp32 [M][2*ceil(N/64)][4]: per row and 32-column piece {max, column of the max (int bits,
+  float* rowstat;      /* optional (any M), fp32 [M][2*ceil(N/64)][4]: per row and 32-column piece {max, column of the max (int bits,
                           lowest on ties), sum exp(x - max), 0} of the finished values -- what argmax / log_softmax over the
                           row are assembled from (vitcap_greedy_select_embed) without reading C back.  Needs fp32 output,
                           no activation / residual; 64x64 tiles. */
@@ -294,6 +294,11 @@ typedef struct {
 
 int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, float* out_val, int32_t* out_idx,
                         float* out_lse, int rows, void* stream);
+/* the same outputs from the vocabulary GEMM's row statistics (vitcap_gemm_desc.rowstat, `pieces` = 2*ceil(V_pad/64) per row): the k
+ * pieces with the largest maxima hold the row's k largest logits, so only k x 32 of them are read back (vitcap_row_topk_lse reads
+ * the 30522-wide row); identical values and indices, logsumexp assembled from the pieces (same value up to fp32 summation order) */
+int vitcap_row_topk_pieces(const float* logits, int ldl, int V, const float* rowstat, int pieces, int k, float* out_val,
+                           int32_t* out_idx, float* out_lse, int rows, void* stream);
 int vitcap_beam_init(const vitcap_beam_state* s, int B, int beams, int max_len, int bos, int pad, void* stream);
 int vitcap_beam_step(const float* cand_val, const int32_t* cand_idx, const float* lse, const vitcap_beam_state* s,
                      int B, int beams, int V, int t, int max_len, int eos, int pad, float length_penalty,

@@ -426,3 +426,36 @@ def test_attn_dense_backward(ops, B, S):
         rel = float((g - w_).norm() / w_.norm())
         print(name, 'max err %.3e (max %.3e) rel L2 %.3e' % (err, float(w_.abs().max()), rel))
         assert err <= tol and rel < 2e-2, name
+
+
+@pytest.mark.parametrize('M,k', [(37, 4), (300, 10), (1280, 16)])
+def test_row_topk_from_pieces_equals_row_scan(ops, M, k):
+    """Beam candidates from the vocabulary GEMM's row statistics (vitcap_row_topk_pieces) against the scan of the whole rows
+    (vitcap_row_topk_lse) and against torch.topk: values and columns identical (ties: lowest column first), logsumexp to fp32
+    summation order.  M = 37 runs the 64x64-tile form of the GEMM, 300 and 1280 (256 images x 5 beams) the 128x128 one; rows
+    with exact ties inside one piece, across pieces, and with all k winners inside a single 32-column piece."""
+    V, VP = 30522, 30592
+    g = torch.Generator().manual_seed(100 + M)
+    wl = torch.zeros(VP, 768)
+    wl[:V] = torch.randn(V, 768, generator=g) * 0.05
+    wl = _bf(wl).cuda()
+    bias = torch.full((VP,), -1e30)
+    bias[:V] = torch.randn(V, generator=g)
+    h = _bf(torch.randn(M, 768, generator=g))
+    h[3] = 0                                               # row 3: logits = bias only ...
+    bias[700] = bias[12345] = bias[701] = 40.0             # ... with exact ties inside a piece (700, 701) and across pieces
+    bias[2000:2000 + 20] = 30.0 + torch.arange(20) * 0.01  # 20 large values inside one piece (columns 1984..2015 hold 16 of them)
+    logits, rs = ops.gemm_rowstat(h.cuda(), wl, bias.cuda())
+    ref = (h.float() @ wl.float().cpu().t() + bias)[:, :V]
+    assert float((logits[:, :V].cpu() - ref).abs().max()) < 2e-3
+    v0, i0, l0 = ops.row_topk(logits, V, k)
+    v1, i1, l1 = ops.row_topk(logits, V, k, rowstat=rs)
+    torch.cuda.synchronize()
+    assert torch.equal(v0, v1) and torch.equal(i0, i1)
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=0, atol=2e-5)
+    tv, ti = torch.topk(logits[:, :V].cpu(), k, dim=1)
+    assert torch.equal(v1.cpu(), tv)
+    untied = (tv[:, :-1] != tv[:, 1:]).all(1)
+    assert torch.equal(i1.cpu().long()[untied], ti[untied])
+    assert i1[3, :3].tolist() == [700, 701, 12345]
+    np.testing.assert_allclose(l1.cpu().numpy(), torch.logsumexp(logits[:, :V].cpu().double(), 1).numpy(), atol=1e-4)

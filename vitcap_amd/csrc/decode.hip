@@ -563,6 +563,104 @@ __global__ __launch_bounds__(1024) void row_topk_lse_kernel(const float* __restr
   }
 }
 
+// The same candidates from the vocabulary GEMM's row statistics (vitcap_gemm_desc.rowstat: per row and 32-column piece the
+// maximum, its column and sum exp(x - max)) instead of from the 30522-wide rows.  With T = the k-th largest (piece maximum,
+// column) key, every element of the row's top k has a key >= T and therefore lives in one of the k pieces whose maximum key
+// is >= T (those k maxima are k distinct elements, so the k-th largest element is >= T): only k x 32 logits are read back.
+// logsumexp = rowmax + log(sum_p se_p * exp(max_p - rowmax)).  One 256-thread workgroup per row.
+__global__ __launch_bounds__(256) void row_topk_pieces_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                              const float* __restrict__ rowstat, int pieces, int k,
+                                                              float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                              float* __restrict__ out_lse, const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
+  constexpr int PPT = 4;                               // pieces per thread (956 pieces / 256 threads)
+  __shared__ unsigned long long s_cand[4][16];
+  __shared__ unsigned long long s_sel[16];             // the k largest piece keys, descending
+  __shared__ unsigned long long s_list[512];           // k <= 16 pieces x 32 columns
+  __shared__ float s_sum[4];
+  __shared__ int s_n;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const f32x4* rs = (const f32x4*)rowstat + (size_t)b * pieces;
+  unsigned long long key[PPT], mine[PPT];
+  float pm[PPT], ps[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = tid + j * 256;
+    if (i < pieces) {
+      const f32x4 r = rs[i];
+      key[j] = tk_key(r[0], __float_as_int(r[1]));
+      pm[j] = r[0];
+      ps[j] = r[2];
+    } else {
+      key[j] = 0ull; pm[j] = -INFINITY; ps[j] = 0.f;
+    }
+    mine[j] = key[j];
+  }
+  if (tid == 0) s_n = 0;
+  for (int r = 0; r < k; ++r) {                        // the k best piece keys of this wave
+    unsigned long long best = mine[0];
+#pragma unroll
+    for (int j = 1; j < PPT; ++j) best = mine[j] > best ? mine[j] : best;
+    best = wave_max_u64(best);
+    if (lane == 0) s_cand[w][r] = best;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      if (mine[j] == best) mine[j] = 0ull;
+  }
+  __syncthreads();
+  if (w == 0) {
+    unsigned long long c = lane < 4 * k ? s_cand[lane / k][lane % k] : 0ull;
+    for (int r = 0; r < k; ++r) {
+      const unsigned long long best = wave_max_u64(c);
+      if (lane == 0) s_sel[r] = best;
+      if (c == best) c = 0ull;
+    }
+  }
+  __syncthreads();
+  const unsigned long long thr = s_sel[k - 1];
+  const float rowmax = tk_val(s_sel[0]);
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j)
+    if (ps[j] > 0.f) se += ps[j] * expf(pm[j] - rowmax);
+  se = wave_sum(se);
+  if (lane == 0) s_sum[w] = se;
+  // the k selected pieces' 32 columns each: keep what is >= the threshold key
+  for (int e = tid; e < k * 32; e += 256) {
+    const unsigned long long sk = s_sel[e >> 5];
+    if (sk == 0ull) continue;
+    const int col = ((tk_idx(sk) >> 5) << 5) + (e & 31);
+    if (col < V) {
+      const unsigned long long kk = tk_key(logits[(size_t)b * ldl + col], col);
+      if (kk >= thr) s_list[atomicAdd(&s_n, 1)] = kk;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    const int n = s_n;
+    unsigned long long c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = lane + u * 64;
+      c[u] = idx < n ? s_list[idx] : 0ull;
+    }
+    for (int r = 0; r < k; ++r) {
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) best = c[u] > best ? c[u] : best;
+      best = wave_max_u64(best);
+      if (lane == 0) {
+        out_val[(size_t)b * k + r] = tk_val(best);
+        out_idx[(size_t)b * k + r] = tk_idx(best);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c[u] == best) c[u] = 0ull;
+    }
+    if (lane == 0) out_lse[b] = rowmax + logf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+  }
+}
+
 constexpr int MAXBEAM = 8;
 
 struct BeamState {
@@ -858,6 +956,17 @@ extern "C" int vitcap_row_topk_lse(const float* logits, int ldl, int V, int k, f
   hipLaunchKernelGGL(row_topk_lse_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, k, out_val,
                      out_idx, out_lse, vc_tls_live);
   VC_LAUNCH_CHECK("row_topk_lse");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_row_topk_pieces(const float* logits, int ldl, int V, const float* rowstat, int pieces, int k,
+                                      float* out_val, int32_t* out_idx, float* out_lse, int rows, void* stream) {
+  VC_REQUIRE(logits && rowstat && out_val && out_idx && out_lse && rows > 0, "row_topk_pieces: bad arguments");
+  VC_REQUIRE(k >= 1 && k <= 16 && ldl >= V && pieces >= k && pieces <= 1024 && pieces * 32 >= V,
+             "row_topk_pieces: k=%d V=%d pieces=%d unsupported", k, V, pieces);
+  hipLaunchKernelGGL(row_topk_pieces_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, rowstat, pieces, k,
+                     out_val, out_idx, out_lse, vc_tls_live);
+  VC_LAUNCH_CHECK("row_topk_pieces");
   return VITCAP_OK;
 }
 

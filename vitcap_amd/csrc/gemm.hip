@@ -234,44 +234,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
   }
   if (ROWSTAT) {
-    // Vocabulary GEMM of the greedy decode step: next to the logits, every wave emits for each of its rows the maximum of
-    // its WN*16 columns, the column of that maximum (lowest on ties, torch.argmax's rule) and sum exp(x - max) -- the
-    // pieces `argmax` and `log_softmax` (modeling_utils.py:846-851) are assembled from by vitcap_greedy_select_embed, so the
-    // 30522-wide rows are never read back.  Piece index = tn * 2 + wn; columns >= N never win (skipped here, and the padded
-    // vocabulary columns carry a -1e30 bias).
-    const int pieces = p.tiles_n * 2;
+    // Vocabulary GEMM of a decode step: next to the logits, every wave emits for each of its rows and each 32-column piece of
+    // its WN*16 columns the maximum, the column of that maximum (lowest on ties, torch.argmax's rule) and sum exp(x - max) --
+    // the pieces `argmax` and `log_softmax` (modeling_utils.py:846-851) are assembled from by vitcap_greedy_select_embed, and
+    // the beam step's 2*beams best candidates by vitcap_row_topk_pieces, so the 30522-wide rows are never read back.
+    // Piece index = first column / 32 (row stride 2*ceil(N/64) pieces whatever the tile); columns >= N never win (skipped
+    // here, and the padded vocabulary columns carry a -1e30 bias).
+    const int pieces = 2 * ((p.N + 63) / 64);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int m = m0 + wm * WM * 16 + i * 16 + frow;
-      float bm = -INFINITY;
-      int bi = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+      for (int jp = 0; jp < WN / 2; ++jp) {
+        float bm = -INFINITY;
+        int bi = 0x7fffffff;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = acc[i][j][e];
-          if (n + e < p.N && (x > bm || (x == bm && n + e < bi))) { bm = x; bi = n + e; }
+        for (int j = 2 * jp; j < 2 * jp + 2; ++j) {
+          const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = acc[i][j][e];
+            if (n + e < p.N && (x > bm || (x == bm && n + e < bi))) { bm = x; bi = n + e; }
+          }
         }
-      }
 #pragma unroll
-      for (int o = 16; o <= 32; o <<= 1) {             // the row's columns are spread over the 4 lane groups fk = lane >> 4
-        const float om = __shfl_xor(bm, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
-      }
-      float se = 0.f;
+        for (int o = 16; o <= 32; o <<= 1) {             // the row's columns are spread over the 4 lane groups fk = lane >> 4
+          const float om = __shfl_xor(bm, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+        }
+        float se = 0.f;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
+        for (int j = 2 * jp; j < 2 * jp + 2; ++j) {
+          const int n = n0 + wn * WN * 16 + j * 16 + fk * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) se += expf(acc[i][j][e] - bm);
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) se += expf(acc[i][j][e] - bm);
+        }
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        const int piece = (n0 + wn * WN * 16 + jp * 32) >> 5;
+        if (fk == 0 && m < p.M && piece < pieces)
+          *(f32x4*)(p.rowstat + ((size_t)m * pieces + piece) * 4) = f32x4{bm, __int_as_float(bi), se, 0.f};
       }
-      se += __shfl_xor(se, 16, 64);
-      se += __shfl_xor(se, 32, 64);
-      if (fk == 0 && m < p.M)
-        *(f32x4*)(p.rowstat + ((size_t)m * pieces + tn * 2 + wn) * 4) = f32x4{bm, __int_as_float(bi), se, 0.f};
     }
   }
 }
@@ -1467,21 +1472,27 @@ int dispatch_resident(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
   return VITCAP_EINVAL;
 }
 
-// 64 x 64 tiles + row statistics (vitcap_gemm_desc.rowstat): the vocabulary GEMM of the greedy decode step
-int launch_rowstat(const GemmArgs& a, hipStream_t s) {
-  constexpr int NST = 4, smem = NST * (64 + 64) * 64 * 2;
-  auto kern = gemm_nt_kernel<2, 2, VITCAP_ACT_NONE, 1, false, NST, true>;
+// Vocabulary GEMM + row statistics (vitcap_gemm_desc.rowstat): 64 x 64 tiles for the greedy decode step (M <= 256 rows: weights
+// stream once, most workgroups win), 128 x 128 tiles for beam batches (M = images x beams rows)
+template <int WM, int WN, int NST>
+int launch_rowstat_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, smem = NST * (BM + BN) * 64 * 2;
+  auto kern = gemm_nt_kernel<WM, WN, VITCAP_ACT_NONE, 1, false, NST, true>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   GemmArgs p = a;
-  p.tiles_m = (a.M + 63) / 64;
-  p.tiles_n = (a.N + 63) / 64;
+  p.tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(256), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt(rowstat)");
   return VITCAP_OK;
+}
+
+int launch_rowstat(const GemmArgs& a, hipStream_t s) {
+  return a.M <= 256 ? launch_rowstat_t<2, 2, 4>(a, s) : launch_rowstat_t<4, 4, 2>(a, s);
 }
 
 template <int WM, int WN>

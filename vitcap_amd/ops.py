@@ -194,6 +194,21 @@ def gemm_rowstat(a, w, bias):
     return out, rs
 
 
+def row_topk(logits, V, k, rowstat=None):
+    """The k largest logits of every row (sorted, lowest column on ties) + logsumexp over the V columns: from the whole rows
+    (vitcap_row_topk_lse) or, given the vocabulary GEMM's row statistics, from the k best 32-column pieces."""
+    rows = logits.shape[0]
+    val = torch.empty((rows, k), device=logits.device, dtype=torch.float32)
+    idx = torch.empty((rows, k), device=logits.device, dtype=torch.int32)
+    lse = torch.empty((rows,), device=logits.device, dtype=torch.float32)
+    if rowstat is None:
+        check(lib.vitcap_row_topk_lse(_p(logits), logits.stride(0), V, k, _p(val), _p(idx), _p(lse), rows, _stream()), 'row_topk_lse')
+    else:
+        check(lib.vitcap_row_topk_pieces(_p(logits), logits.stride(0), V, _p(rowstat), rowstat.shape[1], k, _p(val), _p(idx), _p(lse),
+                                         rows, _stream()), 'row_topk_pieces')
+    return val, idx, lse
+
+
 def greedy_select_embed(rowstat, st, t, word, pos, typ, gamma, beta, eps=1e-12, mask_token=103, eos=102, pad=0):
     """greedy_step from row statistics + embed_step for t+1 in one launch; returns (x_f32, x_bf16) of step t+1 (None at the end)."""
     B, max_len = st['ids'].shape
