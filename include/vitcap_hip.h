@@ -320,6 +320,15 @@ int vitcap_beam_reorder_cache(const void* src, void* dst, const int32_t* parent,
 int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B, int max_len,
                          int eos, int pad, void* stream);
 
+/* Decode-step attention for SEVERAL sequences per image (beam search), one workgroup per (image, head): the 2*K <= 16 query rows
+ * of an image are scored against its 578 visual key rows on the matrix pipe (K rows loaded once for all beams), the <= 41 text
+ * keys of each sequence on the vector ALU; same softmax as vitcap_attn_decode_step (BertSelfAttention, modeling_bert.py:320-340),
+ * results equal up to fp32 summation order.  vis_vt: per (image, head) transposed copy of the visual V rows, [n_images][12][64][608]
+ * bf16 (keys padded with zeros), written once per batch by vitcap_attn_beam_vt from the packed visual q|k|v rows. */
+int vitcap_attn_beam_vt(const void* vis_qkv, void* vis_vt, int n_images, int S_vis, void* stream);
+int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out, int n_images,
+                             int seq_per_image, int S_vis, int t, int max_len, float scale, void* stream);
+
 /* small data movers used by the engine and exposed for tests */
 int vitcap_assemble_visual(const float* hidden, const float* tag_hidden, float* vis_f32, void* vis_bf16,
                            int B, int n_tok, void* stream);  /* modeling_bert.py:1493 */

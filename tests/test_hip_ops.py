@@ -459,3 +459,34 @@ def test_row_topk_from_pieces_equals_row_scan(ops, M, k):
     assert torch.equal(i1.cpu().long()[untied], ti[untied])
     assert i1[3, :3].tolist() == [700, 701, 12345]
     np.testing.assert_allclose(l1.cpu().numpy(), torch.logsumexp(logits[:, :V].cpu().double(), 1).numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize('K,t', [(5, 1), (5, 7), (2, 19), (3, 12), (8, 4)])
+def test_attn_decode_beams_vs_single_sequences(ops, K, t):
+    """Beam-size decode attention on the matrix pipe (one workgroup per (image, head), all 2*K query rows of the image in one
+    MFMA, visual K rows loaded once) against the per-sequence vector-ALU kernel on the same inputs: same softmax, same bf16
+    rounding of P, different fp32 summation order -> outputs within one bf16 ulp (2^-7 relative, 2e-3 absolute), cache rows
+    published identically; and against the fp32 reference like test_attn_decode_step."""
+    from oracle import vitcap_oracle as O
+    n_img, S = 3, 578
+    B = n_img * K
+    vis = _bf(_rand((n_img, S, 2304), 40 + K, 2.0))
+    step = _bf(_rand((B, 2, 2304), 41 + t, 2.0))
+    cache = _bf(_rand((B, 20, 2, 768), 42, 2.0))
+    c1, c2 = cache.cuda().contiguous(), cache.cuda().contiguous()
+    step_d = step.reshape(B * 2, 2304).cuda().contiguous()
+    vis_d = vis.reshape(n_img * S, 2304).cuda().contiguous()
+    got = ops.attn_decode_beams(step_d, vis_d, c1, n_img, K, S, t)
+    want = ops.attn_decode_step(step_d, vis_d, c2, B, S, t, seq_per_image=K)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    _close(got.float().cpu(), want.float().cpu(), 2 ** -7, 2e-3, 'beam attention vs per-sequence kernel K=%d t=%d' % (K, t))
+    r = O._R(True)
+    visr = vis.repeat_interleave(K, 0)
+    Kk = torch.cat([visr[..., 768:1536].float(), cache[:, :t - 1, 0].float(), step[:, :, 768:1536].float()], 1)
+    V = torch.cat([visr[..., 1536:].float(), cache[:, :t - 1, 1].float(), step[:, :, 1536:].float()], 1)
+    q = step[..., :768].float().view(B, 2, 12, 64).transpose(1, 2)
+    s = q @ Kk.view(B, -1, 12, 64).transpose(1, 2).transpose(-1, -2)
+    s[:, :, 0, -1] = float('-inf')
+    ref = O.softmax_pv_rounded(s, V.view(B, -1, 12, 64).transpose(1, 2), r).transpose(1, 2).reshape(B, 2, 768)
+    _close(got.view(B, 2, 768), ref, 2 ** -7, 2e-3, 'beam attention vs reference K=%d t=%d' % (K, t))

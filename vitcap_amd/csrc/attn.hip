@@ -455,7 +455,329 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decode step for SEVERAL sequences per image (beam search): one workgroup per (image, head).
+// At 256 images x 5 beams the per-sequence kernel above is vector-ALU bound (~1500 VALU instructions per thread and
+// (sequence, head): 207 us per launch, half of the decode phase).  The 2*beams <= 16 query rows of an image are the 16 columns
+// of one mfma_f32_16x16x32_bf16, and every sequence of an image sees the SAME 578 visual key rows:
+//   scores   S[q][key]  = Q . K_vis^T        2 MFMAs per 16 keys, the K rows loaded once for all beams;
+//   context  O[q][d]    = P . V_vis          4 MFMAs per 32 keys; V is read k-contiguous from a per-(image, head) TRANSPOSED copy
+//                                            V^T[d][key] written once per batch by vt_build_kernel (vitcap_attn_beam_vt);
+//   the <= 41 text keys of each sequence (its own cache rows) on the vector ALU as before.
+// Softmax exactly as above: raw scores staged in LDS, m = ceil(max * c), P = exp2(s*c - m) rounded to bf16 for the product,
+// row sum from the unrounded P.  4 waves split the key blocks; partial O / row sums are added in wave order.
+// ------------------------------------------------------------------------------------------------
+constexpr int VT_KP = 608;            // 578 visual keys padded to a multiple of 32 (zeros)
+constexpr int BEAM_SC_LD = 656;       // 608 visual + 41 text + pad, fp32 scores per query row
+
+__global__ __launch_bounds__(256) void vt_build_kernel(const bf16_t* __restrict__ vis_qkv, bf16_t* __restrict__ vt, int S_vis) {
+  // grid (VT_KP / 32, NH, images): thread = (dim = tid & 63, key group = tid >> 6 -> 8 keys)
+  const int img = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * 32 + (threadIdx.x >> 6) * 8, d = threadIdx.x & 63;
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = key0 + i;
+    const bf16_t raw = k < S_vis ? vis_qkv[((size_t)img * S_vis + k) * QKV_LD + 1536 + h * HD + d] : (bf16_t)0;
+    v[i] = __builtin_bit_cast(__bf16, raw);
+  }
+  *(bf16x8*)(vt + (((size_t)img * NH + h) * HD + d) * VT_KP + key0) = v;
+}
+
+// MAXP: (sequence, text key) pairs per 8-lane group in phase 1b (K * (t+1) <= 32 * MAXP); MAXT: text keys per group and sequence
+// in phase 2b (t + 1 <= 8 * MAXT).  Two instantiations: <4, 3> (5 beams x 20 tokens: fits two workgroups per CU), <11, 6> (any).
+template <int MAXP, int MAXT>
+__global__ __launch_bounds__(256) void attn_decode_beam_kernel(const bf16_t* __restrict__ qkv_step,
+                                                               const bf16_t* __restrict__ vis_qkv,
+                                                               const bf16_t* __restrict__ vis_vt,
+                                                               bf16_t* __restrict__ text_kv, bf16_t* __restrict__ out,
+                                                               int S_vis, int t, int max_len, int K, float c_log2,
+                                                               const int32_t* __restrict__ live) {
+  VC_LIVE_EXIT(live);
+  // dynamic LDS sized by the image's 2*K query rows (5 beams: 47 KB -> three workgroups per CU): scores [NQ][BEAM_SC_LD], the
+  // four waves' partial contexts [4][NQ][64], the text part [NQ][64]
+  extern __shared__ __attribute__((aligned(16))) char beam_smem[];
+  const int NQ_ = 2 * K;
+  float (*sc)[BEAM_SC_LD] = (float (*)[BEAM_SC_LD])beam_smem;
+  float (*s_o)[HD] = (float (*)[HD])(beam_smem + (size_t)NQ_ * BEAM_SC_LD * 4);      // [4 * NQ][64]: wave w, query q -> row w * NQ + q
+  float (*s_ot)[HD] = s_o + 4 * NQ_;
+  __shared__ float s_max[16][4];
+  __shared__ float s_l[16][4];
+  __shared__ float s_lt[16];
+  __shared__ __attribute__((aligned(16))) bf16_t s_q[16][HD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = blockIdx.x, img = blockIdx.y;
+  const int frow = lane & 15, fk = lane >> 4;
+  const int NQ = 2 * K;                       // query rows of this image: row n = sequence n / 2, step row n % 2
+  const int b0 = img * K;
+  const int ntext = t + 1;                    // text keys per sequence: cache rows 0..t-2, this step's row 0, the [MASK] row
+
+  // publish this step's real-token K/V (row 0) of every sequence into its cache at position t-1
+  if (tid < 16 * K) {
+    const int j = tid >> 4, which = (tid >> 3) & 1, sub8 = tid & 7;
+    const uint4 v = *(const uint4*)(qkv_step + ((size_t)(b0 + j) * 2) * QKV_LD + 768 * (1 + which) + h * HD + sub8 * 8);
+    *(uint4*)(text_kv + (size_t)(b0 + j) * max_len * 2 * 768 + ((size_t)(t - 1) * 2 + which) * 768 + h * HD + sub8 * 8) = v;
+  }
+
+  // every global load of the workgroup is requested up front (visual K, V^T, the sequences' text K and V rows): one memory
+  // round trip per workgroup instead of one per loop iteration (the first version spent ~10 dependent round trips: 139 us)
+  const int sub = lane & 7, grp = tid >> 3;   // vector-ALU part: 32 groups of 8 lanes, one (sequence, text key) pair each
+  auto text_ptr = [&](int j, int tp, int which) -> const bf16_t* {
+    if (tp < t - 1) return text_kv + (size_t)(b0 + j) * max_len * 2 * 768 + ((size_t)tp * 2 + which) * 768 + h * HD + sub * 8;
+    return qkv_step + ((size_t)(b0 + j) * 2 + (tp - (t - 1))) * QKV_LD + 768 * (1 + which) + h * HD + sub * 8;
+  };
+  const int npair = K * ntext;
+  bf16x8 tk[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pr = grp + 32 * i;
+    if (pr < npair) {
+      const int j = pr / ntext;
+      tk[i] = *(const bf16x8*)text_ptr(j, pr - j * ntext, 0);
+    }
+  }
+  bf16x8 tv[2][MAXT];                         // wave w: sequences w and w + 4
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int j = w + 4 * jj, tp = (lane >> 3) + 8 * i;
+      if (j < K && tp < ntext) tv[jj][i] = *(const bf16x8*)text_ptr(j, tp, 1);
+    }
+  if (tid < NQ * 8) {                         // the query rows for the vector-ALU part
+    const int n = tid >> 3;
+    *(bf16x8*)&s_q[n][(tid & 7) * 8] = *(const bf16x8*)(qkv_step + ((size_t)b0 * 2 + n) * QKV_LD + h * HD + (tid & 7) * 8);
+  }
+
+  // ---- phase 1a: visual scores on the matrix pipe.  Y operand = Q (row = query frow, 8 dims at fk*8 [+32]); X = K rows.
+  bf16x8 qf[2];
+  {
+    const bf16_t* qp = qkv_step + ((size_t)b0 * 2 + (frow < NQ ? frow : 0)) * QKV_LD + h * HD + fk * 8;
+    qf[0] = *(const bf16x8*)qp;
+    qf[1] = *(const bf16x8*)(qp + 32);
+    if (frow >= NQ) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qf[0][j] = (__bf16)0.f; qf[1][j] = (__bf16)0.f; }
+    }
+  }
+  const int nkb = (S_vis + 15) >> 4;          // 16-key blocks (37)
+  constexpr int MAXB = 10;                    // blocks per wave: ceil(37 / 4)
+  bf16x8 kf[MAXB][2];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int kb = w + 4 * i;
+    if (kb < nkb) {
+      int key = kb * 16 + frow;
+      key = key < S_vis ? key : S_vis - 1;
+      const bf16_t* kp = vis_qkv + ((size_t)img * S_vis + key) * QKV_LD + 768 + h * HD + fk * 8;
+      kf[i][0] = *(const bf16x8*)kp;
+      kf[i][1] = *(const bf16x8*)(kp + 32);
+    }
+  }
+  float mx = -1e30f;                          // this lane's query (frow) over its keys
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int kb = w + 4 * i;
+    if (kb < nkb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][0], qf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][1], qf[1], acc, 0, 0, 0);
+      // lane holds S[query frow][key kb*16 + fk*4 + e]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kb * 16 + fk * 4 + e;
+        const float v = key < S_vis ? acc[e] : -INFINITY;
+        if (frow < NQ) sc[frow][key] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  // the V^T fragments of phase 2a are requested here (the K fragments' registers are free again): their latency is covered by
+  // the text scores and the maxima below
+  constexpr int MAXV = 5;                     // 32-key blocks per wave: ceil(19 / 4)
+  bf16x8 vf[MAXV][4];
+  const bf16_t* vtb = vis_vt + ((size_t)img * NH + h) * HD * VT_KP;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int kb = w + 4 * i;
+    if (kb < VT_KP / 32) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) vf[i][db] = *(const bf16x8*)(vtb + (size_t)(db * 16 + frow) * VT_KP + kb * 32 + fk * 8);
+    }
+  }
+  if (w == 0 && fk == 0) {                    // keys S_vis .. VT_KP-1 of the padded blocks: no weight
+    if (frow < NQ)
+      for (int key = nkb * 16; key < VT_KP; ++key) sc[frow][key] = -INFINITY;
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (fk == 0) s_max[frow][w] = mx;
+
+  // ---- phase 1b: text scores on the vector ALU: 8 lanes per (sequence, text key) pair, as attn_decode_kernel
+  __syncthreads();                            // s_q
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pr = grp + 32 * i;
+    if (pr < npair) {
+      const int j = pr / ntext, tp = pr - j * ntext;
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, *(const uint4*)&s_q[2 * j][sub * 8]);
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4*)&s_q[2 * j + 1][sub * 8]);
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float kx = (float)tk[i][e];
+        d0 += (float)a0[e] * kx;
+        d1 += (float)a1[e] * kx;
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) {
+        d0 += __shfl_xor(d0, o, 64);
+        d1 += __shfl_xor(d1, o, 64);
+      }
+      if (tp == t) d0 = -INFINITY;            // row 0 (position t-1) cannot see the [MASK] row
+      if (sub == 0) { sc[2 * j][VT_KP + tp] = d0; sc[2 * j + 1][VT_KP + tp] = d1; }
+    }
+  }
+  __syncthreads();
+  // row maxima: the 4 waves' visual maxima and the text scores
+  float m_q;                                  // for query (tid >> 4) -- 16 threads per query
+  {
+    const int qn = tid >> 4, i16 = tid & 15;
+    float m = fmaxf(fmaxf(s_max[qn][0], s_max[qn][1]), fmaxf(s_max[qn][2], s_max[qn][3]));
+    if (qn < NQ)
+      for (int tp = i16; tp < ntext; tp += 16) m = fmaxf(m, sc[qn][VT_KP + tp]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m_q = ceilf(m * c_log2);
+  }
+  __syncthreads();
+  if ((tid & 15) == 0) s_max[tid >> 4][0] = m_q;
+  __syncthreads();
+
+  // ---- phase 2a: P . V over the visual keys on the matrix pipe.  Y = P (row = query frow, 8 keys at fk*8 of a 32-key block)
+  const float mrow = s_max[frow][0];
+  f32x4 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int kb = w + 4 * i;
+    if (kb < VT_KP / 32) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = frow < NQ ? fast_exp2(fmaf(sc[frow][kb * 32 + fk * 8 + e], c_log2, -mrow)) : 0.f;
+        lsum += p;
+        pf[e] = (__bf16)p;
+      }
+      // mfma(X = V^T rows (dims), Y = P rows (queries)): lane holds O[query frow][dim db*16 + fk*4 + e]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i][db], pf, oacc[db], 0, 0, 0);
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (fk == 0) s_l[frow][w] = lsum;
+  if (frow < NQ) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_o[w * NQ + frow][db * 16 + fk * 4 + e] = oacc[db][e];
+  }
+
+  // ---- phase 2b: text keys on the vector ALU; wave w takes sequences w, w + 4 (8 key groups of 8 lanes each)
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = w + 4 * jj;
+    if (j < K) {
+      float o0[8], o1[8], l0 = 0.f, l1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+      const float m0 = s_max[2 * j][0], m1 = s_max[2 * j + 1][0];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const int tp = (lane >> 3) + 8 * i;
+        if (tp < ntext) {
+          const float p0 = fast_exp2(fmaf(sc[2 * j][VT_KP + tp], c_log2, -m0)), p1 = fast_exp2(fmaf(sc[2 * j + 1][VT_KP + tp], c_log2, -m1));
+          l0 += p0;
+          l1 += p1;
+          const float p0b = (float)(__bf16)p0, p1b = (float)(__bf16)p1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float vx = (float)tv[jj][i][e];
+            o0[e] += p0b * vx;
+            o1[e] += p1b * vx;
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        l0 += __shfl_xor(l0, o, 64);
+        l1 += __shfl_xor(l1, o, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o0[e] += __shfl_xor(o0[e], o, 64);
+          o1[e] += __shfl_xor(o1[e], o, 64);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s_ot[2 * j][lane * 8 + e] = o0[e];
+          s_ot[2 * j + 1][lane * 8 + e] = o1[e];
+        }
+      }
+      if (lane == 0) { s_lt[2 * j] = l0; s_lt[2 * j + 1] = l1; }
+    }
+  }
+  __syncthreads();
+  // ---- merge: out[q][d] = (sum over waves of the visual part + the text part) / (row sums)
+  for (int i = tid; i < NQ * HD; i += 256) {
+    const int qn = i >> 6, d = i & 63;
+    const float l = ((s_l[qn][0] + s_l[qn][1]) + (s_l[qn][2] + s_l[qn][3])) + s_lt[qn];
+    const float o = ((s_o[qn][d] + s_o[NQ + qn][d]) + (s_o[2 * NQ + qn][d] + s_o[3 * NQ + qn][d])) + s_ot[qn][d];
+    out[((size_t)b0 * 2 + qn) * 768 + h * HD + d] = f2bf(o / l);
+  }
+}
+
 }  // namespace
+
+extern "C" int vitcap_attn_beam_vt(const void* vis_qkv, void* vis_vt, int n_images, int S_vis, void* stream) {
+  VC_REQUIRE(vis_qkv && vis_vt && n_images > 0 && S_vis > 0 && S_vis <= VT_KP, "attn_beam_vt: bad arguments (S_vis <= %d)", VT_KP);
+  hipLaunchKernelGGL(vt_build_kernel, dim3(VT_KP / 32, NH, n_images), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)vis_qkv,
+                     (bf16_t*)vis_vt, S_vis);
+  VC_LAUNCH_CHECK("attn_beam_vt");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out,
+                                        int n_images, int seq_per_image, int S_vis, int t, int max_len, float scale, void* stream) {
+  VC_REQUIRE(qkv_step && vis_qkv && vis_vt && text_kv && out && n_images > 0, "attn_decode_beams: bad arguments");
+  VC_REQUIRE(seq_per_image >= 1 && seq_per_image <= 8, "attn_decode_beams: 1..8 sequences per image (got %d)", seq_per_image);
+  VC_REQUIRE(t >= 1 && t < max_len && max_len <= 41 && S_vis > 16 && S_vis <= VT_KP && (S_vis + 15) / 16 <= 40,
+             "attn_decode_beams: t=%d max_len=%d S_vis=%d out of range", t, max_len, S_vis);
+  const float c = scale * 1.4426950408889634f;
+  const int nq = 2 * seq_per_image;
+  const size_t smem = (size_t)nq * BEAM_SC_LD * 4 + (size_t)5 * nq * HD * 4;      // <= 62.5 KB at 8 sequences per image
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_decode_beam_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_decode_beam_kernel<11, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+  }
+  if (seq_per_image * (t + 1) <= 32 * 4 && t + 1 <= 8 * 3)
+    hipLaunchKernelGGL((attn_decode_beam_kernel<4, 3>), dim3(NH, n_images), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
+                       (const bf16_t*)vis_qkv, (const bf16_t*)vis_vt, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len,
+                       seq_per_image, c, vc_tls_live);
+  else
+    hipLaunchKernelGGL((attn_decode_beam_kernel<11, 6>), dim3(NH, n_images), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
+                       (const bf16_t*)vis_qkv, (const bf16_t*)vis_vt, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len,
+                       seq_per_image, c, vc_tls_live);
+  VC_LAUNCH_CHECK("attn_decode_beams");
+  return VITCAP_OK;
+}
 
 extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream) {
   VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");

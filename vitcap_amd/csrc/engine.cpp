@@ -125,6 +125,8 @@ int check_opts(const vitcap_gen_opts& o) {
   return VITCAP_OK;
 }
 
+constexpr size_t VT_BYTES = (size_t)12 * 64 * 608 * 2;   // one image's transposed visual V rows of one layer (include/vitcap_hip.h: vitcap_attn_beam_vt)
+
 struct Layout {
   size_t off = 0;
   size_t take(size_t bytes) {
@@ -140,6 +142,7 @@ struct Layout {
   size_t hd_f, hd_b, logits, rowstat;
   size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok, live;
   size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok, fin_ids, fin_lp;
+  size_t vt[4];      // beam search: per decoder layer the visual V rows transposed per (image, head) for vitcap_attn_decode_beams (0: unused)
   // tag rows visible to the caption (vitcap_gen_opts.tag_visible = n > 0): per embedding branch v in {A, B}
   size_t tagx_f[2], tagx_b[2], tqkv_c[2][4], jqkv, jout, jlse, tg_ctx, tg_sa_f, tg_sa_b, tg_mlp, tg_tmp;
   int NT;
@@ -156,6 +159,7 @@ struct Layout {
     v.vis_f += i * SV * D * 4; v.vis_b += i * SV * D * 2;
     for (int l = 0; l < 4; ++l) v.dqkv[l] += i * SV * 3 * D * 2;
     v.da_f += i * SV * D * 4; v.da_b += i * SV * D * 2; v.dtmp += i * SV * D * 4;
+    for (int l = 0; l < 4; ++l) if (v.vt[l]) v.vt[l] += i * VT_BYTES;
     v.pool_in += i * D * 2; v.pooled += i * D * 2; v.tg_f += i * D * 4; v.tg_b += i * D * 2;
     v.tag_logits += i * VP * 4; v.tag_ids += i * TOPK * 8; v.tag_prob += i * TOPK * 4; v.tag_len += i * 8;
     return v;
@@ -237,6 +241,9 @@ struct Layout {
       tg_tmp = take(r * D * 4);
     }
     cand_val = cand_idx = lse = beam_scores = parent = done = has_hyp = hyp_score = hyp_len = hyp_tok = fin_ids = fin_lp = 0;
+    for (int i = 0; i < 4; ++i) vt[i] = 0;
+    if (beam && NT == 0)
+      for (int i = 0; i < 4; ++i) vt[i] = take(b * VT_BYTES);
     if (beam) {
       cand_val = take(n * 16 * 4);
       cand_idx = take(n * 16 * 4);
@@ -778,9 +785,11 @@ static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
     if (l == 3) {        // the last layer's visual-row outputs feed nothing: only its K/V are needed (no Q either)
       CK(gemm(vis_b, D, (const char*)lw.qkv_w + (size_t)D * D * 2, lw.qkv_b + D, nullptr, 0, (char*)dq + (size_t)D * 2, 3 * D, M,
               2 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+      if (lo.vt[l]) CK(vitcap_attn_beam_vt(dq, ws + lo.vt[l], B, SV, s));
       break;
     }
     CK(gemm(vis_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, dq, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+    if (lo.vt[l]) CK(vitcap_attn_beam_vt(dq, ws + lo.vt[l], B, SV, s));
     CK(vitcap_attn_dense_fwd(dq, ws + lo.h, B, SV, 0.125f, s));
     CK(gemm(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, D, ws + lo.dtmp, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
     CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,
@@ -837,6 +846,7 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
   // resident whole-K kernels for greedy / sampling batches; beams keep the split-K path.  The choice follows the WHOLE batch, so
   // that a sequence's arithmetic does not depend on how the batch is sliced.
   const bool small = 2 * NS <= 256 && !force_old;
+  static const int no_beam_attn = [] { const char* e = getenv("VITCAP_BEAM_ATTN_VALU"); return e ? atoi(e) : 0; }();   // A/B measurements
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
     char* tc = tcache + ((size_t)l * NS + pt.s0) * L * 2 * D * 2;
@@ -849,6 +859,9 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
       CK(vitcap_attn_decode_step_tags(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f,
                                       ws + lo.tqkv_c[0][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2, ws + lo.tqkv_c[1][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2,
                                       lo.NT, (const int64_t*)(ws + lo.tag_len), s));
+    else if (lo.vt[l] && K >= 2 && !no_beam_attn)
+      // several sequences per image (beam search): all of an image's query rows against its visual rows on the matrix pipe
+      CK(vitcap_attn_decode_beams(sqkv, vis, ws + lo.vt[l] + (size_t)pt.i0 * VT_BYTES, tc, sctx, ns / K, K, SV, t, L, 0.125f, s));
     else
       CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
     // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),

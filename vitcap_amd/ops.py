@@ -150,6 +150,19 @@ def attn_decode_step(qkv_step, vis_qkv, text_kv, B, S_vis, t, max_len=20, seq_pe
     return out
 
 
+def attn_decode_beams(qkv_step, vis_qkv, text_kv, n_images, K, S_vis, t, max_len=20, scale=0.125):
+    """Decode-step attention for K sequences per image on the matrix pipe (vitcap_attn_decode_beams); builds V^T first."""
+    _dev_bf16(qkv_step)
+    _dev_bf16(vis_qkv)
+    _dev_bf16(text_kv)
+    vt = torch.empty((n_images, 12, 64, 608), device=qkv_step.device, dtype=torch.bfloat16)
+    check(lib.vitcap_attn_beam_vt(_p(vis_qkv), _p(vt), n_images, S_vis, _stream()), 'attn_beam_vt')
+    out = torch.empty((n_images * K * 2, 768), device=qkv_step.device, dtype=torch.bfloat16)
+    check(lib.vitcap_attn_decode_beams(_p(qkv_step), _p(vis_qkv), _p(vt), _p(text_kv), _p(out), n_images, K, S_vis, t, max_len,
+                                       scale, _stream()), 'attn_decode_beams')
+    return out
+
+
 def embed_step(ids, t, word, pos, typ, gamma, beta, eps=1e-12, mask_token=103):
     B, max_len = ids.shape
     xf = torch.empty((2 * B, 768), device=ids.device, dtype=torch.float32)
