@@ -866,12 +866,17 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
       CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
     // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),
     // reduced inside the fused bias + residual + LayerNorm kernel (BertSelfOutput / BertOutput, modeling_bert.py:353-357, 415-419)
-    int s_ao = SPLIT_AO, s_fc2 = SPLIT_FC2;
+    // split-K of the two N = 768 GEMMs by the WHOLE batch's rows (a sequence's sums must not depend on how the batch is sliced):
+    // 6 / 12 slabs fill the chip at a few hundred rows; from ~1000 rows on the output tiles alone do, and the fp32 slabs (47 /
+    // 94 MB per GEMM at 2560 rows) cost more than they buy -- decode phase at 5 beams x 256 images 24.6 -> 22.0 ms, 512 greedy
+    // sequences 21.5 -> 20.8 ms, 256 sequences unchanged (measured)
+    const int rows_all = 2 * NS;
+    int s_ao = rows_all >= 2048 ? 1 : (rows_all >= 1024 ? 2 : SPLIT_AO), s_fc2 = rows_all >= 1024 ? 4 : SPLIT_FC2;
     if (small) {
       CK(gemm_small(sctx, D, lw.ao_w, nullptr, part, D, R, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
       s_ao = 1;
     } else {
-      CK(gemm_split(sctx, D, lw.ao_w, part, R, D, D, SPLIT_AO, s));
+      CK(gemm_split(sctx, D, lw.ao_w, part, R, D, D, s_ao, s));
     }
     CK(vitcap_sum_layernorm(part, s_ao, (size_t)R * D, lw.ao_b, xs_f, D, 0, lw.ao_g, lw.ao_beta, 1e-12f, sa_b, sa_f, R, D, s));
     if (small)
@@ -882,7 +887,7 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
       CK(gemm_small(smlp, 4 * D, lw.o_w, nullptr, part, D, R, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 20, s));
       s_fc2 = 4;
     } else {
-      CK(gemm_split(smlp, 4 * D, lw.o_w, part, R, D, 4 * D, SPLIT_FC2, s));
+      CK(gemm_split(smlp, 4 * D, lw.o_w, part, R, D, 4 * D, s_fc2, s));
     }
     CK(vitcap_sum_layernorm(part, s_fc2, (size_t)R * D, lw.o_b, sa_f, D, 0, lw.o_g, lw.o_beta, 1e-12f, xs_b, xs_f, R, D, s));
   }
@@ -891,8 +896,9 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
     CK(gemm_small(xs_b + D * 2, 2 * D, w.cls.dense_w, nullptr, part, D, ns, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, 21, s));
     CK(vitcap_sum_layernorm(part, 1, (size_t)ns * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f, hd_b, nullptr, ns, D, s));
   } else {
-    CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, ns, D, D, SPLIT_AO, s));
-    CK(vitcap_sum_layernorm(part, SPLIT_AO, (size_t)ns * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f, hd_b, nullptr,
+    const int s_hd = NS >= 2048 ? 1 : (NS >= 1024 ? 2 : SPLIT_AO);      // as above, by the whole batch's [MASK] rows
+    CK(gemm_split(xs_b + D * 2, 2 * D, w.cls.dense_w, part, ns, D, D, s_hd, s));
+    CK(vitcap_sum_layernorm(part, s_hd, (size_t)ns * D, w.cls.dense_b, nullptr, 0, 1, w.cls.ln_g, w.cls.ln_b, 1e-12f, hd_b, nullptr,
                             ns, D, s));
   }
   {
