@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // row sum from the unrounded P.  4 waves split the key blocks; partial O / row sums are added in wave order.
 // ------------------------------------------------------------------------------------------------
 constexpr int VT_KP = 608;            // 578 visual keys padded to a multiple of 32 (zeros)
-constexpr int BEAM_SC_LD = 656;       // 608 visual + 41 text + pad, fp32 scores per query row
+constexpr int BEAM_SC_LD = 657;       // 608 visual + 41 text + pad, fp32 scores per query row (odd: rows start in different LDS banks)
 
 __global__ __launch_bounds__(256) void vt_build_kernel(const bf16_t* __restrict__ vis_qkv, bf16_t* __restrict__ vt, int S_vis) {
   // grid (VT_KP / 32, NH, images): thread = (dim = tid & 63, key group = tid >> 6 -> 8 keys)
