@@ -461,23 +461,24 @@ def test_row_topk_from_pieces_equals_row_scan(ops, M, k):
     np.testing.assert_allclose(l1.cpu().numpy(), torch.logsumexp(logits[:, :V].cpu().double(), 1).numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize('K,t', [(5, 1), (5, 7), (2, 19), (3, 12), (8, 4)])
-def test_attn_decode_beams_vs_single_sequences(ops, K, t):
+@pytest.mark.parametrize('K,t,L', [(5, 1, 20), (5, 7, 20), (2, 19, 20), (3, 12, 20), (8, 4, 20), (8, 19, 20), (5, 38, 40), (1, 5, 20)])
+def test_attn_decode_beams_vs_single_sequences(ops, K, t, L):
     """Beam-size decode attention on the matrix pipe (one workgroup per (image, head), all 2*K query rows of the image in one
     MFMA, visual K rows loaded once) against the per-sequence vector-ALU kernel on the same inputs: same softmax, same bf16
     rounding of P, different fp32 summation order -> outputs within one bf16 ulp (2^-7 relative, 2e-3 absolute), cache rows
-    published identically; and against the fp32 reference like test_attn_decode_step."""
+    published identically; and against the fp32 reference like test_attn_decode_step.  (8, 19) and (5, 38, max_length 40) run the
+    large instantiation of the kernel, (1, 5) a single sequence per image."""
     from oracle import vitcap_oracle as O
     n_img, S = 3, 578
     B = n_img * K
     vis = _bf(_rand((n_img, S, 2304), 40 + K, 2.0))
     step = _bf(_rand((B, 2, 2304), 41 + t, 2.0))
-    cache = _bf(_rand((B, 20, 2, 768), 42, 2.0))
+    cache = _bf(_rand((B, L, 2, 768), 42, 2.0))
     c1, c2 = cache.cuda().contiguous(), cache.cuda().contiguous()
     step_d = step.reshape(B * 2, 2304).cuda().contiguous()
     vis_d = vis.reshape(n_img * S, 2304).cuda().contiguous()
-    got = ops.attn_decode_beams(step_d, vis_d, c1, n_img, K, S, t)
-    want = ops.attn_decode_step(step_d, vis_d, c2, B, S, t, seq_per_image=K)
+    got = ops.attn_decode_beams(step_d, vis_d, c1, n_img, K, S, t, max_len=L)
+    want = ops.attn_decode_step(step_d, vis_d, c2, B, S, t, max_len=L, seq_per_image=K)
     torch.cuda.synchronize()
     assert torch.equal(c1, c2)
     _close(got.float().cpu(), want.float().cpu(), 2 ** -7, 2e-3, 'beam attention vs per-sequence kernel K=%d t=%d' % (K, t))
