@@ -68,8 +68,12 @@ typedef struct {
   int out_dtype;
   int row_group, out_group_rows, out_row_off, res_periodic;
   int tile_hint; /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x128 three-stage, 4 = skinny (tuning/tests);
-                    5 = 256x256 one tile per workgroup, 12 = 256x256 persistent workgroups (auto picks 12 where it wins
-                    on an otherwise idle GPU; a caller that overlaps a second stream asks for 5 per call) */
+                    5 = 256x256 tiles, one per workgroup (what a caller that overlaps a second stream asks for: the other
+                    stream's kernels fill the partial last round, and CU-time, not the launch's length, is what counts);
+                    33 = the same with 192- or 128-row tiles for the rows behind the last whole round of the chip's CUs where
+                    that shortens the launch (vitcap_gemm_tile_plan; auto picks it for M >= 2048 on an otherwise idle GPU);
+                    30 / 31 = every tile 192 / 128 rows (measurements, tests); 12 = 256x256 persistent workgroups.
+                    Tile shape never changes a result bit. */
   int split_k;   /* > 1: C is fp32 [split_k][M][ldc] partial slabs (no bias/act/residual applied); the consumer
                     (vitcap_sum_layernorm) reduces them.  K must be a multiple of 128*split_k. */
   const int32_t* live; /* optional device counter: the kernel returns at entry when *live == 0 (decode loop after every
@@ -83,6 +87,10 @@ typedef struct {
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                          void* C, const vitcap_gemm_desc* d, void* stream);
+/* The tile plan the 256-column kernel uses for an M x N x K problem on the current device (host-side query, no launch):
+ * plan[0] = number of 256-row m-tiles, plan[1] = height class of the tiles behind them (0 = none, 3 = 192 rows, 2 = 128 rows),
+ * plan[2] = number of those m-tiles. */
+int vitcap_gemm_tile_plan(int M, int N, int K, int* plan3);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (768): y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 statistics.

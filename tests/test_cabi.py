@@ -43,6 +43,24 @@ def test_argument_validation_without_gpu(L):
     assert L.lib.vitcap_sigmoid_topk(a, 30592, 30522, 65, 0.2, a, a, a, 1, None) == -1      # k > 64
 
 
+def test_gemm_tile_plan_host_logic(L):
+    """vitcap_gemm_tile_plan (host only): the 256-row tiles plus the short tiles behind them cover every row exactly once,
+    the 256-row region ends on a tile boundary, and the hot B = 64 shapes whose plain grids waste a partial round get a mix."""
+    from vitcap_amd import ops
+    for M in (577, 2048, 4616, 9232, 36928, 36992, 73856, 295424):
+        for N, K in ((768, 768), (768, 3072), (2304, 768), (3072, 768)):
+            tb, mts, ts = ops.gemm_tile_plan(M, N, K)
+            assert mts in (0, 2, 3) and tb >= 0 and ts >= 0
+            if mts == 0:
+                assert ts == 0 and tb == (M + 255) // 256
+            else:
+                h = 64 * mts
+                assert tb * 256 < M and (ts - 1) * h < M - tb * 256 <= ts * h, (M, N, K, tb, mts, ts)
+    for N, K in ((768, 768), (768, 3072), (2304, 768)):       # 435 tiles = 1.7 rounds, 1305 = 5.1 rounds on 256 CUs
+        assert ops.gemm_tile_plan(36928, N, K)[1] != 0
+    assert L.lib.vitcap_gemm_tile_plan(0, 768, 768, (C.c_int * 3)()) == -1
+
+
 def test_engine_lifecycle_and_workspace(L):
     h = C.c_void_p()
     assert L.lib.vitcap_engine_create(C.byref(h)) == 0 and h.value

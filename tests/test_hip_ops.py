@@ -91,6 +91,50 @@ def test_gemm_residual_inplace(ops):
     _close(x, want, 1e-4, 1e-4, 'gemm residual in place')
 
 
+@pytest.mark.parametrize('variant', ['bias_bf16', 'gelu_bf16', 'res_f32', 'rowmap_res_f32'])
+def test_gemm_256_tile_heights_bit_identical(ops, variant):
+    """The 256-column kernel with 256-row tiles only (hint 32), with every tile 192 / 128 rows (30 / 31) and with the planned
+    mix of 256-row tiles + short tiles in the last round (hint 33 / auto): the same k order per output element and the same
+    epilogue arithmetic, so every bit must agree -- and hint 32 is checked against fp32 torch."""
+    from vitcap_amd import _lib as L
+    M, N, K = (9232, 2304, 768) if variant != 'res_f32' else (10386, 768, 768)       # ragged last tiles; the plan mixes heights here
+    if variant == 'rowmap_res_f32':
+        M, N, K = 16 * 576, 768, 768
+    a = _bf(_rand((M, K), 71)).cuda()
+    w = _bf(_rand((N, K), 72, 0.05)).cuda()
+    bias = _rand((N,), 73, 0.1).cuda()
+    plan = ops.gemm_tile_plan(M, N, K)
+    assert plan[1] in (2, 3) and plan[2] > 0 and plan[0] * 256 + plan[2] * 64 * plan[1] >= M, plan
+    outs = {}
+    for hint in (32, 30, 31, 33, 5, 0):
+        if variant == 'bias_bf16':
+            outs[hint] = ops.gemm_bias_act(a, w, bias, tile_hint=hint)
+        elif variant == 'gelu_bf16':
+            outs[hint] = ops.gemm_bias_act(a, w, bias, act=L.ACT_GELU_ERF, tile_hint=hint)
+        elif variant == 'res_f32':
+            x = _rand((M, N), 74).cuda()
+            outs[hint] = ops.gemm_bias_act(a, w, bias, residual=x, out=x.clone(), tile_hint=hint)
+        else:   # patch-embed row map: out row = (r / 576) * 577 + 1 + r % 576, residual = pos_embed[1 + r % 576] (periodic)
+            pos = _rand((577, N), 75).cuda()
+            out = torch.zeros(16 * 577, N, device='cuda')
+            outs[hint] = ops.gemm_bias_act(a, w, bias, residual=pos[1:], out=out, row_group=576, out_group_rows=577,
+                                           out_row_off=1, res_periodic=1, tile_hint=hint)
+    torch.cuda.synchronize()
+    z = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    if variant == 'bias_bf16':
+        _close(outs[32], z, 2 ** -7, 2e-3, 'hint 32 vs torch')
+    elif variant == 'gelu_bf16':
+        _close(outs[32], torch.nn.functional.gelu(z), 2 ** -7, 2e-3, 'hint 32 vs torch')
+    elif variant == 'res_f32':
+        _close(outs[32], z + _rand((M, N), 74), 1e-4, 1e-4, 'hint 32 vs torch')
+    else:
+        want = torch.zeros(16 * 577, N)
+        want.view(16, 577, N)[:, 1:] = (z.view(16, 576, N) + pos.cpu()[1:])
+        _close(outs[32], want, 1e-4, 1e-4, 'hint 32 vs torch')
+    for hint in (30, 31, 33, 5, 0):
+        assert torch.equal(outs[hint], outs[32]), 'tile_hint %d differs from 256-row tiles (%s)' % (hint, variant)
+
+
 @pytest.mark.parametrize('M,N,K,split', [(128, 768, 768, 6), (128, 768, 3072, 12), (64, 768, 768, 6), (128, 2304, 768, 1),
                                           (64, 30592, 768, 1), (100, 3072, 768, 1), (256, 768, 3072, 4)])
 def test_gemm_skinny_splitk(ops, M, N, K, split):

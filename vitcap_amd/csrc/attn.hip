@@ -759,14 +759,8 @@ extern "C" int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qk
   const float c = scale * 1.4426950408889634f;
   const int nq = 2 * seq_per_image;
   const size_t smem = (size_t)nq * BEAM_SC_LD * 4 + (size_t)5 * nq * HD * 4;      // <= 62.5 KB at 8 sequences per image
-  {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn_decode_beam_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      (void)hipFuncSetAttribute((const void*)attn_decode_beam_kernel<11, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
-    }
-  }
+  VC_FUNC_SMEM((attn_decode_beam_kernel<4, 3>), 64 * 1024);
+  VC_FUNC_SMEM((attn_decode_beam_kernel<11, 6>), 64 * 1024);
   if (seq_per_image * (t + 1) <= 32 * 4 && t + 1 <= 8 * 3)
     hipLaunchKernelGGL((attn_decode_beam_kernel<4, 3>), dim3(NH, n_images), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
                        (const bf16_t*)vis_qkv, (const bf16_t*)vis_vt, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len,

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/vitcap_hip.h"
 
@@ -49,6 +50,27 @@ extern thread_local bool vc_tls_kev_used;
       vitcap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
       return VITCAP_ELAUNCH;                                                    \
     }                                                                           \
+  } while (0)
+
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device), from
+// whichever thread gets there first (two racing threads both set it: idempotent), and report a failure instead of letting
+// it surface later as a generic launch error.  One bit per device ordinal in a per-call-site word.
+#define VC_FUNC_SMEM(kern, bytes)                                                                                   \
+  do {                                                                                                              \
+    static std::atomic<unsigned long long> vc_done_{0ull};                                                          \
+    int vc_dev_ = 0;                                                                                                \
+    (void)hipGetDevice(&vc_dev_);                                                                                   \
+    const unsigned long long vc_bit_ = 1ull << (vc_dev_ & 63);                                                      \
+    if (!(vc_done_.load(std::memory_order_acquire) & vc_bit_)) {                                                    \
+      hipError_t vc_e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+      if (vc_e_ != hipSuccess) {                                                                                    \
+        vitcap_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed on device %d: %s", (int)(bytes), vc_dev_, \
+                         hipGetErrorString(vc_e_));                                                                 \
+        return VITCAP_ELAUNCH;                                                                                      \
+      }                                                                                                             \
+      vc_done_.fetch_or(vc_bit_, std::memory_order_release);                                                        \
+    }                                                                                                               \
   } while (0)
 
 // round-to-nearest-even fp32 -> bf16 (matches torch .to(bfloat16) for finite values and NaN->qNaN)

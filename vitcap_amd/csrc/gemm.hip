@@ -19,6 +19,11 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace {
 
 struct GemmArgs {
@@ -31,6 +36,7 @@ struct GemmArgs {
   int lda, ldw, ldc, ldr;
   int row_group, out_group_rows, out_row_off, res_periodic;
   int tiles_m, tiles_n;
+  int n_big, tiles_m_small;     // mixed launch of the 256-wide kernel: workgroups [0, n_big) own 256-row tiles, the rest short ones
   // training extras
   const bf16_t* aux;   // epilogue multiplies by gelu'(aux) (backward of the MLP activation); bf16 [M][ldaux]
   int ldaux;
@@ -41,12 +47,9 @@ struct GemmArgs {
   int kt_per_split;
   size_t slab;
   int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
-  unsigned long long* trace;   // instrumentation (tools/gemm_trace.py): [workgroup][8 tiles][4] s_memtime stamps, else null
   const int32_t* live;         // decode loop: return at entry once *live == 0 (vitcap_gemm_desc.live)
   float* rowstat;              // ROWSTAT kernels: per (row, 32-column piece) {max, argmax column, sum exp(x - max), 0}
 };
-
-unsigned long long* g_gemm_trace = nullptr;
 
 // launch of a large-tile GEMM: with kernel-bound timing events when the engine's timing run asked for them (common.h)
 #define VC_LAUNCH_GEMM(kern, grid, block, smem, s, p)                                                              \
@@ -416,11 +419,7 @@ template <int ACT, int OUT_F32, bool HAS_RES>
 int launch_big(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = 3 * (256 + 128) * 64 * 2;
   auto kern = gemm_nt_big_kernel<ACT, OUT_F32, HAS_RES>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  VC_FUNC_SMEM(kern, smem);
   GemmArgs p = a;
   p.tiles_m = (a.M + 255) / 256;
   p.tiles_n = (a.N + 127) / 128;
@@ -485,9 +484,9 @@ __device__ __forceinline__ void lane_tile_transpose(unsigned (&r)[4][NREG]) {
     }
 }
 
-// acc[8][4]: the wave's 128 x 64 block (8 row tiles of 16, 4 column tiles of 16); row0/col0 = its origin in C
-template <int ACT, int OUT_F32, bool HAS_RES>
-__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[8][4], const GemmArgs& p, int row0, int col0, int lane,
+// acc[NI][4]: the wave's (16*NI) x 64 block (NI row tiles of 16, 4 column tiles of 16); row0/col0 = its origin in C
+template <int ACT, int OUT_F32, bool HAS_RES, int NI>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[NI][4], const GemmArgs& p, int row0, int col0, int lane,
                                                 bool no_store) {
   const int frow = lane & 15, fk = lane >> 4;
   f32x4 bias4[4];
@@ -508,8 +507,8 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[8][4], const GemmAr
   }
   ISSUE_RES_D(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i + 1 < 8) { ISSUE_RES_D(i + 1); }
+  for (int i = 0; i < NI; ++i) {
+    if (i + 1 < NI) { ISSUE_RES_D(i + 1); }
     const int m = row0 + i * 16 + frow;
     f32x4 v[4];
 #pragma unroll
@@ -556,13 +555,18 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[8][4], const GemmAr
 #undef ISSUE_RES_D
 }
 
-template <int ACT, int OUT_F32, bool HAS_RES, int PH>
-__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int A_BYTES = BM * BK * 2, BUF_BYTES = 2 * A_BYTES;
+// One (64*MT) x 256 output tile at (m0, n0): MT = 4 is the 256 x 256 tile; MT = 3 / 2 are the 192- / 128-row tiles a mixed
+// launch uses for the rows behind the last full round of 256-row tiles (launch_256).  Same k order per output element and the
+// same epilogue arithmetic whatever MT, so the results do not depend on the tile height.
+template <int ACT, int OUT_F32, bool HAS_RES, int PH, int MT>
+__device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, const int m0, const int n0) {
+  constexpr int BK = 64;
+  constexpr int A_BYTES = 256 * BK * 2, BUF_BYTES = 2 * A_BYTES;   // the W tile sits behind a full-height A slot whatever MT
+  constexpr int WR = 32 * MT;                                      // rows of one wave's block (2 waves along M, 4 along N)
+  constexpr int NI = 2 * MT;                                       // ... in 16-row MFMA tiles
+  constexpr int NP = MT + 4;                                       // LDS-DMA pieces (8 rows x 128 B per lane group) per wave and k-tile
   constexpr int ABL = PH >> 4;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
   constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4, NO_STORE = ABL & 8, NO_EPI = ABL & 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -570,44 +574,39 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   const int grp = w >> 2;            // 0 = group A, 1 = group B
   const int wm = w >> 2, wn = w & 3;
 
-  const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  // column groups of group_n tiles, as in the persistent form (TILE_COORDS there): workgroups are dispatched in blockIdx
-  // order, so the ones an XCD runs at once are consecutive positions of its chunk
-  const int per_g = p.tiles_m * p.group_n;
-  const int gi = bid / per_g, rem = bid - gi * per_g;
-  const int gleft = p.tiles_n - gi * p.group_n;
-  const int gw = gleft < p.group_n ? gleft : p.group_n;
-  const int tm = rem / gw, tn = gi * p.group_n + rem - tm * gw;
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ (srow & 7);
-  const bf16_t* aptr[4];
+  const bf16_t* aptr[MT];
   const bf16_t* wptr[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = m0 + w * 32 + i * 8 + srow;
+  for (int i = 0; i < MT; ++i) {
+    int r = m0 + w * (8 * MT) + i * 8 + srow;
     r = r < p.M ? r : p.M - 1;
     aptr[i] = p.A + (size_t)r * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
     int c = n0 + w * 32 + i * 8 + srow;
     c = c < p.N ? c : p.N - 1;
     wptr[i] = p.W + (size_t)c * p.ldw + schunk * 8;
   }
-#define STAGE_A(buf_, k0_)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-      glds16(aptr[i] + (k0_), smem + (buf_) * BUF_BYTES + (w * 32 + i * 8) * 128)
-#define STAGE_W(buf_, k0_)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-      glds16(wptr[i] + (k0_), smem + (buf_) * BUF_BYTES + A_BYTES + (w * 32 + i * 8) * 128)
+  // piece q of a k-tile: q < MT -> 8 rows of A, else 8 rows of W
+#define STAGE_PIECES(q0_, q1_, buf_, k0_)                                                                          \
+  _Pragma("unroll") for (int q = (q0_); q < (q1_); ++q) {                                                          \
+    if (q < MT)                                                                                                    \
+      glds16(aptr[q < MT ? q : 0] + (k0_), smem + (buf_) * BUF_BYTES + (w * (8 * MT) + q * 8) * 128);              \
+    else                                                                                                           \
+      glds16(wptr[q < MT ? 0 : q - MT] + (k0_), smem + (buf_) * BUF_BYTES + A_BYTES + (w * 32 + (q - MT) * 8) * 128); \
+  }
+  // DMA schedule: the pieces of k-tile t+1 are spread two per load segment over L3(t-1), L0(t), L1(t), L2(t) (slot s takes
+  // pieces 2s, 2s+1; MT = 3 leaves one piece for the last slot, MT = 2 none).  Buffer (t+1)&1 is free from L3(t-1) on (its
+  // last reader was L2(t-1)); the pieces must have landed before the barrier after which group A starts L0(t+1): that wait
+  // is vmcnt(2) -- the two pieces of tile t+2 issued in L3(t) may stay in flight -- or vmcnt(0) when nothing newer was issued.
+#define STAGE_SLOT(s_, buf_, k0_) STAGE_PIECES(2 * (s_), (2 * (s_) + 2 < NP ? 2 * (s_) + 2 : NP), buf_, k0_)
 
-  f32x4 acc[8][4];
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -615,16 +614,16 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   const int fk = lane >> 4;
   const int coff0 = ((0 * 4 + fk) ^ (frow & 7)) * 16;
   const int coff1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
-  const int a_base = (wm * 128 + frow) * 128;
+  const int a_base = (wm * WR + frow) * 128;
   const int b_base = A_BYTES + (wn * 64 + frow) * 128;
   const int nk = p.K / BK;
 
-  bf16x8 afr[4][2];      // current m-half: 4 m-tiles x 2 k-steps
+  bf16x8 afr[MT][2];     // current m-half: MT m-tiles x 2 k-steps
   bf16x8 bfr[2][2][2];   // both n-halves: [nh][n-tile][k-step]
 
 #define LOAD_A(buf_, mh_)                                                                        \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                             \
-    const char* ra_ = smem + (buf_) * BUF_BYTES + a_base + ((mh_) * 4 + mt) * 16 * 128;          \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                            \
+    const char* ra_ = smem + (buf_) * BUF_BYTES + a_base + ((mh_) * MT + mt) * 16 * 128;         \
     afr[mt][0] = *(const bf16x8*)(ra_ + coff0);                                                  \
     afr[mt][1] = *(const bf16x8*)(ra_ + coff1);                                                  \
   }
@@ -642,58 +641,16 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   __builtin_amdgcn_s_setprio(1);                                                                        \
   if (!NO_MFMA)                                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                   \
       _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
-        acc[(mh_) * 4 + mt][(nh_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-            bfr[nh_][nt][ks], afr[mt][ks], acc[(mh_) * 4 + mt][(nh_) * 2 + nt], 0, 0, 0);               \
+        acc[(mh_) * MT + mt][(nh_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+            bfr[nh_][nt][ks], afr[mt][ks], acc[(mh_) * MT + mt][(nh_) * 2 + nt], 0, 0, 0);              \
   __builtin_amdgcn_s_setprio(0)
 
-  // DMA schedule: the 8 LDS-DMA pieces of k-tile t+1 are spread two per load segment over L3(t-1), L0(t), L1(t),
-  // L2(t).  Buffer (t+1)&1 is free from L3(t-1) on (its last reader was L2(t-1)); the pieces must have landed
-  // before the barrier after which group A starts L0(t+1): that wait is vmcnt(2) -- the two pieces of tile t+2
-  // issued in L3(t) may stay in flight -- or vmcnt(0) when nothing newer was issued.
-#define STAGE2(base_, row0_, p0_, buf_, k0_)                                                            \
-  _Pragma("unroll") for (int i = (p0_); i < (p0_) + 2; ++i)                                             \
-      glds16((base_)[i] + (k0_), smem + (buf_) * BUF_BYTES + (row0_) + (w * 32 + i * 8) * 128)
-
-  if constexpr ((PH & 15) == 2) {
-    // Two phases per k-tile (32 MFMAs per compute segment): the load segment of phase 0 reads A(m-half 0) and both
-    // n-halves and issues all 8 DMA pieces of the next k-tile; phase 1 reads A(m-half 1).
-    STAGE_A(0, 0);
-    STAGE_W(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; ++t) {
-      const int buf = t & 1;
-      const bool more = t + 1 < nk;
-      LOAD_A(buf, 0);
-      LOAD_B(buf, 0);
-      LOAD_B(buf, 1);
-      if (more) {
-        STAGE_A(buf ^ 1, (t + 1) * BK);
-        STAGE_W(buf ^ 1, (t + 1) * BK);
-      }
-      END_LOAD();
-      COMPUTE(0, 0);
-      COMPUTE(0, 1);
-      __builtin_amdgcn_s_barrier();
-      LOAD_A(buf, 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      COMPUTE(1, 1);
-      COMPUTE(1, 0);
-      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  } else {
   // prologue: k-tile 0 into buffer 0, first two pieces of k-tile 1 into buffer 1
-  STAGE_A(0, 0);
-  STAGE_W(0, 0);
+  STAGE_PIECES(0, NP, 0, 0);
   if (nk > 1 && !NO_DMA) {
-    STAGE2(aptr, 0, 0, 1, BK);
+    STAGE_SLOT(0, 1, BK);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -708,25 +665,25 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     const bool rd = !NO_LDS || t == 0;
     // ---- phase 0: quadrant (m-half 0, n-half 0)
     if (rd) { LOAD_A(buf, 0); LOAD_B(buf, 0); }
-    if (more) { STAGE2(aptr, 0, 2, buf ^ 1, (t + 1) * BK); }
+    if (more) { STAGE_SLOT(1, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(0, 0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: (m-half 0, n-half 1)
     if (rd) { LOAD_B(buf, 1); }
-    if (more) { STAGE2(wptr, A_BYTES, 0, buf ^ 1, (t + 1) * BK); }
+    if (more) { STAGE_SLOT(2, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(0, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: (m-half 1, n-half 1)
     if (rd) { LOAD_A(buf, 1); }
-    if (more) { STAGE2(wptr, A_BYTES, 2, buf ^ 1, (t + 1) * BK); }
+    if (more) { STAGE_SLOT(3, buf ^ 1, (t + 1) * BK); }
     END_LOAD();
     COMPUTE(1, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: (m-half 1, n-half 0); no LDS reads; first two pieces of k-tile t+2 (its buffer, `buf`, was last
     // read in L2 above by both groups before the barrier that precedes this segment for either group)
-    if (more2) { STAGE2(aptr, 0, 0, buf, (t + 2) * BK); }
+    if (more2) { STAGE_SLOT(0, buf, (t + 2) * BK); }
     if (grp == 1) {
       if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -739,11 +696,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_s_barrier();
   }
-  }
   if (grp == 0) __builtin_amdgcn_s_barrier();   // match group B's extra barrier
-#undef STAGE_A
-#undef STAGE_W
-#undef STAGE2
+#undef STAGE_PIECES
+#undef STAGE_SLOT
 #undef LOAD_A
 #undef LOAD_B
 #undef END_LOAD
@@ -751,8 +706,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. 32-byte (bf16)
   // pieces of 16 different rows per store instruction; measured, that caps the output stream at ~2.2 TB/s and costs
-  // 75 us per 36928x2304 GEMM.  Each wave therefore parks its accumulators (fp32) in a private 64x64 LDS patch
-  // (two halves of its 128 rows), reads them back row-major and issues full-line stores: 16 lanes cover one
+  // 75 us per 36928x2304 GEMM.  Each wave therefore parks its accumulators (fp32) in a private (16*MT)x64 LDS patch
+  // (two halves of its rows), reads them back row-major and issues full-line stores: 16 lanes cover one
   // 64-column row segment (256 B fp32 / 128 B bf16), bias / GELU / residual are applied in this coalesced pass.
   constexpr int EP_ROWB = 272;                       // 64 fp32 + 16 B pad: conflict-free ds_write_b128
   char* ep = smem + w * (64 * EP_ROWB);
@@ -761,9 +716,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias && ncol < p.N) bias4 = *(const f32x4*)(p.bias + ncol);
   if (NO_EPI) return;                 // ablation: no epilogue at all
-  // residual rows are requested one chunk (8 iterations = 32 rows) ahead of their use
+  // residual rows are requested one chunk (2*MT iterations = 8*MT rows) ahead of their use
   const bool col_ok = ncol < p.N && !(NO_STORE && m0 >= 0);   // ablation: LDS staging and arithmetic but no global stores
-  f32x4 rres[2][8];
+  f32x4 rres[2][2 * MT];
 #define ROWS_OF(m_, orow_, rrow_)                                             \
   int orow_ = (m_), rrow_ = (m_);                                             \
   if (p.row_group > 0) {                                                      \
@@ -773,8 +728,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   }
 #define ISSUE_RES(c_)                                                                                        \
   if (HAS_RES) {                                                                                             \
-    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                       \
-      const int m_ = m0 + wm * 128 + (c_) * 32 + it * 4 + er;                                                \
+    _Pragma("unroll") for (int it = 0; it < 2 * MT; ++it) {                                                  \
+      const int m_ = m0 + wm * WR + (c_) * (8 * MT) + it * 4 + er;                                           \
       ROWS_OF(m_, o_, r_);                                                                                   \
       (void)o_;                                                                                              \
       rres[(c_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + ncol)        \
@@ -786,13 +741,13 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
   // plain bf16 (qkv), SLOWER for the fp32 + residual outputs (proj 0.078 -> 0.106 ms) -- so it is used for GELU only
   if (p.direct_epilogue && ACT == VITCAP_ACT_GELU_ERF && !OUT_F32 && !HAS_RES && !p.zout && !p.aux && p.row_group == 0 &&
       (p.N & 15) == 0 && (p.ldc & 7) == 0) {
-    epilogue_direct<ACT, OUT_F32, HAS_RES>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, NO_STORE);
+    epilogue_direct<ACT, OUT_F32, HAS_RES, NI>(acc, p, m0 + wm * WR, n0 + wn * 64, lane, NO_STORE);
     return;
   }
   // bf16 output, plain rows, no residual: 8 columns per lane, one 16-byte store (8 lanes = one 128-byte line of the output
   // row) -- half the store instructions of the general path below.  The training extras ride along in the same shape: the
   // pre-activation copy (zout, fc1 forward) leaves as a second 16-byte store, the gelu'(aux) factor (fc2's input gradient)
-  // arrives as 16-byte loads issued for a whole 64-row half BEFORE the LDS staging, so their latency hides behind it
+  // arrives as 16-byte loads issued for a whole half BEFORE the LDS staging, so their latency hides behind it
   // (before: 8-byte loads used immediately, scalar gelu': 337 us per call at M = 36928, N = 3072)
   if constexpr (!OUT_F32 && !HAS_RES) {
     if (p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.zout || (p.ldz & 7) == 0) && (!p.aux || (p.ldaux & 7) == 0)) {
@@ -806,25 +761,25 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
-        uint4 axv[8];
+        uint4 axv[2 * MT];
         if (p.aux) {
 #pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int m = m0 + wm * 128 + hm * 64 + it * 8 + wr;
+          for (int it = 0; it < 2 * MT; ++it) {
+            const int m = m0 + wm * WR + hm * (16 * MT) + it * 8 + wr;
             axv[it] = (m < p.M && okc) ? *(const uint4*)(p.aux + (size_t)m * p.ldaux + ncw) : uint4{0u, 0u, 0u, 0u};
           }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * 4 + i][j];
+            *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * MT + i][j];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 2 * MT; ++it) {
           const int rl = it * 8 + wr;
           f32x4 v0 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4);
           f32x4 v1 = *(const f32x4*)(ep + rl * EP_ROWB + wc * 4 + 16);
-          const int m = m0 + wm * 128 + hm * 64 + rl;
+          const int m = m0 + wm * WR + hm * (16 * MT) + rl;
           const bool ok = m < p.M && okc;
           v0 += b_lo;
           v1 += b_hi;
@@ -864,19 +819,19 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * 4 + i][j];
+        *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[hm * MT + i][j];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
       const int c = hm * 2 + ch;
       if (c + 1 < 4) { ISSUE_RES(c + 1); }
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int rl = ch * 32 + it * 4 + er;
+      for (int it = 0; it < 2 * MT; ++it) {
+        const int rl = ch * (8 * MT) + it * 4 + er;
         f32x4 v = *(const f32x4*)(ep + rl * EP_ROWB + ec * 4);
-        const int m = m0 + wm * 128 + hm * 64 + rl;
+        const int m = m0 + wm * WR + hm * (16 * MT) + rl;
         const bool ok = m < p.M && col_ok;
         ROWS_OF(m, orow, rrow);
         (void)rrow;
@@ -912,30 +867,137 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #undef ROWS_OF
 }
 
-template <int ACT, int OUT_F32, bool HAS_RES, int PH>
-int launch_256(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = 8 * 64 * 272;   // max(2 x 64 KiB k-tile buffers, 8 x 17 KiB epilogue patches)
-  auto kern = gemm_nt_256_kernel<ACT, OUT_F32, HAS_RES, PH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
+// The launch: n_big workgroups own 256-row tiles of rows [0, 256 * tiles_m); with MTS != 0 the workgroups behind them own
+// (64*MTS)-row tiles of the remaining rows.  Workgroups are dispatched in blockIdx order (block b on XCD b % 8), so every XCD
+// works through its share of the big tiles first and fills the last, partial round with the short ones.
+template <int ACT, int OUT_F32, bool HAS_RES, int PH, int MTS>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  const bool small = MTS != 0 && bid >= p.n_big;
+  if (small) bid -= p.n_big;       // the XCD of block b is b % 8: subtracting a constant rotates the XCD ids, chunks stay whole
+  const int tiles_m = small ? p.tiles_m_small : p.tiles_m;
+  {
+    // XCD-aware, bijective remap: the blocks of one XCD get a contiguous chunk of the region's tile list
+    const int nwg = tiles_m * p.tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  GemmArgs p = a;
-  p.tiles_m = (a.M + 255) / 256;
-  p.tiles_n = (a.N + 255) / 256;
-  p.group_n = tile_group_n(p.tiles_n);
-  VC_LAUNCH_GEMM(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+  // column groups of group_n tiles: the tiles an XCD runs at once are consecutive positions of its chunk, so they span few W
+  // tiles (which stay in its L2 for the walk down M) and each A tile is fetched once for group_n consumers
+  const int per_g = tiles_m * p.group_n;
+  const int gi = bid / per_g, rem = bid - gi * per_g;
+  const int gleft = p.tiles_n - gi * p.group_n;
+  const int gw = gleft < p.group_n ? gleft : p.group_n;
+  const int tm = rem / gw, tn = gi * p.group_n + rem - tm * gw;
+  if (!small) {
+    gemm256_tile<ACT, OUT_F32, HAS_RES, PH, 4>(p, smem, tm * 256, tn * 256);
+  } else {
+    if constexpr (MTS != 0) gemm256_tile<ACT, OUT_F32, HAS_RES, PH, MTS>(p, smem, p.tiles_m * 256 + tm * (64 * MTS), tn * 256);
+  }
+}
+
+// ---- tile plan of a launch: how many rows go to 256-row tiles, and the height of the tiles behind them ----------------------
+// A launch of T equal tiles on C CUs costs ceil(T / C) tile times: 435 tiles (M = 36928, N = 768) pay 2 rounds for 1.7 rounds of
+// work, 1305 (N = 2304) pay 6 for 5.1.  The plan keeps 256-row tiles for the rows that fill whole rounds and cuts the rest into
+// 192- or 128-row tiles, chosen by simulating the dispatch (earliest free CU takes the next workgroup) with tile costs relative
+// to the 256-row tile (a shorter tile has the same W traffic and per-phase overheads for fewer flops: measured, tools/gemm_bench.py).
+struct TilePlan { int tm_big, mts, tm_small; };
+TilePlan plan_tiles(int M, int tiles_n, int K) {
+  static const int mix_env = [] { const char* e = getenv("VITCAP_GEMM_MIX"); return e ? atoi(e) : -1; }();   // 0 = off; 3 / 2 = force height
+  static const int c3_env = [] { const char* e = getenv("VITCAP_GEMM_MIX_C3"); return e ? atoi(e) : 0; }();  // tile costs in permille (tuning)
+  static const int c2_env = [] { const char* e = getenv("VITCAP_GEMM_MIX_C2"); return e ? atoi(e) : 0; }();
+  static const int big_env = [] { const char* e = getenv("VITCAP_GEMM_MIX_BIG"); return e ? atoi(e) : -1; }(); // force the number of 256-row m-tiles
+  static const int n_cu = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      return prop.multiProcessorCount;
+    return 256;
+  }();
+  const int tm_full = (M + 255) / 256;
+  TilePlan best{tm_full, 0, 0};
+  if (mix_env == 0) return best;
+  struct Key { int M, tn, K; };
+  static std::mutex mu;
+  static std::vector<std::pair<Key, TilePlan>> cache;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (const auto& e : cache)
+      if (e.first.M == M && e.first.tn == tiles_n && e.first.K == K) return e.second;
+  }
+  // relative tile costs: main loop ~ (64 MT + overhead) cycles per phase, epilogue ~ MT; K = 768 tiles are about half epilogue
+  const float c3 = c3_env > 0 ? c3_env * 1e-3f : 0.80f, c2 = c2_env > 0 ? c2_env * 1e-3f : 0.60f;
+  float best_t = ceilf((float)(tm_full * tiles_n) / n_cu);
+  const float need = best_t * 0.97f;                         // a plan must win 3 % to replace the plain grid
+  const int span = (int)(2.5f * n_cu / tiles_n) + 2;         // rows worth ~2.5 rounds can move to short tiles
+  std::vector<float> heap;
+  for (int mts = 3; mts >= 2; --mts) {
+    if (mix_env > 0 && mix_env != mts) continue;
+    const float cs = mts == 3 ? c3 : c2;
+    for (int tb = tm_full - 1; tb >= 0 && tb >= tm_full - span; --tb) {
+      if (big_env >= 0 && tb != big_env) continue;
+      const int rows_left = M - tb * 256;
+      const int ts = (rows_left + 64 * mts - 1) / (64 * mts);
+      const int nb = tb * tiles_n, ns = ts * tiles_n;
+      // big tiles: CU j is free at (nb / C + (j < nb % C)); the short tiles go to the earliest free CU
+      heap.assign(n_cu, 0.f);
+      for (int j = 0; j < n_cu; ++j) heap[j] = -(float)(nb / n_cu + (j < nb % n_cu ? 1 : 0));
+      std::make_heap(heap.begin(), heap.end());              // max-heap of negated free times
+      float end = nb ? (float)((nb + n_cu - 1) / n_cu) : 0.f;
+      for (int i = 0; i < ns; ++i) {
+        std::pop_heap(heap.begin(), heap.end());
+        const float f = -heap.back() + cs;
+        heap.back() = -f;
+        std::push_heap(heap.begin(), heap.end());
+        end = f > end ? f : end;
+      }
+      if (end < need && end < best_t - 1e-4f) { best_t = end; best = TilePlan{tb, mts, ts}; }
+    }
+  }
+  std::lock_guard<std::mutex> g(mu);
+  cache.push_back({Key{M, tiles_n, K}, best});
+  return best;
+}
+
+template <int ACT, int OUT_F32, bool HAS_RES, int PH, int MTS>
+int launch_256_t(const GemmArgs& p, int nwg, hipStream_t s) {
+  constexpr int smem = 8 * 64 * 272;   // max(2 x 64 KiB k-tile buffers, 8 x 17 KiB epilogue patches)
+  auto kern = gemm_nt_256_kernel<ACT, OUT_F32, HAS_RES, PH, MTS>;
+  VC_FUNC_SMEM(kern, smem);
+  VC_LAUNCH_GEMM(kern, dim3(nwg), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256");
   return VITCAP_OK;
 }
 
+// mix: -1 = plan_tiles decides, 0 = 256-row tiles only, 3 / 2 = every tile 192 / 128 rows (tile-cost measurements)
+template <int ACT, int OUT_F32, bool HAS_RES, int PH>
+int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
+  GemmArgs p = a;
+  p.tiles_n = (a.N + 255) / 256;
+  p.group_n = tile_group_n(p.tiles_n);
+  TilePlan pl{(a.M + 255) / 256, 0, 0};
+  if constexpr ((PH >> 4) == 0) {
+    if (mix < 0) pl = plan_tiles(a.M, p.tiles_n, a.K);
+    else if (mix > 0) pl = TilePlan{0, mix, (a.M + 64 * mix - 1) / (64 * mix)};
+  }
+  p.tiles_m = pl.tm_big;
+  p.tiles_m_small = pl.tm_small;
+  p.n_big = pl.tm_big * p.tiles_n;
+  const int nwg = p.n_big + pl.tm_small * p.tiles_n;
+  if constexpr ((PH >> 4) == 0) {
+    if (pl.mts == 3) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 3>(p, nwg, s);
+    if (pl.mts == 2) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 2>(p, nwg, s);
+  }
+  return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 0>(p, nwg, s);
+}
+
 template <int PH>
-int dispatch_256(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
+int dispatch_256(const GemmArgs& a, int act, int out_f32, hipStream_t s, int mix = 0) {
   const bool res = a.res != nullptr;
 #define CASE(ACT_, OUT_)                                                  \
   if (act == ACT_ && out_f32 == OUT_)                                     \
-    return res ? launch_256<ACT_, OUT_, true, PH>(a, s) : launch_256<ACT_, OUT_, false, PH>(a, s);
+    return res ? launch_256<ACT_, OUT_, true, PH>(a, s, mix) : launch_256<ACT_, OUT_, false, PH>(a, s, mix);
   CASE(VITCAP_ACT_NONE, 0)
   CASE(VITCAP_ACT_NONE, 1)
   CASE(VITCAP_ACT_GELU_ERF, 0)
@@ -1053,12 +1115,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int tslot = (tile - (int)blockIdx.x) / (int)gridDim.x;
-#define TRACE(i_)                                                                                         \
-  if (p.trace && lane == 0 && (w & 3) == 0 && tslot < 8)                                                  \
-    p.trace[(((size_t)blockIdx.x * 2 + grp) * 8 + tslot) * 4 + (i_)] = __builtin_amdgcn_s_memtime()
-    TRACE(0);
     // every wave has left the previous epilogue (its staging patch lives in buffer pb^1) before anyone DMAs into it
     __builtin_amdgcn_s_barrier();
     if (nk > 1) {
@@ -1104,7 +1160,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
-    TRACE(1);
 
     // ---- prefetch k-tile 0 of the next tile into the buffer the last k-tile did NOT use
     const int ep_buf = (pb + nk - 1) & 1;      // last k-tile's buffer: free now, used for epilogue staging
@@ -1219,9 +1274,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmArgs p) {
     }
 #undef ISSUE_RES
     }
-    TRACE(2);
   }
-#undef TRACE
 #undef TILE_COORDS
 #undef TILE_PTRS
 #undef STAGE_A
@@ -1237,21 +1290,18 @@ template <int ACT, int OUT_F32, bool HAS_RES>
 int launch_256p(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = 2 * 2 * 256 * 64 * 2;
   auto kern = gemm_nt_256p_kernel<ACT, OUT_F32, HAS_RES>;
-  static bool attr_set = false;
-  static int n_cu = 256;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  VC_FUNC_SMEM(kern, smem);
+  static const int n_cu = [] {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+      return prop.multiProcessorCount;
+    return 256;
+  }();
   GemmArgs p = a;
   p.tiles_m = (a.M + 255) / 256;
   p.tiles_n = (a.N + 255) / 256;
   const int nwg = p.tiles_m * p.tiles_n;
-  p.trace = g_gemm_trace;
   p.group_n = tile_group_n(p.tiles_n);
   VC_LAUNCH_GEMM(kern, dim3(nwg < n_cu ? nwg : n_cu), dim3(512), smem, s, p);
   VC_LAUNCH_CHECK("gemm_nt_256p");
@@ -1417,11 +1467,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   constexpr int NST = (WM <= 2 && WN <= 2) ? 4 : 2;     // small tiles (decode shapes): 4 stages
   constexpr int smem = NST * (BM + BN) * 64 * 2;
   auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES, NST>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  if (smem > 48 * 1024) VC_FUNC_SMEM(kern, smem);
   GemmArgs p = a;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
@@ -1440,11 +1486,7 @@ int launch_resident(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = NST * (BM + BN) * 64 * 2;
   static_assert(smem <= 160 * 1024, "resident tile does not fit the LDS");
   auto kern = gemm_nt_kernel<WM, WN, ACT, OUT_F32, HAS_RES, NST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  VC_FUNC_SMEM(kern, smem);
   GemmArgs p = a;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
@@ -1478,11 +1520,7 @@ template <int WM, int WN, int NST>
 int launch_rowstat_t(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, smem = NST * (BM + BN) * 64 * 2;
   auto kern = gemm_nt_kernel<WM, WN, VITCAP_ACT_NONE, 1, false, NST, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  VC_FUNC_SMEM(kern, smem);
   GemmArgs p = a;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
@@ -1523,7 +1561,14 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
 // kernels should slip in between (the batch pipeline of ImageCaptioning.generate_async) the non-persistent form wins,
 // because a persistent grid owns every CU for the whole GEMM (3277 vs 3133 img/s at B=64) -- the engine asks for it through
 // vitcap_gen_opts.gemm_mode.  There is no process-wide switch.
-extern "C" void vitcap_gemm_set_trace(unsigned long long* buf) { g_gemm_trace = buf; }
+extern "C" int vitcap_gemm_tile_plan(int M, int N, int K, int* plan3) {
+  VC_REQUIRE(M > 0 && N > 0 && K > 0 && plan3, "gemm_tile_plan: bad arguments");
+  const TilePlan pl = plan_tiles(M, (N + 255) / 256, K);
+  plan3[0] = pl.tm_big;
+  plan3[1] = pl.mts;
+  plan3[2] = pl.tm_small;
+  return VITCAP_OK;
+}
 
 extern "C" int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
                                     void* C, const vitcap_gemm_desc* d, void* stream) {
@@ -1630,7 +1675,10 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // the persistent kernel's bf16 epilogue stores 8 columns (16 bytes) per lane
   const bool wide_ok = d->out_dtype == VITCAP_OUT_F32 || residual || (d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)C & 15) == 0);
   if (hint == 12 && wide_ok) return dispatch_256p(a, d->act, d->out_dtype, s);
-  if (hint == 6) return dispatch_256<2>(a, d->act, d->out_dtype, s);
+  if (hint == 30) return dispatch_256<4>(a, d->act, d->out_dtype, s, 3);    // every tile 192 x 256 (tile-cost measurement)
+  if (hint == 31) return dispatch_256<4>(a, d->act, d->out_dtype, s, 2);    // every tile 128 x 256
+  if (hint == 5 || hint == 32) return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);    // 256 x 256 tiles only (no short tail tiles)
+  if (hint == 33) return dispatch_256<4>(a, d->act, d->out_dtype, s, -1);   // 256-row tiles + the planned short tiles (what auto picks)
   if (hint == 7) return launch_256<0, 0, false, 4 + 16 * 1>(a, s);   // ablation: no DMA in the loop
   if (hint == 8) return launch_256<0, 0, false, 4 + 16 * 2>(a, s);   // ablation: no ds_read in the loop
   if (hint == 9) return launch_256<0, 0, false, 4 + 16 * 4>(a, s);   // ablation: no MFMA
@@ -1648,5 +1696,5 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // with a residual: long-K shapes (fc2) gain from the persistent form, short-K ones (proj) do not (gemm_res_bench.py)
   if (hint == 0 && use_persistent && wide_ok && !aux_bf16 && !zout_bf16 && d->row_group == 0 && (!residual || d->K > 1024))
     return dispatch_256p(a, d->act, d->out_dtype, s);
-  return dispatch_256<4>(a, d->act, d->out_dtype, s);
+  return dispatch_256<4>(a, d->act, d->out_dtype, s, -1);      // 256 x 256 tiles, short tiles in the last round where the plan wins
 }

@@ -211,7 +211,6 @@ extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
   VC_REQUIRE(N % 256 == 0 && K % 256 == 0, "gemm_tn: N=%d and K=%d must be multiples of 256", N, K);
   VC_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gemm_tn: misaligned operands");
   static bf16_t* zeros[64] = {nullptr};
-  static bool attr_set = false;
   int dev = 0;
   VC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "gemm_tn: bad device");
   if (!zeros[dev]) {
@@ -219,10 +218,7 @@ extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
                "gemm_tn: zero page allocation failed");
   }
   constexpr int smem = 2 * STAGE_BYTES;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  VC_FUNC_SMEM(gemm_tn_kernel, smem);
   TnArgs p;
   p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.C = C_slabs; p.zeros = zeros[dev];
   p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx;

@@ -269,7 +269,18 @@ class ImageCaptioning(nn.Module):
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
-    def check_text_inputs(self, data, max_length=L.MAXLEN):
+    @staticmethod
+    def _text_mask_pattern(T, max_length, n_tag, dtype, device):
+        """The attention_mask the kernels implement for n_tag visible tag slots (dataset.py:377-390): tril on the caption slots,
+        ones on [0:L, L:L+n] and [L:L+n, L:L+n], zeros elsewhere."""
+        want = torch.zeros((T, T), dtype=dtype, device=device)
+        want[:max_length, :max_length] = torch.tril(torch.ones(max_length, max_length, dtype=dtype, device=device))
+        if n_tag:
+            want[max_length:max_length + n_tag, max_length:max_length + n_tag] = 1
+            want[:max_length, max_length:max_length + n_tag] = 1
+        return want
+
+    def check_text_inputs(self, data, max_length=L.MAXLEN, expect_n_tag=None):
         """The text side of the test-time batch (CaptionTensorizer.tensorize_ab at test time, dataset.py:218-219, 326, 377-390;
         consumed by ImageCaptioning.construct_attn_mask ..._bertemb.py:57-85 and ViTCAP.generate modeling_bert.py:955-1001).
         The engine hard-wires the mask STRUCTURE those tensors describe -- caption row i attends caption rows <= i and the 578
@@ -281,31 +292,45 @@ class ImageCaptioning(nn.Module):
           caption row and to each other (what tensorize_ab builds for a text_b of n tokens): returns n;
         * token_type_ids: zeros;  masked_pos: not read by generate() beyond slicing;
         * input_ids (B, T): only the od-label slots [max_length:] are read by generate() (modeling_bert.py:959); their
-          embeddings are overwritten by the predicted tag tokens (1435-1489) and never attended, so any value is harmless."""
+          embeddings are overwritten by the predicted tag tokens (1435-1489) and never attended, so any value is harmless.
+
+        expect_n_tag=None: returns n, read off the mask (host tensors: no GPU involved; device tensors: one host synchronisation).
+        expect_n_tag=n (the pipeline's steady state, pipeline.predict): tensors that live on the device are compared with the
+        pattern for n ON THEIR STREAM and nothing is read back -- returns (n, flag) with flag a 0-d device bool (True = inputs
+        acceptable) that the caller tests when it next synchronises anyway, or None when everything was checked on the host."""
         am = data.get('attention_mask')
-        n_tag = 0
+        defer = expect_n_tag is not None
+        n_tag = int(expect_n_tag) if defer else 0
+        flag = None
+
+        def _verdict(ok_tensor, make_error):
+            nonlocal flag
+            if defer and ok_tensor.is_cuda:
+                flag = ok_tensor if flag is None else (flag & ok_tensor)
+            elif not bool(ok_tensor):
+                raise make_error()
+
         if am is not None:
             if am.dim() != 3 or am.shape[1] != am.shape[2] or am.shape[1] < max_length:
                 raise ValueError('attention_mask must be (B, T, T) with T >= max_length=%d, got %s' % (max_length, tuple(am.shape)))
             T = am.shape[1]
             # tags visible to the caption (a text_b of n tokens, dataset.py:240-252, 387-390): ones on [L0:L0+n, L0:L0+n] and on
             # [0:L0, L0:L0+n]; n is read off the first caption row of the first sample and must describe the whole batch
-            n_tag = int((am[0, 0, max_length:] != 0).sum())
-            want = torch.zeros((T, T), dtype=am.dtype, device=am.device)
-            want[:max_length, :max_length] = torch.tril(torch.ones(max_length, max_length, dtype=am.dtype, device=am.device))
-            if n_tag:
-                want[max_length:max_length + n_tag, max_length:max_length + n_tag] = 1
-                want[:max_length, max_length:max_length + n_tag] = 1
-            if not bool((am == want.unsqueeze(0)).all()):
-                raise NotImplementedError(
-                    'attention_mask is neither the test-time seq2seq pattern (tril on the first %d caption slots, zeros elsewhere: '
-                    'dataset.py:377-390) nor that pattern with the first n tag slots visible to the caption and to each other '
-                    '(dataset.py:387-390); the HIP engine implements these two mask structures only' % max_length)
+            if not defer or not am.is_cuda:
+                n_tag = int((am[0, 0, max_length:] != 0).sum())
+                if defer and n_tag != int(expect_n_tag):
+                    raise ValueError('attention_mask shows %d visible tag slots, the batches before it showed %d' % (n_tag, int(expect_n_tag)))
+            want = self._text_mask_pattern(T, max_length, n_tag, am.dtype, am.device)
+            _verdict((am == want.unsqueeze(0)).all(), lambda: NotImplementedError(
+                'attention_mask is neither the test-time seq2seq pattern (tril on the first %d caption slots, zeros elsewhere: '
+                'dataset.py:377-390) nor that pattern with the first n tag slots visible to the caption and to each other '
+                '(dataset.py:387-390); the HIP engine implements these two mask structures only' % max_length))
             if n_tag > 50 or (n_tag and max_length != L.MAXLEN):
                 raise NotImplementedError('tag tokens visible to the caption need max_length == 20 and at most 50 tag slots')
         tt = data.get('token_type_ids')
-        if tt is not None and bool((tt != 0).any()):
-            raise NotImplementedError('token_type_ids must be all zero at test time (dataset.py:326); segment-1 text tokens are not built')
+        if tt is not None:
+            _verdict((tt == 0).all(), lambda: NotImplementedError(
+                'token_type_ids must be all zero at test time (dataset.py:326); segment-1 text tokens are not built'))
         ii = data.get('input_ids')
         if ii is not None and (ii.dim() != 2 or ii.shape[1] < max_length):
             raise ValueError('input_ids must be (B, T) with T >= max_length=%d, got %s' % (max_length, tuple(ii.shape)))
@@ -313,7 +338,7 @@ class ImageCaptioning(nn.Module):
             v = data.get(k)
             if v is not None and v.shape[0] != data['image'].shape[0]:
                 raise ValueError('%s has batch %d but image has %d' % (k, v.shape[0], data['image'].shape[0]))
-        return n_tag
+        return (n_tag, flag) if defer else n_tag
 
     def _check_image(self, image):
         if self._packed is None:

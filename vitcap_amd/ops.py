@@ -69,6 +69,14 @@ def gemm_bias_act(a, w, bias=None, residual=None, act=L.ACT_NONE, out_dtype=torc
     return out
 
 
+def gemm_tile_plan(M, N, K):
+    """(256-row m-tiles, height class of the tiles behind them: 0 none / 3 = 192 rows / 2 = 128 rows, their count) of the
+    256-column GEMM kernel for this problem on the current device (host-side query)."""
+    plan = (C.c_int * 3)()
+    check(lib.vitcap_gemm_tile_plan(int(M), int(N), int(K), plan), 'gemm_tile_plan')
+    return int(plan[0]), int(plan[1]), int(plan[2])
+
+
 def layernorm(x, gamma, beta, eps, want_bf16=True, want_f32=False):
     _dev_f32(x)
     M, D = x.shape

@@ -360,25 +360,53 @@ class CaptionUniPipeline(object):
         overlap = not te.get('do_sample', False)
         # the same option validation ImageCaptioning.forward applies (max_length, repetition_penalty, num_keep_best, use_cbs,
         # token ids ...): an option this build does not implement raises here instead of being decoded with defaults
-        popts = model.gen_options(gemm_mode=1) if overlap else None
+        base = model.gen_options(gemm_mode=1) if overlap else None
+        popts = {}                                # vitcap_gen_opts per number of visible tag slots: the caller's mask decides
+
+        def opts_for(n_tag):
+            if n_tag not in popts:
+                if base.tag_visible and n_tag != base.tag_visible:
+                    raise ValueError('test_extra_input tag_visible=%d but the attention_mask shows %d tag slots' % (base.tag_visible, n_tag))
+                popts[n_tag] = base if n_tag == base.tag_visible else model.gen_options(gemm_mode=1, tag_visible=n_tag)
+            return popts[n_tag]
+
+        def collect(entry):
+            b, out, flag = entry
+            out = out.result() if overlap else out          # synchronises with the batch's decode stream
+            if flag is not None and not bool(flag):
+                raise NotImplementedError('a batch\'s attention_mask / token_type_ids on the device do not describe the mask structure '
+                                          'the HIP engine implements (ImageCaptioning.check_text_inputs)')
+            return self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu()))
 
         def gen_rows():
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
+            n_seen = None                         # visible tag slots of the first batch whose text tensors live on the device
             with torch.no_grad():
                 for batch in self.iter_test_batches():
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
+                    flag = None
                     if overlap:
-                        model.check_text_inputs(batch, popts.max_length)
-                    pending.append((batch, model.generate_async(batch['image'], opts=popts) if overlap else model(batch)))
+                        # host tensors (what the loader yields) are checked on the host; tensors already on the device cost ONE host
+                        # synchronisation (the first batch, to read the number of visible tag slots), afterwards they are compared on
+                        # their stream and the verdict is read when the batch's captions are collected -- nothing stalls the
+                        # 2-slot pipeline
+                        am = batch.get('attention_mask')
+                        if am is not None and am.is_cuda and n_seen is not None:
+                            n_tag, flag = model.check_text_inputs(batch, base.max_length, expect_n_tag=n_seen)
+                        else:
+                            n_tag = model.check_text_inputs(batch, base.max_length)
+                            if am is not None and am.is_cuda:
+                                n_seen = n_tag
+                        out = model.generate_async(batch['image'], opts=opts_for(n_tag))
+                    else:
+                        out = model(batch)
+                    pending.append((batch, out, flag))
                     while len(pending) > (1 if overlap else 0):
-                        b, out = pending.pop(0)
-                        out = out.result() if overlap else out
-                        for key, js in self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu())):
+                        for key, js in collect(pending.pop(0)):
                             yield key, js
-                for b, out in pending:
-                    out = out.result() if overlap else out
-                    for key, js in self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu())):
+                for entry in pending:
+                    for key, js in collect(entry):
                         yield key, js
         tsv_writer(gen_rows(), sub)                 # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
         if self.world > 1:

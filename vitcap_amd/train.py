@@ -169,6 +169,30 @@ def grad_buckets(order, off, shape):
     return out
 
 
+def train_text_inputs_ok(batch):
+    """0-d bool tensor (on the device the batch's attention_mask lives on): True when `attention_mask` (B, L, L) and
+    `masked_pos` describe the training mask the kernels implement -- tril on the real caption rows ([CLS] .. [SEP]) of the
+    first 20 slots and zeros elsewhere, masked positions on real rows only (TrainEngine.check_text_inputs).  None when the
+    batch carries no attention_mask (or is a self-critical batch, which has no text inputs)."""
+    am = batch.get('attention_mask')
+    if am is None or 'sample_ids' in batch:
+        return None
+    if am.dim() != 3 or am.shape[1] != am.shape[2] or am.shape[1] < T:
+        raise NotImplementedError('training attention_mask must be the (B, L, L) seq2seq mask with L >= %d, got %s '
+                                  '(mask_type bidirectional is not built)' % (T, tuple(am.shape)))
+    Lm = am.shape[1]
+    a = am != 0
+    n_real = a[:, :T, :T].diagonal(dim1=1, dim2=2).sum(1)                         # real caption rows: [CLS] .. [SEP]
+    idx = torch.arange(Lm, device=am.device)
+    real = idx.view(1, Lm) < n_real.view(-1, 1)                                   # (B, L)
+    want = (idx.view(1, 1, Lm) <= idx.view(1, Lm, 1)) & real.unsqueeze(2) & real.unsqueeze(1)
+    ok = (a == want).all()
+    mp = batch.get('masked_pos')
+    if mp is not None:
+        ok = ok & ((mp != 0).to(am.device) <= real[:, :mp.shape[1]]).all()
+    return ok
+
+
 class _FusedLoss(torch.autograd.Function):
     """Loss tensor of a fused forward+backward: .backward() scales the gradients the engine already holds."""
     @staticmethod
@@ -188,8 +212,9 @@ class _FusedLoss(torch.autograd.Function):
         # communication stream: join it BEFORE touching G on the compute stream, or the multiply races with the reduce and the
         # ranks end up with different gradients
         eng.all_reduce_grads()
-        if float(g) != 1.0:                     # d(sum of losses)/d(masked_loss), 1 in do_train_dict (trainer.py:117-119)
-            eng.G.mul_(g.to(eng.G.dtype))
+        # d(sum of losses)/d(masked_loss): 1 in do_train_dict (trainer.py:117-119).  Applied on the device whatever its value --
+        # testing it on the host would be a device-to-host synchronisation per step right behind the gradient exchange
+        eng.G.mul_(g.to(eng.G.dtype))
         return None, None, None
 
 
@@ -236,6 +261,34 @@ class TrainEngine(object):
     def loss_dict(self, batch):
         """What ImageCaptioning.forward returns in training mode (..._bertemb.py:170-171)."""
         return {'masked_loss': _FusedLoss.apply(self._anchor, self, batch)}
+
+    def check_text_inputs(self, batch):
+        """The training kernels hard-wire the mask CaptionTensorizer.tensorize_ab builds for a caption without text_b
+        (dataset.py:377-390, mask_type seq2seq): token row i attends the visual rows and token rows <= i; rows behind the
+        caption's [SEP] are padding whose outputs the loss never reads.  A caller's `attention_mask` (B, L, L) is verified
+        against exactly that -- tril on the real caption rows, zeros elsewhere (no text_b columns, no seq2seq_off diagonal,
+        no bidirectional vector) -- and `masked_pos` must select real caption rows only; anything else is refused instead of
+        being trained with a different mask than the caller asked for.
+        Host tensors (what the loader yields) are checked on the host.  Tensors that already live on the device are checked
+        with a host read on the first step only; afterwards the comparison runs on their stream into a device counter that is
+        read every 50 steps (a per-step read would be a device-to-host synchronisation in front of every step)."""
+        ok = train_text_inputs_ok(batch)
+        if ok is None:
+            return
+        if not ok.is_cuda or not getattr(self, '_text_checked', False):
+            self._text_checked = True
+            if not bool(ok):
+                raise NotImplementedError(
+                    'training attention_mask / masked_pos do not describe the mask the HIP training kernels implement (tril on the '
+                    'real caption rows of the first %d slots, zeros elsewhere: tensorize_ab without text_b, mask_type seq2seq, '
+                    'dataset.py:377-390)' % T)
+            return
+        if getattr(self, '_text_bad', None) is None:
+            self._text_bad = torch.zeros((), dtype=torch.int32, device=ok.device)
+        self._text_bad += (~ok).to(torch.int32)
+        if self.step_no % 50 == 49 and int(self._text_bad) != 0:
+            raise NotImplementedError('a training batch of the last 50 steps carried an attention_mask / masked_pos the HIP '
+                                      'training kernels do not implement (TrainEngine.check_text_inputs)')
 
     # ------------------------------------------------------------------ views
     def p(self, k):
@@ -437,6 +490,7 @@ class TrainEngine(object):
         forwards the reference differentiates through (one full re-encode per generated token) collapse into ONE pass:
         the decoder runs on [578 visual | 20 token rows | 19 [MASK] probe rows], probe j sees tokens 0..j."""
         dev = self.dev
+        self.check_text_inputs(batch)
         img = batch['image']
         Be = img.shape[0]                       # images the encoder runs on
         KS = int(batch.get('seq_per_image', 1))   # decoder sequences per image (self-critical step: the samples of an image
