@@ -297,9 +297,10 @@ def apply_repetition_penalty(logits, prefix_ids, penalty):
 
 
 def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_start_posid=20,
-                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0, eos=EOS, n_tag_visible=0):
+                      reuse_encoder=False, return_trace=False, repetition_penalty=1.0, eos=EOS, n_tag_visible=0, max_steps=None):
     """Reference greedy decode.  ``reuse_encoder=True`` computes the (step-invariant) ViT encoder
-    once instead of 19 times -- same numbers, used only to keep CPU tests fast."""
+    once instead of 19 times -- same numbers, used only to keep CPU tests fast.  ``max_steps`` stops after that many
+    decode steps (bench.py's bounded CPU-baseline sample; the returned caption is then a prefix)."""
     B = image.shape[0]
     img_feats = patch_embed(sd, image)
     input_ids0, am = test_text_inputs(B, max_length, n_tag_visible=n_tag_visible)
@@ -338,6 +339,8 @@ def greedy_as_written(sd, image, tagemb='cls', max_length=MAX_LEN, od_labels_sta
             unfinished = unfinished * add.ne(eid).long()
         cur_len += 1
         if unfinished.max() == 0:
+            break
+        if max_steps is not None and cur_len - 1 >= max_steps:
             break
     if cur_len == max_length:
         ids[:, -1].masked_fill_(unfinished.bool(), _eos_list(eos)[0])
@@ -383,7 +386,7 @@ def encoder_incremental(sdw, image, r):
 
     residual stream x: fp32.  LN output, qkv, attention output, GELU output: bf16.
     GEMMs: bf16 operands, fp32 accumulate, fp32 bias/residual epilogue.
-    Softmax: scores fp32, P rounded to bf16 before P.V, row sum accumulated from the unrounded fp32 P.
+    Softmax: scores fp32, P rounded to bf16 before P.V, row sum accumulated from the same rounded P (dense kernel).
     """
     p = 'image_encoder.module.'
     B = image.shape[0]
@@ -415,23 +418,25 @@ def encoder_incremental(sdw, image, r):
 C_LOG2 = float(torch.tensor(0.125, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
 
 
-def softmax_pv_rounded(s_raw, v, r):
+def softmax_pv_rounded(s_raw, v, r, sum_rounded=False):
     """Device softmax.V in the log2 domain: m = ceil(max(s) * c) with c = fp32(0.125*log2 e) (row max rounded UP to
     an integer so every online-softmax rescale is an exact power of two), P = exp2(fma(s, c, -m)) -- the fused
-    multiply-add is reproduced exactly by doing it in float64 -- bf16(P) for the product, row sum from the unrounded
-    P.  Mathematically softmax(s/8) @ v (modeling_bert.py:320-336)."""
+    multiply-add is reproduced exactly by doing it in float64 -- bf16(P) for the product.  Row sum: from the unrounded
+    P in the decode-step kernels (vector ALU), from bf16(P) in the dense kernel (`sum_rounded`: it sums through the
+    matrix pipe, ones . P^T, csrc/attn.hip).  Mathematically softmax(s/8) @ v (modeling_bert.py:320-336)."""
     c32 = torch.tensor(C_LOG2, dtype=torch.float32)
     m = torch.ceil(s_raw.max(dim=-1, keepdim=True).values * c32)
     t = (s_raw.double() * float(C_LOG2) - m.double()).float()
     e = torch.exp2(t)
-    return (r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    den = r(e).sum(dim=-1, keepdim=True) if sum_rounded else e.sum(dim=-1, keepdim=True)
+    return (r(e) @ v) / den
 
 
 def attn_rounded(qkv, S, r):
     """softmax(QK^T/8)V over packed (B,S,2304) qkv with the device's rounding points."""
     B = qkv.shape[0]
     q, k, v = qkv.view(B, S, 3, HEADS, HD).permute(2, 0, 3, 1, 4)
-    o = softmax_pv_rounded(q @ k.transpose(-1, -2), v, r)
+    o = softmax_pv_rounded(q @ k.transpose(-1, -2), v, r, sum_rounded=True)
     return o.transpose(1, 2).reshape(B, S, HID)
 
 

@@ -118,7 +118,9 @@ def _reduce_worker(rank, world, port, out, algo='all_reduce'):
     for st in ('last', 'mid', 'first'):
         red.stage_done(st)
     red.finish()
-    out.put((rank, mine, flat.clone(), err, missing_caught, red.launched_bytes))
+    # plain numpy through the queue: a torch tensor travels as a file descriptor owned by THIS process, and the parent's q.get
+    # fails with FileNotFoundError when it runs after the worker has exited
+    out.put((rank, mine.numpy().copy(), flat.numpy().copy(), err, missing_caught, red.launched_bytes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -138,6 +140,7 @@ def test_bucketed_all_reduce_two_ranks_gloo(algo):
         p.join(60)
         assert p.exitcode == 0
     (_, m0, f0, e0, c0, nb), (_, m1, f1, e1, c1, _) = res
+    m0, f0, m1, f1 = (torch.from_numpy(a) for a in (m0, f0, m1, f1))
     assert e0 and 'out of order' in e0 and e1 and c0 and c1
     mean = (m0 + m1) / 2                        # after step 1 both hold the mean; step 2 averages two equal copies
     inside = torch.zeros(4096, dtype=torch.bool)

@@ -25,20 +25,59 @@ constexpr int HD = 64;          // head dim
 constexpr int NH = 12;          // heads
 constexpr int QKV_LD = 2304;    // packed row: [q | k | v] x [head][64]
 constexpr int KT = 64;          // keys per tile
-constexpr int LDS_ROW = 144;    // bytes per LDS row: 64 bf16 + 16 B pad (conflict-free ds_read_b128)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+// 16-byte chunk c of LDS row r (128 B = one key's 64 head dims) is stored at chunk c ^ kv_swz(r): the 16-lane groups of the
+// K fragment reads (ds_read_b128: 16 different rows, one chunk) and the 32-lane groups of the V transpose reads
+// (ds_read_b64_tr_b16: 4 consecutive rows x 64 B) then touch every bank once (MI355X_MICROARCH.md, LDS).
+__device__ __forceinline__ int kv_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// LDS transpose read as inline asm.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr16 INTRINSIC when an
+// LDS-DMA is in flight (it cannot tell that the DMA fills another ring slot; plain ds_read_b128 loads are not affected): the
+// tile just requested would be awaited before the current one is multiplied.  The asm form is invisible to that pass; its
+// results are fenced by an explicit lgkmcnt(0) (tr_fence) before the MFMAs that consume them.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr_read(uint32_t addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+constexpr int NSTG = 3;                  // K/V tile ring: tile t+2 is in flight while tile t is multiplied
+constexpr int TILE_B = KT * 128;         // one K (or V) tile: 64 keys x 128 B
+constexpr int STG_B = 2 * TILE_B;        // [K | V]
 
 // DROP: attention dropout of the decoder in training -- the probabilities that feed P.V are zeroed where
 // vc_drop_keep() says so and the output is scaled by 1/(1-p); the softmax statistics (and lse) are those of the
 // undropped row.
+//
+// Data path: K and V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write),
+// both ROW-major (key x 64 dims) with XOR-swizzled 16-byte chunks; S^T = K . Q^T reads K rows with ds_read_b128, and the
+// A operand of O^T += V^T . P^T is read TRANSPOSED straight from the row-major V tile (ds_read_b64_tr_b16: a 16-lane
+// group fetches 4 keys x 16 dims and lane i receives dim i of the 4 keys).  The C layout of S^T holds, per lane, keys
+// (r&3) + 8(r>>2) + 4 half of each 32-key block: exactly two runs of 4 consecutive keys per 16-key MFMA step, i.e. two
+// transpose reads -- P^T goes from the score registers into the next MFMA without any cross-lane traffic.
+// Row sums run through the matrix pipe as well: one more MFMA per 16-key block with an all-ones A operand accumulates
+// sum_k bf16(P) for the lane's query in every register of `lacc` (the loop is bound by vector-ALU issue; the matrix pipe
+// has room) -- so the normaliser is the sum of the ROUNDED probabilities the numerator uses.
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
                                                          int causal_from, int mask_from, int q_lo, int q_rows) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * LDS_ROW];   // [buf][K | V^T]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ __attribute__((aligned(1024))) char smem[NSTG * STG_B];   // [stage][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31, half = lane >> 5;
   // XCD-aware work mapping (1-D grid): workgroups are dealt round-robin to the 8 XCDs, so the q-blocks of one
   // (image, head) -- which share that head's K/V -- are made consecutive *within* an XCD and hit its L2 instead of
@@ -68,10 +107,6 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
     for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
   }
 
-  // staging maps
-  const int k_key = tid >> 2, k_d = (tid & 3) * 16;             // K: 2 x 16 B per thread
-  const int v_kg = tid & 15, v_dg = tid >> 4;                   // V: 4 keys x 4 d per thread
-  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);  // permuted key slot
   const int nfull = S / KT;                                     // tiles with 64 valid keys
   const int rem = S - nfull * KT;                               // 0..63 left-over keys
   // causal_from > 0 (decoder in training, rows [visual | caption]): keys >= causal_from are caption rows, visible only
@@ -79,133 +114,146 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
   const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);   // many left-overs: one masked MFMA tile
   const int ntiles = nfull + (tail_tile ? 1 : 0);
 
-  // tile sources = wave-uniform tile base (SGPR pair, advanced by the scalar unit) + per-lane 32-bit byte offsets that
-  // never change: no vector address arithmetic inside the loop
+  // ---- staging: each wave moves rows [8w, 8w+8) and [32+8w, 32+8w+8) of the K and of the V tile (4 LDS-DMA pieces of 1 KiB);
+  // lane l lands at LDS byte 16 l of the piece = row l>>3, physical chunk l&7, so it FETCHES logical chunk (l&7) ^ swz(row)
+  const int srow = w * 8 + (lane >> 3);                          // (row + 32 has the same swizzle)
+  const uint32_t s_off = (uint32_t)(srow * QKV_LD + 768) * 2u + (uint32_t)(((lane & 7) ^ kv_swz(srow)) * 16);
   const char* gbase = (const char*)base;
-  const uint32_t k_off = (uint32_t)(k_key * QKV_LD + 768 + k_d) * 2u;
-  const uint32_t v_off0 = (uint32_t)((v_kg * 4) * QKV_LD + 1536 + v_dg * 4) * 2u;
-  const uint32_t v_off1 = v_off0 + QKV_LD * 2u, v_off2 = v_off0 + 2u * QKV_LD * 2u, v_off3 = v_off0 + 3u * QKV_LD * 2u;
-  uint4 kreg0, kreg1;
-  uint2 vreg0, vreg1, vreg2, vreg3;
-#define LOAD_TILE_FAST(t_)                                                                      \
-  do {                                                                                          \
-    const char* tb_ = gbase + (size_t)(t_) * (KT * QKV_LD * 2);                                 \
-    kreg0 = *(const uint4*)(tb_ + k_off);                                                       \
-    kreg1 = *(const uint4*)(tb_ + k_off + 16);                                                  \
-    vreg0 = *(const uint2*)(tb_ + v_off0);                                                      \
-    vreg1 = *(const uint2*)(tb_ + v_off1);                                                      \
-    vreg2 = *(const uint2*)(tb_ + v_off2);                                                      \
-    vreg3 = *(const uint2*)(tb_ + v_off3);                                                      \
-  } while (0)
-#define LOAD_TILE_CLAMPED(kv0_)                                                                 \
-  do {                                                                                          \
-    int kr_ = (kv0_) + k_key;                                                                   \
-    kr_ = kr_ < S ? kr_ : S - 1;                                                                \
-    const bf16_t* kq_ = base + (size_t)kr_ * QKV_LD + 768 + k_d;                                \
-    kreg0 = *(const uint4*)kq_;                                                                 \
-    kreg1 = *(const uint4*)(kq_ + 8);                                                           \
-    const int v0_ = (kv0_) + v_kg * 4;                                                          \
-    const int r0_ = v0_ < S ? v0_ : S - 1, r1_ = v0_ + 1 < S ? v0_ + 1 : S - 1;                 \
-    const int r2_ = v0_ + 2 < S ? v0_ + 2 : S - 1, r3_ = v0_ + 3 < S ? v0_ + 3 : S - 1;         \
-    vreg0 = *(const uint2*)(base + (size_t)r0_ * QKV_LD + 1536 + v_dg * 4);                     \
-    vreg1 = *(const uint2*)(base + (size_t)r1_ * QKV_LD + 1536 + v_dg * 4);                     \
-    vreg2 = *(const uint2*)(base + (size_t)r2_ * QKV_LD + 1536 + v_dg * 4);                     \
-    vreg3 = *(const uint2*)(base + (size_t)r3_ * QKV_LD + 1536 + v_dg * 4);                     \
-  } while (0)
-#define LOAD_TILE(t_)                                  \
-  do {                                                 \
-    if ((t_) < nfull) LOAD_TILE_FAST(t_);              \
-    else LOAD_TILE_CLAMPED((t_) * KT);                 \
-  } while (0)
-  // K rows as they are; V transposed 4x4 per thread: vregJ = V[key J][d0..d0+3] -> rows d0+dd hold keys 0..3
-#define STORE_TILE(buf_)                                                                        \
-  do {                                                                                          \
-    char* kl_ = smem + (buf_) * (2 * KT * LDS_ROW);                                             \
-    char* vl_ = kl_ + KT * LDS_ROW;                                                             \
-    *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2) = kreg0;                                         \
-    *(uint4*)(kl_ + k_key * LDS_ROW + k_d * 2 + 16) = kreg1;                                    \
-    uint2 t0_, t1_, t2_, t3_;                                                                   \
-    t0_.x = __builtin_amdgcn_perm(vreg1.x, vreg0.x, 0x05040100);                                \
-    t0_.y = __builtin_amdgcn_perm(vreg3.x, vreg2.x, 0x05040100);                                \
-    t1_.x = __builtin_amdgcn_perm(vreg1.x, vreg0.x, 0x07060302);                                \
-    t1_.y = __builtin_amdgcn_perm(vreg3.x, vreg2.x, 0x07060302);                                \
-    t2_.x = __builtin_amdgcn_perm(vreg1.y, vreg0.y, 0x05040100);                                \
-    t2_.y = __builtin_amdgcn_perm(vreg3.y, vreg2.y, 0x05040100);                                \
-    t3_.x = __builtin_amdgcn_perm(vreg1.y, vreg0.y, 0x07060302);                                \
-    t3_.y = __builtin_amdgcn_perm(vreg3.y, vreg2.y, 0x07060302);                                \
-    char* vp_ = vl_ + (v_dg * 4) * LDS_ROW + v_pos * 2;                                         \
-    *(uint2*)(vp_) = t0_;                                                                       \
-    *(uint2*)(vp_ + LDS_ROW) = t1_;                                                             \
-    *(uint2*)(vp_ + 2 * LDS_ROW) = t2_;                                                         \
-    *(uint2*)(vp_ + 3 * LDS_ROW) = t3_;                                                         \
+#define STAGE_TILE(t_, stg_)                                                                                    \
+  do {                                                                                                          \
+    char* sb_ = smem + (stg_) * STG_B + w * 1024;                                                               \
+    if ((t_) < nfull) {                                                                                         \
+      const char* tb_ = gbase + (size_t)(t_) * (KT * QKV_LD * 2) + s_off;                                       \
+      glds16(tb_, sb_);                                                                                         \
+      glds16(tb_ + 32 * QKV_LD * 2, sb_ + 4096);                                                                \
+      glds16(tb_ + 768 * 2, sb_ + TILE_B);                                                                      \
+      glds16(tb_ + 768 * 2 + 32 * QKV_LD * 2, sb_ + TILE_B + 4096);                                             \
+    } else { /* tail tile: rows past the sequence re-read its last row (their scores are masked) */            \
+      const int r0_ = (t_) * KT + srow, r1_ = r0_ + 32;                                                         \
+      const uint32_t c_ = (uint32_t)(768 * 2 + ((lane & 7) ^ kv_swz(srow)) * 16);                               \
+      const char* a0_ = gbase + (size_t)(r0_ < S ? r0_ : S - 1) * (QKV_LD * 2) + c_;                            \
+      const char* a1_ = gbase + (size_t)(r1_ < S ? r1_ : S - 1) * (QKV_LD * 2) + c_;                            \
+      glds16(a0_, sb_);                                                                                         \
+      glds16(a1_, sb_ + 4096);                                                                                  \
+      glds16(a0_ + 768 * 2, sb_ + TILE_B);                                                                      \
+      glds16(a1_ + 768 * 2, sb_ + TILE_B + 4096);                                                               \
+    }                                                                                                           \
   } while (0)
 
-  f32x16 ot[2];
-  f32x16 zero16;
+  // fragment read offsets inside a stage (per lane, fixed): K row qi (+32 kt), chunk (2 ds + half) ^ swz(qi);
+  // V transpose read rd of a 16-key block: lane supplies row 8 rd + 4 half + j (j = (lane & 15) >> 2), 8 bytes at dims
+  // 32 dt + 16 ((lane >> 4) & 1) + 4 (lane & 3)
+  int koff[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) koff[ds] = qi * 128 + (((2 * ds + half) ^ kv_swz(qi)) * 16);
+  int voff[2][2];
+  {
+    const int j = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int r = 8 * rd + 4 * half + j;                       // row within the 16-key block (block base is a multiple of 16)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        voff[rd][dt] = TILE_B + r * 128 + (((c2 + 4 * dt) ^ kv_swz(r)) * 16) + (lane & 1) * 8;
+    }
+  }
+
+  f32x16 ot[2], lacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     ot[0][r] = 0.f;
     ot[1][r] = 0.f;
-    zero16[r] = 0.f;
+    lacc[r] = 0.f;
   }
   float m_i = -1e30f;   // running max, log2 domain, integer valued once set
-  float l_i = 0.f;      // this half-wave's partial row sum
+  float l_i = 0.f;      // left-over keys (vector ALU path): this half-wave's partial row sum
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-  if (ntiles > 0) LOAD_TILE(0);
-  // ---- left-over keys (S = 577/578 leaves 1/2) FIRST, while tile 0 is in flight: one online-softmax step per key on
-  // the vector ALU (the online softmax does not care about key order; done after the loop its two dependent global
-  // round trips were fully exposed, ~2 us of the ~8 us a workgroup spent outside its main loop).  The lane owns
-  // 32 of the 64 q dims (its partner lane^32 the rest) and 32 of the 64 output dims.
-  if (active && !tail_tile) {
-    for (int key = nfull * KT; key < S; ++key) {
-      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
+  // ---- left-over keys (S = 577/578 leaves 1/2) FIRST: one online-softmax step per key on the vector ALU (the online softmax
+  // does not care about key order).  The lane owns 32 of the 64 q dims (its partner lane^32 the rest) and 32 of the 64 output
+  // dims.  The first left-over key's K/V rows are requested BEFORE the first two tiles' LDS-DMA (loads retire in order: behind
+  // the tiles they would wait for 32 KB to land) and consumed after, so tiles 0 and 1 fly while the key is processed.
+  const int key0 = nfull * KT;
+  const bool left = active && !tail_tile && key0 < S;
+  bf16x8 lk[4];
+  bf16x4 lv[2][4];
+  if (left) {
+    const bf16_t* kr = base + (size_t)key0 * QKV_LD + 768 + half * 8;
+    const bf16_t* vr = base + (size_t)key0 * QKV_LD + 1536 + 4 * half;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) lk[ds] = *(const bf16x8*)(kr + ds * 16);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) lv[dt][g] = *(const bf16x4*)(vr + dt * 32 + g * 8);
+  }
+  if (ntiles > 0) STAGE_TILE(0, 0);
+  if (ntiles > 1) STAGE_TILE(1, 1);
+  if (left) {
+    for (int key = key0; key < S; ++key) {
+      if (key > key0) {
+        const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
+        const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) lk[ds] = *(const bf16x8*)(kr + ds * 16);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) lv[dt][g] = *(const bf16x4*)(vr + dt * 32 + g * 8);
+      }
       float sp = 0.f;
 #pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
+      for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sp += (float)qf[ds][j] * (float)kv[j];
-      }
+        for (int j = 0; j < 8; ++j) sp += (float)qf[ds][j] * (float)lk[ds][j];
       const float sc = sp + __shfl_xor(sp, 32, 64);
       const float m_new = fmaxf(m_i, ceilf(sc * c_log2));
-      const float alpha = fast_exp2(m_i - m_new);
+      const float alpha = fast_exp2(m_i - m_new);       // 0 for the first key (m_i = -1e30)
       m_i = m_new;
       const float pv = fast_exp2(fmaf(sc, c_log2, -m_new));
-      l_i = l_i * alpha + (half == 0 ? pv : 0.f);
-      float pb = (float)(__bf16)pv;
+      float pb = (float)(__bf16)pv;                      // the row sum counts the ROUNDED probability, as the MFMA path does
+      l_i = l_i * alpha + (half == 0 ? pb : 0.f);
       if (DROP) pb = vc_lowbias32((hq ^ (4u * half)) ^ (uint32_t)key) >= drop_thr ? pb : 0.f;
-      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + 4 * half;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x4 vv = *(const bf16x4*)(vr + dt * 32 + g * 8);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ot[dt][g * 4 + e] = fmaf(pb, (float)vv[e], ot[dt][g * 4 + e] * alpha);
-        }
+          for (int e = 0; e < 4; ++e) ot[dt][g * 4 + e] = fmaf(pb, (float)lv[dt][g][e], ot[dt][g * 4 + e] * alpha);
     }
   }
-
-  if (ntiles > 0) STORE_TILE(0);
-  // Every load so far (Q fragments, tile 0) must be provably complete on ALL paths into the loop: otherwise the
-  // compiler's waitcnt pass keeps the Q registers "possibly pending" across the loop and puts vmcnt(3..0) in front of
-  // the first four QK^T MFMAs of every iteration, i.e. it waits for the NEXT tile's loads before computing this one
-  // (found by reading the ISA; see DESIGN.md "waitcnt false dependency").
+  // Every VGPR load so far (Q fragments, left-over rows) must be provably complete on ALL paths into the loop: otherwise the
+  // compiler's waitcnt pass keeps those registers "possibly pending" across the loop and puts vmcnt(0) in front of the first
+  // MFMAs of every iteration, i.e. it waits for the tile it has just requested (DESIGN.md "waitcnt false dependency")
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  __syncthreads();
 
   // One key-tile step; MASKED_ is a literal so the left-over masking exists only in the peeled tail instance
   // (inside the loop hipcc if-converted it into 97 extra VALU ops per tile).
-#define TILE_COMPUTE(buf_, t_, MASKED_)                                                                         \
+#define TILE_COMPUTE(stg_, t_, MASKED_)                                                                         \
   do {                                                                                                          \
-    const char* kl = smem + (buf_) * (2 * KT * LDS_ROW);                                                        \
-    const char* vl = kl + KT * LDS_ROW;                                                                         \
+    const char* kl = smem + (stg_) * STG_B;                                                                     \
     f32x16 st[2];                                                                                               \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
-      const char* kr = kl + (kt * 32 + qi) * LDS_ROW + half * 16;                                               \
-      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr), qf[0], zero16, 0, 0, 0);           \
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],       \
+                                                       f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
       _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr + ds * 32), qf[ds], st[kt], 0, 0, 0); \
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[ds]), qf[ds], st[kt], 0, 0, 0); \
+    }                                                                                                           \
+    /* the 16 transpose reads of this tile's V fragments go out now: their latency hides behind the softmax */  \
+    s16x4 vt[4][2][2];                                                                                          \
+    {                                                                                                           \
+      const uint32_t vb_ = lds_addr(kl);                                                                        \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                          \
+        _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {                                                      \
+          const uint32_t a_ = vb_ + (uint32_t)voff[rd][dt];                                                     \
+          vt[0][dt][rd] = lds_tr_read<0>(a_);                                                                   \
+          vt[1][dt][rd] = lds_tr_read<2048>(a_);                                                                \
+          vt[2][dt][rd] = lds_tr_read<4096>(a_);                                                                \
+          vt[3][dt][rd] = lds_tr_read<6144>(a_);                                                                \
+        }                                                                                                       \
     }                                                                                                           \
     if (MASKED_) {                                                                                              \
       const int kv0 = (t_) * KT;                                                                                \
@@ -231,58 +279,63 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const bf16_t* __restric
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
         ot[0][r] *= alpha;                                                                                      \
         ot[1][r] *= alpha;                                                                                      \
+        lacc[r] *= alpha;                                                                                       \
       }                                                                                                         \
       m_i = m_new;                                                                                              \
     }                                                                                                           \
-    /* P = exp2(s*c - m) with one fma per score; row sum from the unrounded P */                                \
+    /* P = exp2(s*c - m) with one fma per score */                                                              \
     const float nm = -m_i;                                                                                      \
-    float ps0 = 0.f, ps1 = 0.f;                                                                                 \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
-      _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                       \
-        const float p0 = fast_exp2(fmaf(st[kt][r], c_log2, nm));                                                \
-        const float p1 = fast_exp2(fmaf(st[kt][r + 1], c_log2, nm));                                            \
-        st[kt][r] = p0;                                                                                         \
-        st[kt][r + 1] = p1;                                                                                     \
-        ps0 += p0;                                                                                              \
-        ps1 += p1;                                                                                              \
-      }                                                                                                         \
-    l_i += ps0 + ps1;                                                                                           \
-    if (DROP) {                                                                                                 \
-      const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                           \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-          const uint32_t kbits = (uint32_t)(kt * 32 + (r & 3) + 8 * (r >> 2));                                  \
-          st[kt][r] = vc_lowbias32(hx ^ kbits) >= drop_thr ? st[kt][r] : 0.f;                                   \
-        }                                                                                                       \
-    }                                                                                                           \
-    /* O^T += V^T . P^T over the four 16-key blocks */                                                          \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kt][r] = fast_exp2(fmaf(st[kt][r], c_log2, nm));        \
+    /* O^T += V^T . P^T over the four 16-key blocks; row sums: ones . P^T */                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                         \
+                 : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),                  \
+                   "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),                  \
+                   "+v"(vt[2][0][0]), "+v"(vt[2][0][1]), "+v"(vt[2][1][0]), "+v"(vt[2][1][1]),                  \
+                   "+v"(vt[3][0][0]), "+v"(vt[3][0][1]), "+v"(vt[3][1][0]), "+v"(vt[3][1][1]));                 \
+    const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                             \
     _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
       const int kt = kb >> 1, ks = kb & 1;                                                                      \
       bf16x8 pf;                                                                                                \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];                         \
+      lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);                                  \
+      if (DROP) {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
+          const int r = ks * 8 + j;                                                                             \
+          const uint32_t kbits = (uint32_t)(kt * 32 + (r & 3) + 8 * (r >> 2));                                  \
+          pf[j] = vc_lowbias32(hx ^ kbits) >= drop_thr ? pf[j] : (__bf16)0.0f;                                  \
+        }                                                                                                       \
+      }                                                                                                         \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
-        const bf16x8 vf = *(const bf16x8*)(vl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);           \
-        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);                              \
+        const s16x8 v8 = __builtin_shufflevector(vt[kb][dt][0], vt[kb][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);         \
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);  \
       }                                                                                                         \
     }                                                                                                           \
   } while (0)
 
+  int stg = 0;                       // ring slot of tile t (wave-uniform)
   for (int t = 0; t < nfull; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) LOAD_TILE(t + 1);
-    if (active) TILE_COMPUTE(buf, t, false);
-    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
+    // tile t landed (this wave's 4 pieces; tile t+1's 4 may stay in flight), then for every wave -- and every wave is done
+    // with tile t-1, whose slot tile t+2 is about to overwrite
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const int stg2 = stg == 0 ? 2 : stg - 1;                     // (stg + 2) % 3
+    if (t + 2 < ntiles) STAGE_TILE(t + 2, stg2);
+    if (active) TILE_COMPUTE(stg, t, false);
+    stg = stg == 2 ? 0 : stg + 1;
   }
-  if (tail_tile && active) TILE_COMPUTE(nfull & 1, nfull, true);
+  if (tail_tile) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) TILE_COMPUTE(stg, nfull, true);
+  }
 #undef TILE_COMPUTE
-#undef LOAD_TILE
-#undef LOAD_TILE_FAST
-#undef LOAD_TILE_CLAMPED
-#undef STORE_TILE
+#undef STAGE_TILE
 
-  // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]
-  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+  // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]; every register of lacc holds the MFMA part of
+  // the row sum, l_i the left-over keys' part (one half-wave)
+  const float l_tot = lacc[0] + l_i + __shfl_xor(l_i, 32, 64);
   const float inv = DROP ? drop_scale / l_tot : 1.0f / l_tot;
   const int q = q0 + qi;
   if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)
