@@ -3,6 +3,8 @@
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...      (no WORLD_SIZE in the environment: the process starts that torch.distributed.run
+                                     command itself as a CHILD, before it has touched a GPU, and exits with its code)
 
 One "step" = one pass of the captioning hot path (patch embed -> 16 ViT blocks -> tag head -> decoder
 prefill -> 19 incremental decode steps with device-side greedy bookkeeping) over one batch of 64 synthetic
@@ -217,6 +219,35 @@ def bench_scst(args, rank, world, local, dist, D):
         dist.destroy_process_group()
 
 
+def bench_stub(args, rank, world, D):
+    """The bench's launch / timing protocol on a CPU stand-in (gloo): warm-up, barrier, K timed steps, barrier, MAX over ranks,
+    one JSON line from rank 0.  Exists so that the N > 1 entry (self-launch included) is covered by a test without a GPU; the
+    line says so and carries no roofline."""
+    dist = D.init('gloo') if world > 1 else None
+    x = torch.ones(256, 256)
+
+    def step():
+        return float((x @ x).sum())
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0 + 1e-3 * rank, dist)
+    if rank == 0:
+        print(json.dumps({'metric': 'stub steps/sec (plumbing test, not a measurement)', 'value': round(D.whole_job_rate(1, args.steps, world, elapsed), 2),
+                          'unit': 'steps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': {'workload': 'stub (CPU, gloo)'}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -234,11 +265,30 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1: two-slot batch pipeline (encode+prefill of step i+1 overlaps the decode of step i on a second '
                          'stream; same results); 0: one stream, steps strictly back to back')
+    ap.add_argument('--stub', action='store_true',
+                    help='CPU stand-in for the workload (tests of the launch / barrier / max-over-ranks / JSON plumbing only: gloo, no '
+                         'GPU, no kernels; never a measurement)')
     args = ap.parse_args()
 
     from vitcap_amd import dist_util as D
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Started as plain `python bench.py --gpus N`: run one rank per GPU under torch.distributed.run as a CHILD process and
+        # hand back its exit code.  Nothing in this process has initialised the GPU yet (importing torch does not), and it never
+        # will: replacing a process that has touched the GPU (exec) takes the node down on this pool, a child does not.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        sys.exit(subprocess.call(cmd, env=env))
     rank, world, local = D.env_rank_world()
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node == --gpus'
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus' % (args.gpus, world)
+    if args.stub:
+        return bench_stub(args, rank, world, D)
     torch.cuda.set_device(local)
     dist = D.init('nccl', torch.device('cuda', local)) if world > 1 else None
 

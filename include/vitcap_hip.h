@@ -416,7 +416,8 @@ typedef struct vitcap_gen_opts {
                                  modeling_bert.py:976-994; the copies share the image's encoder output and visual K/V)  */
   int32_t num_keep_best;      /* BeamHypotheses.n_hyp, 1..8; > 1 needs num_beams > 1 (modeling_utils.py:790)            */
   int32_t max_length;         /* 2..VITCAP_MAXLEN_CAP; output rows are max_length wide                                  */
-  int32_t bos_token_id, eos_token_id, pad_token_id, mask_token_id;   /* 101 / 102 / 0 / 103; eos_token_ids has one entry */
+  int32_t bos_token_id, eos_token_id, pad_token_id, mask_token_id;   /* 101 / 102 / 0 / 103; eos_token_id = eos_token_ids[0]
+                                                                        (further ids: eos_extra below)                     */
   float length_penalty;       /* beam search                                                                            */
   float repetition_penalty;   /* CTRL penalty, 1 = off (modeling_utils.py:828-836, 955-963)                             */
   vitcap_sample_params sampling;   /* do_sample / temperature / top_k / top_p / seed (with num_beams > 1: beam sampling) */
@@ -438,6 +439,9 @@ typedef struct vitcap_gen_opts {
   int32_t encode_parts;       /* encoder + prefill of the batch as 1..4 independent chains of batch parts on separate streams
                                  (engine-owned, forked from / joined to the caller's): one part's GEMM tails are filled by
                                  the other's kernels (2 parts: +1..2 % images/s at 32..128 images); 0 = auto = 1.  Same results.  */
+  int32_t eos_extra[3];       /* eos_token_ids[1..3], -1 = unused: the greedy / sampling loop finishes a sequence at ANY of the ids
+                                 (modeling_utils.py:862-865) and forces eos_token_ids[0] at the last position (:870-871).  Needs
+                                 num_beams == 1: the reference's beam search asserts with several ids (modeling_utils.py:1037).  */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */

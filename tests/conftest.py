@@ -61,7 +61,8 @@ def relevant_margins(want_row, margins_row, eos):
     import numpy as np
     m = np.array(margins_row, dtype=np.float64)
     L = len(want_row)
-    hits = [k for k in range(1, L) if want_row[k] == eos]
+    eos_set = set(int(e) for e in eos) if isinstance(eos, (list, tuple, set)) else {int(eos)}     # eos_token_ids may hold several ids
+    hits = [k for k in range(1, L) if int(want_row[k]) in eos_set]
     end = hits[0] if hits else L - 1           # position of the terminating EOS (chosen or forced)
     m[end:] = np.inf                           # decisions for positions > end
     if not hits or hits[0] == L - 1:

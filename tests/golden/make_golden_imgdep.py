@@ -1,0 +1,159 @@
+"""Image-dependent golden family (container only; imports /root/reference through make_golden.py's shims).
+
+Run:  python tests/golden/make_golden_imgdep.py        (writes tests/golden/reference_imgdep.npz)
+
+Why: on uniform-noise images a random-init model's captions hardly depend on the image (near-uniform attention summarises
+every noise image to the same vector: the round-2 goldens share 17 of 19 tokens), so token-exact parity on them says little about
+the encoder, the visual K/V or cross-attention.  This family uses STRUCTURED images (vitcap_amd.weights.gen_structured_images:
+per-image colour offsets and 64-pixel colour blocks): the reference's captions then differ between images in most positions --
+asserted below -- and an error in anything image-dependent moves tokens.
+
+Contents (all produced by the REFERENCE's own modules on the seeded recipe):
+  sel_index                 4 of 48 candidate images (seed 777): among those whose every greedy decision clears the bf16 noise
+                            floor, the quadruple whose captions differ most from each other (selection by the oracle's fp32
+                            incremental path, which is token-exact with the reference)
+  greedy_ids/logprobs/margins          tied / tagemb='cls' pipeline flow on those 4 images
+  step_logits[step][image][col]        the reference's own [MASK]-row logits at decode steps 1, 5, 10, 19 on a fixed column
+                                       subset (every 15th column + each row's 8 largest), for direct float comparison per step
+  beam5_ids/logprobs/margins           beam = 5 on the 2 best-conditioned images
+  multi_eos_ids/logprobs/margins       greedy with eos_token_ids = [102, a, b] (a list of three: sequences stop at any of them)
+  untied_ids/logprobs/margins          notebook flow (untied LM head, tagemb=None) with vocabulary-bias sigma 0.25 so that the
+                                       caption does not end at the second token (the sigma-1 recipe's [SEP] bias wins at once)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G      # noqa: E402  (shims + reference builders; importing it runs nothing)
+
+STEPS = (1, 5, 10, 19)
+COLS = np.arange(0, 30522, 15)
+
+
+class _LogitRecorder(object):
+    """Keeps the rows the reference's greedy loop hands to torch.argmax (modeling_utils.py:846) at the wanted steps."""
+
+    def __init__(self, steps):
+        self.steps, self.rows, self.n = set(steps), {}, 0
+
+    def __enter__(self):
+        self._argmax = torch.argmax
+        rec = self
+
+        def argmax(x, *a, **k):
+            if x.dim() == 2 and x.shape[-1] == 30522:
+                rec.n += 1
+                if rec.n in rec.steps:
+                    rec.rows[rec.n] = x.detach().clone()
+            return rec._argmax(x, *a, **k)
+        torch.argmax = argmax
+        return self
+
+    def __exit__(self, *exc):
+        torch.argmax = self._argmax
+
+
+def main():
+    G.install_shims()
+    from vitcap_amd import weights as W
+    from oracle import vitcap_oracle as O
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out = {}
+    sd_np = W.make_state_dict(seed=0, tie_weights=True)
+    model, enc = G.build_reference('cls', True)
+    G.load_recipe(model, enc, sd_np)
+    cand = torch.from_numpy(W.gen_structured_images(48, 777))
+    sd_t = O.to_torch(sd_np)
+    with torch.no_grad():
+        oids, _, tr = O.greedy_incremental(sd_t, cand, emulate_bf16=False, return_trace=True)
+    cm = torch.stack([st['margin'] for st in tr['steps']], 1).min(1).values
+    ocap = oids[:, 0].numpy()
+    ok = [i for i in range(len(cand)) if float(cm[i]) >= 0.0135]     # whole-caption comparable with head-room over the 0.012 floor
+    print('candidate min margins', [round(float(x), 4) for x in cm], 'comparable', ok)
+
+    def dist(i, j):
+        return float((ocap[i, 1:19] != ocap[j, 1:19]).mean())
+    # the 4 comparable images whose captions differ most from each other (max-min pairwise distance, exhaustive)
+    import itertools
+    best, best_d = None, -1.0
+    for quad in itertools.combinations(ok, 4):
+        d = min(dist(a, b) for a, b in itertools.combinations(quad, 2))
+        if d > best_d:
+            best, best_d = quad, d
+    sel = torch.tensor(sorted(best))
+    print('selected', sel.tolist(), 'min pairwise differing fraction (oracle captions)', best_d)
+    with _LogitRecorder(STEPS) as lrec:
+        ids, lp, m = G.ref_generate(model, enc, cand[sel])
+    caps = ids[:, 0].numpy()
+    differing = [float((caps[i, 1:19] != caps[j, 1:19]).mean()) for i in range(4) for j in range(i)]
+    print('greedy', caps.tolist(), lp.tolist(), 'min margin', m.min(1).tolist(), 'pairwise differing positions', differing)
+    assert min(differing) >= 0.5, 'the captions of this family must differ between images in most positions'
+    assert float(m.min()) >= 0.012, 'every selected image must be whole-caption comparable (tests/conftest.py floor)'
+    out['image_seed'] = np.array([777])
+    out['sel_index'] = sel.numpy().copy()
+    out['greedy_ids'] = ids.numpy().copy()
+    out['greedy_logprobs'] = lp.numpy().copy()
+    out['greedy_margins'] = m
+    out['step_list'] = np.array(STEPS)
+    cols = []
+    for s in STEPS:
+        row = lrec.rows[s]
+        top = torch.topk(row, 8, dim=-1).indices.numpy()
+        cols.append(np.stack([np.unique(np.concatenate([COLS, top[b]]))[:len(COLS) + 8] if len(np.unique(np.concatenate([COLS, top[b]]))) >= len(COLS) + 8
+                              else np.pad(np.unique(np.concatenate([COLS, top[b]])), (0, len(COLS) + 8 - len(np.unique(np.concatenate([COLS, top[b]])))), mode='edge')
+                              for b in range(4)]))
+    cols = np.stack(cols)                                           # (steps, 4, ncol)
+    out['step_cols'] = cols.astype(np.int32)
+    out['step_logits'] = np.stack([np.stack([lrec.rows[s][b].numpy()[cols[i, b]] for b in range(4)]) for i, s in enumerate(STEPS)]).astype(np.float32)
+    out['step_logit_std'] = np.array([float(lrec.rows[s].std()) for s in STEPS], dtype=np.float32)
+    # beam 5 on the two best-conditioned images
+    best2 = sel[torch.argsort(cm[sel], descending=True)[:2]].sort().values      # the two largest margins among the selected
+    ids, lp, m = G.ref_generate(model, enc, cand[best2], num_beams=5)
+    print('beam5', ids.tolist(), lp.tolist(), 'min gap', m.min(1).tolist())
+    out['beam_index'] = best2.numpy().copy()
+    out['beam5_ids'] = ids.numpy().copy()
+    out['beam5_logprobs'] = lp.numpy().copy()
+    out['beam5_margins'] = m
+    # several EOS ids (eos_token_ids with more than one entry, modeling_utils.py:862-871): a sequence stops at ANY of them.  Besides
+    # [SEP], one token taken from image 1's caption and one from image 2's, neither occurring in the captions of images 0 and 3:
+    # two sequences stop early at different ids, two run to the forced [SEP]
+    cap = out['greedy_ids'][:, 0]
+
+    def pick(b, avoid):
+        for k in range(2, 18):
+            t = int(cap[b, k])
+            if t not in (0, 101, 102) and t not in avoid and t not in cap[0] and t not in cap[3]:
+                return t
+        raise RuntimeError('no usable token')
+    e1 = pick(1, ())
+    e2 = pick(2, (e1,))
+    ids, lp, m = G.ref_generate(model, enc, cand[sel], eos_token_ids=[102, e1, e2])
+    print('multi eos', [102, e1, e2], ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    assert len(set(int((r != 0).sum()) for r in ids[:, 0])) >= 3, 'the sequences should end at different lengths'
+    out['multi_eos_ids_list'] = np.array([102, e1, e2])
+    out['multi_eos_ids'] = ids.numpy().copy()
+    out['multi_eos_logprobs'] = lp.numpy().copy()
+    out['multi_eos_margins'] = m
+    # notebook flow, untied, vocabulary-bias sigma 0.25: a caption of several tokens
+    sd2 = W.make_state_dict(seed=0, tie_weights=False, vbias_std=0.25)
+    model2, enc2 = G.build_reference(None, False)
+    G.load_recipe(model2, enc2, sd2)
+    ids, lp, m = G.ref_generate(model2, enc2, cand[sel][:2])
+    print('untied sigma 0.25', ids.tolist(), lp.tolist(), 'min margin', m.min(1).tolist())
+    assert int((ids[:, 0] != 0).sum(1).min()) > 4, 'the untied golden should run for several tokens'
+    out['untied_vbias_std'] = np.array([0.25], dtype=np.float32)
+    out['untied_ids'] = ids.numpy().copy()
+    out['untied_logprobs'] = lp.numpy().copy()
+    out['untied_margins'] = m
+    out['torch_version'] = np.array([torch.__version__])
+    np.savez_compressed(os.path.join(HERE, 'reference_imgdep.npz'), **out)
+    print('wrote reference_imgdep.npz')
+
+
+if __name__ == '__main__':
+    main()

@@ -94,7 +94,7 @@ def test_struct_sizes_match_header(L):
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
     assert C.sizeof(L.GemmDesc) == 16 * 4 + 16          # 15 ints, padding, two pointers (live, rowstat)
-    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4
+    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4
 
 
 def test_model_surface(L, sd_np):

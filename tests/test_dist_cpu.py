@@ -149,3 +149,26 @@ def test_bucketed_all_reduce_two_ranks_gloo(algo):
     assert torch.allclose(f0[inside], mean[inside]) and torch.equal(f0[inside], f1[inside])
     assert torch.equal(f0[~inside], m0[~inside]) and torch.equal(f1[~inside], m1[~inside])   # untouched outside buckets
     assert nb == int(inside.sum()) * 4
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver calls --gpus 1) must start the two ranks
+    itself -- as a child torch.distributed.run, before the parent touches a GPU -- and print ONE JSON line from rank 0.  Driven on
+    the CPU stand-in workload (gloo); the launch path is the one the GPU workloads use."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
+    assert rec['value'] > 0 and abs(rec['value'] - 2 * 3 / (rec['ms_per_step'] * 3e-3)) < 1e-2 * rec['value'] + 1.0
+    # a world size that contradicts --gpus is refused, not silently benchmarked
+    bad = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--stub', '--steps', '1'],
+                         env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr

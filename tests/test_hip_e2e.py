@@ -29,6 +29,13 @@ pytestmark = pytest.mark.gpu
 # 3.9e-3 relative L2 against the emulation, 5.6e-3 against fp32).  The same floors apply as against the reference.
 MARGIN_TOL = GREEDY_MARGIN_FLOOR
 BEAM_GAP_TOL = BEAM_MARGIN_FLOOR
+# beam goldens (name, image) accepted on score evidence instead of identical ids -- reviewed exceptions only; empty = all exact
+BEAM_SCORE_ONLY_OK = {
+    # round 3 (dense attention now sums the bf16-ROUNDED probabilities through the matrix pipe): image 1 of beam5_b2 resolves a
+    # 9.2e-6 decision gap (floor 3e-2) the other way; best score -6.44116 vs the reference's -6.44042
+    ('beam5_b2', 1),
+    ('beam3_alteos_b2', 1),      # the same image and the same 9.2e-6 gap (the alternative EOS is not reached before it)
+}
 
 
 @pytest.fixture(scope='module')
@@ -127,6 +134,121 @@ def test_untied_notebook_flow_equals_reference(golden):
     assert np.array_equal(ids1.cpu().numpy(), vec['greedy_untied_nocls_b1_ids'])
 
 
+# ------------------------------------------------------------------------------------------------ image-dependent family
+@pytest.fixture(scope='module')
+def imgdep():
+    """tests/golden/reference_imgdep.npz (make_golden_imgdep.py): the reference on STRUCTURED images, whose captions differ between
+    images in most positions -- parity on them is sensitive to everything image-dependent (encoder, visual K/V, cross-attention)."""
+    import os
+    from vitcap_amd import weights as W
+    vec = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_imgdep.npz')))
+    cand = torch.from_numpy(W.gen_structured_images(48, int(vec['image_seed'][0])))
+    return vec, cand
+
+
+def test_image_dependent_captions_equal_reference(model, imgdep):
+    """Whole captions, token for token, on four images whose reference captions share at most 2 of 18 positions pairwise; every
+    decision clears the bf16 noise floor (min margin 0.0185), so nothing is excused."""
+    vec, cand = imgdep
+    want = vec['greedy_ids']
+    caps = want[:, 0]
+    assert min(float((caps[i, 1:19] != caps[j, 1:19]).mean()) for i in range(4) for j in range(i)) >= 0.5
+    assert float(vec['greedy_margins'].min()) > GREEDY_MARGIN_FLOOR
+    img = cand[torch.from_numpy(vec['sel_index'])].cuda()
+    ids, lp = model({'image': img, 'key': [0, 1, 2, 3]})
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), want, vec['greedy_margins'], GREEDY_MARGIN_FLOOR, min_full=4,
+                                        what='image-dependent goldens')
+    assert all(r[4] for r in rep)
+    np.testing.assert_allclose(lp.cpu().numpy(), vec['greedy_logprobs'], rtol=0, atol=1e-2)
+    # the same images one at a time (other batch composition, other tile plans): identical ids
+    ids1, _ = model.generate(img[2:3].contiguous())
+    assert torch.equal(ids1.cpu(), ids[2:3].cpu())
+
+
+@pytest.mark.parametrize('step_i', [0, 1, 2, 3])
+def test_per_step_logits_vs_reference(model, imgdep, step_i):
+    """The [MASK]-row logits the reference's greedy loop hands to argmax at decode steps 1, 5, 10 and 19 (recorded while the
+    reference ran) against the device's logits of the same step: a run with max_length = step + 1 ends at that step, and the
+    engine keeps the last step's row.  Tolerance = the measured bf16 noise on a logit (1.8e-3 rms / 9e-3 max, DESIGN.md
+    section 5) with a factor of two of head-room; the reference's 8 largest logits of every row are among the compared columns."""
+    vec, cand = imgdep
+    step = int(vec['step_list'][step_i])
+    img = cand[torch.from_numpy(vec['sel_index'])].cuda()
+    opts = model.gen_options(max_length=step + 1)
+    ids, _ = model.run(img, opts)
+    torch.cuda.synchronize()
+    # the prefix decided so far must be the reference's (else the rows are not comparable)
+    assert np.array_equal(ids.cpu().numpy()[:, 0, :step], vec['greedy_ids'][:, 0, :step])
+    logits = model.tap('logits_last', 4, (4, 30592), opts=opts).cpu().numpy()
+    cols, want = vec['step_cols'][step_i], vec['step_logits'][step_i]
+    got = np.take_along_axis(logits, cols.astype(np.int64), axis=1)
+    err = got - want
+    rms, mx = float(np.sqrt((err ** 2).mean())), float(np.abs(err).max())
+    print('step %d logits vs reference: rms %.3e max %.3e (row std %.3f)' % (step, rms, mx, float(vec['step_logit_std'][step_i])))
+    assert rms < 4e-3 and mx < 2e-2
+
+
+def test_several_eos_ids_equal_reference(model, imgdep):
+    """eos_token_ids = [102, a, b] (modeling_utils.py:862-871): a sequence finishes at ANY of the ids and the forced token at the
+    last position is the first id.  Reference golden on the four structured images: two stop early at different ids, two run to
+    the end; the early-exit counter and the PAD fill behind a finished row ride along.  Also: the sampling loop takes the list
+    (same bookkeeping kernel family), beam search refuses it like the reference's own assert does."""
+    vec, cand = imgdep
+    eos = [int(x) for x in vec['multi_eos_ids_list']]
+    img = cand[torch.from_numpy(vec['sel_index'])].cuda()
+    ids, lp = model.generate(img, eos_token_ids=eos)
+    want = vec['multi_eos_ids']
+    lens = sorted(int((r != 0).sum()) for r in want[:, 0])
+    assert lens[0] < lens[-1]
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), want, vec['multi_eos_margins'], GREEDY_MARGIN_FLOOR, min_full=3,
+                                        what='several EOS ids', eos=eos)
+    print('several EOS ids', eos, rep)
+    full = [r[0] for r in rep if r[4]]
+    np.testing.assert_allclose(lp.cpu().numpy()[full], vec['multi_eos_logprobs'][full], rtol=0, atol=1e-2)
+    ids_off, _ = model.generate(img, eos_token_ids=eos, early_exit=False)
+    assert torch.equal(ids_off, ids)
+    ids_s, _ = model.generate_multi(img, 2, eos_token_ids=eos, seed=3, temperature=0.7)
+    got = ids_s.cpu().numpy()[:, 0]
+    for r in got:       # after the first EOS id of the list only PAD may follow
+        hit = [k for k in range(1, 20) if int(r[k]) in eos]
+        assert hit and all(int(t) == 0 for t in r[hit[0] + 1:])
+    with pytest.raises(NotImplementedError, match='num_beams == 1'):
+        model.generate_beam(img, 3, eos_token_ids=eos)
+
+
+def test_image_dependent_beam5_equals_reference(model, imgdep):
+    vec, cand = imgdep
+    img = cand[torch.from_numpy(vec['beam_index'])].cuda()
+    ids, lp = model.generate_beam(img, 5)
+    got, want = ids.cpu().numpy(), vec['beam5_ids']
+    for b in range(2):
+        same = bool((got[b] == want[b]).all())
+        print('imgdep beam5 image %d: ids equal %s, score %.5f vs %.5f (min gap %.2e)' % (b, same, float(lp[b, 0]), float(vec['beam5_logprobs'][b, 0]),
+                                                                                       float(vec['beam5_margins'][b].min())))
+        if ('imgdep_beam5', b) in BEAM_SCORE_ONLY_OK:
+            assert same or abs(float(lp[b, 0]) - float(vec['beam5_logprobs'][b, 0])) < 1e-2
+        else:
+            assert same, 'imgdep beam5 image %d no longer matches the reference exactly: review, then list it in BEAM_SCORE_ONLY_OK' % b
+        assert abs(float(lp[b, 0]) - float(vec['beam5_logprobs'][b, 0])) < 2e-2
+
+
+def test_untied_flow_multi_token_caption(imgdep):
+    """The notebook flow (untied LM head, tagemb=None) on a recipe whose vocabulary-bias sigma (0.25) lets the caption run for
+    15-19 tokens (with sigma 1 the [SEP] bias wins at the second token): comparable prefixes of 4 and 13 decisions here."""
+    from vitcap_amd.model import ImageCaptioning
+    vec, cand = imgdep
+    m = ImageCaptioning(tie_weights=False, tagemb=None).load_recipe(0, vbias_std=float(vec['untied_vbias_std'][0])).eval()
+    m.pack('cuda')
+    img = cand[torch.from_numpy(vec['sel_index'])][:2].cuda()
+    ids, lp = m({'image': img, 'key': [0, 1]})
+    rep = assert_tokens_match_reference(ids.cpu().numpy(), vec['untied_ids'], vec['untied_margins'], GREEDY_MARGIN_FLOOR, min_full=0,
+                                        what='untied flow, sigma 0.25')
+    print('untied sigma 0.25 (sequence, comparable decisions, whole, prefix ok, whole caption equal):', rep)
+    assert sum(r[1] for r in rep) >= 8, 'too few comparable decisions to mean anything'
+    if all(r[4] for r in rep):
+        np.testing.assert_allclose(lp.cpu().numpy(), vec['untied_logprobs'], rtol=0, atol=1e-2)
+
+
 @pytest.mark.parametrize('name,beams', [('beam2_b1', 2), ('beam5_b1', 5), ('beam5_b2', 5), ('beam5_sel', 5), ('beam3_alteos_b2', 3)])
 def test_beam_search_vs_reference_goldens(model, golden, name, beams):
     """a13 against the reference's own beam output.  Beam decisions on random-init logits are ill-conditioned (the stored
@@ -145,8 +267,48 @@ def test_beam_search_vs_reference_goldens(model, golden, name, beams):
                                                                                          float(got_lp[b, 0]), float(want_lp[b, 0])))
         if float(gaps[b].min()) >= BEAM_MARGIN_FLOOR:
             assert same, 'beam result differs from the reference although every decision gap clears the floor'
-        assert same or abs(float(got_lp[b, 0]) - float(want_lp[b, 0])) < 1e-2
+        # Expected state, recorded: EVERY beam golden is reproduced token for token.  None of them is gap-comparable (random-init
+        # logits leave decision gaps of 1e-5..1e-3), so a kernel change may legitimately flip one -- then the case goes on the
+        # reviewed allow-list below with its score evidence (|score - reference| < 1e-2), instead of passing silently.
+        if (name, b) in BEAM_SCORE_ONLY_OK:
+            assert same or abs(float(got_lp[b, 0]) - float(want_lp[b, 0])) < 1e-2
+        else:
+            assert same, ('beam golden %s image %d no longer matches the reference exactly (score %.5f vs %.5f, min decision gap %.2e): '
+                          'review, then list it in BEAM_SCORE_ONLY_OK' % (name, b, float(got_lp[b, 0]), float(want_lp[b, 0]), float(gaps[b].min())))
         assert abs(float(got_lp[b, 0]) - float(want_lp[b, 0])) < 2e-2
+
+
+def test_device_floats_vs_reference_goldens(model, golden):
+    """Device FLOATS against the reference's own fp32 floats (tests/golden, written by running /root/reference), not through the
+    oracle's bf16 emulation: the encoder's hidden rows (a5), the tag head's logits (a6) and the whole 30522-wide logits row of
+    decode step 1 (`encode_forward`, modeling_bert.py:751-807).  bf16 operands / fp32 accumulation against fp32 everywhere:
+    the stated tolerances are the measured activation-rounding noise (1.8e-3 rms / 9e-3 max on a logit,
+    5.6e-3 relative L2 on the encoder output) with a factor of two of head-room."""
+    vec, _ = golden
+    img = _images(2)
+    # one decode step: max_length = 2 makes step 1 the last (and only) step, whose logits row the engine keeps
+    opts = model.gen_options(max_length=2)
+    model.run(img.cuda(), opts)
+    torch.cuda.synchronize()
+    logits = model.tap('logits_last', 2, (2, 30592), opts=opts).cpu()[0, :30522].numpy()
+    want = vec['step1_logits_row']
+    err = logits - want
+    print('step-1 logits vs reference: rms %.3e max %.3e (logit std %.3f)' % (float(np.sqrt((err ** 2).mean())), float(np.abs(err).max()), float(want.std())))
+    assert float(np.sqrt((err ** 2).mean())) < 4e-3 and float(np.abs(err).max()) < 2e-2
+    assert int(np.argmax(logits)) == int(np.argmax(want)) or np.sort(want)[-1] - np.sort(want)[-2] < GREEDY_MARGIN_FLOOR
+    hid = model.tap('hidden', 2, (2, 577, 768), opts=opts).cpu()[:, :2].numpy()
+    rel = float(np.linalg.norm(hid - vec['a5_hidden_rows']) / np.linalg.norm(vec['a5_hidden_rows']))
+    print('hidden[:, :2] vs reference: rel L2 %.3e' % rel)
+    assert rel < 1.2e-2
+    tagc = model.tap('tag_hidden', 2, (2, 577, 768), opts=opts).cpu()[:, 0].numpy()
+    rel_t = float(np.linalg.norm(tagc - vec['a5_tag_hidden_cls']) / np.linalg.norm(vec['a5_tag_hidden_cls']))
+    print('tag_hidden[:, 0] vs reference: rel L2 %.3e' % rel_t)
+    assert rel_t < 1.2e-2
+    model.generate(img.cuda(), want_tags=True)
+    tl = model.last_tags[0].cpu().numpy()[:, :64]
+    terr = float(np.abs(tl - vec['a6_logit_head']).max())
+    print('tag logits[:, :64] vs reference: max abs %.3e' % terr)
+    assert terr < 2e-2
 
 
 # ------------------------------------------------------------------------------------------------ vs the bf16 emulation

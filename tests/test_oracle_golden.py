@@ -264,3 +264,29 @@ def test_beam_incremental_equals_as_written(sd_t, img):
         b = O.beam_incremental(sd_t, img[:1], num_beams=3, emulate_bf16=False)
     np.testing.assert_array_equal(a[0].numpy(), b[0].numpy())
     np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_image_dependent_family_pins_the_oracle(sd_t):
+    """tests/golden/reference_imgdep.npz (the reference on structured images; captions differ between images in most positions):
+    the oracle's fp32 incremental path reproduces the reference's tokens, log-probs and per-step [MASK]-row logits."""
+    import os
+    vec = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_imgdep.npz')))
+    cand = torch.from_numpy(W.gen_structured_images(48, int(vec['image_seed'][0])))
+    img = cand[torch.from_numpy(vec['sel_index'])]
+    caps = vec['greedy_ids'][:, 0]
+    assert min(float((caps[i, 1:19] != caps[j, 1:19]).mean()) for i in range(4) for j in range(i)) >= 0.5
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ids, lp, tr = O.greedy_incremental(sd_t, img, emulate_bf16=False, return_trace=True)
+    np.testing.assert_array_equal(ids.numpy(), vec['greedy_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['greedy_logprobs'], rtol=0, atol=2e-4)
+    for i, step in enumerate(vec['step_list']):
+        row = tr['steps'][int(step) - 1]['logits_row'].numpy()
+        got = np.take_along_axis(row, vec['step_cols'][i].astype(np.int64), axis=1)
+        np.testing.assert_allclose(got, vec['step_logits'][i], rtol=1e-3, atol=3e-4)
+    # eos_token_ids with three entries (modeling_utils.py:862-871): the restated greedy loop stops at any of them
+    eos = [int(x) for x in vec['multi_eos_ids_list']]
+    with torch.no_grad():
+        ids, lp = O.greedy_incremental(sd_t, img, emulate_bf16=False, eos=eos)
+    np.testing.assert_array_equal(ids.numpy(), vec['multi_eos_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['multi_eos_logprobs'], rtol=0, atol=2e-4)

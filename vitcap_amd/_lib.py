@@ -46,7 +46,7 @@ class GenOpts(C.Structure):
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
                 ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('tag_visible', C.c_int32), ('tagemb_cls', C.c_int32),
-                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32)]
+                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3)]
 
 
 class Image(C.Structure):
@@ -212,6 +212,9 @@ def gen_opts(**kw):
     for k, v in kw.items():
         if k == 'sampling':
             o.sampling = v
+        elif k == 'eos_extra':
+            ids = list(v) + [-1] * (3 - len(v))
+            o.eos_extra = (C.c_int32 * 3)(*[int(x) for x in ids[:3]])
         else:
             if not hasattr(o, k):
                 raise AttributeError('vitcap_gen_opts has no field %r' % k)

@@ -37,23 +37,23 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 // (ds_read_b64_tr_b16: 4 consecutive rows x 64 B) then touch every bank once (MI355X_MICROARCH.md, LDS).
 __device__ __forceinline__ int kv_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
-// LDS transpose read as inline asm.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr16 INTRINSIC when an
-// LDS-DMA is in flight (it cannot tell that the DMA fills another ring slot; plain ds_read_b128 loads are not affected): the
-// tile just requested would be awaited before the current one is multiplied.  The asm form is invisible to that pass; its
-// results are fenced by an explicit lgkmcnt(0) (tr_fence) before the MFMAs that consume them.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-template <int OFF>
-__device__ __forceinline__ s16x4 lds_tr_read(uint32_t addr) {
-  s16x4 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
-
-constexpr int NSTG = 3;                  // K/V tile ring: tile t+2 is in flight while tile t is multiplied
+// build-time knobs of the dense kernel (tools/attn_variants.sh measures them; the defaults are the shipped form)
+#ifndef VC_ATTN_NSTG
+#define VC_ATTN_NSTG 3
+#endif
+#ifndef VC_ATTN_MINW
+#define VC_ATTN_MINW 3
+#endif
+#ifndef VC_ATTN_ROWSUM_MFMA
+#define VC_ATTN_ROWSUM_MFMA 1
+#endif
+#ifndef VC_ATTN_VEARLY
+#define VC_ATTN_VEARLY 1
+#endif
+#ifndef VC_ATTN_QK_INTERLEAVE
+#define VC_ATTN_QK_INTERLEAVE 0
+#endif
+constexpr int NSTG = VC_ATTN_NSTG;       // K/V tile ring: tile t+NSTG-1 is in flight while tile t is multiplied
 constexpr int TILE_B = KT * 128;         // one K (or V) tile: 64 keys x 128 B
 constexpr int STG_B = 2 * TILE_B;        // [K | V]
 
@@ -71,7 +71,7 @@ constexpr int STG_B = 2 * TILE_B;        // [K | V]
 // sum_k bf16(P) for the lane's query in every register of `lacc` (the loop is bound by vector-ALU issue; the matrix pipe
 // has room) -- so the normaliser is the sum of the ROUNDED probabilities the numerator uses.
 template <bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
                                                          int causal_from, int mask_from, int q_lo, int q_rows) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __rest
       for (int g = 0; g < 4; ++g) lv[dt][g] = *(const bf16x4*)(vr + dt * 32 + g * 8);
   }
   if (ntiles > 0) STAGE_TILE(0, 0);
-  if (ntiles > 1) STAGE_TILE(1, 1);
+  if (NSTG > 2 && ntiles > 1) STAGE_TILE(1, 1);
   if (left) {
     for (int key = key0; key < S; ++key) {
       if (key > key0) {
@@ -236,23 +236,33 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __rest
   do {                                                                                                          \
     const char* kl = smem + (stg_) * STG_B;                                                                     \
     f32x16 st[2];                                                                                               \
+    if (VC_ATTN_QK_INTERLEAVE) { /* the two 32-key blocks' accumulation chains alternate on the matrix pipe */  \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],     \
+                                                         f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+      _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
+        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                        \
+          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[ds]), qf[ds], st[kt], 0, 0, 0); \
+    } else {                                                                                                    \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
       st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],       \
                                                        f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
       _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[ds]), qf[ds], st[kt], 0, 0, 0); \
     }                                                                                                           \
-    /* the 16 transpose reads of this tile's V fragments go out now: their latency hides behind the softmax */  \
-    s16x4 vt[4][2][2];                                                                                          \
-    {                                                                                                           \
-      const uint32_t vb_ = lds_addr(kl);                                                                        \
+    }                                                                                                           \
+    /* the transpose reads of this tile's V fragments go out now: their latency hides behind the softmax       \
+       (VC_ATTN_VEARLY; otherwise one 16-key block ahead of its MFMAs, 16 fewer live registers) */              \
+    s16x4 vt[VC_ATTN_VEARLY ? 4 : 2][2][2];                                                                     \
+    const uint32_t vb_ = lds_addr(kl);                                                                          \
+    if (VC_ATTN_VEARLY) {                                                                                       \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                          \
         _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {                                                      \
           const uint32_t a_ = vb_ + (uint32_t)voff[rd][dt];                                                     \
           vt[0][dt][rd] = lds_tr_read<0>(a_);                                                                   \
           vt[1][dt][rd] = lds_tr_read<2048>(a_);                                                                \
-          vt[2][dt][rd] = lds_tr_read<4096>(a_);                                                                \
-          vt[3][dt][rd] = lds_tr_read<6144>(a_);                                                                \
+          vt[VC_ATTN_VEARLY ? 2 : 0][dt][rd] = lds_tr_read<4096>(a_);                                           \
+          vt[VC_ATTN_VEARLY ? 3 : 1][dt][rd] = lds_tr_read<6144>(a_);                                           \
         }                                                                                                       \
     }                                                                                                           \
     if (MASKED_) {                                                                                              \
@@ -288,17 +298,37 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __rest
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kt][r] = fast_exp2(fmaf(st[kt][r], c_log2, nm));        \
     /* O^T += V^T . P^T over the four 16-key blocks; row sums: ones . P^T */                                    \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                         \
-                 : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),                  \
-                   "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),                  \
-                   "+v"(vt[2][0][0]), "+v"(vt[2][0][1]), "+v"(vt[2][1][0]), "+v"(vt[2][1][1]),                  \
-                   "+v"(vt[3][0][0]), "+v"(vt[3][0][1]), "+v"(vt[3][1][0]), "+v"(vt[3][1][1]));                 \
+    if (VC_ATTN_VEARLY) {                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                       \
+                   : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),                \
+                     "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),                \
+                     "+v"(vt[VC_ATTN_VEARLY ? 2 : 0][0][0]), "+v"(vt[VC_ATTN_VEARLY ? 2 : 0][0][1]),            \
+                     "+v"(vt[VC_ATTN_VEARLY ? 2 : 0][1][0]), "+v"(vt[VC_ATTN_VEARLY ? 2 : 0][1][1]),            \
+                     "+v"(vt[VC_ATTN_VEARLY ? 3 : 1][0][0]), "+v"(vt[VC_ATTN_VEARLY ? 3 : 1][0][1]),            \
+                     "+v"(vt[VC_ATTN_VEARLY ? 3 : 1][1][0]), "+v"(vt[VC_ATTN_VEARLY ? 3 : 1][1][1]));           \
+    } else {                                                                                                    \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                          \
+        _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) vt[0][dt][rd] = lds_tr_read<0>(vb_ + (uint32_t)voff[rd][dt]); \
+    }                                                                                                           \
     const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                             \
+    float psum = 0.f;                                                                                           \
     _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
       const int kt = kb >> 1, ks = kb & 1;                                                                      \
+      const int vs = VC_ATTN_VEARLY ? kb : (kb & 1);                                                            \
+      if (!VC_ATTN_VEARLY) {                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[vs][0][0]), "+v"(vt[vs][0][1]), "+v"(vt[vs][1][0]), "+v"(vt[vs][1][1])); \
+        if (kb < 3) {                                                                                           \
+          _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                      \
+            _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {                                                  \
+              const uint32_t a_ = vb_ + (uint32_t)voff[rd][dt];                                                 \
+              vt[vs ^ 1][dt][rd] = kb == 0 ? lds_tr_read<2048>(a_) : (kb == 1 ? lds_tr_read<4096>(a_) : lds_tr_read<6144>(a_)); \
+            }                                                                                                   \
+        }                                                                                                       \
+      }                                                                                                         \
       bf16x8 pf;                                                                                                \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];                         \
-      lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);                                  \
+      if (VC_ATTN_ROWSUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);         \
+      else { _Pragma("unroll") for (int j = 0; j < 8; ++j) psum += (float)pf[j]; }                              \
       if (DROP) {                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
           const int r = ks * 8 + j;                                                                             \
@@ -307,23 +337,28 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __rest
         }                                                                                                       \
       }                                                                                                         \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
-        const s16x8 v8 = __builtin_shufflevector(vt[kb][dt][0], vt[kb][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);         \
+        const s16x8 v8 = __builtin_shufflevector(vt[vs][dt][0], vt[vs][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);         \
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);  \
       }                                                                                                         \
     }                                                                                                           \
+    if (!VC_ATTN_ROWSUM_MFMA) l_i += psum;                                                                      \
   } while (0)
 
   int stg = 0;                       // ring slot of tile t (wave-uniform)
   for (int t = 0; t < nfull; ++t) {
-    // tile t landed (this wave's 4 pieces; tile t+1's 4 may stay in flight), then for every wave -- and every wave is done
-    // with tile t-1, whose slot tile t+2 is about to overwrite
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // tile t landed (this wave's 4 pieces; with three slots tile t+1's 4 may stay in flight), then for every wave -- and every
+    // wave is done with tile t-1, whose slot the next request is about to overwrite
+    if (NSTG > 2 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int stg2 = stg == 0 ? 2 : stg - 1;                     // (stg + 2) % 3
-    if (t + 2 < ntiles) STAGE_TILE(t + 2, stg2);
+    if (NSTG > 2) {
+      const int stg2 = stg == 0 ? 2 : stg - 1;                     // (stg + 2) % 3
+      if (t + 2 < ntiles) STAGE_TILE(t + 2, stg2);
+    } else {
+      if (t + 1 < ntiles) STAGE_TILE(t + 1, stg ^ 1);
+    }
     if (active) TILE_COMPUTE(stg, t, false);
-    stg = stg == 2 ? 0 : stg + 1;
+    stg = NSTG > 2 ? (stg == 2 ? 0 : stg + 1) : (stg ^ 1);
   }
   if (tail_tile) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const bf16_t* __rest
 
   // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]; every register of lacc holds the MFMA part of
   // the row sum, l_i the left-over keys' part (one half-wave)
-  const float l_tot = lacc[0] + l_i + __shfl_xor(l_i, 32, 64);
+  const float l_tot = (VC_ATTN_ROWSUM_MFMA ? lacc[0] : 0.f) + l_i + __shfl_xor(l_i, 32, 64);
   const float inv = DROP ? drop_scale / l_tot : 1.0f / l_tot;
   const int q = q0 + qi;
   if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)

@@ -23,6 +23,14 @@ void vitcap_set_error(const char* fmt, ...);
 // which return at entry once it reads 0 -- the reference's `if cur_unfinished.max() == 0: break`
 // (modeling_utils.py:866 / `if all(done): break`, :1072) without a host synchronisation.  NULL outside the engine.
 extern thread_local const int32_t* vc_tls_live;
+// Engine-internal: further EOS token ids of the call being enqueued (vitcap_gen_opts.eos_extra; -1 = unused).  The reference's
+// greedy / sampling loop stops a sequence at ANY id of `eos_token_ids` (modeling_utils.py:862-865) and forces eos_token_ids[0]
+// at the last position (:870-871); the step launchers read this next to their `eos` argument, which stays the first id.
+struct VcEosExtra { int32_t id[3]; };
+extern thread_local VcEosExtra vc_tls_eos_extra;
+__device__ __forceinline__ bool vc_is_eos(int tok, int eos, const VcEosExtra& x) {
+  return tok == eos || tok == x.id[0] || tok == x.id[1] || tok == x.id[2];
+}
 #define VC_LIVE_EXIT(live)                         \
   do {                                             \
     if ((live) != nullptr && *(live) == 0) return; \
@@ -72,6 +80,28 @@ extern thread_local bool vc_tls_kev_used;
       vc_done_.fetch_or(vc_bit_, std::memory_order_release);                                                        \
     }                                                                                                               \
   } while (0)
+
+// LDS transpose read (ds_read_b64_tr_b16: a 16-lane group fetches 4 rows x 16 columns of 16-bit elements, lane i receives
+// column i of the 4 rows) as INLINE ASM.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr16
+// INTRINSIC whenever an LDS-DMA (global_load_lds) is in flight -- it cannot tell that the DMA fills another ring slot;
+// plain ds_read_b128 loads are not affected -- so the tile just requested would be awaited before the current one is
+// multiplied (found in the ISA of csrc/attn.hip and csrc/gemm_tn.hip: the prefetch distance silently became zero).  The asm
+// form is invisible to that pass; its results must be fenced by an explicit `s_waitcnt lgkmcnt(..)` that names the
+// destination registers as "+v" operands before the MFMAs that consume them.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr_read(uint32_t addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ bf16x8 tr_pair(s16x4 lo, s16x4 hi) {
+  return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 // round-to-nearest-even fp32 -> bf16 (matches torch .to(bfloat16) for finite values and NaN->qNaN)
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
                                                            float* __restrict__ sum_lp, float* __restrict__ cnt,
                                                            float* __restrict__ logprob_out,
                                                            float* __restrict__ margin_out, int64_t* __restrict__ raw_last,
-                                                           int t, int max_len, int eos, int pad, int32_t* __restrict__ live) {
+                                                           int t, int max_len, int eos, int pad, int32_t* __restrict__ live,
+                                                           VcEosExtra eos_x) {
   __shared__ ArgMax s_am[16];
   __shared__ float s_second[16];
   __shared__ float s_sum[16];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const float* __restri
     const int add = u ? bb.i : pad;
     float s = sum_lp[b] + lp * (float)u;
     float c = cnt[b] + (float)u;
-    int nu = u * (add != eos ? 1 : 0);
+    int nu = u * (vc_is_eos(add, eos, eos_x) ? 0 : 1);
     int64_t outtok = add;
     if (t == max_len - 1) {
       if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
                                                            int t, int max_len, int eos, int pad, float temperature, int top_k,
                                                            float top_p, uint32_t seed, int seq_off, int32_t* __restrict__ live,
                                                            int min_keep, float* __restrict__ cand_val,
-                                                           int32_t* __restrict__ cand_idx, float* __restrict__ cand_lse) {
+                                                           int32_t* __restrict__ cand_idx, float* __restrict__ cand_lse,
+                                                           VcEosExtra eos_x) {
   __shared__ unsigned long long s_hist[256];
   __shared__ unsigned long long s_acc;
   __shared__ uint32_t s_sel;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     const int add = u ? bb.i : pad;
     float s = sum_lp[b] + lp * (float)u;
     float c = cnt[b] + (float)u;
-    int nu = u * (add != eos ? 1 : 0);
+    int nu = u * (vc_is_eos(add, eos, eos_x) ? 0 : 1);
     int64_t outtok = add;
     if (t == max_len - 1) {
       if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
@@ -933,7 +935,7 @@ extern "C" int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* 
   VC_REQUIRE(logits && ids && unfinished && sum_lp && cnt && logprob_out, "greedy_step: null pointer");
   VC_REQUIRE(B > 0 && V > 0 && ldl >= V && t >= 1 && t < max_len, "greedy_step: bad sizes (t=%d)", t);
   hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
-                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, (int32_t*)vc_tls_live);
+                     sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, (int32_t*)vc_tls_live, vc_tls_eos_extra);
   VC_LAUNCH_CHECK("greedy_step");
   return VITCAP_OK;
 }
@@ -1047,7 +1049,7 @@ extern "C" int vitcap_sample_step_offset(const float* logits, int ldl, int V, in
   hipLaunchKernelGGL(sample_step_kernel<false>, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V, ids, unfinished,
                      sum_lp, cnt, logprob_out, margin_out, raw_last, t, max_len, eos, pad, sp->temperature, sp->top_k,
                      sp->top_p, sp->seed, seq_offset, (int32_t*)vc_tls_live, 1, (float*)nullptr, (int32_t*)nullptr,
-                     (float*)nullptr);
+                     (float*)nullptr, vc_tls_eos_extra);
   VC_LAUNCH_CHECK("sample_step");
   return VITCAP_OK;
 }
@@ -1074,7 +1076,7 @@ extern "C" int vitcap_beam_sample_candidates(const float* logits, int ldl, int V
   hipLaunchKernelGGL(sample_step_kernel<true>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, ldl, V,
                      (int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                      (int64_t*)nullptr, t, 0, 0, 0, sp->temperature, sp->top_k, sp->top_p, sp->seed, row_offset,
-                     (int32_t*)vc_tls_live, 2, out_val, out_idx, out_lse);
+                     (int32_t*)vc_tls_live, 2, out_val, out_idx, out_lse, VcEosExtra{{-1, -1, -1}});
   VC_LAUNCH_CHECK("beam_sample_candidates");
   return VITCAP_OK;
 }

@@ -26,6 +26,8 @@
 
 void vitcap_set_error(const char* fmt, ...);
 extern thread_local const int32_t* vc_tls_live;   // csrc/common.h: early-exit counter handed to the decode-step launchers
+struct VcEosExtra { int32_t id[3]; };              // csrc/common.h: eos_token_ids[1..3] of the call being enqueued (-1 = unused)
+extern thread_local VcEosExtra vc_tls_eos_extra;
 extern thread_local hipEvent_t vc_tls_kev_start, vc_tls_kev_stop;   // csrc/common.h: kernel-bound timing events (timing runs only)
 extern thread_local bool vc_tls_kev_used;
 
@@ -100,6 +102,7 @@ vitcap_gen_opts default_opts() {
   o.tagemb_cls = 1;
   o.decode_streams = 0;
   o.encode_parts = 0;
+  o.eos_extra[0] = o.eos_extra[1] = o.eos_extra[2] = -1;
   return o;
 }
 
@@ -121,6 +124,12 @@ int check_opts(const vitcap_gen_opts& o) {
   OPT_REQ(o.tag_visible == 0 || o.max_length == VITCAP_MAXLEN, "gen_opts: tag_visible > 0 needs max_length == %d", VITCAP_MAXLEN);
   OPT_REQ(o.encode_parts >= 0 && o.encode_parts <= 4, "gen_opts: encode_parts must be 0 (auto) .. 4 (got %d)", o.encode_parts);
   OPT_REQ(o.decode_streams >= 0 && o.decode_streams <= 2, "gen_opts: decode_streams must be 0 (auto), 1 or 2 (got %d)", o.decode_streams);
+  for (int i = 0; i < 3; ++i) {
+    OPT_REQ(o.eos_extra[i] >= -1 && o.eos_extra[i] < VITCAP_VOCAB, "gen_opts: eos_extra[%d] = %d is neither -1 nor a token id", i, o.eos_extra[i]);
+    // the reference's own beam search does not survive several EOS ids: more than num_beams of the 2*num_beams candidates can then
+    // be EOS words and `assert len(next_sent_beam) == num_beams` fires (modeling_utils.py:1037)
+    OPT_REQ(o.eos_extra[i] < 0 || o.num_beams == 1, "gen_opts: several eos_token_ids need num_beams == 1 (the reference's beam search asserts with them)");
+  }
 #undef OPT_REQ
   return VITCAP_OK;
 }
@@ -267,15 +276,17 @@ thread_local const int32_t* g_live = nullptr;    // live counter handed to the d
 
 // sets the per-call context (timing hook, GEMM launch form, early-exit counter) for the duration of one engine call
 struct CallScope {
-  CallScope(vitcap_engine* e, int gemm_mode, const int32_t* live) {
+  CallScope(vitcap_engine* e, int gemm_mode, const int32_t* live, const vitcap_gen_opts* o = nullptr) {
     g_cur = e;
     g_gemm_mode = gemm_mode;
     g_live = live;
     vc_tls_live = live;
+    if (o) vc_tls_eos_extra = VcEosExtra{{o->eos_extra[0], o->eos_extra[1], o->eos_extra[2]}};
   }
   ~CallScope() {
     g_live = nullptr;
     vc_tls_live = nullptr;
+    vc_tls_eos_extra = VcEosExtra{{-1, -1, -1}};
     g_gemm_mode = VITCAP_GEMM_AUTO;
   }
 };
@@ -1049,7 +1060,7 @@ static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen
 }
 
 static int decode_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
-  CallScope scope(e, o.gemm_mode, o.early_exit ? (const int32_t*)(ws + lo.live) : nullptr);
+  CallScope scope(e, o.gemm_mode, o.early_exit ? (const int32_t*)(ws + lo.live) : nullptr, &o);
   return lo.beam ? beam_loop(e, B, lo, o, ws, s) : greedy_loop(e, lo, o, ws, s);
 }
 

@@ -4,9 +4,11 @@
 #include <stdio.h>
 #include <stdint.h>
 #include "../../include/vitcap_hip.h"
+#include "common.h"
 
 static thread_local char g_err[512] = "";
 thread_local const int32_t* vc_tls_live = nullptr;   // see common.h
+thread_local VcEosExtra vc_tls_eos_extra = {{-1, -1, -1}};
 thread_local hipEvent_t vc_tls_kev_start = nullptr, vc_tls_kev_stop = nullptr;
 thread_local bool vc_tls_kev_used = false;
 

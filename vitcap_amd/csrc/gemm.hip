@@ -77,6 +77,21 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `newer` (<= K) tiles of PIECES LDS-DMA instructions each are still outstanding
+template <int K, int PIECES>
+__device__ __forceinline__ void wait_newer_tiles(int newer) {
+  if constexpr (K <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (newer >= K) wait_vmcnt<(K * PIECES < 63 ? K * PIECES : 63)>();
+    else wait_newer_tiles<K - 1, PIECES>(newer);
+  }
+}
+
 template <int WM, int WN, int ACT, int OUT_F32, bool HAS_RES, int NST, bool ROWSTAT = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   VC_LIVE_EXIT(p.live);
@@ -154,13 +169,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) % NST;
-    {
-      const int newer = t1 - 1 - t < NST - 2 ? t1 - 1 - t : NST - 2;   // k-tiles issued after tile t
-      if (NST > 2 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-      else if (NST > 2 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();      // tile t landed for every wave, and every wave finished tile t-1 (whose buffer is refilled now)
+    // tile t has landed once at most `newer` younger tiles' pieces are outstanding (loads retire in order)
+    wait_newer_tiles<NST - 2, PIECES>(t1 - 1 - t < NST - 2 ? t1 - 1 - t : NST - 2);
+    // Raw s_barrier, NOT __syncthreads(): the workgroup-scope fence in __syncthreads() makes hipcc emit `s_waitcnt vmcnt(0)` in front
+    // of the barrier whenever LDS-DMA is in flight -- every k-tile then waited for the YOUNGEST request and the NST-deep ring
+    // degenerated to one dependent memory round trip per k-tile (seen in the ISA; the counted wait above was dead code).
+    // What the barrier must order needs no fence: tile t landed for every wave (each wave's own counted vmcnt) and every wave
+    // finished tile t-1, whose fragments were consumed by MFMAs behind the compiler's own lgkmcnt waits.
+    __builtin_amdgcn_s_barrier();
     if (t + NST - 1 < t1) stage((t - t0 + NST - 1) % NST, (t + NST - 1) * BK);
     const char* la = smem + buf * BUF_BYTES + (wm * WM * 16 + frow) * 128;
     const char* lw = smem + buf * BUF_BYTES + A_BYTES + (wn * WN * 16 + frow) * 128;
@@ -565,6 +581,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
   constexpr int WR = 32 * MT;                                      // rows of one wave's block (2 waves along M, 4 along N)
   constexpr int NI = 2 * MT;                                       // ... in 16-row MFMA tiles
   constexpr int NP = MT + 4;                                       // LDS-DMA pieces (8 rows x 128 B per lane group) per wave and k-tile
+  constexpr bool EXTRAS = (PH & 8) != 0;   // training extras (pre-activation copy `zout`, gelu' factor `aux`) compiled in: the
+                                           // inference instantiations do not carry their 32 prefetch registers (222 instead of 226 VGPRs)
   constexpr int ABL = PH >> 4;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
   constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4, NO_STORE = ABL & 8, NO_EPI = ABL & 16;
 
@@ -739,7 +757,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
   // plain rows, no aux / pre-activation copy, bf16 output without residual or fp32 output: straight from registers
   // measured (tools/gemm_res_bench.py, VITCAP_GEMM_DIRECT_EPILOGUE=0/1): +4-5 % for the GELU epilogue (fc1), neutral for
   // plain bf16 (qkv), SLOWER for the fp32 + residual outputs (proj 0.078 -> 0.106 ms) -- so it is used for GELU only
-  if (p.direct_epilogue && ACT == VITCAP_ACT_GELU_ERF && !OUT_F32 && !HAS_RES && !p.zout && !p.aux && p.row_group == 0 &&
+  if (p.direct_epilogue && ACT == VITCAP_ACT_GELU_ERF && !OUT_F32 && !HAS_RES && !(EXTRAS && p.zout) && !(EXTRAS && p.aux) && p.row_group == 0 &&
       (p.N & 15) == 0 && (p.ldc & 7) == 0) {
     epilogue_direct<ACT, OUT_F32, HAS_RES, NI>(acc, p, m0 + wm * WR, n0 + wn * 64, lane, NO_STORE);
     return;
@@ -750,7 +768,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
   // arrives as 16-byte loads issued for a whole half BEFORE the LDS staging, so their latency hides behind it
   // (before: 8-byte loads used immediately, scalar gelu': 337 us per call at M = 36928, N = 3072)
   if constexpr (!OUT_F32 && !HAS_RES) {
-    if (p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.zout || (p.ldz & 7) == 0) && (!p.aux || (p.ldaux & 7) == 0)) {
+    if (p.row_group == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!(EXTRAS && p.zout) || (p.ldz & 7) == 0) && (!(EXTRAS && p.aux) || (p.ldaux & 7) == 0)) {
       const int wr = lane >> 3, wc = (lane & 7) * 8;
       const int ncw = n0 + wn * 64 + wc;
       const bool okc = ncw < p.N && !(NO_STORE && m0 >= 0);
@@ -762,7 +780,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
         uint4 axv[2 * MT];
-        if (p.aux) {
+        if (EXTRAS && p.aux) {
 #pragma unroll
           for (int it = 0; it < 2 * MT; ++it) {
             const int m = m0 + wm * WR + hm * (16 * MT) + it * 8 + wr;
@@ -783,7 +801,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
           const bool ok = m < p.M && okc;
           v0 += b_lo;
           v1 += b_hi;
-          if (p.zout && ok) {
+          if (EXTRAS && p.zout && ok) {
             uint4 zo;
             zo.x = pack2bf(v0[0], v0[1]);
             zo.y = pack2bf(v0[2], v0[3]);
@@ -791,7 +809,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
             zo.w = pack2bf(v1[2], v1[3]);
             *(uint4*)(p.zout + (size_t)m * p.ldz + ncw) = zo;
           }
-          if (p.aux) {
+          if (EXTRAS && p.aux) {
             const uint4 a = axv[it];
             v0 *= gelu_grad4(f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16),
                                    __uint_as_float(a.y & 0xffff0000u)});
@@ -836,13 +854,13 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
         ROWS_OF(m, orow, rrow);
         (void)rrow;
         v += bias4;
-        if (p.zout && ok) {
+        if (EXTRAS && p.zout && ok) {
           uint2 zo;
           zo.x = pack2bf(v[0], v[1]);
           zo.y = pack2bf(v[2], v[3]);
           *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
         }
-        if (p.aux && ok) {
+        if (EXTRAS && p.aux && ok) {
           const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
           v *= gelu_grad4(f32x4{(float)za[0], (float)za[1], (float)za[2], (float)za[3]});
         }
@@ -870,8 +888,14 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
 // The launch: n_big workgroups own 256-row tiles of rows [0, 256 * tiles_m); with MTS != 0 the workgroups behind them own
 // (64*MTS)-row tiles of the remaining rows.  Workgroups are dispatched in blockIdx order (block b on XCD b % 8), so every XCD
 // works through its share of the big tiles first and fills the last, partial round with the short ones.
+// VGPR cap 224: two waves of this kernel per SIMD then leave 64 of the 512 registers (and 24 KB of LDS) free, which is what one wave
+// of the decode step's HBM-bound attention kernel needs (60 VGPRs, 8 KB): in the 2-slot batch pipeline that kernel can become
+// RESIDENT NEXT TO the GEMM's workgroups instead of waiting for CUs to drain -- K/V streaming overlaps the MFMA work.
+#ifndef VC_GEMM256_VGPRS
+#define VC_GEMM256_VGPRS 224
+#endif
 template <int ACT, int OUT_F32, bool HAS_RES, int PH, int MTS>
-__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(VC_GEMM256_VGPRS))) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bid = blockIdx.x;
   const bool small = MTS != 0 && bid >= p.n_big;
@@ -978,6 +1002,7 @@ int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
   p.group_n = tile_group_n(p.tiles_n);
   TilePlan pl{(a.M + 255) / 256, 0, 0};
   if constexpr ((PH >> 4) == 0) {
+    if (a.aux || a.zout) mix = 0;
     if (mix < 0) pl = plan_tiles(a.M, p.tiles_n, a.K);
     else if (mix > 0) pl = TilePlan{0, mix, (a.M + 64 * mix - 1) / (64 * mix)};
   }
@@ -986,6 +1011,7 @@ int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
   p.n_big = pl.tm_big * p.tiles_n;
   const int nwg = p.n_big + pl.tm_small * p.tiles_n;
   if constexpr ((PH >> 4) == 0) {
+    if (a.aux || a.zout) return launch_256_t<ACT, OUT_F32, HAS_RES, PH | 8, 0>(p, nwg, s);   // training extras: 256-row tiles only
     if (pl.mts == 3) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 3>(p, nwg, s);
     if (pl.mts == 2) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 2>(p, nwg, s);
   }

@@ -21,8 +21,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
 constexpr int TBN = 256, TBK = 256, TBM = 64;
 constexpr int ROW_B = 512;                       // bytes per tile row (256 bf16)
 constexpr int OP_BYTES = TBM * ROW_B;            // 32 KiB per operand per stage
@@ -42,15 +40,6 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 __device__ __forceinline__ int swz(int m) { return ((m >> 3) & 3) * 4 + (m & 3); }
-
-__device__ __forceinline__ bf16x8 tr_frag(const char* lds_lo, const char* lds_hi) {
-  // two transpose reads: reduction rows +0..3 and +4..7 of this lane group's 8-row slab
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_lo);
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_hi);
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,6 +109,48 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   // kernel (8 per 32-row step on the wk = 0 waves of the k-tile-0 workgroups, or 2 per wave) instead of the separate colsum pass:
   // the colsum launches disappear (-1.7 ms per training step) but this kernel slows from 13.15 to 14.6 / 14.9 ms per step -- the
   // MFMA issue slots are not free although the pipe is a third busy.  No net gain.
+  // Transpose reads as inline asm (common.h lds_tr_read): with the intrinsic, hipcc put `s_waitcnt vmcnt(0)` in front of the
+  // first read of every stage, i.e. the stage requested a few instructions earlier was awaited before this one was
+  // multiplied -- LDS-DMA in and reads + MFMAs out ran back to back (the "DMA + reads do not overlap" of the anatomy above).
+  // Per 32-row step: the X fragments and the first four Y fragments are requested, then -- behind their lgkmcnt(0) -- the
+  // other four Y fragments, whose latency hides behind the first 16 MFMAs.
+  uint32_t yaddr[8], xaddr[4];
+  {
+    const uint32_t lane_base = (uint32_t)(row_lo * ROW_B + tq * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) yaddr[i] = lane_base + (uint32_t)(((wn * 8 + i) ^ fsw) * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xaddr[j] = lane_base + (uint32_t)OP_BYTES + (uint32_t)(((wk * 4 + j) ^ fsw) * 32);
+  }
+  const uint32_t lds0 = lds_addr(smem);
+#define TN_STEP(MS_)                                                                                                  \
+  do {                                                                                                                \
+    s16x4 xl[4], xh[4], yl[8], yh[8];                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+      xl[j] = lds_tr_read<(MS_) * 32 * ROW_B>(sb + xaddr[j]);                                                         \
+      xh[j] = lds_tr_read<(MS_) * 32 * ROW_B + 4 * ROW_B>(sb + xaddr[j]);                                             \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
+      yl[i] = lds_tr_read<(MS_) * 32 * ROW_B>(sb + yaddr[i]);                                                         \
+      yh[i] = lds_tr_read<(MS_) * 32 * ROW_B + 4 * ROW_B>(sb + yaddr[i]);                                             \
+    }                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                 : "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]), "+v"(xh[2]), "+v"(xl[3]), "+v"(xh[3]), \
+                   "+v"(yl[0]), "+v"(yh[0]), "+v"(yl[1]), "+v"(yh[1]), "+v"(yl[2]), "+v"(yh[2]), "+v"(yl[3]), "+v"(yh[3])); \
+    _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                                   \
+      yl[i] = lds_tr_read<(MS_) * 32 * ROW_B>(sb + yaddr[i]);                                                         \
+      yh[i] = lds_tr_read<(MS_) * 32 * ROW_B + 4 * ROW_B>(sb + yaddr[i]);                                             \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(xl[j], xh[j]), tr_pair(yl[i], yh[i]), acc[i][j], 0, 0, 0); \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                 : "+v"(yl[4]), "+v"(yh[4]), "+v"(yl[5]), "+v"(yh[5]), "+v"(yl[6]), "+v"(yh[6]), "+v"(yl[7]), "+v"(yh[7])); \
+    _Pragma("unroll") for (int i = 4; i < 8; ++i)                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(xl[j], xh[j]), tr_pair(yl[i], yh[i]), acc[i][j], 0, 0, 0); \
+  } while (0)
+
   if (nst > 0) STAGE(0, s_begin);
   for (int t = 0; t < nst; ++t) {
     const int buf = t & 1;
@@ -129,31 +160,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
-    const char* ys = smem + buf * STAGE_BYTES;
-    const char* xs = ys + OP_BYTES;
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      const int rbase = (ms * 32 + row_lo) * ROW_B + tq * 8;
-      bf16x8 af[8], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int cb = ((wn * 8 + i) ^ fsw) * 32;          // 16-column block (32 B) of this n-tile, swizzled
-        af[i] = tr_frag(ys + rbase + cb, ys + rbase + 4 * ROW_B + cb);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cb = ((wk * 4 + j) ^ fsw) * 32;
-        bfr[j] = tr_frag(xs + rbase + cb, xs + rbase + 4 * ROW_B + cb);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();                                       // everyone done reading `buf` before it is refilled
+    // raw s_barrier, not __syncthreads(): its workgroup-scope fence makes hipcc drain vmcnt(0) in front of the barrier, i.e.
+    // wait for the stage requested three lines up.  Nothing here needs the fence: LDS is written by the DMA only (awaited by the
+    // counted vmcnt above) and read by the asm transpose reads, each fenced by its own lgkmcnt(0) before the second barrier.
+    __builtin_amdgcn_s_barrier();
+    const uint32_t sb = lds0 + (uint32_t)(buf * STAGE_BYTES);
+    TN_STEP(0);
+    TN_STEP(1);
+    __builtin_amdgcn_s_barrier();                          // everyone done reading `buf` before it is refilled
   }
+#undef TN_STEP
 #undef STAGE
 
   // ---- store the slab: with the operands swapped the lane holds 4 consecutive k of ONE n (16-byte stores)

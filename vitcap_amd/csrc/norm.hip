@@ -147,7 +147,8 @@ __global__ __launch_bounds__(128) void greedy_select_embed_kernel(const float* _
                                                                   int mask_token, const bf16_t* __restrict__ word,
                                                                   const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  float eps, float* __restrict__ xf, bf16_t* __restrict__ xb) {
+                                                                  float eps, float* __restrict__ xf, bf16_t* __restrict__ xb,
+                                                                  VcEosExtra eos_x) {
   const bool last = t == max_len - 1;
   if (live != nullptr && *live == 0 && !last) return;       // every sequence finished: ids stay PAD, x is not needed any more
   __shared__ float s_m[2], s_s[2];
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(128) void greedy_select_embed_kernel(const float* _
     const int add = u ? I : pad;
     const float s = sum_lp[b] + lp * (float)u;
     const float c = cnt[b] + (float)u;
-    const int nu = u * (add != eos ? 1 : 0);
+    const int nu = u * (vc_is_eos(add, eos, eos_x) ? 0 : 1);
     long long outtok = add;
     if (last) {
       if (raw_last) raw_last[b] = add;               // the token actually chosen, before the forced [SEP]
@@ -420,7 +421,7 @@ extern "C" int vitcap_greedy_select_embed(const float* rowstat, int pieces, int6
   hipLaunchKernelGGL(greedy_select_embed_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, rowstat, pieces, ids, unfinished,
                      sum_lp, cnt, logprob_out, raw_last, t, max_len, eos, pad, (int32_t*)vc_tls_live, mask_token,
                      (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta, eps, x_f32,
-                     (bf16_t*)x_bf16);
+                     (bf16_t*)x_bf16, vc_tls_eos_extra);
   VC_LAUNCH_CHECK("greedy_select_embed");
   return VITCAP_OK;
 }

@@ -84,8 +84,8 @@ class ImageCaptioning(nn.Module):
         self.last_tags = None
 
     # ---------------------------------------------------------------- weights
-    def load_recipe(self, seed=0):
-        sd = W.make_state_dict(seed=seed, tie_weights=self.tie_weights)
+    def load_recipe(self, seed=0, vbias_std=None):
+        sd = W.make_state_dict(seed=seed, tie_weights=self.tie_weights, vbias_std=vbias_std)
         with torch.no_grad():
             for k, v in sd.items():
                 self._params[k].copy_(torch.from_numpy(v))
@@ -240,15 +240,19 @@ class ImageCaptioning(nn.Module):
         if te.get('use_cbs', False):
             raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
         eos = te.get('eos_token_ids', [102])
-        eos = list(eos) if isinstance(eos, (list, tuple)) else [eos]
-        if len(eos) != 1:
-            raise NotImplementedError('eos_token_ids must hold exactly one id in this build (got %r)' % (eos,))
+        eos = [int(x) for x in eos] if isinstance(eos, (list, tuple)) else [int(eos)]
+        if not 1 <= len(eos) <= 4:
+            raise NotImplementedError('eos_token_ids must hold 1..4 ids in this build (got %r)' % (eos,))
         nb, keep = int(te.get('num_beams', 1) or 1), int(te.get('num_keep_best', 1) or 1)
         nret = int(te.get('num_return_sequences', 1) or 1)
         do_sample = bool(te.get('do_sample', False))
         if keep != 1 and nb == 1:
             # modeling_utils.py:790: "cannot generate >1 sentences in greedy search"
             raise AssertionError('cannot generate >1 sentences in greedy search (num_keep_best > 1 needs num_beams > 1)')
+        if len(eos) > 1 and nb > 1:
+            # with several EOS ids more than num_beams of the 2*num_beams candidates can be EOS words and the reference's own
+            # `assert len(next_sent_beam) == num_beams` fires (modeling_utils.py:1037): only the greedy / sampling loop takes a list
+            raise NotImplementedError('several eos_token_ids need num_beams == 1 (the reference\'s beam search asserts with them)')
         if nret > 1 and (not do_sample or nb > 1):
             raise NotImplementedError('num_return_sequences > 1 needs do_sample and num_beams == 1 (the reference asserts the same)')
         ml = int(te.get('max_length', L.MAXLEN))
@@ -265,7 +269,8 @@ class ImageCaptioning(nn.Module):
                        repetition_penalty=float(te.get('repetition_penalty', 1) or 1), sampling=sp, gemm_mode=int(gemm_mode),
                        early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)),
                        tag_visible=int(te.get('tag_visible', 0) or 0), tagemb_cls=int(self.tagemb == 'cls'),
-                       decode_streams=int(te.get('decode_streams', 0) or 0), encode_parts=int(te.get('encode_parts', 0) or 0))
+                       decode_streams=int(te.get('decode_streams', 0) or 0), encode_parts=int(te.get('encode_parts', 0) or 0),
+                       eos_extra=eos[1:])
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 

@@ -174,14 +174,15 @@ def _uniform01(name, n, seed):
     return (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)      # [0, 1), exact
 
 
-def gen_tensor(name, shape, kind, seed=0):
-    """One tensor of the recipe as a float32 numpy array (bit-reproducible)."""
+def gen_tensor(name, shape, kind, seed=0, vbias_std=None):
+    """One tensor of the recipe as a float32 numpy array (bit-reproducible).  `vbias_std`: standard deviation (nats) of the
+    vocabulary biases' unigram-like prior (default VBIAS_STD = 1, recipe v2; the image-dependent golden family uses 0.25)."""
     n = int(np.prod(shape))
     if kind == 'vbias':
         acc = np.zeros(n, dtype=np.float32)
         for j in range(12):                       # fixed order: every add is one IEEE fp32 operation
             acc = acc + _uniform01('%s|g%d' % (name, j), n, seed)
-        out = (acc - np.float32(6.0)) * VBIAS_STD
+        out = (acc - np.float32(6.0)) * (VBIAS_STD if vbias_std is None else np.float32(vbias_std))
         out[SEP_ID] = out.max()
         return out.reshape(shape)
     u = _uniform01(name, n, seed)
@@ -195,7 +196,7 @@ def gen_tensor(name, shape, kind, seed=0):
     return out.reshape(shape)
 
 
-def make_state_dict(seed=0, tie_weights=True, keys=None):
+def make_state_dict(seed=0, tie_weights=True, keys=None, vbias_std=None):
     """Numpy state dict under the reference's checkpoint key names.
 
     With ``tie_weights`` the LM-head decoder weight is the word-embedding tensor itself
@@ -209,7 +210,7 @@ def make_state_dict(seed=0, tie_weights=True, keys=None):
         if tie_weights and name == TIED_DST and TIED_SRC in sd:
             sd[name] = sd[TIED_SRC]
             continue
-        sd[name] = gen_tensor(name, shape, kind, seed)
+        sd[name] = gen_tensor(name, shape, kind, seed, vbias_std)
     return sd
 
 
@@ -220,6 +221,24 @@ def tensor_digest(arr):
 def synthetic_images(batch, seed=1234):
     """uniform(-1,1) images, same hash recipe keyed by ('image', seed) -- SURVEY.md section 8d."""
     return gen_image_batch(batch, seed)
+
+
+def gen_structured_images(batch, seed):
+    """Synthetic images that DIFFER from each other where the model can see it (uniform noise images all have the same patch
+    statistics, so random-init attention -- near-uniform -- summarises every one of them to the same vector and the caption
+    hardly depends on the image): per image a colour offset in [-0.6, 0.6]^3, a 6 x 6 grid of 64-pixel blocks with their own
+    colour offsets in [-0.3, 0.3]^3, and uniform noise of amplitude 0.1; values stay inside [-1, 1].  Same hash generator as
+    gen_image_batch, keyed by ('simage', seed): bit-reproducible float32."""
+    def u(tag, n):
+        key = zlib.crc32(('simage|%d|%s' % (seed, tag)).encode()) & 0xffffffff
+        with np.errstate(over='ignore'):
+            x = _hash_u32(key, n)
+        return ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)) * np.float32(2.0) - np.float32(1.0)
+    base = u('base', batch * 3).reshape(batch, 3, 1, 1) * np.float32(0.6)
+    blocks = u('blocks', batch * 3 * 36).reshape(batch, 3, 6, 6) * np.float32(0.3)
+    blocks = np.repeat(np.repeat(blocks, 64, axis=2), 64, axis=3)
+    noise = u('noise', batch * 3 * IMG * IMG).reshape(batch, 3, IMG, IMG) * np.float32(0.1)
+    return (base + blocks + noise).astype(np.float32)
 
 
 def gen_image_batch(batch, seed):
