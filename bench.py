@@ -31,15 +31,16 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r03_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 # What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
 # visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row
 # attention block 0.23.  Reported next to the algorithmic figure; `value` (images/s) does not depend on either.
 FLOP_EXECUTED_PER_IMAGE = FLOP_PER_IMAGE - (9.19e9 - 1.36e9 - 0.23e9)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4>', 0: 'void gemm_nt_256_kernel<0, 0, false, 4>',
-              4: 'void gemm_nt_256_kernel<1, 0, false, 4>'}
+# kernel names in the PMC file: <activation, fp32 output, residual, schedule, short-tile height class (0 = 256-row tiles only)>
+PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4, 0>', 0: 'void gemm_nt_256_kernel<0, 0, false, 4, 0>',
+              4: 'void gemm_nt_256_kernel<1, 0, false, 4, 0>'}
 VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
                  2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
                  4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}

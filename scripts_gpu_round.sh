@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of BASELINE configs[1..4], rocprof summaries, PMC traffic.
 # Usage: bash scripts_gpu_round.sh [tag] [notests]
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
@@ -16,6 +16,7 @@ python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.j
 python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
 bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
+bash tools/pmc_hot.sh $TAG > gpurun_out/pmc_hot_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline >> $R/gpurun_out/prof_$TAG.log 2>&1

@@ -50,11 +50,19 @@ for wl in ('greedy', 'train'):
                                         'wait_inst_any(issue stall)': round(a.get('SQ_WAIT_INST_ANY', 0) / wc, 4),
                                         'active_inst_any': round(a.get('SQ_ACTIVE_INST_ANY', 0) / wc, 4),
                                         'wait_inst_lds': round(a.get('SQ_WAIT_INST_LDS', 0) / wc, 4)}
-        if a.get('SQ_BUSY_CU_CYCLES') and a.get('SQ_VALU_MFMA_BUSY_CYCLES'):
-            # MFMA_BUSY counts cycles summed over the 4 SIMDs of every CU; BUSY_CU_CYCLES counts busy cycles summed over CUs (quad-cycle units x4)
-            d['mfma_busy_over_cu_busy_x4simd'] = round(a['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * a['SQ_BUSY_CU_CYCLES']), 4)
-        if busy and a.get('SQ_VALU_MFMA_BUSY_CYCLES'):
-            d['mfma_busy_over_sq_busy'] = round(a['SQ_VALU_MFMA_BUSY_CYCLES'] / busy, 4)
+        mf = a.get('SQ_VALU_MFMA_BUSY_CYCLES')
+        if mf and a.get('GRBM_GUI_ACTIVE'):
+            # MFMA_BUSY: matrix-pipe busy cycles summed over the chip's 1024 SIMDs (= 16 x the bf16 16x16x32 MFMA count, 32 x the 32x32x16
+            # count); GRBM_GUI_ACTIVE: the kernel's duration in cycles summed over the 8 XCDs -> fraction of the chip's matrix-pipe cycles
+            d['mfma_busy_frac_of_chip'] = round(mf / (1024.0 * a['GRBM_GUI_ACTIVE'] / 8.0), 4)
+        if mf and a.get('SQ_BUSY_CU_CYCLES'):
+            # the same while a CU has any wave resident (SQ_BUSY_CU_CYCLES: busy cycles summed over the 256 CUs; 4 SIMDs each)
+            d['mfma_busy_frac_while_cu_busy'] = round(mf / (4.0 * a['SQ_BUSY_CU_CYCLES']), 4)
+            if a.get('GRBM_GUI_ACTIVE'):
+                d['cu_busy_frac'] = round(a['SQ_BUSY_CU_CYCLES'] / (256.0 * a['GRBM_GUI_ACTIVE'] / 8.0), 4)
+        if a.get('SQ_ACTIVE_INST_VALU') and a.get('GRBM_GUI_ACTIVE'):
+            # ACTIVE_INST_VALU counts quad-cycles with a VALU-class instruction (MFMA included) active, summed over SIMDs
+            d['valu_class_active_frac_of_chip'] = round(4.0 * a['SQ_ACTIVE_INST_VALU'] / (1024.0 * a['GRBM_GUI_ACTIVE'] / 8.0), 4)
         ins = {k: a.get(k, 0.0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM', 'SQ_INSTS_SALU', 'SQ_INSTS_VALU_TRANS')}
         tot = ins['SQ_INSTS_VALU'] + ins['SQ_INSTS_LDS'] + ins['SQ_INSTS_VMEM'] + ins['SQ_INSTS_SALU']
         if tot:
@@ -65,5 +73,5 @@ json.dump(res, open('gpurun_out/%s_mfma_busy_pmc.json' % tag, 'w'), indent=1, so
 for wl, out in res.items():
     print('==', wl)
     for n, d in sorted(out.items(), key=lambda x: -x[1]['counters_avg_per_launch'].get('SQ_BUSY_CYCLES', 0) * x[1]['counters_avg_per_launch']['launches_sampled'])[:14]:
-        print('%-58s mfma/busy %s  frac %s' % (n[:58], d.get('mfma_busy_over_sq_busy'), d.get('wave_time_fractions')))
+        print('%-58s mfma busy %s (while CU busy %s, CU busy %s)  %s' % (n[:58], d.get('mfma_busy_frac_of_chip'), d.get('mfma_busy_frac_while_cu_busy'), d.get('cu_busy_frac'), d.get('wave_time_fractions')))
 PY

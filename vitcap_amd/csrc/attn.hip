@@ -405,6 +405,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ tag_a, const bf16_t* __restrict__ tag_b,
                                                           int n_tag, const int64_t* __restrict__ tag_len) {
   VC_LIVE_EXIT(live);
+#ifdef VC_ATTN_DECODE_FAT     // measurement build (tools/coresident_probe.py): 80 registers, cannot be resident next to two GEMM waves per SIMD
+  asm volatile("" ::: "v72");
+#endif
   __shared__ float sc[2][MAXKEYS];
   __shared__ float red[2][4];
   __shared__ float oacc[4][2][HD];
