@@ -26,3 +26,6 @@ for k in pipe seq train; do
 DB=$(find gpurun_out/prof_$TAG -name "${k}_results.db" | head -1)
 python tools/rocprof_summary.py "$DB" "bench.py ($k), B=64" > gpurun_out/prof_${TAG}_${k}.md 2>&1 || true
 done
+# raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_$TAG gpurun_out/traffic_${TAG}_FETCH_SIZE gpurun_out/traffic_${TAG}_WRITE_SIZE
+du -sh gpurun_out | tail -1

@@ -140,3 +140,9 @@ def test_recipe_is_reproducible():
     assert abs(float(v.std()) - 0.02) < 1e-3
     img4, img2 = W.gen_image_batch(4, 7), W.gen_image_batch(2, 7)
     assert (img4[:2] == img2).all() and img4.min() >= -1 and img4.max() < 1
+    # the structured images of the image-dependent golden family (tests/golden/reference_imgdep.npz was produced on exactly these)
+    st = W.gen_structured_images(48, 777)
+    assert W.tensor_digest(st[:4]) == '1107fefeeaeba281' and st.min() >= -1 and st.max() <= 1
+    assert (st.mean(axis=(1, 2, 3)).std() > 0.15), 'the images must differ in their colour offsets'
+    vb = W.gen_tensor('module.cls.predictions.bias', (30522,), 'vbias', 0, 0.25)     # the untied golden's vocabulary-bias sigma
+    assert abs(float(vb.std()) - 0.25) < 1e-2 and (vb * 4 == a).all()

@@ -324,7 +324,9 @@ def test_patch_embed_matches_conv(ops, sd_t):
     _close(x.view(B, 577, 768), want, 1e-4, 1e-4, 'patch embed')
 
 
-@pytest.mark.parametrize('B,S', [(1, 64), (2, 577), (1, 578), (3, 130)])
+# S = 5: left-over keys only (no tile at all); 40: one masked tail tile; 128 / 200 / 276 / 777: 2 / 3 / 4+tail / 12 tiles through the
+# 3-slot LDS-DMA ring (wrap-around), 8 left-over keys on the vector ALU (200), tail tile behind full tiles (276)
+@pytest.mark.parametrize('B,S', [(1, 64), (2, 577), (1, 578), (3, 130), (1, 5), (2, 40), (2, 128), (1, 200), (1, 276), (1, 777)])
 def test_attn_dense(ops, B, S):
     from oracle import vitcap_oracle as O
     qkv = _bf(_rand((B, S, 2304), 20 + S, 2.0))
