@@ -84,8 +84,8 @@ class ImageCaptioning(nn.Module):
         self.last_tags = None
 
     # ---------------------------------------------------------------- weights
-    def load_recipe(self, seed=0, vbias_std=None):
-        sd = W.make_state_dict(seed=seed, tie_weights=self.tie_weights, vbias_std=vbias_std)
+    def load_recipe(self, seed=0, vbias_std=None, bf16_exact=True):
+        sd = W.make_state_dict(seed=seed, tie_weights=self.tie_weights, vbias_std=vbias_std, bf16_exact=bf16_exact)
         with torch.no_grad():
             for k, v in sd.items():
                 self._params[k].copy_(torch.from_numpy(v))

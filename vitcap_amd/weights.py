@@ -174,9 +174,11 @@ def _uniform01(name, n, seed):
     return (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)      # [0, 1), exact
 
 
-def gen_tensor(name, shape, kind, seed=0, vbias_std=None):
+def gen_tensor(name, shape, kind, seed=0, vbias_std=None, bf16_exact=True):
     """One tensor of the recipe as a float32 numpy array (bit-reproducible).  `vbias_std`: standard deviation (nats) of the
-    vocabulary biases' unigram-like prior (default VBIAS_STD = 1, recipe v2; the image-dependent golden family uses 0.25)."""
+    vocabulary biases' unigram-like prior (default VBIAS_STD = 1, recipe v2; the image-dependent golden family uses 0.25).
+    `bf16_exact=False` leaves the matrices at their fp32 values (the recipe rounds them to bf16-representable values so that the
+    reference and the device hold IDENTICAL weights): the case of a real fp32 checkpoint, whose weights `pack()` has to round."""
     n = int(np.prod(shape))
     if kind == 'vbias':
         acc = np.zeros(n, dtype=np.float32)
@@ -191,12 +193,12 @@ def gen_tensor(name, shape, kind, seed=0, vbias_std=None):
     out = v * a
     if kind == 'ln_w':
         out = out + np.float32(1.0)
-    if kind == 'w':
+    if kind == 'w' and bf16_exact:
         out = bf16_round(out)
     return out.reshape(shape)
 
 
-def make_state_dict(seed=0, tie_weights=True, keys=None, vbias_std=None):
+def make_state_dict(seed=0, tie_weights=True, keys=None, vbias_std=None, bf16_exact=True):
     """Numpy state dict under the reference's checkpoint key names.
 
     With ``tie_weights`` the LM-head decoder weight is the word-embedding tensor itself
@@ -210,7 +212,7 @@ def make_state_dict(seed=0, tie_weights=True, keys=None, vbias_std=None):
         if tie_weights and name == TIED_DST and TIED_SRC in sd:
             sd[name] = sd[TIED_SRC]
             continue
-        sd[name] = gen_tensor(name, shape, kind, seed, vbias_std)
+        sd[name] = gen_tensor(name, shape, kind, seed, vbias_std, bf16_exact)
     return sd
 
 
