@@ -16,6 +16,8 @@
 //     makes the bf16 path reproducible by the CPU oracle's rounding emulation).
 // (2) attn_decode_step: 2 query rows per sequence against the cached visual K/V (read in place from
 //     the prefill's packed qkv buffer) plus the text K/V cache; HBM-bound, 8 lanes per key row.
+#include <stdlib.h>
+
 #include "common.h"
 #include "rng.h"
 
@@ -52,6 +54,9 @@ __device__ __forceinline__ int kv_swz(int r) { return (((r >> 1) & 1) << 2) | ((
 #endif
 #ifndef VC_ATTN_QK_INTERLEAVE
 #define VC_ATTN_QK_INTERLEAVE 0
+#endif
+#ifndef VC_ATTN_PRIO          // 1: the matrix-pipe phases (QK^T, P.V) of a wave run at s_setprio 1, its softmax at 0; 2: the reverse
+#define VC_ATTN_PRIO 0
 #endif
 constexpr int NSTG = VC_ATTN_NSTG;       // K/V tile ring: tile t+NSTG-1 is in flight while tile t is multiplied
 constexpr int TILE_B = KT * 128;         // one K (or V) tile: 64 keys x 128 B
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
   do {                                                                                                          \
     const char* kl = smem + (stg_) * STG_B;                                                                     \
     f32x16 st[2];                                                                                               \
+    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
+    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                       \
     if (VC_ATTN_QK_INTERLEAVE) { /* the two 32-key blocks' accumulation chains alternate on the matrix pipe */  \
       _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],     \
@@ -274,6 +281,8 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
           st[kt][r] = vis_ ? st[kt][r] : -INFINITY;                                                             \
         }                                                                                                       \
     }                                                                                                           \
+    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                       \
+    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                       \
     /* running max on the raw scores (scale > 0), integer ceiling in the log2 domain */                         \
     float mx0 = fmaxf(st[0][0], st[1][0]), mx1 = fmaxf(st[0][1], st[1][1]);                                     \
     _Pragma("unroll") for (int r = 2; r < 16; r += 2) {                                                         \
@@ -312,6 +321,8 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     }                                                                                                           \
     const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                             \
     float psum = 0.f;                                                                                           \
+    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
+    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                       \
     _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
       const int kt = kb >> 1, ks = kb & 1;                                                                      \
       const int vs = VC_ATTN_VEARLY ? kb : (kb & 1);                                                            \
@@ -864,13 +875,16 @@ extern "C" int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qk
   return VITCAP_OK;
 }
 
+
+#define VC_LAUNCH_DENSE(DROP_, grid_, stream_, ...) \
+  hipLaunchKernelGGL(attn_dense_kernel<DROP_>, grid_, dim3(256), 0, (hipStream_t)(stream_), __VA_ARGS__)
+
 extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream) {
   VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense: misaligned");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((S + 127) / 128) * NH * B);   // 1-D work list, remapped per XCD inside the kernel
-  hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, S);
+  VC_LAUNCH_DENSE(false, grid, stream, (const bf16_t*)qkv, (bf16_t*)out, (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, S);
   VC_LAUNCH_CHECK("attn_dense");
   return VITCAP_OK;
 }
@@ -880,8 +894,7 @@ extern "C" int vitcap_attn_dense_fwd_rows(const void* qkv, void* out, int B, int
   VC_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_dense_rows: misaligned");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((q_rows + 127) / 128) * NH * B);
-  hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                     (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, q_rows);
+  VC_LAUNCH_DENSE(false, grid, stream, (const bf16_t*)qkv, (bf16_t*)out, (float*)nullptr, S, B, S, c, 0u, 0u, 1.0f, 0, 0, 0, q_rows);
   VC_LAUNCH_CHECK("attn_dense_rows");
   return VITCAP_OK;
 }
@@ -900,12 +913,11 @@ extern "C" int vitcap_attn_dense_fwd_train_rows(const void* qkv, void* out, floa
   const float c = scale * 1.4426950408889634f;
   dim3 grid(((q_hi - q_lo + 127) / 128) * NH * B);
   if (p_drop > 0.f)
-    hipLaunchKernelGGL(attn_dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out,
-                       lse, S, B, ld_rows, c, drop_seed, (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop),
-                       causal_from, mask_from, q_lo, q_hi - q_lo);
+    VC_LAUNCH_DENSE(true, grid, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, B, ld_rows, c, drop_seed,
+                    (uint32_t)((double)p_drop * 4294967296.0), 1.0f / (1.0f - p_drop), causal_from, mask_from, q_lo, q_hi - q_lo);
   else
-    hipLaunchKernelGGL(attn_dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from, mask_from, q_lo, q_hi - q_lo);
+    VC_LAUNCH_DENSE(false, grid, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, B, ld_rows, c, 0u, 0u, 1.0f, causal_from,
+                    mask_from, q_lo, q_hi - q_lo);
   VC_LAUNCH_CHECK("attn_dense_train");
   return VITCAP_OK;
 }
