@@ -52,11 +52,8 @@ __device__ __forceinline__ int kv_swz(int r) { return (((r >> 1) & 1) << 2) | ((
 #ifndef VC_ATTN_VEARLY
 #define VC_ATTN_VEARLY 1
 #endif
-#ifndef VC_ATTN_QK_INTERLEAVE
-#define VC_ATTN_QK_INTERLEAVE 0
-#endif
-#ifndef VC_ATTN_PRIO          // 1: the matrix-pipe phases (QK^T, P.V) of a wave run at s_setprio 1, its softmax at 0; 2: the reverse
-#define VC_ATTN_PRIO 0
+#ifndef VC_ATTN_ABL           // timing ablations (tools/attn_variants.sh; results are WRONG when != 0): 1 no QK^T MFMAs, 2 no exp2 / convert
+#define VC_ATTN_ABL 0         // arithmetic, 4 no P.V / row-sum MFMAs, 8 no per-tile barrier, 16 no LDS-DMA after the first two tiles, 32 no V reads
 #endif
 constexpr int NSTG = VC_ATTN_NSTG;       // K/V tile ring: tile t+NSTG-1 is in flight while tile t is multiplied
 constexpr int TILE_B = KT * 128;         // one K (or V) tile: 64 keys x 128 B
@@ -241,27 +238,25 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
   do {                                                                                                          \
     const char* kl = smem + (stg_) * STG_B;                                                                     \
     f32x16 st[2];                                                                                               \
-    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
-    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                       \
-    if (VC_ATTN_QK_INTERLEAVE) { /* the two 32-key blocks' accumulation chains alternate on the matrix pipe */  \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                          \
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],     \
-                                                         f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-      _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
-        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                        \
-          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[ds]), qf[ds], st[kt], 0, 0, 0); \
-    } else {                                                                                                    \
+    if (VC_ATTN_ABL & 1) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { st[0][r] = (float)(r + qi) * 1e-3f; st[1][r] = (float)(r - qi) * 1e-3f; } } else { \
+    /* all eight K fragments are requested before the first MFMA (left to itself hipcc reads them two at a time, each pair     \
+       behind its own lgkmcnt(0): four exposed LDS round trips per tile; measured anatomy in DESIGN.md 4.2 iii) */          \
+    bf16x8 kfr[2][4];                                                                                           \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) kfr[kt][ds] = *(const bf16x8*)(kl + kt * 4096 + koff[ds]); \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
-      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[0]), qf[0],       \
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][0], qf[0],                                       \
                                                        f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
       _Pragma("unroll") for (int ds = 1; ds < 4; ++ds)                                                          \
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kl + kt * 4096 + koff[ds]), qf[ds], st[kt], 0, 0, 0); \
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][ds], qf[ds], st[kt], 0, 0, 0);                 \
     }                                                                                                           \
     }                                                                                                           \
     /* the transpose reads of this tile's V fragments go out now: their latency hides behind the softmax       \
        (VC_ATTN_VEARLY; otherwise one 16-key block ahead of its MFMAs, 16 fewer live registers) */              \
     s16x4 vt[VC_ATTN_VEARLY ? 4 : 2][2][2];                                                                     \
     const uint32_t vb_ = lds_addr(kl);                                                                          \
+    if (VC_ATTN_ABL & 32) { _Pragma("unroll") for (int i_ = 0; i_ < (VC_ATTN_VEARLY ? 4 : 2); ++i_) _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) vt[i_][dt][rd] = s16x4{(short)(0x3c00 + i_), (short)0x3c00, (short)(0x3c00 + dt), (short)(0x3c00 + rd)}; } else \
     if (VC_ATTN_VEARLY) {                                                                                       \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                          \
         _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {                                                      \
@@ -281,8 +276,6 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
           st[kt][r] = vis_ ? st[kt][r] : -INFINITY;                                                             \
         }                                                                                                       \
     }                                                                                                           \
-    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                       \
-    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                       \
     /* running max on the raw scores (scale > 0), integer ceiling in the log2 domain */                         \
     float mx0 = fmaxf(st[0][0], st[1][0]), mx1 = fmaxf(st[0][1], st[1][1]);                                     \
     _Pragma("unroll") for (int r = 2; r < 16; r += 2) {                                                         \
@@ -305,9 +298,9 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     /* P = exp2(s*c - m) with one fma per score */                                                              \
     const float nm = -m_i;                                                                                      \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kt][r] = fast_exp2(fmaf(st[kt][r], c_log2, nm));        \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kt][r] = (VC_ATTN_ABL & 2) ? st[kt][r] + nm : fast_exp2(fmaf(st[kt][r], c_log2, nm)); \
     /* O^T += V^T . P^T over the four 16-key blocks; row sums: ones . P^T */                                    \
-    if (VC_ATTN_VEARLY) {                                                                                       \
+    if (VC_ATTN_VEARLY && !(VC_ATTN_ABL & 32)) {                                                                \
       asm volatile("s_waitcnt lgkmcnt(0)"                                                                       \
                    : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),                \
                      "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),                \
@@ -321,8 +314,6 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     }                                                                                                           \
     const uint32_t hx = hq ^ (uint32_t)((t_) * KT);                                                             \
     float psum = 0.f;                                                                                           \
-    if (VC_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
-    if (VC_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                       \
     _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
       const int kt = kb >> 1, ks = kb & 1;                                                                      \
       const int vs = VC_ATTN_VEARLY ? kb : (kb & 1);                                                            \
@@ -338,7 +329,9 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
       }                                                                                                         \
       bf16x8 pf;                                                                                                \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][ks * 8 + j];                         \
-      if (VC_ATTN_ROWSUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);         \
+      if (VC_ATTN_ABL & 4) { ot[0][kb] += (float)pf[0]; ot[1][kb] += (float)pf[5]; } else {                      \
+      if (VC_ATTN_ROWSUM_MFMA == 1) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);    \
+      else if (VC_ATTN_ROWSUM_MFMA == 2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) psum += st[kt][ks * 8 + j]; } /* unrounded P (timing) */ \
       else { _Pragma("unroll") for (int j = 0; j < 8; ++j) psum += (float)pf[j]; }                              \
       if (DROP) {                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
@@ -351,8 +344,9 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
         const s16x8 v8 = __builtin_shufflevector(vt[vs][dt][0], vt[vs][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);         \
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);  \
       }                                                                                                         \
+      }                                                                                                         \
     }                                                                                                           \
-    if (!VC_ATTN_ROWSUM_MFMA) l_i += psum;                                                                      \
+    if (VC_ATTN_ROWSUM_MFMA != 1) l_i += psum;                                                                      \
   } while (0)
 
   int stg = 0;                       // ring slot of tile t (wave-uniform)
@@ -361,10 +355,10 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     // wave is done with tile t-1, whose slot the next request is about to overwrite
     if (NSTG > 2 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(VC_ATTN_ABL & 8)) __syncthreads();
     if (NSTG > 2) {
       const int stg2 = stg == 0 ? 2 : stg - 1;                     // (stg + 2) % 3
-      if (t + 2 < ntiles) STAGE_TILE(t + 2, stg2);
+      if (t + 2 < ntiles && !(VC_ATTN_ABL & 16)) STAGE_TILE(t + 2, stg2);
     } else {
       if (t + 1 < ntiles) STAGE_TILE(t + 1, stg ^ 1);
     }
@@ -381,7 +375,7 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
 
   // ---- normalise and store: lane holds O[q][dt*32 + 8*g + 4*half + 0..3]; every register of lacc holds the MFMA part of
   // the row sum, l_i the left-over keys' part (one half-wave)
-  const float l_tot = (VC_ATTN_ROWSUM_MFMA ? lacc[0] : 0.f) + l_i + __shfl_xor(l_i, 32, 64);
+  const float l_tot = (VC_ATTN_ROWSUM_MFMA == 1 ? lacc[0] : 0.f) + l_i + __shfl_xor(l_i, 32, 64);
   const float inv = DROP ? drop_scale / l_tot : 1.0f / l_tot;
   const int q = q0 + qi;
   if (lse && q < S && half == 0) lse[((size_t)b * NH + h) * S + q] = m_i + log2f(l_tot);   // log2-domain logsumexp (training)
