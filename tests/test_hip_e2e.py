@@ -846,6 +846,53 @@ def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch, golden):
     assert cap['caption'].startswith(first) and 0 < cap['conf'] < 1
 
 
+def test_pipeline_predict_honours_the_batches_masks(tmp_path, monkeypatch, golden):
+    """pipeline.predict (the overlapped 2-slot path) decodes every batch with the options ITS attention_mask asks for: a batch whose
+    mask shows 7 visible tag slots gets tag_visible = 7 (round 2 validated the mask and then decoded with tag_visible = 0), host and
+    device text tensors alike; the device tensors of the steady state are checked without a host synchronisation and a bad one is
+    reported when its captions are collected."""
+    import json
+    from oracle import vitcap_oracle as O
+    from vitcap_amd.pipeline import CaptionUniPipeline
+    vec, _ = golden
+    monkeypatch.chdir(tmp_path)
+    enc = tmp_path / 'enc'
+    enc.mkdir()
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
+    img = _images(2)
+
+    def batch(n_tag, dev, keys):
+        input_ids, am = O.test_text_inputs(2, n_tag_visible=n_tag)
+        return {'image': img.clone(), 'key': keys, 'input_ids': input_ids.to(dev), 'attention_mask': am.to(dev),
+                'token_type_ids': torch.zeros(2, 70, dtype=torch.long, device=dev)}
+
+    def run(batches, name):
+        p = CaptionUniPipeline(full_expid='E', init_recipe_seed=0, text_encoder_type=str(enc), tagemb='cls', force_predict=True,
+                               test_batches=batches, model_file=str(tmp_path / (name + '.pt')))
+        out = p.ensure_predict()
+        return {l.split('\t')[0]: json.loads(l.rstrip('\n').split('\t')[1])[0]['caption'].split() for l in open(out)}
+
+    def words(ids_row):
+        toks_ = [int(t) for t in ids_row[1:] if int(t) not in (0, 101, 102)]
+        return ['w%d' % t for t in toks_]
+
+    rows = run([batch(0, 'cpu', ['a0', 'a1']), batch(7, 'cpu', ['b0', 'b1']), batch(7, 'cuda', ['c0', 'c1']), batch(7, 'cuda', ['d0', 'd1'])],
+               'mixed')
+    n_cmp = 8      # leading tokens: inside the comparable prefix of both goldens
+    for k, name in (('a', 'greedy_b2'), ('b', 'greedy_tags7_b2'), ('c', 'greedy_tags7_b2'), ('d', 'greedy_tags7_b2')):
+        for i in range(2):
+            want = words(vec[name + '_ids'][i, 0])
+            assert rows['%s%d' % (k, i)][:n_cmp] == want[:n_cmp], (k, i)
+    assert rows['b0'] == rows['c0'] == rows['d0']
+    assert not np.array_equal(vec['greedy_tags7_b2_ids'], vec['greedy_b2_ids'])
+    bad = batch(7, 'cuda', ['e0', 'e1'])
+    bad['attention_mask'][1, 3, 9] = 1
+    with pytest.raises(NotImplementedError, match='mask structure'):
+        run([batch(7, 'cuda', ['c0', 'c1']), bad], 'bad')
+
+
 def test_generate_async_pipeline_equals_generate(model):
     """Two-slot batch pipeline (encode of batch i+1 overlapping the decode of batch i on a second stream): every batch's
     ids / log-probs are bit-identical to the one-stream generate(), in order, across slot reuse and changing batch size."""
