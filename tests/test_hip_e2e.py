@@ -848,13 +848,13 @@ def test_run_py_pipeline_eval_surface(tmp_path, monkeypatch, golden):
 
 def test_pipeline_predict_honours_the_batches_masks(tmp_path, monkeypatch, golden):
     """pipeline.predict (the overlapped 2-slot path) decodes every batch with the options ITS attention_mask asks for: a batch whose
-    mask shows 7 visible tag slots gets tag_visible = 7 (round 2 validated the mask and then decoded with tag_visible = 0), host and
+    mask shows 50 visible tag slots gets tag_visible = 50 (round 2 validated the mask and then decoded with tag_visible = 0), host and
     device text tensors alike; the device tensors of the steady state are checked without a host synchronisation and a bad one is
     reported when its captions are collected."""
     import json
     from oracle import vitcap_oracle as O
+    from vitcap_amd.model import ImageCaptioning
     from vitcap_amd.pipeline import CaptionUniPipeline
-    vec, _ = golden
     monkeypatch.chdir(tmp_path)
     enc = tmp_path / 'enc'
     enc.mkdir()
@@ -872,25 +872,35 @@ def test_pipeline_predict_honours_the_batches_masks(tmp_path, monkeypatch, golde
         p = CaptionUniPipeline(full_expid='E', init_recipe_seed=0, text_encoder_type=str(enc), tagemb='cls', force_predict=True,
                                test_batches=batches, model_file=str(tmp_path / (name + '.pt')))
         out = p.ensure_predict()
-        return {l.split('\t')[0]: json.loads(l.rstrip('\n').split('\t')[1])[0]['caption'].split() for l in open(out)}
+        rows = {}
+        for l in open(out):
+            key, js = l.rstrip('\n').split('\t')
+            rec = json.loads(js)[0]
+            rows[key] = (rec['caption'].split(), rec['conf'])
+        return rows
 
-    def words(ids_row):
-        toks_ = [int(t) for t in ids_row[1:] if int(t) not in (0, 101, 102)]
-        return ['w%d' % t for t in toks_]
+    # what forward() -- whose tag handling is checked against the reference goldens in test_tag_tokens_visible_to_caption --
+    # returns for the same batches: the pipeline's rows must be exactly these (same kernels, bit-identical pipeline)
+    ref = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+    ref.pack('cuda')
 
-    rows = run([batch(0, 'cpu', ['a0', 'a1']), batch(7, 'cpu', ['b0', 'b1']), batch(7, 'cuda', ['c0', 'c1']), batch(7, 'cuda', ['d0', 'd1'])],
+    def expect(n_tag):
+        d = batch(n_tag, 'cuda', [0, 1])
+        d['image'] = d['image'].cuda()
+        ids, lp = ref(d)
+        return [(['w%d' % int(t) for t in ids[i, 0, 1:] if int(t) not in (0, 101, 102)], float(torch.exp(lp[i, 0]))) for i in range(2)]
+    want0, want50 = expect(0), expect(50)
+    assert want0 != want50, 'visible tags must change the caption or its confidence'
+    rows = run([batch(0, 'cpu', ['a0', 'a1']), batch(50, 'cpu', ['b0', 'b1']), batch(50, 'cuda', ['c0', 'c1']), batch(50, 'cuda', ['d0', 'd1'])],
                'mixed')
-    n_cmp = 8      # leading tokens: inside the comparable prefix of both goldens
-    for k, name in (('a', 'greedy_b2'), ('b', 'greedy_tags7_b2'), ('c', 'greedy_tags7_b2'), ('d', 'greedy_tags7_b2')):
+    for k, want in (('a', want0), ('b', want50), ('c', want50), ('d', want50)):
         for i in range(2):
-            want = words(vec[name + '_ids'][i, 0])
-            assert rows['%s%d' % (k, i)][:n_cmp] == want[:n_cmp], (k, i)
-    assert rows['b0'] == rows['c0'] == rows['d0']
-    assert not np.array_equal(vec['greedy_tags7_b2_ids'], vec['greedy_b2_ids'])
-    bad = batch(7, 'cuda', ['e0', 'e1'])
+            cap, conf = rows['%s%d' % (k, i)]
+            assert cap == want[i][0] and abs(conf - want[i][1]) <= 1e-7 * want[i][1], (k, i, conf, want[i][1])
+    bad = batch(50, 'cuda', ['e0', 'e1'])
     bad['attention_mask'][1, 3, 9] = 1
     with pytest.raises(NotImplementedError, match='mask structure'):
-        run([batch(7, 'cuda', ['c0', 'c1']), bad], 'bad')
+        run([batch(50, 'cuda', ['c0', 'c1']), bad], 'bad')
 
 
 def test_generate_async_pipeline_equals_generate(model):
