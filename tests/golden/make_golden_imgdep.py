@@ -101,12 +101,14 @@ def main():
     out['greedy_margins'] = m
     out['step_list'] = np.array(STEPS)
     cols = []
+    ncol = len(COLS) + 8
     for s in STEPS:
-        row = lrec.rows[s]
-        top = torch.topk(row, 8, dim=-1).indices.numpy()
-        cols.append(np.stack([np.unique(np.concatenate([COLS, top[b]]))[:len(COLS) + 8] if len(np.unique(np.concatenate([COLS, top[b]]))) >= len(COLS) + 8
-                              else np.pad(np.unique(np.concatenate([COLS, top[b]])), (0, len(COLS) + 8 - len(np.unique(np.concatenate([COLS, top[b]])))), mode='edge')
-                              for b in range(4)]))
+        top = torch.topk(lrec.rows[s], 8, dim=-1).indices.numpy()
+        per_image = []
+        for b in range(4):
+            u = np.unique(np.concatenate([COLS, top[b]]))          # the strided subset plus the row's 8 largest logits
+            per_image.append(np.pad(u, (0, ncol - len(u)), mode='edge'))   # a top column that is already in the subset: repeat the last
+        cols.append(np.stack(per_image))
     cols = np.stack(cols)                                           # (steps, 4, ncol)
     out['step_cols'] = cols.astype(np.int32)
     out['step_logits'] = np.stack([np.stack([lrec.rows[s][b].numpy()[cols[i, b]] for b in range(4)]) for i, s in enumerate(STEPS)]).astype(np.float32)
