@@ -15,6 +15,7 @@ python bench.py --steps 30 --warmup 3 --mode train > gpurun_out/bench_train_$TAG
 python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
+(python tools/library_yardstick.py; python tools/library_yardstick.py 295424) 2>&1 | grep -v amdgpu.ids > gpurun_out/library_yardstick_$TAG.txt
 bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
 bash tools/pmc_hot.sh $TAG > gpurun_out/pmc_hot_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp

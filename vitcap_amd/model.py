@@ -44,6 +44,26 @@ def _build_tree(root, spec, tie_weights):
     return params
 
 
+def _encode_stream(dev):
+    """The pipeline's encoder stream.  VITCAP_ENC_CUS = n < 256 (experiment, DESIGN.md 4.2 vi) confines it to the CUs of the
+    low n mask bits (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8), which leaves 256 - n CUs that the encoder's GEMM
+    workgroups never occupy for the decode chain's dependent launches to start on."""
+    import os
+    n = int(os.environ.get('VITCAP_ENC_CUS', '256'))
+    if n >= 256:
+        return torch.cuda.Stream(dev)
+    words = (C.c_uint32 * 8)()
+    for cu in range(n):
+        words[cu // 32] |= 1 << (cu % 32)
+    hip = C.CDLL('libamdhip64.so')
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, words)
+    if rc != 0:
+        raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class _Pending(object):
     """Handle of one batch in flight in ImageCaptioning.generate_async."""
 
@@ -424,7 +444,7 @@ class ImageCaptioning(nn.Module):
         if pipe is None:
             import os
             prio = int(os.environ.get('VITCAP_DECODE_PRIORITY', '-1'))     # -1 = high: the latency-bound chain goes first
-            pipe = pipes[lane] = {'enc': torch.cuda.Stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
+            pipe = pipes[lane] = {'enc': _encode_stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
                                   'done': [None, None], 'n': 0}
         slot = pipe['n'] % 2
         pipe['n'] += 1
