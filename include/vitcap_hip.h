@@ -222,9 +222,11 @@ int vitcap_greedy_step(const float* logits, int ldl, int V, int64_t* ids, int32_
 /* Embeddings of the predicted tag tokens written over the last 50 text slots (ViTSplitCLSEmbModel.forward,
  * modeling_bert.py:1435-1489, encode_tag_to_embedding 1381-1406): rows (b, j < n), token = tag_ids[b][j] (int64 [B][50]; slot 49
  * forced to 102).  branch_a / tagemb_cls select the four forms: raw rows of the caption head's decoder matrix (A, 'cls'),
- * LN(word + pos[20+j] + type) (A, other), LN(cls_w + pos[20+j] + type) (B, 'cls'), bert.extra_embeddings (B, other; the x* tables).
+ * LN(word + pos[20+j] + type) (A, other), LN(cls_w + pos[20+j] + type) (B, 'cls') -- encode_tag_to_embedding's literal caption_len = 20 --
+ * and bert.extra_embeddings LN_x(xword + xpos[pos0+j] + xtype) (B, other; the x* tables), the one form that takes the caller's
+ * position_ids: pos0 = max(od_labels_start_posid, max_length) (modeling_bert.py:958-959, 983-992, 1484-1485), pos0 + n <= 512.
  * Outputs fp32 and bf16 [B*n][768]. */
-int vitcap_tag_embed(const int64_t* tag_ids, int n, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
+int vitcap_tag_embed(const int64_t* tag_ids, int n, int pos0, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
                      const void* pos_emb, const void* type_emb, const float* gamma, const float* beta, const void* xword_emb,
                      const void* xpos_emb, const void* xtype_emb, const float* xgamma, const float* xbeta, float eps, float* x_f32,
                      void* x_bf16, int B, void* stream);
@@ -442,6 +444,12 @@ typedef struct vitcap_gen_opts {
   int32_t eos_extra[3];       /* eos_token_ids[1..3], -1 = unused: the greedy / sampling loop finishes a sequence at ANY of the ids
                                  (modeling_utils.py:862-865) and forces eos_token_ids[0] at the last position (:870-871).  Needs
                                  num_beams == 1: the reference's beam search asserts with several ids (modeling_utils.py:1037).  */
+  int32_t tag_pos0;           /* position id of tag slot 0 = max(od_labels_start_posid, max_length) (modeling_bert.py:958-959,
+                                 983-992; the pipeline passes od_labels_start_posid = max_seq_a_length, ..._bertemb.py:597: 20 in
+                                 the shipped YAML, 40 by the pipeline's default).  20 (default) .. 462.  Reaches the model through
+                                 ONE path only, as in the reference: bert.extra_embeddings of the tag rows (tagemb != 'cls',
+                                 branch B, modeling_bert.py:1484-1485; every other tag embedding uses the literal 20 of
+                                 encode_tag_to_embedding), so it is read when tag_visible > 0 and tagemb_cls == 0             */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */

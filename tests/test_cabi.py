@@ -75,7 +75,7 @@ def test_engine_lifecycle_and_workspace(L):
     assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(num_beams=5))) > w64
     assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(max_length=40))) > w64
     for bad in (dict(num_beams=9), dict(max_length=41), dict(max_length=1), dict(num_beams=1, num_keep_best=2),
-                dict(num_beams=2, seqs_per_image=2), dict(repetition_penalty=0.0), dict(eos_token_id=30522), dict(gemm_mode=7)):
+                dict(num_beams=2, seqs_per_image=2), dict(repetition_penalty=0.0), dict(eos_token_id=30522), dict(gemm_mode=7), dict(tag_pos0=19), dict(tag_pos0=463)):
         ob = L.gen_opts(**bad)
         assert L.lib.vitcap_gen_opts_check(C.byref(ob)) == -1 and L.lib.vitcap_last_error(), bad
         assert L.lib.vitcap_engine_workspace_bytes(4, C.byref(ob)) == 0
@@ -94,7 +94,7 @@ def test_struct_sizes_match_header(L):
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
     assert C.sizeof(L.GemmDesc) == 16 * 4 + 16          # 15 ints, padding, two pointers (live, rowstat)
-    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4
+    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4
 
 
 def test_model_surface(L, sd_np):
@@ -121,6 +121,9 @@ def test_model_surface(L, sd_np):
         with pytest.raises(NotImplementedError):                    # unsupported generate() options are refused, not ignored
             m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
         m.test_extra_input = keep
+    # the tag slots' start position follows generate(): max(od_labels_start_posid, max_length) (modeling_bert.py:958-959)
+    assert m.gen_options().tag_pos0 == 20 and m.gen_options(od_labels_start_posid=40).tag_pos0 == 40
+    assert m.gen_options(od_labels_start_posid=8, max_length=33).tag_pos0 == 33
     m.test_extra_input['num_keep_best'] = 3                        # greedy + n-best: the reference asserts (modeling_utils.py:790)
     with pytest.raises(AssertionError, match='greedy'):
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})

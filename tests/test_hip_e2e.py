@@ -13,6 +13,7 @@ What is asserted (tolerances stated inline; the noise floors are defined in test
   3. properties at the benchmark sizes (B=64 greedy, 256 x beam 5): determinism, batch-composition invariance, well-formed
      ids; hipGraph replay, early exit, max_length != 20, option and text-input validation, two host threads on one engine.
 """
+import os
 import threading
 
 import numpy as np
@@ -247,6 +248,42 @@ def test_untied_flow_multi_token_caption(imgdep):
     assert sum(r[1] for r in rep) >= 8, 'too few comparable decisions to mean anything'
     if all(r[4] for r in rep):
         np.testing.assert_allclose(lp.cpu().numpy(), vec['untied_logprobs'], rtol=0, atol=1e-2)
+
+
+def test_tag_slot_start_position(imgdep):
+    """`od_labels_start_posid` above the generation length (the pipeline's own default is max_seq_a_length = 40, ..._bertemb.py:197,
+    597): the position ids of the tag slots reach the model through bert.extra_embeddings only (tagemb != 'cls', branch B,
+    modeling_bert.py:1484-1485) -- tests/golden/make_golden_tagpos.py shows the reference's tied flow identical for 20 and 40 and
+    its untied flow different.  Device, tags visible, against the reference's own output at 40 and at 20; the option must reach
+    the kernel (the two device runs differ) and must not move the tied flow."""
+    from vitcap_amd.model import ImageCaptioning
+    _, cand = imgdep
+    vec = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_tagpos.npz')))
+    img = cand[torch.from_numpy(vec['sel_index'])].cuda()
+    assert np.array_equal(vec['tied_pos20_ids'], vec['tied_pos40_ids']) and np.array_equal(vec['tied_pos20_logprobs'], vec['tied_pos40_logprobs'])
+    assert not np.array_equal(vec['untied_pos20_logprobs'], vec['untied_pos40_logprobs'])
+    m = ImageCaptioning(tie_weights=False, tagemb=None).load_recipe(0, vbias_std=float(vec['untied_vbias_std'][0])).eval()
+    m.pack('cuda')
+    got = {}
+    for pos in (20, 40):
+        assert m.gen_options(tag_visible=50, od_labels_start_posid=pos).tag_pos0 == pos
+        ids, lp = m.generate(img, tag_visible=50, od_labels_start_posid=pos)
+        rep = assert_tokens_match_reference(ids.cpu().numpy(), vec['untied_pos%d_ids' % pos], vec['untied_pos%d_margins' % pos],
+                                            GREEDY_MARGIN_FLOOR, min_full=0, what='untied, tags visible, start position %d' % pos)
+        print('start position', pos, rep, lp.flatten().tolist(), vec['untied_pos%d_logprobs' % pos].flatten().tolist())
+        assert sum(r[1] for r in rep) >= 8 or all(r[4] for r in rep), 'too few comparable decisions to mean anything'
+        same = np.array([r[4] for r in rep])
+        if same.any():
+            np.testing.assert_allclose(lp.cpu().numpy()[same], vec['untied_pos%d_logprobs' % pos][same], rtol=0, atol=1e-2)
+        got[pos] = (ids.clone(), lp.clone())
+    assert not torch.equal(got[20][1], got[40][1]), 'the start position never reached bert.extra_embeddings'
+    mt = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+    mt.pack('cuda')
+    a = [t.clone() for t in mt.generate(img, tag_visible=50, od_labels_start_posid=20)]
+    b = mt.generate(img, tag_visible=50, od_labels_start_posid=40)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "tagemb 'cls' uses encode_tag_to_embedding's literal 20"
+    assert_tokens_match_reference(b[0].cpu().numpy(), vec['tied_pos40_ids'], vec['tied_pos40_margins'], GREEDY_MARGIN_FLOOR, min_full=0,
+                                  what='tied, tags visible, start position 40')
 
 
 @pytest.mark.parametrize('name,beams', [('beam2_b1', 2), ('beam5_b1', 5), ('beam5_b2', 5), ('beam5_sel', 5), ('beam3_alteos_b2', 3)])

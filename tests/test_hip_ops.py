@@ -181,8 +181,8 @@ def test_gemm_resident_whole_k(ops, M, N, K, hint, act):
         _close(got, z + bias.cpu() + x.cpu(), 1e-4, 1e-4, 'resident f32 + residual')
 
 
-@pytest.mark.parametrize('branch_a,cls', [(1, 1), (1, 0), (0, 1), (0, 0)])
-def test_tag_embed_four_forms(ops, branch_a, cls):
+@pytest.mark.parametrize('branch_a,cls,pos0', [(1, 1, 20), (1, 0, 20), (0, 1, 20), (0, 0, 20), (1, 0, 40), (0, 1, 40), (0, 0, 462)])
+def test_tag_embed_four_forms(ops, branch_a, cls, pos0):
     """vitcap_tag_embed: the four tag-row embeddings of modeling_bert.py:1435-1489 against their torch definition."""
     import ctypes as C
     from vitcap_amd._lib import lib, check
@@ -197,11 +197,12 @@ def test_tag_embed_four_forms(ops, branch_a, cls):
     xf = torch.empty(B * n, 768, device='cuda')
     xb = torch.empty(B * n, 768, device='cuda', dtype=torch.bfloat16)
     p = lambda t: C.c_void_p(t.data_ptr())
-    check(lib.vitcap_tag_embed(p(tags), n, branch_a, cls, p(cls_w), p(word), p(pos), p(typ), p(gam), p(bet), p(xword), p(xpos), p(xtyp),
+    check(lib.vitcap_tag_embed(p(tags), n, pos0, branch_a, cls, p(cls_w), p(word), p(pos), p(typ), p(gam), p(bet), p(xword), p(xpos), p(xtyp),
                                p(xgam), p(xbet), 1e-12, p(xf), p(xb), B, None), 'tag_embed')
     t = tags.clone()
     t[:, -1] = 102
-    j = torch.arange(50, device='cuda') + 20
+    j = torch.arange(50, device='cuda') + 20            # encode_tag_to_embedding's literal caption_len; pos0 reaches the last form only
+    jx = torch.arange(50, device='cuda') + pos0
     if branch_a and cls:
         want = cls_w[t].float()
     elif branch_a:
@@ -209,9 +210,11 @@ def test_tag_embed_four_forms(ops, branch_a, cls):
     elif cls:
         want = torch.nn.functional.layer_norm(cls_w[t].float() + pos[j].float() + typ[0].float(), (768,), gam, bet, 1e-12)
     else:
-        want = torch.nn.functional.layer_norm(xword[t].float() + xpos[j].float() + xtyp[0].float(), (768,), xgam, xbet, 1e-12)
+        want = torch.nn.functional.layer_norm(xword[t].float() + xpos[jx].float() + xtyp[0].float(), (768,), xgam, xbet, 1e-12)
     _close(xf.view(B, 50, 768), want.cpu(), 2e-5, 2e-5, 'tag_embed')
     assert torch.equal(xb.cpu(), xf.cpu().to(torch.bfloat16))
+    assert lib.vitcap_tag_embed(p(tags), n, 463, branch_a, cls, p(cls_w), p(word), p(pos), p(typ), p(gam), p(bet), p(xword), p(xpos), p(xtyp),
+                                p(xgam), p(xbet), 1e-12, p(xf), p(xb), B, None) == -1          # past the position table
 
 
 def test_greedy_select_embed_equals_step_plus_embed(ops):

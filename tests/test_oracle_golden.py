@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/vitcap_oracle.py) against vectors produced by the reference itself
 (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -184,6 +186,20 @@ def test_tags_visible_as_written_matches_reference(golden, sd_t, img):
     np.testing.assert_allclose(lp.numpy(), vec['greedy_tags50_b2_logprobs'], rtol=1e-5, atol=1e-5)
     assert not np.array_equal(vec['greedy_tags50_b2_ids'], vec['greedy_b2_ids'])
     assert int(vec['tags_topk_len_b2'][0]) == 50            # recipe: branch B at steps 1..18, branch A at step 19
+
+
+@pytest.mark.slow
+def test_tag_slot_start_position_as_written_matches_reference():
+    """od_labels_start_posid = 40 (> max_length) with the tags visible, notebook flow: the oracle's as-written path against the
+    reference's own output (tests/golden/make_golden_tagpos.py); the position ids reach bert.extra_embeddings (:1484-1485)."""
+    vec = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_tagpos.npz')))
+    sd = O.to_torch(W.make_state_dict(seed=0, tie_weights=False, vbias_std=float(vec['untied_vbias_std'][0])))
+    img = torch.from_numpy(W.gen_structured_images(48, int(vec['image_seed'][0])))[torch.from_numpy(vec['sel_index'])]
+    with torch.no_grad():
+        ids, lp = O.greedy_as_written(sd, img, tagemb=None, reuse_encoder=True, n_tag_visible=50, od_labels_start_posid=40)
+    np.testing.assert_array_equal(ids.numpy(), vec['untied_pos40_ids'])
+    np.testing.assert_allclose(lp.numpy(), vec['untied_pos40_logprobs'], rtol=1e-5, atol=1e-5)
+    assert not np.array_equal(vec['untied_pos40_ids'], vec['untied_pos20_ids'])
 
 
 def test_beam2_as_written_matches_reference(golden, sd_t, img):

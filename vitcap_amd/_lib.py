@@ -46,7 +46,7 @@ class GenOpts(C.Structure):
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
                 ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('tag_visible', C.c_int32), ('tagemb_cls', C.c_int32),
-                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3)]
+                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3), ('tag_pos0', C.c_int32)]
 
 
 class Image(C.Structure):
@@ -130,7 +130,7 @@ _SIGS = {
                                           C.c_float, vp]),
     'vitcap_attn_decode_step_tags': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp,
                                                C.c_int, vp, vp]),
-    'vitcap_tag_embed': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp,
+    'vitcap_tag_embed': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp,
                                    C.c_int, vp]),
     'vitcap_copy_row_blocks': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, vp]),

@@ -103,6 +103,7 @@ vitcap_gen_opts default_opts() {
   o.decode_streams = 0;
   o.encode_parts = 0;
   o.eos_extra[0] = o.eos_extra[1] = o.eos_extra[2] = -1;
+  o.tag_pos0 = VITCAP_MAXLEN;
   return o;
 }
 
@@ -121,6 +122,7 @@ int check_opts(const vitcap_gen_opts& o) {
           "gen_opts: temperature %g / top_k %d / top_p %g out of range", (double)o.sampling.temperature, o.sampling.top_k, (double)o.sampling.top_p);
   OPT_REQ(o.gemm_mode == VITCAP_GEMM_AUTO || o.gemm_mode == VITCAP_GEMM_TILES, "gen_opts: gemm_mode %d unknown", o.gemm_mode);
   OPT_REQ(o.tag_visible >= 0 && o.tag_visible <= 50, "gen_opts: tag_visible must be 0..50 (got %d)", o.tag_visible);
+  OPT_REQ(o.tag_pos0 >= VITCAP_MAXLEN && o.tag_pos0 <= 512 - 50, "gen_opts: tag_pos0 must be %d..462 (got %d)", VITCAP_MAXLEN, o.tag_pos0);
   OPT_REQ(o.tag_visible == 0 || o.max_length == VITCAP_MAXLEN, "gen_opts: tag_visible > 0 needs max_length == %d", VITCAP_MAXLEN);
   OPT_REQ(o.encode_parts >= 0 && o.encode_parts <= 4, "gen_opts: encode_parts must be 0 (auto) .. 4 (got %d)", o.encode_parts);
   OPT_REQ(o.decode_streams >= 0 && o.decode_streams <= 2, "gen_opts: decode_streams must be 0 (auto), 1 or 2 (got %d)", o.decode_streams);
@@ -747,7 +749,7 @@ static int prefill_tags(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
     return VITCAP_ESTATE;
   }
   for (int v = 0; v < 2; ++v)
-    CK(vitcap_tag_embed((const int64_t*)(ws + lo.tag_ids), n, v == 0, o.tagemb_cls, w.cls.dec_w, w.word_emb, w.pos_emb, w.type_emb,
+    CK(vitcap_tag_embed((const int64_t*)(ws + lo.tag_ids), n, o.tag_pos0, v == 0, o.tagemb_cls, w.cls.dec_w, w.word_emb, w.pos_emb, w.type_emb,
                         w.emb_ln_g, w.emb_ln_b, w.xword_emb, w.xpos_emb, w.xtype_emb, w.xemb_ln_g, w.xemb_ln_b, 1e-12f,
                         (float*)(ws + lo.tagx_f[v]), ws + lo.tagx_b[v], B, s));
   for (int l = 0; l < 4; ++l) {

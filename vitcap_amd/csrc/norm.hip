@@ -229,8 +229,8 @@ __global__ __launch_bounds__(128) void greedy_select_embed_kernel(const float* _
 //   branch A (topk_len[0] + 20 <= L), tagemb == 'cls': the raw row of the caption head's decoder matrix (F.embedding, :1456-1462)
 //   branch A, otherwise        : LN_emb(word[tok] + pos[20 + j] + type[0])                       (encode_tag_to_embedding, :1381-1406)
 //   branch B, tagemb == 'cls'  : LN_emb(cls_w[tok] + pos[20 + j] + type[0])                      (:1481)
-//   branch B, otherwise        : LN_x(xword[tok] + xpos[20 + j] + xtype[0])   (bert.extra_embeddings, :1484-1485)
-__global__ __launch_bounds__(256) void tag_embed_kernel(const int64_t* __restrict__ tag_ids, int n, int branch_a, int tagemb_cls,
+//   branch B, otherwise        : LN_x(xword[tok] + xpos[pos0 + j] + xtype[0])   (bert.extra_embeddings, :1484-1485)
+__global__ __launch_bounds__(256) void tag_embed_kernel(const int64_t* __restrict__ tag_ids, int n, int pos0, int branch_a, int tagemb_cls,
                                                         const bf16_t* __restrict__ cls_w, const bf16_t* __restrict__ word,
                                                         const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void tag_embed_kernel(const int64_t* __restric
   const bf16_t* tab = tagemb_cls ? cls_w : (extra ? xword : word);
   const bf16_t* ptab = extra ? xpos : pos;
   const bf16_t* ttab = extra ? xtype : type;
+  const int pbase = extra ? pos0 : 20;     // encode_tag_to_embedding's literal caption_len = 20 (:1381, :1396); the caller's position_ids reach bert.extra_embeddings only (:1484-1485)
   f32x4 v[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void tag_embed_kernel(const int64_t* __restric
     if (branch_a && tagemb_cls) {
       v[i] = a;
     } else {
-      const f32x4 q = ld_bf4(ptab + (size_t)(20 + j) * D768 + c);
+      const f32x4 q = ld_bf4(ptab + (size_t)(pbase + j) * D768 + c);
       const f32x4 ty = ld_bf4(ttab + c);
       v[i] = (a + q) + ty;
     }
@@ -426,18 +427,19 @@ extern "C" int vitcap_greedy_select_embed(const float* rowstat, int pieces, int6
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_tag_embed(const int64_t* tag_ids, int n, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
+extern "C" int vitcap_tag_embed(const int64_t* tag_ids, int n, int pos0, int branch_a, int tagemb_cls, const void* cls_w, const void* word_emb,
                                 const void* pos_emb, const void* type_emb, const float* gamma, const float* beta,
                                 const void* xword_emb, const void* xpos_emb, const void* xtype_emb, const float* xgamma,
                                 const float* xbeta, float eps, float* x_f32, void* x_bf16, int B, void* stream) {
   VC_REQUIRE(tag_ids && x_f32 && x_bf16 && B > 0 && n >= 1 && n <= 50, "tag_embed: bad arguments (n=%d)", n);
+  VC_REQUIRE(pos0 >= 0 && pos0 + n <= 512, "tag_embed: positions %d..%d are outside the 512-row position table", pos0, pos0 + n - 1);
   const bool need_extra = !tagemb_cls && !branch_a, raw = tagemb_cls && branch_a;
   VC_REQUIRE(!tagemb_cls || cls_w, "tag_embed: tagemb == 'cls' needs the caption head's decoder matrix");
   VC_REQUIRE(tagemb_cls || need_extra || word_emb, "tag_embed: missing word embedding table");
   VC_REQUIRE(raw || need_extra || (pos_emb && type_emb && gamma && beta), "tag_embed: missing position / type tables or LayerNorm");
   VC_REQUIRE(!need_extra || (xword_emb && xpos_emb && xtype_emb && xgamma && xbeta), "tag_embed: bert.extra_embeddings tables missing");
   const int rows = B * n;
-  hipLaunchKernelGGL(tag_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, tag_ids, n, branch_a, tagemb_cls,
+  hipLaunchKernelGGL(tag_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, tag_ids, n, pos0, branch_a, tagemb_cls,
                      (const bf16_t*)cls_w, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_emb, gamma, beta,
                      (const bf16_t*)xword_emb, (const bf16_t*)xpos_emb, (const bf16_t*)xtype_emb, xgamma, xbeta, eps, x_f32,
                      (bf16_t*)x_bf16, rows);

@@ -290,7 +290,7 @@ class ImageCaptioning(nn.Module):
                        early_exit=int(bool(te.get('early_exit', True))), use_graph=int(bool(use_graph)),
                        tag_visible=int(te.get('tag_visible', 0) or 0), tagemb_cls=int(self.tagemb == 'cls'),
                        decode_streams=int(te.get('decode_streams', 0) or 0), encode_parts=int(te.get('encode_parts', 0) or 0),
-                       eos_extra=eos[1:])
+                       eos_extra=eos[1:], tag_pos0=max(int(te.get('od_labels_start_posid', 20) or 0), ml, 20))
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
