@@ -114,7 +114,7 @@ def test_model_surface(L, sd_np):
     with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    for bad in ({'eos_token_ids': [102, 1012, 5, 6, 7]}, {'eos_token_ids': [102, 1012], 'num_beams': 2}, {'use_cbs': True}, {'max_length': 41},
+    for bad in ({'eos_token_ids': [102, 1012, 5, 6, 7]}, {'eos_token_ids': [102, 1012], 'num_beams': 2}, {'use_cbs': True}, {'max_length': 41}, {'add_od_labels': False},
                 {'num_return_sequences': 2}):
         keep = dict(m.test_extra_input)
         m.test_extra_input.update(bad)

@@ -199,7 +199,7 @@ def test_pipeline_train_then_eval(tmp_path, monkeypatch, scst):
     (enc / 'vocab.txt').write_text('\n'.join(toks) + '\n')
     cfg = {'type': 'pipeline_train_eval_multi',
            'all_test_data': [{'test_data': 'synthetic', 'test_split': 'test'}],
-           'param': {'full_expid': 'T', 'max_iter': 2, 'effective_batch_size': 2, 'init_recipe_seed': 0, 'log_step': 1,
+           'param': {'full_expid': 'T', 'max_iter': 2, 'drop_out': 0, 'effective_batch_size': 2, 'init_recipe_seed': 0, 'log_step': 1,
                      'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'test_batch_size': 2,
                      'synthetic_num_images': 2, 'force_train': True, 'force_predict': True,
                      'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
@@ -237,7 +237,7 @@ def test_pipeline_basemodel_is_the_init_and_training_resumes(tmp_path, monkeypat
     torch.save({'model': {'module.' + k: v for k, v in ImageCaptioning().load_recipe(0).state_dict().items()}}, base)
 
     def cfg(expid, max_iter, **kw):
-        p = {'full_expid': expid, 'max_iter': max_iter, 'effective_batch_size': 2, 'basemodel': str(base), 'log_step': 1,
+        p = {'full_expid': expid, 'max_iter': max_iter, 'drop_out': 0, 'effective_batch_size': 2, 'basemodel': str(base), 'log_step': 1,
              'snapshot_steps': 1, 'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'test_batch_size': 2,
              'synthetic_num_images': 2, 'force_predict': True, 'base_lr': 1e-3,
              'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}
@@ -681,7 +681,7 @@ def test_pipeline_trains_on_tsv_data(tmp_path, monkeypatch, scst):
     tsv_writer(img_rows, str(d / 'train.tsv'))
     tsv_writer(cap_rows, str(d / 'train.caption.tsv'))
     tsv_writer(lab_rows, str(d / 'train.label.vvinvl.tsv'))
-    param = {'full_expid': 'R', 'max_iter': 3, 'effective_batch_size': 4, 'init_recipe_seed': 0, 'log_step': 1, 'data': 'toy',
+    param = {'full_expid': 'R', 'max_iter': 3, 'drop_out': 0, 'effective_batch_size': 4, 'init_recipe_seed': 0, 'log_step': 1, 'data': 'toy',
              'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'force_train': True, 'max_seq_a_length': 20,
              'train_label_version': 'vinvl', 'encode': 'bert', 'input_small_scale': 0.08, 'num_workers': 2, 'random_seed': 5,
              'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}

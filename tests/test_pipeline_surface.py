@@ -64,3 +64,37 @@ def test_detokenizer_matches_reference_rules():
     assert t.decode(ids, skip_special_tokens=True) == 'a cat walking on a beach.'
     assert t.decode(ids[:4]) == '[CLS] a cat walk'
     assert t.decode(t.convert_tokens_to_ids(['cat', "'", 's', 'beach'])) == "cat's beach"
+
+
+def test_unbuilt_model_variants_are_refused():
+    """A configuration that names a model variant or training rule this build does not implement is refused, not run as if the key
+    had not been said: another ViT, tag-branch depth, top-k, tied tag head, mask family, optimizer / schedule; training needs
+    `drop_out: 0` as in the shipped YAML (cfg.drop_out is BertConfig.hidden_dropout_prob, ..._bertemb.py:535; default 0.1)."""
+    import pytest
+    import yaml
+    from vitcap_amd.pipeline import CaptionUniPipeline, check_model_config
+    shipped = yaml.safe_load("""
+        drop_out: 0
+        mask_type: seq2seq
+        image_encoder_type: VitEmb_vit_base_patch16_384
+        split_blocks: 4
+        topk: 50
+        use_img_layernorm: False
+        use_amp: False
+        tagemb: cls
+        loss: focal
+        category: bert
+        max_seq_a_length: 20
+    """)
+    check_model_config(CaptionUniPipeline(**shipped).cfg, training=True)          # the shipped YAML's values pass
+    check_model_config(CaptionUniPipeline().cfg, training=False)                  # an empty config is the built model
+    for bad in ({'split_blocks': 2}, {'topk': 20}, {'topk': None}, {'image_encoder_type': 'VitEmb_vit_large_patch16_384'},
+                {'tie_tag_weights': True}, {'mask_type': 'bidirectional'}, {'optimizer_type': 'LAMB'}, {'scheduler_type': 'cosine'},
+                {'use_img_layernorm': True}, {'loss': 'bce'}, {'ln_no_weight_decay': False}, {'use_amp': True}):
+        with pytest.raises(NotImplementedError, match=list(bad)[0]):
+            check_model_config(CaptionUniPipeline(**dict(shipped, **bad)).cfg, training=False)
+    with pytest.raises(NotImplementedError, match='drop_out'):
+        check_model_config(CaptionUniPipeline().cfg, training=True)               # the pipeline's own default is 0.1
+    with pytest.raises(NotImplementedError, match='drop_out'):
+        CaptionUniPipeline(drop_out=0.1, init_recipe_seed=0).ensure_train()
+    check_model_config(CaptionUniPipeline(drop_out=0.1).cfg, training=False)      # inference: dropout is inactive

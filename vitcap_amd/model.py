@@ -259,6 +259,10 @@ class ImageCaptioning(nn.Module):
         te.update(over)
         if te.get('use_cbs', False):
             raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
+        if not te.get('add_od_labels', True):
+            # without the 50 od slots ViTSplitCLSEmbModel.forward has no rows to write its tag embeddings over
+            # (`embedding_output[:, -pred_topk.shape[1]:] = tag_embedding`, modeling_bert.py:1467 / 1489) and the reference fails
+            raise NotImplementedError('add_od_labels=False: the reference model needs the 50 tag slots behind the caption')
         eos = te.get('eos_token_ids', [102])
         eos = [int(x) for x in eos] if isinstance(eos, (list, tuple)) else [int(eos)]
         if not 1 <= len(eos) <= 4:

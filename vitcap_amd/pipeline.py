@@ -43,6 +43,44 @@ _CAPTION_DEFAULT = {   # CaptionUniPipeline._default.update (..._bertemb.py:195-
 }
 
 
+# Configuration keys that select another model or training rule in the reference and that this build implements for ONE value (the
+# shipped YAML's): a config that sets another value is refused, not run as if it had not been said.  (key, accepted explicit
+# values, what the reference does with it.)  A key the config does not mention is accepted: the built value is then the default.
+_BUILT_FOR = (
+    ('image_encoder_type', ('VitEmb_vit_base_patch16_384',), 'config.net: another timm ViT (..._bertemb.py:545)'),
+    ('split_blocks', (4, '4'), 'depth of the tag branch (config.split_blocks, modeling_bert.py:440-478)'),
+    ('topk', (50,), 'tag tokens kept per image (modeling_bert.py:1424-1432); None selects the threshold mode'),
+    ('use_img_layernorm', (False, 0), 'LayerNorm on the image features (config.use_img_layernorm)'),
+    ('tie_tag_weights', (False, 0), 'tag head tied to the word embeddings (modeling_bert.py:724-726)'),
+    ('mask_type', ('seq2seq',), 'attention mask family (dataset.py:377-417)'),
+    ('scheduler_type', ('linear',), 'LR schedule (..._bertemb.py:358-371)'),
+    ('optimizer_type', ('MAdamW',), 'optimizer (..._bertemb.py:346-356)'),
+    ('bias_no_weight_decay', (True, 1), 'parameter groups (..._bertemb.py:280-322)'),
+    ('ln_no_weight_decay', (True, 1), 'parameter groups (..._bertemb.py:280-322)'),
+    ('loss', ('focal',), 'tag loss reported next to masked_loss (config.loss, modeling_bert.py:1327-1333)'),
+    ('later_captioning', (None, False, 0), 'config.later_captioning'),
+    ('attn_token_sample', (None, False, 0), 'config.attn_token_sample'),
+    ('topktagger', (None, False, 0), 'config.topktagger'),
+    ('tagemb_gradient', (None, False, 0), 'config.tagemb_gradient'),
+    ('pert_img_prob', (None, 0, 0.0), 'image perturbation during training'),
+    ('use_amp', (False, 0), 'apex / autocast mixed precision; this build computes in bf16 with fp32 accumulation throughout'),
+)
+
+
+def check_model_config(cfg, training):
+    """Refuses configurations that name a model variant or training rule this build does not implement (see _BUILT_FOR).  Training
+    additionally needs `drop_out: 0` as in the shipped YAML: cfg.drop_out becomes BertConfig.hidden_dropout_prob
+    (..._bertemb.py:535; the pipeline's own default is 0.1) and hidden-state dropout is not built -- only the decoder's attention
+    dropout (attention_probs_dropout_prob) is."""
+    given = cfg.overwrite
+    for key, ok, what in _BUILT_FOR:
+        if key in given and given[key] not in ok:
+            raise NotImplementedError('%s: %r is not built (accepted: %s) -- %s' % (key, given[key], ', '.join(repr(v) for v in ok), what))
+    if training and float(cfg.drop_out or 0) != 0:
+        raise NotImplementedError('drop_out: %r -- hidden-state dropout (BertConfig.hidden_dropout_prob, ..._bertemb.py:535) is not built; '
+                                  'the shipped YAML trains with drop_out: 0 (the pipeline\'s own default is 0.1)' % (cfg.drop_out,))
+
+
 class _EngineState(object):
     """state_dict() / load_state_dict() views of the training engine for Checkpointer (same keys as the reference
     checkpoint: 'model' / 'optimizer' / 'scheduler', src/tools/opt/checkpoint.py:60-102)."""
@@ -215,6 +253,7 @@ class CaptionUniPipeline(object):
     def ensure_train(self):
         """do_train_dict (trainer.py:33-213) on the HIP training engine: per-GPU batch = effective_batch_size // world,
         AdamW on the reference's parameter groups, linear LR decay, snapshot every snapshot_steps and at max_iter."""
+        check_model_config(self.cfg, training=True)
         import time
         self._ensure_initialized()
         last = self.get_checkpoint_file()
@@ -425,6 +464,7 @@ class CaptionUniPipeline(object):
         return predict_result_file
 
     def ensure_predict(self, model_file=None):
+        check_model_config(self.cfg, training=False)
         if self.cfg.ignore_predict:
             logging.info('ignore to predict as instructed')
             return None
