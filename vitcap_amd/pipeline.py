@@ -230,8 +230,12 @@ class CaptionUniPipeline(object):
         from .tokenizer import BertWordPieceTokenizer
         c = self.cfg
         if int(c.max_seq_a_length) > 20:
-            raise NotImplementedError('the training engine is built for max_seq_a_length <= 20 (the shipped YAML value), got %s'
-                                      % c.max_seq_a_length)
+            # not a size limit: ViTSplitCLSEmbModel.forward hard-codes 20 caption slots -- `topk_len[0] + 20 <= L` and
+            # `embedding_output[:, -50:] = tag_embedding` (modeling_bert.py:1435, 1467) overwrite rows 20..69 of the 70 text rows,
+            # i.e. the caption slots 20..max_seq_a_length-1 themselves; the shipped YAML sets 20 for that reason
+            raise NotImplementedError('max_seq_a_length = %s: the reference model itself only works with 20 caption slots (its forward '
+                                      'writes the 50 tag embeddings over text rows 20..69, modeling_bert.py:1435-1467); set '
+                                      'max_seq_a_length: 20 as the shipped YAML does' % c.max_seq_a_length)
         vf = op.join(c.text_encoder_type or '.', 'vocab.txt')
         tok = BertWordPieceTokenizer(vf)
         tz = CaptionTensorizer(tok, max_img_seq_length=int(c.max_img_seq_length), max_seq_length=int(c.max_seq_length),
