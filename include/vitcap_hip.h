@@ -83,6 +83,10 @@ typedef struct {
                           lowest on ties), sum exp(x - max), 0} of the finished values -- what argmax / log_softmax over the
                           row are assembled from (vitcap_greedy_select_embed) without reading C back.  Needs fp32 output,
                           no activation / residual; 64x64 tiles. */
+  float* colsum;       /* optional, fp32 [N]: colsum[n] += sum over the M rows of the finished bf16 OUTPUT values (atomic
+                          accumulation, as vitcap_colsum_bf16 of C would add them) -- the bias gradient of the layer whose output
+                          gradient this GEMM produces, without another pass over C.  Needs bf16 output, no residual / row remap /
+                          split-K, M >= 2048, N and ldc multiples of 8 (the 256x256 kernel's 16-byte-store epilogue). */
 } vitcap_gemm_desc;
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,
@@ -509,10 +513,14 @@ int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float*
 int vitcap_transpose_colsum(const void* x, int ldx, void* xt, int ldt, float* colsum, int R, int C, void* stream);
 /* LayerNorm backward (nn.LayerNorm): dx = LNbwd(dy; x, gamma) + dres;  dgamma/dbeta accumulated with atomics */
 int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32, const float* gamma, float eps,
-                         const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, int M, int D,
-                         void* stream);
+                         const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_bf16_colsum,
+                         int M, int D, void* stream);
+/* dx_bf16_colsum (optional, fp32 [768]): += column sums of the bf16-rounded dx (the bias gradient of the linear layer whose
+ * output gradient dx is; what vitcap_colsum_bf16(dx_bf16) would add). */
 int vitcap_reduce_slabs(const float* slabs, size_t slab_stride, int S, float* out, size_t n, int accumulate, void* stream);
 int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream);
+/* the same over [M][768] rows, with colsum[c] += sum over rows of the ROUNDED values (cast + vitcap_colsum_bf16 in one pass) */
+int vitcap_cast_bf16_colsum(const float* x, void* y, float* colsum, int M, int D, void* stream);
 /* BertEmbeddings backward: scatter-add into word / position / token-type gradient tables (modeling_bert.py:230-234) */
 int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
                      int rows, int pos_wrap, void* stream);

@@ -94,6 +94,37 @@ def test_layernorm_backward(ops, dy_f32):
     assert _rel(dxf, xx.grad + dres) < 1e-5
     assert torch.equal(dxb.cpu(), dxf.cpu().to(torch.bfloat16))
     assert _rel(dgam, gg.grad) < 1e-4 and _rel(dbet, bb.grad) < 1e-4
+    # the same with the column sums of the bf16 result added on the way out (bias gradient of the layer dx is the output
+    # gradient of): identical dx, sums of the ROUNDED values, accumulated into what the buffer held
+    cs = torch.full((768,), 0.5, device='cuda')
+    dgam2 = torch.zeros(768, device='cuda'); dbet2 = torch.zeros(768, device='cuda')
+    dxf2, dxb2 = ops.layernorm_bwd(x.cuda(), dy.cuda(), gam.cuda(), 1e-6, dgam2, dbet2, dres=dres.cuda(), dxb_colsum=cs)
+    assert torch.equal(dxf2, dxf) and torch.equal(dxb2, dxb)
+    assert _rel(cs, 0.5 + dxb.float().sum(0)) < 1e-5 and _rel(dgam2, dgam) < 1e-5
+
+
+def test_fused_bias_gradients(ops):
+    """Bias gradients = column sums of a backward operand, added by the kernel that WRITES the operand: the fp32 -> bf16 cast of a
+    residual-stream gradient (vitcap_cast_bf16_colsum), the 256x256 GEMM's epilogue (vitcap_gemm_desc.colsum, with the gelu'
+    factor), against a separate pass over the stored bf16 values (vitcap_colsum_bf16) and torch."""
+    M, N, K = 2308, 1024, 768
+    x = _rand((M, 768), 31, 1.5).cuda()
+    cs = torch.full((768,), -2.0, device='cuda')
+    y = ops.cast_bf16_colsum(x, cs)
+    assert torch.equal(y, ops.cast_bf16(x)) and _rel(cs, -2.0 + y.float().sum(0)) < 1e-5
+    dy = _bf(_rand((M, K), 32)).cuda()
+    wt = _bf(_rand((N, K), 33, 0.05)).cuda()
+    z = _bf(_rand((M, N), 34, 2.0)).cuda()
+    for aux in (z, None):
+        plain = ops.gemm_ex(dy, wt, aux=aux, tile_hint=5)
+        cs = torch.full((N,), 1.0, device='cuda')
+        fused = ops.gemm_ex(dy, wt, aux=aux, colsum=cs)
+        assert torch.equal(fused, plain)
+        sep = torch.full((N,), 1.0, device='cuda')
+        ops.colsum_bf16(plain, sep)
+        assert _rel(cs, 1.0 + plain.float().sum(0)) < 1e-5 and _rel(cs, sep) < 1e-5
+    with pytest.raises(Exception, match='colsum'):            # below the 256x256 kernel's range: refused, not dropped
+        ops.gemm_ex(dy[:512], wt, colsum=torch.zeros(N, device='cuda'))
 
 
 @pytest.mark.parametrize('p_drop', [0.0, 0.1, 0.5])

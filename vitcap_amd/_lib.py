@@ -26,7 +26,7 @@ vp = C.c_void_p
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
                                        'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')] \
-        + [('live', C.c_void_p), ('rowstat', C.c_void_p)]
+        + [('live', C.c_void_p), ('rowstat', C.c_void_p), ('colsum', C.c_void_p)]
 
 
 class BeamState(C.Structure):
@@ -93,9 +93,10 @@ _SIGS = {
                                        C.c_int, C.c_int, vp]),
     'vitcap_gemm_ex': (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(GemmDesc), vp, C.c_int, vp, C.c_int, vp]),
     'vitcap_transpose_colsum': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
-    'vitcap_layernorm_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    'vitcap_layernorm_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_reduce_slabs': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp]),
     'vitcap_cast_bf16': (C.c_int, [vp, vp, C.c_size_t, vp]),
+    'vitcap_cast_bf16_colsum': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_focal_loss_sum': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp]),

@@ -38,6 +38,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int n_big, tiles_m_small;     // mixed launch of the 256-wide kernel: workgroups [0, n_big) own 256-row tiles, the rest short ones
   // training extras
+  float* colsum;       // training: colsum[n] += sum over rows of the finished bf16 outputs (bias gradient of the layer whose
+                       // output gradient this GEMM produces); fp32 [N], atomics; 256x256 kernel, bf16 output, plain rows
   const bf16_t* aux;   // epilogue multiplies by gelu'(aux) (backward of the MLP activation); bf16 [M][ldaux]
   int ldaux;
   bf16_t* zout;        // pre-activation copy (bias added, before the activation) for the backward; bf16 [M][ldz]
@@ -773,6 +775,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
       const int ncw = n0 + wn * 64 + wc;
       const bool okc = ncw < p.N && !(NO_STORE && m0 >= 0);
       f32x4 b_lo = f32x4{0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+      f32x4 cs_lo = f32x4{0.f, 0.f, 0.f, 0.f}, cs_hi = cs_lo;      // EXTRAS && p.colsum: this lane's 8 columns summed over its 4*MT rows
       if (p.bias && ncw < p.N) {
         b_lo = *(const f32x4*)(p.bias + ncw);
         b_hi = *(const f32x4*)(p.bias + ncw + 4);
@@ -827,6 +830,31 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
             o.z = pack2bf(v1[0], v1[1]);
             o.w = pack2bf(v1[2], v1[3]);
             *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncw) = o;
+            if (EXTRAS && p.colsum) {         // the ROUNDED values, as vitcap_colsum_bf16 over the stored output would add them
+              cs_lo += f32x4{__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                             __uint_as_float(o.y & 0xffff0000u)};
+              cs_hi += f32x4{__uint_as_float(o.z << 16), __uint_as_float(o.z & 0xffff0000u), __uint_as_float(o.w << 16),
+                             __uint_as_float(o.w & 0xffff0000u)};
+            }
+          }
+        }
+      }
+      if (EXTRAS && p.colsum) {
+        // the 8 lanes wr = 0..7 with the same (lane & 7) hold the same 8 columns: butterfly over lane bits 3..5, then one atomic
+        // per column and wave (two waves of the workgroup share each column: 512 atomics per 256x256 tile)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 8; o <= 32; o <<= 1) {
+            cs_lo[e] += __shfl_xor(cs_lo[e], o, 64);
+            cs_hi[e] += __shfl_xor(cs_hi[e], o, 64);
+          }
+        }
+        if (wr == 0 && okc) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(p.colsum + ncw + e, cs_lo[e]);
+            atomicAdd(p.colsum + ncw + 4 + e, cs_hi[e]);
           }
         }
       }
@@ -1002,7 +1030,7 @@ int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
   p.group_n = tile_group_n(p.tiles_n);
   TilePlan pl{(a.M + 255) / 256, 0, 0};
   if constexpr ((PH >> 4) == 0) {
-    if (a.aux || a.zout) mix = 0;
+    if (a.aux || a.zout || a.colsum) mix = 0;
     if (mix < 0) pl = plan_tiles(a.M, p.tiles_n, a.K);
     else if (mix > 0) pl = TilePlan{0, mix, (a.M + 64 * mix - 1) / (64 * mix)};
   }
@@ -1011,7 +1039,7 @@ int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
   p.n_big = pl.tm_big * p.tiles_n;
   const int nwg = p.n_big + pl.tm_small * p.tiles_n;
   if constexpr ((PH >> 4) == 0) {
-    if (a.aux || a.zout) return launch_256_t<ACT, OUT_F32, HAS_RES, PH | 8, 0>(p, nwg, s);   // training extras: 256-row tiles only
+    if (a.aux || a.zout || a.colsum) return launch_256_t<ACT, OUT_F32, HAS_RES, PH | 8, 0>(p, nwg, s);   // training extras: 256-row tiles only
     if (pl.mts == 3) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 3>(p, nwg, s);
     if (pl.mts == 2) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 2>(p, nwg, s);
   }
@@ -1625,6 +1653,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.out_row_off = d->out_row_off; a.res_periodic = d->res_periodic;
   a.tiles_m = a.tiles_n = 0;
   a.aux = (const bf16_t*)aux_bf16; a.ldaux = ldaux;
+  a.colsum = d->colsum;
   a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
   a.live = d->live;
@@ -1644,6 +1673,13 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && !residual && plain_rows && split_k == 1 && !aux_bf16 && !zout_bf16,
                "gemm(rowstat): fp32 output, no activation / residual / split-K");
     return launch_rowstat(a, s);
+  }
+  if (d->colsum) {
+    // column sums of the finished bf16 output ride in the 256x256 kernel's 16-byte-store epilogue (training extras build)
+    VC_REQUIRE(d->out_dtype == VITCAP_OUT_BF16 && !residual && plain_rows && split_k == 1 && d->M >= 2048 && d->N % 8 == 0 && d->ldc % 8 == 0 &&
+                   (!aux_bf16 || ldaux % 8 == 0) && (!zout_bf16 || ldz % 8 == 0) && d->act != VITCAP_ACT_TANH,
+               "gemm(colsum): needs bf16 output, no residual / row remap / split-K, M >= 2048, N, ldc (ldaux, ldz) multiples of 8");
+    return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);
   }
   if (hint == 20 || hint == 21 || hint == 22) {
     // resident whole-K form (decode-step shapes); K > 768 -> K/768 fp32 partial slabs in C = [K/768][M][ldc]

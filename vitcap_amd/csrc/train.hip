@@ -50,20 +50,24 @@ __global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __r
 // of the output; dres: optional fp32 gradient arriving through the residual path (added to the result).
 //   dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) + dres ;  dgamma += sum dy*xhat ; dbeta += sum dy
 // ---------------------------------------------------------------------------------------------------------------
-template <bool DY_F32, int NW>
+//   CS: additionally dxb_colsum[c] += sum over rows of the bf16-ROUNDED dx (what vitcap_colsum_bf16 of dx_bf16 would add: the bias
+//   gradient of the linear layer whose output gradient dx is -- one pass over dx less per layer)
+template <bool DY_F32, int NW, bool CS>
 __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dyv,
                                                             const float* __restrict__ gamma, float eps,
                                                             const float* __restrict__ dres, float* __restrict__ dxf,
                                                             bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int M, int rows_per_wave) {
+                                                            float* __restrict__ dbeta, float* __restrict__ dxb_colsum, int M,
+                                                            int rows_per_wave) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * NW + (threadIdx.x >> 6);
-  f32x4 g[3], ag[3], ab[3];
+  f32x4 g[3], ag[3], ab[3], ac[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     g[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // rows are dealt round-robin over ALL waves of the grid (rows_per_wave = the stride = total waves): the grid is a whole
   // number of workgroups per CU, so nobody waits for a ragged last round (289 workgroups on 256 CUs cost two rounds)
@@ -122,6 +126,8 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const float* __r
         u.x = pack2bf(o[0], o[1]);
         u.y = pack2bf(o[2], o[3]);
         *(uint2*)(dxb + (size_t)row * D768 + c) = u;
+        if (CS) ac[i] += f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                               __uint_as_float(u.y & 0xffff0000u)};
       }
     }
   }
@@ -129,23 +135,63 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const float* __r
   // (per-wave atomics: 3.5 M atomics on 1536 addresses per call made this kernel 7x slower than its HBM time).
   // Measured at M = 36928 (tools/lnbwd_bench.py): 4 waves x 32 consecutive rows in 289 workgroups 130 us (two rounds on 256
   // CUs); 8 waves, 2 workgroups per CU, rows dealt round-robin 90 us = 5.0 TB/s
-  extern __shared__ float red[];            // [2][NW][768]
+  extern __shared__ float red[];            // [2 (+1 with CS)][NW][768]
   const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     *(f32x4*)(&red[(0 * NW + wv) * D768 + i * 256 + lane * 4]) = ag[i];
     *(f32x4*)(&red[(1 * NW + wv) * D768 + i * 256 + lane * 4]) = ab[i];
+    if (CS) *(f32x4*)(&red[(2 * NW + wv) * D768 + i * 256 + lane * 4]) = ac[i];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < D768; c += NW * 64) {
-    float sg = 0.f, sb = 0.f;
+    float sg = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
       sg += red[(0 * NW + q) * D768 + c];
       sb += red[(1 * NW + q) * D768 + c];
+      if (CS) sc += red[(2 * NW + q) * D768 + c];
     }
     atomicAdd(dgamma + c, sg);
     atomicAdd(dbeta + c, sb);
+    if (CS) atomicAdd(dxb_colsum + c, sc);
+  }
+}
+
+// y (bf16) = x (fp32) over 768-wide rows, and colsum[c] += sum over rows of the ROUNDED values -- the cast of a residual-stream
+// gradient to the bf16 operand of the backward GEMMs, fused with the bias gradient of the layer it is the output gradient of
+// (vitcap_cast_bf16 + vitcap_colsum_bf16 in one pass).  Rows dealt round-robin over the grid's waves as in layernorm_bwd_kernel.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void cast_bf16_colsum_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                                  float* __restrict__ colsum, int M, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * NW + (threadIdx.x >> 6);
+  f32x4 ac[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int row = wave; row < M; row += rows_per_wave) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      const f32x4 v = *(const f32x4*)(x + (size_t)row * D768 + c);
+      uint2 u;
+      u.x = pack2bf(v[0], v[1]);
+      u.y = pack2bf(v[2], v[3]);
+      *(uint2*)(y + (size_t)row * D768 + c) = u;
+      ac[i] += f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u)};
+    }
+  }
+  extern __shared__ float red[];            // [NW][768]
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) *(f32x4*)(&red[wv * D768 + i * 256 + lane * 4]) = ac[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D768; c += NW * 64) {
+    float sc = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sc += red[q * D768 + c];
+    atomicAdd(colsum + c, sc);
   }
 }
 
@@ -422,11 +468,7 @@ extern "C" int vitcap_transpose_colsum(const void* x, int ldx, void* xt, int ldt
   return VITCAP_OK;
 }
 
-extern "C" int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32, const float* gamma, float eps,
-                                    const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, int M,
-                                    int D, void* stream) {
-  VC_REQUIRE(x && dy && gamma && dgamma && dbeta && (dx_f32 || dx_bf16) && D == D768 && M > 0, "layernorm_bwd: bad arguments");
-  static const int nw = [] { const char* e = getenv("VITCAP_LNBWD_WAVES"); const int v = e ? atoi(e) : 8; return v == 4 || v == 16 ? v : 8; }();
+static int ln_bwd_grid(int M, int nw, int* rows_per_wave) {
   static const int wg_per_cu = [] { const char* e = getenv("VITCAP_LNBWD_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
   static const int n_cu = [] {
     int dev = 0;
@@ -436,19 +478,44 @@ extern "C" int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int
   }();
   int wgs = n_cu * wg_per_cu;
   if ((long long)wgs * nw > M) wgs = (M + nw - 1) / nw;
+  *rows_per_wave = wgs * nw;                      // the row stride = total waves
+  return wgs;
+}
+
+extern "C" int vitcap_cast_bf16_colsum(const float* x, void* y, float* colsum, int M, int D, void* stream) {
+  VC_REQUIRE(x && y && colsum && M > 0 && D == D768, "cast_bf16_colsum: bad arguments (D must be 768)");
+  constexpr int NW = 8;
+  int rpw = 0;
+  const int wgs = ln_bwd_grid(M, NW, &rpw);
+  hipLaunchKernelGGL(cast_bf16_colsum_kernel<NW>, dim3(wgs), dim3(NW * 64), NW * D768 * sizeof(float), (hipStream_t)stream, x,
+                     (bf16_t*)y, colsum, M, rpw);
+  VC_LAUNCH_CHECK("cast_bf16_colsum");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32, const float* gamma, float eps,
+                                    const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta,
+                                    float* dx_bf16_colsum, int M, int D, void* stream) {
+  VC_REQUIRE(x && dy && gamma && dgamma && dbeta && (dx_f32 || dx_bf16) && D == D768 && M > 0, "layernorm_bwd: bad arguments");
+  VC_REQUIRE(!dx_bf16_colsum || dx_bf16, "layernorm_bwd: column sums are those of the bf16 output, which was not asked for");
+  static const int nw = [] { const char* e = getenv("VITCAP_LNBWD_WAVES"); const int v = e ? atoi(e) : 8; return v == 4 || v == 16 ? v : 8; }();
+  int rpw = 0;
+  const int wgs = ln_bwd_grid(M, nw, &rpw);
   dim3 grid(wgs);
-  const int rpw = wgs * nw;                       // the row stride = total waves
-  const size_t lds = (size_t)2 * nw * D768 * sizeof(float);
-#define LNB(F32_, NW_)                                                                                                   \
+  const bool cs = dx_bf16_colsum != nullptr;
+  const size_t lds = (size_t)(cs ? 3 : 2) * nw * D768 * sizeof(float);
+#define LNB(F32_, NW_, CS_)                                                                                              \
   do {                                                                                                                  \
-    auto kern = layernorm_bwd_kernel<F32_, NW_>;                                                                         \
-    static bool attr = false;                                                                                           \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    auto kern = layernorm_bwd_kernel<F32_, NW_, CS_>;                                                                    \
+    VC_FUNC_SMEM(kern, (int)lds);                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), lds, (hipStream_t)stream, x, ldx, dy, gamma, eps, dres, dx_f32,       \
-                       (bf16_t*)dx_bf16, dgamma, dbeta, M, rpw);                                                         \
+                       (bf16_t*)dx_bf16, dgamma, dbeta, dx_bf16_colsum, M, rpw);                                         \
   } while (0)
-  if (dy_is_f32) { if (nw == 4) LNB(true, 4); else if (nw == 8) LNB(true, 8); else LNB(true, 16); }
-  else { if (nw == 4) LNB(false, 4); else if (nw == 8) LNB(false, 8); else LNB(false, 16); }
+#define LNB2(F32_, CS_)                                                                                                  \
+  do { if (nw == 4) LNB(F32_, 4, CS_); else if (nw == 8) LNB(F32_, 8, CS_); else LNB(F32_, 16, CS_); } while (0)
+  if (dy_is_f32) { if (cs) LNB2(true, true); else LNB2(true, false); }
+  else { if (cs) LNB2(false, true); else LNB2(false, false); }
+#undef LNB2
 #undef LNB
   VC_LAUNCH_CHECK("layernorm_bwd");
   return VITCAP_OK;

@@ -267,8 +267,9 @@ def sigmoid_topk(logits, k=50, thresh=0.2, V=None):
 
 # ------------------------------------------------------------------------------------------------ training ops
 def gemm_ex(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_dtype=torch.bfloat16, aux=None, zout=None,
-            split_k=0, tile_hint=0):
-    """GEMM with the training extras of vitcap_gemm_ex (gelu' multiply, pre-activation output, ragged split-K slabs)."""
+            split_k=0, tile_hint=0, colsum=None):
+    """GEMM with the training extras of vitcap_gemm_ex (gelu' multiply, pre-activation output, ragged split-K slabs;
+    colsum (fp32 [N]) += column sums of the bf16 output = the bias gradient of the layer this is the output gradient of)."""
     _dev_bf16(a)
     _dev_bf16(w)
     M, K = a.shape
@@ -278,7 +279,8 @@ def gemm_ex(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_dtype=
         out = torch.empty(shape, device=a.device, dtype=torch.float32 if split_k > 1 else out_dtype)
     d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(-2),
                    ldr=residual.stride(0) if residual is not None else 0, act=act,
-                   out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16, tile_hint=tile_hint, split_k=split_k)
+                   out_dtype=L.OUT_F32 if out.dtype == torch.float32 else L.OUT_BF16, tile_hint=tile_hint, split_k=split_k,
+                   colsum=colsum.data_ptr() if colsum is not None else None)
     with _Timed('gemm_nt (forward / input gradients)', 2.0 * M * N * K, M > 256):
         check(lib.vitcap_gemm_ex(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _p(aux),
                                  aux.stride(0) if aux is not None else 0, _p(zout), zout.stride(0) if zout is not None else 0,
@@ -297,13 +299,14 @@ def transpose_colsum(x, colsum=None, out=None):
     return out
 
 
-def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dres=None, want_f32=True, want_bf16=True):
+def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dres=None, want_f32=True, want_bf16=True, dxb_colsum=None):
+    """dxb_colsum (fp32 [768]) += column sums of the bf16 result (bias gradient of the layer dx is the output gradient of)."""
     _dev_f32(x)
     M, D = x.shape
     dxf = torch.empty((M, D), device=x.device, dtype=torch.float32) if want_f32 else None
     dxb = torch.empty((M, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
     check(lib.vitcap_layernorm_bwd(_p(x), x.stride(0), _p(dy), int(dy.dtype == torch.float32), _p(gamma), eps, _p(dres),
-                                   _p(dxf), _p(dxb), _p(dgamma), _p(dbeta), M, D, _stream()), 'layernorm_bwd')
+                                   _p(dxf), _p(dxb), _p(dgamma), _p(dbeta), _p(dxb_colsum), M, D, _stream()), 'layernorm_bwd')
     return dxf, dxb
 
 
@@ -318,6 +321,15 @@ def cast_bf16(x):
     _dev_f32(x)
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
     check(lib.vitcap_cast_bf16(_p(x), _p(y), x.numel(), _stream()), 'cast_bf16')
+    return y
+
+
+def cast_bf16_colsum(x, colsum):
+    """bf16 copy of fp32 x [M][768] and colsum[c] += sum_m bf16(x)[m][c] in one pass (cast_bf16 + colsum_bf16)."""
+    _dev_f32(x); _dev_f32(colsum)
+    assert x.dim() == 2 and x.is_contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib.vitcap_cast_bf16_colsum(_p(x), _p(y), _p(colsum), x.shape[0], x.shape[1], _stream()), 'cast_bf16_colsum')
     return y
 
 

@@ -24,6 +24,7 @@ Gradients of a data-parallel job are summed with ONE RCCL all-reduce per bucket 
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -33,6 +34,7 @@ from . import weights as W
 from ._lib import check, lib
 
 CH = 1024           # optimizer chunk (elements)
+_FUSE_BIAS = os.environ.get('VITCAP_TRAIN_FUSED_BIAS', '1') != '0'      # A/B switch of the measurement in DESIGN.md 7
 NV = 577
 SV = 578
 T = 20
@@ -448,7 +450,9 @@ class TrainEngine(object):
     # ------------------------------------------------------------------ helpers
     def _wgrad_tn(self, dy, x, gview, bias_grad):
         """gview[N][K] = dy^T x and bias_grad[N] += column sums of dy, straight from the row-major backward operands
-        (LDS transpose reads, no transposed copies); M is split so that about one wave of 256x256 tiles fills the chip."""
+        (LDS transpose reads, no transposed copies); M is split so that about one wave of 256x256 tiles fills the chip.
+        bias_grad=None: the kernel that produced dy has already added its column sums (ops.gemm_ex(colsum=),
+        ops.layernorm_bwd(dxb_colsum=), ops.cast_bf16_colsum)."""
         N, Kin = gview.shape
         tiles = (N // 256) * (Kin // 256)
         stages = (dy.shape[0] + 63) // 64
@@ -457,7 +461,8 @@ class TrainEngine(object):
             ops.gemm_tn(dy, x, 1, slabs=gview.view(1, N, Kin))
         else:
             ops.reduce_slabs(ops.gemm_tn(dy, x, S), gview)
-        ops.colsum_bf16(dy, bias_grad)
+        if bias_grad is not None:
+            ops.colsum_bf16(dy, bias_grad)
 
     def _wgrad(self, dyT, xT, gview, accumulate=False):
         """gview[N][K] (+)= dyT[N][Mp] @ xT[K][Mp]^T with split-K sized to fill the chip."""
@@ -475,8 +480,20 @@ class TrainEngine(object):
         slabs = ops.gemm_ex(dyT, xT, split_k=S)
         ops.reduce_slabs(slabs, gview, accumulate=accumulate)
 
-    def _ln_bwd(self, x, dy, gkey, bkey, eps, dres=None):
-        return ops.layernorm_bwd(x, dy, self.vec(gkey), eps, self.g(gkey).view(-1), self.g(bkey).view(-1), dres=dres)
+    def _dgrad_gelu(self, dy, wt, z, bias_grad):
+        """dz = (dy @ W) * gelu'(z) (bf16) with the bias gradient of the layer dz is the output gradient of: added by the GEMM's
+        own epilogue where the 256x256 kernel runs (M >= 2048), by a separate pass over dz otherwise.  Returns (dz, pending) --
+        pending is the bias gradient still to be added by _wgrad_tn, or None."""
+        if _FUSE_BIAS and dy.shape[0] >= 2048:
+            return ops.gemm_ex(dy, wt, aux=z, colsum=bias_grad), None
+        return ops.gemm_ex(dy, wt, aux=z), bias_grad
+
+    def _ln_bwd(self, x, dy, gkey, bkey, eps, dres=None, dxb_colsum=None):
+        dxf, dxb = ops.layernorm_bwd(x, dy, self.vec(gkey), eps, self.g(gkey).view(-1), self.g(bkey).view(-1), dres=dres,
+                                     dxb_colsum=dxb_colsum if _FUSE_BIAS else None)
+        if dxb_colsum is not None and not _FUSE_BIAS:
+            ops.colsum_bf16(dxb, dxb_colsum)
+        return dxf, dxb
 
     # ------------------------------------------------------------------ forward + backward
     def forward_backward(self, batch):
@@ -718,14 +735,16 @@ class TrainEngine(object):
                 dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=res.view(Md, 768), out_dtype=torch.float32)
                 continue
             xb, qkv, ctx, lse, t1, ab, af, z, it, t2 = dsaved[l]
-            dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
-            self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), self.g(pre + '.output.dense.bias').view(-1))
-            dz = ops.gemm_ex(dt2b, self.wt(pre + '.o'), aux=z)                 # [Md,3072] bf16
-            self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), self.g(pre + '.intermediate.dense.bias').view(-1))
+            # bias gradients = column sums of dt2b / dz / dt1b, added by the kernels that write those operands
+            dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12,
+                                      dxb_colsum=self.g(pre + '.output.dense.bias').view(-1))
+            self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), None)
+            dz, pend = self._dgrad_gelu(dt2b, self.wt(pre + '.o'), z, self.g(pre + '.intermediate.dense.bias').view(-1))   # [Md,3072] bf16
+            self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), pend)
             da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
             dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias',
-                                      1e-12)
-            self._wgrad_tn(dt1b, ctx, self.g(pre + '.attention.output.dense.weight'), self.g(pre + '.attention.output.dense.bias').view(-1))
+                                      1e-12, dxb_colsum=self.g(pre + '.attention.output.dense.bias').view(-1))
+            self._wgrad_tn(dt1b, ctx, self.g(pre + '.attention.output.dense.weight'), None)
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
             dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
                                       mask_from=SV + T if scst else 0)
@@ -776,13 +795,20 @@ class TrainEngine(object):
 
         def block_bwd(pre, dxo):
             xin, h1, qkv, ao, lse, xmid, h2, z, g = saved.pop(pre)
-            dxb = ops.cast_bf16(dxo)
-            self._wgrad_tn(dxb, g, self.g(pre + '.mlp.fc2.weight'), self.g(pre + '.mlp.fc2.bias').view(-1))
-            dz = ops.gemm_ex(dxb, self.wt(pre + '.fc2'), aux=z)
-            self._wgrad_tn(dz, h2, self.g(pre + '.mlp.fc1.weight'), self.g(pre + '.mlp.fc1.bias').view(-1))
+            # the three bias gradients below are column sums of a backward operand; each is added by the kernel that WRITES that
+            # operand (cast, GEMM epilogue, LayerNorm backward) instead of a separate pass over it
+            if _FUSE_BIAS:
+                dxb = ops.cast_bf16_colsum(dxo, self.g(pre + '.mlp.fc2.bias').view(-1))
+            else:
+                dxb = ops.cast_bf16(dxo)
+                ops.colsum_bf16(dxb, self.g(pre + '.mlp.fc2.bias').view(-1))
+            self._wgrad_tn(dxb, g, self.g(pre + '.mlp.fc2.weight'), None)
+            dz, pend = self._dgrad_gelu(dxb, self.wt(pre + '.fc2'), z, self.g(pre + '.mlp.fc1.bias').view(-1))
+            self._wgrad_tn(dz, h2, self.g(pre + '.mlp.fc1.weight'), pend)
             dh2 = ops.gemm_ex(dz, self.wt(pre + '.fc1'))
-            dmf, dmb = self._ln_bwd(xmid, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo)
-            self._wgrad_tn(dmb, ao, self.g(pre + '.attn.proj.weight'), self.g(pre + '.attn.proj.bias').view(-1))
+            dmf, dmb = self._ln_bwd(xmid, dh2, pre + '.norm2.weight', pre + '.norm2.bias', 1e-6, dres=dxo,
+                                    dxb_colsum=self.g(pre + '.attn.proj.bias').view(-1))
+            self._wgrad_tn(dmb, ao, self.g(pre + '.attn.proj.weight'), None)
             dao = ops.gemm_ex(dmb, self.wt(pre + '.proj'))
             dqkv = ops.attn_dense_bwd(qkv, ao, dao, lse, Be, NV)
             self._wgrad_tn(dqkv, h1, self.g(pre + '.attn.qkv.weight'), self.g(pre + '.attn.qkv.bias').view(-1))
