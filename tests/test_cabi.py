@@ -93,7 +93,7 @@ def test_struct_sizes_match_header(L):
     # every field is one pointer: 12/12/6 per block struct, total as laid out in vitcap_hip.h
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
-    assert C.sizeof(L.GemmDesc) == 16 * 4 + 16          # 15 ints, padding, two pointers (live, rowstat)
+    assert C.sizeof(L.GemmDesc) == 16 * 4 + 24          # 15 ints, padding, three pointers (live, rowstat, colsum)
     assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4
 
 
