@@ -553,6 +553,17 @@ int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slab
 int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream);
 /* fp32 master W[N][K] -> bf16 W and bf16 W^T[K][N] (the operands of the forward and the dgrad GEMMs) */
 int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int N, int K, int ldt, void* stream);
+/* The same for a table of matrices in one launch (all GEMM weights after an optimizer step).  `items` lives in DEVICE memory,
+ * sorted by tile0 = the running sum of ceil(N/64) * (K/64) over the preceding items (item 0: 0); total_tiles = that sum over all
+ * items.  Per item: K a multiple of 64, ldt >= N and a multiple of 8, w_bf16 or wt_bf16 may be NULL.  The caller validates the
+ * table (it is read on the device). */
+typedef struct {
+  const float* w;
+  void* w_bf16;
+  void* wt_bf16;
+  int32_t N, K, ldt, tile0;
+} vitcap_ct_item;
+int vitcap_cast_transpose_multi(const vitcap_ct_item* items_dev, int n_items, int total_tiles, void* stream);
 int vitcap_gelu_bwd(const float* dg, const void* z_bf16, void* dz_bf16, size_t n, void* stream);
 int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size_t n, void* stream);
 /* BertEmbeddings.forward on all rows of the teacher-forced caption (modeling_bert.py:222-237): optional pre-LN sum */

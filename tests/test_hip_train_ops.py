@@ -103,6 +103,33 @@ def test_layernorm_backward(ops, dy_f32):
     assert _rel(cs, 0.5 + dxb.float().sum(0)) < 1e-5 and _rel(dgam2, dgam) < 1e-5
 
 
+def test_cast_transpose_table_equals_single_calls(ops):
+    """vitcap_cast_transpose_multi (one launch over a device-resident table: what TrainEngine.refresh_weights runs after every
+    optimizer step) writes exactly what one vitcap_cast_transpose per matrix writes -- ragged N (30522 -> ld 30592), a table entry
+    without a transposed copy, a 2-row matrix."""
+    from vitcap_amd import _lib as L
+    from vitcap_amd._lib import lib, check
+    shapes = [(768, 768, 768, True), (2304, 768, 2304, True), (30522, 768, 30592, True), (2, 768, 8, True), (768, 3072, 768, False)]
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    src, single, multi, items, tile0 = [], [], [], [], 0
+    for i, (N, K, ld, want_t) in enumerate(shapes):
+        w = _rand((N, K), 300 + i).cuda()
+        a = (torch.zeros(N, K, device='cuda', dtype=torch.bfloat16), torch.zeros(K, ld, device='cuda', dtype=torch.bfloat16) if want_t else None)
+        b = (torch.zeros(N, K, device='cuda', dtype=torch.bfloat16), torch.zeros(K, ld, device='cuda', dtype=torch.bfloat16) if want_t else None)
+        check(lib.vitcap_cast_transpose(p(w), p(a[0]), p(a[1]), N, K, ld, s), 'cast_transpose')
+        items.append(L.CtItem(w.data_ptr(), b[0].data_ptr(), b[1].data_ptr() if want_t else None, N, K, ld, tile0))
+        tile0 += ((N + 63) // 64) * (K // 64)
+        src.append(w); single.append(a); multi.append(b)
+    tab = torch.frombuffer(bytearray(bytes((L.CtItem * len(items))(*items))), dtype=torch.uint8).cuda()
+    check(lib.vitcap_cast_transpose_multi(p(tab), len(items), tile0, s), 'cast_transpose_multi')
+    for w, a, b, (N, K, ld, want_t) in zip(src, single, multi, shapes):
+        assert torch.equal(a[0], b[0]) and torch.equal(b[0], w.to(torch.bfloat16))
+        if want_t:
+            assert torch.equal(a[1], b[1]) and torch.equal(b[1][:, :N], w.to(torch.bfloat16).t())
+            assert float(b[1][:, N:].float().abs().sum()) == 0.0
+
+
 def test_fused_bias_gradients(ops):
     """Bias gradients = column sums of a backward operand, added by the kernel that WRITES the operand: the fp32 -> bf16 cast of a
     residual-stream gradient (vitcap_cast_bf16_colsum), the 256x256 GEMM's epilogue (vitcap_gemm_desc.colsum, with the gelu'

@@ -29,6 +29,11 @@ class GemmDesc(C.Structure):
         + [('live', C.c_void_p), ('rowstat', C.c_void_p), ('colsum', C.c_void_p)]
 
 
+class CtItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('w_bf16', C.c_void_p), ('wt_bf16', C.c_void_p), ('N', C.c_int32), ('K', C.c_int32),
+                ('ldt', C.c_int32), ('tile0', C.c_int32)]
+
+
 class BeamState(C.Structure):
     _fields_ = [(n, vp) for n in ('ids_in', 'ids_out', 'beam_scores', 'parent', 'done', 'has_hyp', 'hyp_score',
                                   'hyp_len', 'hyp_tok')] + [('n_keep', C.c_int32)]
@@ -112,6 +117,7 @@ _SIGS = {
     'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_cast_transpose_multi': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'vitcap_gelu_bwd': (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     'vitcap_sum_over_batch': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_embed_rows': (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, vp]),

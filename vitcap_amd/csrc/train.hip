@@ -423,6 +423,55 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// The same for a whole table of matrices in ONE launch (the ~110 GEMM weights refreshed after every optimizer step: as separate
+// launches they are 110 x ~6.7 us of mostly launch floor).  Block b finds its matrix by bisection over the items' first tiles.
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const vitcap_ct_item* __restrict__ items, int n_items) {
+  __shared__ bf16_t tile[64][66];
+  int lo = 0, hi = n_items - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const vitcap_ct_item it = items[lo];
+  const int t = b - it.tile0, tn = (it.N + 63) / 64;
+  const int n0 = (t % tn) * 64, k0 = (t / tn) * 64, tid = threadIdx.x;
+  const float* __restrict__ w = it.w;
+  bf16_t* __restrict__ wb = (bf16_t*)it.w_bf16;
+  bf16_t* __restrict__ wt = (bf16_t*)it.wt_bf16;
+  const int N = it.N, K = it.K, ldt = it.ldt;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * 256;
+    const int r = e >> 4, cc = (e & 15) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n0 + r < N) v = *(const f32x4*)(w + (size_t)(n0 + r) * K + k0 + cc);
+    uint2 u;
+    u.x = pack2bf(v[0], v[1]);
+    u.y = pack2bf(v[2], v[3]);
+    if (n0 + r < N && wb) *(uint2*)(wb + (size_t)(n0 + r) * K + k0 + cc) = u;
+    const bf16_t* pu = (const bf16_t*)&u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[r][cc + j] = pu[j];
+  }
+  __syncthreads();
+  if (!wt) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;
+    const int c = e >> 3, rr = (e & 7) * 8;
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = tile[rr + j][c];
+    if (n0 + rr + 7 < N) {
+      *(uint4*)(wt + (size_t)(k0 + c) * ldt + n0 + rr) = *(const uint4*)o;
+    } else {
+      for (int j = 0; j < 8; ++j)
+        if (n0 + rr + j < N) wt[(size_t)(k0 + c) * ldt + n0 + rr + j] = o[j];
+    }
+  }
+}
+
 // dz = dg * gelu'(z)   (backward of BertPredictionHeadTransform's activation; elementwise, tiny)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dg, const bf16_t* __restrict__ z,
                                                        bf16_t* __restrict__ dz, size_t n) {
@@ -588,6 +637,13 @@ extern "C" int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, 
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, chunk_lr, chunk_wd,
                      gsumsq, clip, lr_scale, bc1, bc2s, b1, b2, eps, nchunks);
   VC_LAUNCH_CHECK("adamw");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_cast_transpose_multi(const vitcap_ct_item* items_dev, int n_items, int total_tiles, void* stream) {
+  VC_REQUIRE(items_dev && n_items > 0 && total_tiles > 0, "cast_transpose_multi: bad arguments");
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  VC_LAUNCH_CHECK("cast_transpose_multi");
   return VITCAP_OK;
 }
 
