@@ -504,8 +504,10 @@ const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspac
  * Backward GEMMs reuse vitcap_gemm_*: dX = dY . W is the NT kernel on a transposed weight copy, dW = dY^T . X is the
  * NT kernel on transposed activations with split-K into fp32 slabs.
  * ============================================================================================== */
-/* GEMM with training extras: `aux` (bf16 [M][ldaux]) multiplies the result by gelu'(aux) (backward of nn.GELU /
- * `_gelu_python`); `zout` (bf16 [M][ldz]) receives the pre-activation (bias added) for the backward.  With
+/* GEMM with training extras.  Forward, act == gelu_erf: `zout` (bf16 [M][ldz]) receives gelu'(pre-activation) = Phi(z) + z phi(z),
+ * evaluated in fp32 from the same erfc as the activation itself.  Backward (nn.GELU / `_gelu_python`): `aux` (bf16 [M][ldaux]) =
+ * that stored factor multiplies the result -- the input-gradient GEMM's epilogue is one multiply per element instead of a gelu'
+ * evaluation from a stored z (measured: DESIGN.md 7).  With
  * d->split_k > 1 and M > 256 (weight gradients) K is split raggedly and C is fp32 [split_k][M][ldc]. */
 int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
                    const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz, void* stream);
@@ -564,7 +566,8 @@ typedef struct {
   int32_t N, K, ldt, tile0;
 } vitcap_ct_item;
 int vitcap_cast_transpose_multi(const vitcap_ct_item* items_dev, int n_items, int total_tiles, void* stream);
-int vitcap_gelu_bwd(const float* dg, const void* z_bf16, void* dz_bf16, size_t n, void* stream);
+/* dz = dg * f, f (bf16) = the gelu'(pre-activation) factor a forward vitcap_gemm_ex stored through `zout` */
+int vitcap_gelu_bwd(const float* dg, const void* gelu_grad_bf16, void* dz_bf16, size_t n, void* stream);
 int vitcap_sum_over_batch(const float* x, size_t stride, int B, float* out, size_t n, void* stream);
 /* BertEmbeddings.forward on all rows of the teacher-forced caption (modeling_bert.py:222-237): optional pre-LN sum */
 int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb, const void* pos_emb,

@@ -63,18 +63,20 @@ def test_weight_grad_splitk_and_dgrad(ops):
     check(lib.vitcap_cast_transpose(C.c_void_p(wf.data_ptr()), C.c_void_p(wb.data_ptr()), C.c_void_p(wt.data_ptr()), N, K, N,
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'cast_transpose')
     assert torch.equal(wb.cpu(), w) and torch.equal(wt.cpu(), w.t().contiguous())
-    z = _bf(_rand((M, K), 5, 2.0))
-    dz = ops.gemm_ex(dyd, wt, aux=z.cuda())            # [M][K] bf16
-    zz = z.float().requires_grad_(True)
-    torch.nn.functional.gelu(zz).backward(torch.ones_like(zz))
-    want = (dy.float() @ w.float()) * zz.grad
-    assert _rel(dz, want) < 4e-3
-    # forward with pre-activation output
+    # forward with the activation's derivative stored for the backward: zout = gelu'(pre-activation), g = gelu(pre-activation)
     zout = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
     bias = _rand((N,), 6).cuda()
     g = ops.gemm_ex(xd, wd, bias=bias, act=1, zout=zout)
-    pre = x.float() @ w.float().t() + bias.cpu()
-    assert _rel(zout, pre) < 4e-3 and _rel(g, torch.nn.functional.gelu(pre)) < 4e-3
+    pre = (x.float() @ w.float().t() + bias.cpu()).requires_grad_(True)
+    torch.nn.functional.gelu(pre).backward(torch.ones_like(pre))
+    assert _rel(zout, pre.grad) < 4e-3 and _rel(g, torch.nn.functional.gelu(pre.detach())) < 4e-3
+    assert torch.equal(g, ops.gemm_bias_act(xd, wd, bias, act=1)), 'the activation itself is the same with and without zout'
+    # dgrad with that factor in the epilogue: dz = (dy @ W) * f
+    f = _bf(_rand((M, K), 5, 0.6) + 0.5)
+    dz = ops.gemm_ex(dyd, wt, aux=f.cuda())            # [M][K] bf16
+    assert _rel(dz, (dy.float() @ w.float()) * f.float()) < 4e-3
+    with pytest.raises(Exception, match='zout'):       # zout without the GELU has no meaning any more
+        ops.gemm_ex(xd, wd, bias=bias, zout=zout)
 
 
 @pytest.mark.parametrize('dy_f32', [False, True])

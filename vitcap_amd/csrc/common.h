@@ -165,40 +165,34 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
-// d/dz of the erf GELU: 0.5 (1 + erf(z/sqrt2)) + z exp(-z^2/2)/sqrt(2 pi), same erfc approximation as gelu_erf
-__device__ __forceinline__ float gelu_grad(float z) {
-  const float az = fabsf(z) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);   // exp(-z^2/2)
-  const float erfc_abs = p * t * e;
-  const float one_plus_erf = z >= 0.f ? 2.0f - erfc_abs : erfc_abs;
-  return 0.5f * one_plus_erf + z * e * 0.3989422804014327f;
-}
-
-// gelu_grad on four pre-activations with the polynomial / products on the packed fp32 pipe (same formula as gelu_grad)
-__device__ __forceinline__ f32x2 gelu_grad2(f32x2 z) {
-  const f32x2 az = f32x2{fabsf(z[0]) * 0.70710678118654752f, fabsf(z[1]) * 0.70710678118654752f};
+// GELU and its derivative gelu'(x) = Phi(x) + x phi(x) from ONE erfc evaluation: the training forward stores gelu'(z) (bf16) next
+// to gelu(z), so the input-gradient GEMM's epilogue multiplies by a stored factor instead of evaluating gelu' from a stored z
+// (rcp + exp2 + 9 packed ops per pair there, against one more exp2 + 3 packed ops per pair here).  The returned gelu is
+// bit-identical to gelu_erf2().
+__device__ __forceinline__ f32x2 gelu_erf2_grad(f32x2 x, f32x2& grad) {
+  const f32x2 t = x * f32x2{0.70710678118654752f, 0.70710678118654752f};
+  const f32x2 z = f32x2{fminf(fabsf(t[0]), 4.0f), fminf(fabsf(t[1]), 4.0f)};
 #define VC_C2(c_) f32x2{c_, c_}
-  const f32x2 den = __builtin_elementwise_fma(VC_C2(0.3275911f), az, VC_C2(1.0f));
-  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  f32x2 p = __builtin_elementwise_fma(VC_C2(1.061405429f), t, VC_C2(-1.453152027f));
-  p = __builtin_elementwise_fma(p, t, VC_C2(1.421413741f));
-  p = __builtin_elementwise_fma(p, t, VC_C2(-0.284496736f));
-  p = __builtin_elementwise_fma(p, t, VC_C2(0.254829592f));
-  const f32x2 arg = (VC_C2(-1.4426950408889634f) * az) * az;
+  f32x2 q = __builtin_elementwise_fma(VC_C2(-2.177763781e-05f), z, VC_C2(5.068330793e-04f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(-5.339398049e-03f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(3.423144668e-02f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(-1.528908461e-01f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(-9.167589545e-01f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(-1.628154397e+00f));
+  q = __builtin_elementwise_fma(q, z, VC_C2(6.178960575e-06f - 1.0f));
+  const f32x2 h = f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  const f32x2 c = f32x2{1.0f, 1.0f} - h;
+  const f32x2 sel = f32x2{x[0] >= 0.f ? c[0] : h[0], x[1] >= 0.f ? c[1] : h[1]};      // Phi(x)
+  const f32x2 arg = (t * VC_C2(-1.4426950408889634f)) * t;                              // -x^2/2 in log2 units
   const f32x2 e = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-  const f32x2 erfc_abs = (p * t) * e;
-  const f32x2 two_minus = VC_C2(2.0f) - erfc_abs;
-  const f32x2 ope = f32x2{z[0] >= 0.f ? two_minus[0] : erfc_abs[0], z[1] >= 0.f ? two_minus[1] : erfc_abs[1]};
-  return __builtin_elementwise_fma(VC_C2(0.5f), ope, (z * e) * VC_C2(0.3989422804014327f));
+  grad = __builtin_elementwise_fma(x * VC_C2(0.3989422804014327f), e, sel);            // Phi(x) + x phi(x)
 #undef VC_C2
+  return x * sel;
 }
-__device__ __forceinline__ f32x4 gelu_grad4(f32x4 z) {
-  const f32x2 a = gelu_grad2(f32x2{z[0], z[1]}), b = gelu_grad2(f32x2{z[2], z[3]});
+__device__ __forceinline__ f32x4 gelu_erf4_grad(f32x4 v, f32x4& grad) {
+  f32x2 ga, gb;
+  const f32x2 a = gelu_erf2_grad(f32x2{v[0], v[1]}, ga), b = gelu_erf2_grad(f32x2{v[2], v[3]}, gb);
+  grad = f32x4{ga[0], ga[1], gb[0], gb[1]};
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 

@@ -40,9 +40,9 @@ struct GemmArgs {
   // training extras
   float* colsum;       // training: colsum[n] += sum over rows of the finished bf16 outputs (bias gradient of the layer whose
                        // output gradient this GEMM produces); fp32 [N], atomics; 256x256 kernel, bf16 output, plain rows
-  const bf16_t* aux;   // epilogue multiplies by gelu'(aux) (backward of the MLP activation); bf16 [M][ldaux]
+  const bf16_t* aux;   // epilogue multiplies by aux (the stored gelu' factor: backward of the MLP activation); bf16 [M][ldaux]
   int ldaux;
-  bf16_t* zout;        // pre-activation copy (bias added, before the activation) for the backward; bf16 [M][ldz]
+  bf16_t* zout;        // gelu'(pre-activation) for the backward (act == GELU only; the factor a later launch takes as `aux`); bf16 [M][ldz]
   int ldz;
   int direct_epilogue; // 256x256 kernels: register-transpose epilogue (1) or the LDS-staged one (0)
   int split_k;         // > 1: blockIdx.y = split, ragged k-tile ranges, fp32 partial slabs, no epilogue
@@ -222,19 +222,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         const f32x4 b = *(const f32x4*)(p.bias + n);
         v += b;
       }
-      if (p.zout) {
-        uint2 zo;
-        zo.x = pack2bf(v[0], v[1]);
-        zo.y = pack2bf(v[2], v[3]);
-        *(uint2*)(p.zout + (size_t)orow * p.ldz + n) = zo;
-      }
       if (p.aux) {
         const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad((float)za[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= (float)za[e];
       }
       if (ACT == VITCAP_ACT_GELU_ERF) {
-        v = gelu_erf4(v);
+        if (p.zout) {                  // the activation's derivative at the pre-activation, for the backward's `aux`
+          f32x4 d;
+          v = gelu_erf4_grad(v, d);
+          uint2 zo;
+          zo.x = pack2bf(d[0], d[1]);
+          zo.y = pack2bf(d[2], d[3]);
+          *(uint2*)(p.zout + (size_t)orow * p.ldz + n) = zo;
+        } else {
+          v = gelu_erf4(v);
+        }
       } else if (ACT == VITCAP_ACT_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -804,24 +807,30 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
           const bool ok = m < p.M && okc;
           v0 += b_lo;
           v1 += b_hi;
-          if (EXTRAS && p.zout && ok) {
-            uint4 zo;
-            zo.x = pack2bf(v0[0], v0[1]);
-            zo.y = pack2bf(v0[2], v0[3]);
-            zo.z = pack2bf(v1[0], v1[1]);
-            zo.w = pack2bf(v1[2], v1[3]);
-            *(uint4*)(p.zout + (size_t)m * p.ldz + ncw) = zo;
-          }
           if (EXTRAS && p.aux) {
             const uint4 a = axv[it];
-            v0 *= gelu_grad4(f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16),
-                                   __uint_as_float(a.y & 0xffff0000u)});
-            v1 *= gelu_grad4(f32x4{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16),
-                                   __uint_as_float(a.w & 0xffff0000u)});
+            v0 *= f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16),
+                        __uint_as_float(a.y & 0xffff0000u)};
+            v1 *= f32x4{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16),
+                        __uint_as_float(a.w & 0xffff0000u)};
           }
           if (ACT == VITCAP_ACT_GELU_ERF) {
-            v0 = gelu_erf4(v0);
-            v1 = gelu_erf4(v1);
+            if (EXTRAS && p.zout) {      // gelu'(pre-activation) from the same erfc evaluation, for the backward's `aux`
+              f32x4 d0, d1;
+              v0 = gelu_erf4_grad(v0, d0);
+              v1 = gelu_erf4_grad(v1, d1);
+              if (ok) {
+                uint4 zo;
+                zo.x = pack2bf(d0[0], d0[1]);
+                zo.y = pack2bf(d0[2], d0[3]);
+                zo.z = pack2bf(d1[0], d1[1]);
+                zo.w = pack2bf(d1[2], d1[3]);
+                *(uint4*)(p.zout + (size_t)m * p.ldz + ncw) = zo;
+              }
+            } else {
+              v0 = gelu_erf4(v0);
+              v1 = gelu_erf4(v1);
+            }
           }
           if (ok) {
             uint4 o;
@@ -882,18 +891,23 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
         ROWS_OF(m, orow, rrow);
         (void)rrow;
         v += bias4;
-        if (EXTRAS && p.zout && ok) {
-          uint2 zo;
-          zo.x = pack2bf(v[0], v[1]);
-          zo.y = pack2bf(v[2], v[3]);
-          *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
-        }
         if (EXTRAS && p.aux && ok) {
           const bf16x4 za = *(const bf16x4*)(p.aux + (size_t)orow * p.ldaux + ncol);
-          v *= gelu_grad4(f32x4{(float)za[0], (float)za[1], (float)za[2], (float)za[3]});
+          v *= f32x4{(float)za[0], (float)za[1], (float)za[2], (float)za[3]};
         }
         if (ACT == VITCAP_ACT_GELU_ERF) {
-          v = gelu_erf4(v);
+          if (EXTRAS && p.zout) {
+            f32x4 d;
+            v = gelu_erf4_grad(v, d);
+            if (ok) {
+              uint2 zo;
+              zo.x = pack2bf(d[0], d[1]);
+              zo.y = pack2bf(d[2], d[3]);
+              *(uint2*)(p.zout + (size_t)orow * p.ldz + ncol) = zo;
+            }
+          } else {
+            v = gelu_erf4(v);
+          }
         }
         if (HAS_RES) v += rres[c & 1][it];
         if (ok) {
@@ -1663,6 +1677,9 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     a.direct_epilogue = direct;
   }
   VC_REQUIRE(!(aux_bf16 && d->act != VITCAP_ACT_NONE), "gemm: aux (gelu') epilogue needs act == none");
+  VC_REQUIRE(!zout_bf16 || d->act == VITCAP_ACT_GELU_ERF, "gemm: zout stores the GELU's derivative and needs act == gelu_erf");
+  VC_REQUIRE(!(aux_bf16 || zout_bf16) || (d->tile_hint != 3 && d->tile_hint != 12 && !(d->tile_hint >= 7 && d->tile_hint <= 17 && d->tile_hint != 13 && d->tile_hint != 14 && d->tile_hint != 15)),
+             "gemm: tile_hint %d selects a kernel without the training extras (aux / zout)", d->tile_hint);
   hipStream_t s = (hipStream_t)stream;
   // tile_hint: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 256x128 (3-stage), 4 = skinny (register-fed, optional split-K),
   //            5 = 256x256 role-alternating (the auto choice for M >= 2048)

@@ -472,11 +472,12 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const vitcap_
   }
 }
 
-// dz = dg * gelu'(z)   (backward of BertPredictionHeadTransform's activation; elementwise, tiny)
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dg, const bf16_t* __restrict__ z,
+// dz = dg * f, f = the gelu'(z) factor the forward GEMM stored (vitcap_gemm_ex zout); backward of BertPredictionHeadTransform's
+// activation -- elementwise, tiny
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dg, const bf16_t* __restrict__ f,
                                                        bf16_t* __restrict__ dz, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dz[i] = f2bf(dg[i] * gelu_grad(bf2f(z[i])));
+  if (i < n) dz[i] = f2bf(dg[i] * bf2f(f[i]));
 }
 
 // out[j] = sum_b x[b][j]   (pos_embed / cls_token gradients: the parameter is broadcast over the batch)
