@@ -536,6 +536,9 @@ int vitcap_ls_kl_loss(const float* logits, int ldl, int V, const int64_t* target
 /* FocalLossWithLogitsNegLoss(alpha, gamma=1).sum()  (loss.py:5-22, modeling_bert.py:789-791) */
 int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const float* label, float alpha, float* out, int B,
                           void* stream);
+/* torch.nn.BCEWithLogitsLoss() (mean over B x V) -- the tag loss when the configuration's `loss` is not 'focal'
+ * (modeling_bert.py:713-717): out[0] += mean(max(x,0) - x*y + log1p(exp(-|x|))) */
+int vitcap_bce_logits_mean(const float* logits, int ldl, int V, const float* label, float* out, int B, void* stream);
 /* out[0] = sum g[i]^2 (overwritten, not accumulated), fixed summation order: bit-reproducible, so that data-parallel ranks
  * derive the same clip coefficient from the same all-reduced gradient (torch.nn.utils.clip_grad_norm_, trainer.py:124). */
 int vitcap_sumsq(const float* g, size_t n, float* out, void* stream);

@@ -278,6 +278,10 @@ def test_losses(ops, sd_t):
                                     C.c_void_p(out.data_ptr()), B, s), 'focal')
     wantf = float(O.focal_neg_loss(tl[:, :V], label))
     assert abs(float(out) - wantf) < 2e-4 * abs(wantf)
+    out.zero_()          # the tag loss of a configuration without `loss: focal`: torch.nn.BCEWithLogitsLoss() (modeling_bert.py:716-717)
+    check(lib.vitcap_bce_logits_mean(C.c_void_p(tl_.data_ptr()), ld, V, C.c_void_p(lb_.data_ptr()), C.c_void_p(out.data_ptr()), B, s), 'bce')
+    wantb = float(torch.nn.BCEWithLogitsLoss()(tl[:, :V], label))
+    assert abs(float(out) - wantb) < 2e-4 * abs(wantb)
 
 
 def test_adamw_clip_matches_oracle(ops):

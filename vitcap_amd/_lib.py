@@ -105,6 +105,7 @@ _SIGS = {
     'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, vp]),
     'vitcap_focal_loss_sum': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp]),
+    'vitcap_bce_logits_mean': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     'vitcap_sumsq': (C.c_int, [vp, C.c_size_t, vp, vp]),
     'vitcap_adamw_multi': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_size_t, vp]),

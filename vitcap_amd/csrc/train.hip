@@ -324,6 +324,25 @@ __global__ __launch_bounds__(256) void focal_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(out, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
+// torch.nn.BCEWithLogitsLoss() (mean over B x V): the tag loss of a configuration whose `loss` is not 'focal'
+// (modeling_bert.py:713-717); out += scale * sum of max(x, 0) - x y + log1p(exp(-|x|))
+__global__ __launch_bounds__(256) void bce_sum_kernel(const float* __restrict__ logits, int ldl, int V, const float* __restrict__ label,
+                                                      float scale, float* __restrict__ out, int B) {
+  __shared__ float s_red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc = 0.f;
+  const size_t total = (size_t)B * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i / V), v = (int)(i - (size_t)b * V);
+    const float x = logits[(size_t)b * ldl + v];
+    acc += fmaxf(x, 0.f) - x * label[i] + log1pf(expf(-fabsf(x)));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) s_red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, scale * ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])));
+}
+
 // sum of squares of a flat fp32 buffer -> out[0].  Two fixed-order passes (per-block partials, then one block adds
 // them in index order): the result is bit-reproducible, which data-parallel ranks rely on -- they must derive the SAME
 // clip coefficient from the same all-reduced gradient or their parameters drift apart.
@@ -613,6 +632,14 @@ extern "C" int vitcap_focal_loss_sum(const float* logits, int ldl, int V, const 
   VC_REQUIRE(logits && label && out && B > 0, "focal_loss: bad arguments");
   hipLaunchKernelGGL(focal_sum_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, label, alpha, out, B);
   VC_LAUNCH_CHECK("focal_loss");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_bce_logits_mean(const float* logits, int ldl, int V, const float* label, float* out, int B, void* stream) {
+  VC_REQUIRE(logits && label && out && B > 0 && V > 0, "bce_logits_mean: bad arguments");
+  hipLaunchKernelGGL(bce_sum_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, label,
+                     1.0f / ((float)B * (float)V), out, B);
+  VC_LAUNCH_CHECK("bce_logits_mean");
   return VITCAP_OK;
 }
 

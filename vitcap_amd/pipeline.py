@@ -57,7 +57,6 @@ _BUILT_FOR = (
     ('optimizer_type', ('MAdamW',), 'optimizer (..._bertemb.py:346-356)'),
     ('bias_no_weight_decay', (True, 1), 'parameter groups (..._bertemb.py:280-322)'),
     ('ln_no_weight_decay', (True, 1), 'parameter groups (..._bertemb.py:280-322)'),
-    ('loss', ('focal',), 'tag loss reported next to masked_loss (config.loss, modeling_bert.py:1327-1333)'),
     ('later_captioning', (None, False, 0), 'config.later_captioning'),
     ('attn_token_sample', (None, False, 0), 'config.attn_token_sample'),
     ('topktagger', (None, False, 0), 'config.topktagger'),
@@ -295,7 +294,8 @@ class CaptionUniPipeline(object):
         eng = TrainEngine(model, dev, base_lr=float(self.cfg.base_lr), weight_decay=float(self.cfg.weight_decay),
                           lr_multiplier=float(self.cfg.lr_multiplier or 1.0), clip=float(self.cfg.gradient_clip),
                           max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist,
-                          attn_dropout=attn_drop, dropout_seed=int(self.cfg.random_seed or 0))
+                          attn_dropout=attn_drop, dropout_seed=int(self.cfg.random_seed or 0),
+                          tag_loss='focal' if self.cfg.loss == 'focal' else 'bce')     # modeling_bert.py:713-717
         per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
         ckpt = Checkpointer(model=_EngineState(eng), optimizer=_EngineState(eng, 'optimizer'),
                             scheduler=_EngineState(eng, 'scheduler'), save_dir=self.get_snapshot_dir(),

@@ -222,7 +222,12 @@ class _FusedLoss(torch.autograd.Function):
 
 class TrainEngine(object):
     def __init__(self, model, device='cuda', base_lr=1e-4, weight_decay=0.05, lr_multiplier=0.1, clip=1.0, max_iter=1000,
-                 label_smoothing=0.1, dist=None, attn_dropout=0.1, dropout_seed=0):
+                 label_smoothing=0.1, dist=None, attn_dropout=0.1, dropout_seed=0, tag_loss='focal'):
+        """tag_loss: 'focal' (the shipped YAML's `loss: focal`: summed focal loss) or 'bce' (any other `loss`: BCEWithLogitsLoss mean,
+        modeling_bert.py:713-717) -- the reported `tag_loss`, never back-propagated by this pipeline."""
+        if tag_loss not in ('focal', 'bce'):
+            raise ValueError("tag_loss must be 'focal' or 'bce', got %r" % (tag_loss,))
+        self.tag_loss = tag_loss
         self.model = model
         self.dev = torch.device(device)
         if self.dev.index is None:
@@ -232,7 +237,6 @@ class TrainEngine(object):
         self.attn_dropout = float(attn_dropout)
         # outputs nobody reads are not computed: rows 1..576 of the last tag block, the visual rows of the last decoder layer
         # (forward and backward; same loss and gradients).  VITCAP_TRAIN_FULL_ROWS=1 computes them anyway (A/B measurements).
-        import os
         self.prune_dead_rows = os.environ.get('VITCAP_TRAIN_FULL_ROWS', '0') != '1'
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
         self.dropout_seed = mix32(int(dropout_seed) & 0xffffffff, rank)      # every rank drops differently
@@ -598,8 +602,11 @@ class TrainEngine(object):
         tag_logits = ops.gemm_bias_act(tgb, self.wb('tag.dec'), tbias, out_dtype=torch.float32)
         if 'label' in batch:                 # reported only (never back-propagated); the self-critical step has no labels
             label = batch['label'].to(dev).contiguous()
-            check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), Be, _s()),
-                  'focal')
+            if self.tag_loss == 'focal':       # FocalLossWithLogitsNegLoss(alpha .5, gamma 1).sum(), modeling_bert.py:713-715, 789-791
+                check(lib.vitcap_focal_loss_sum(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), 0.5, _p(self.loss_buf[1:]), Be, _s()),
+                      'focal')
+            else:                              # torch.nn.BCEWithLogitsLoss(), modeling_bert.py:716-717
+                check(lib.vitcap_bce_logits_mean(_p(tag_logits), L.VOCAB_PAD, L.VOCAB, _p(label), _p(self.loss_buf[1:]), Be, _s()), 'bce')
         # ================= forward: decoder on [578 visual | 20 caption] rows per image
         e = 'module.bert.embeddings'
         if scst:
