@@ -217,24 +217,39 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 
 // embedding backward: gword[ids[row]] += d[row]; gpos[pos[row]] += d[row]; gtype[0] += d[row]
+// Waves [0, rows): the word-table scatter of one row.  Waves [rows, rows + rows_per_seq): slot r of every sequence summed first
+// (the position and token-type rows are shared by all sequences: as per-row atomics the token-type row took rows x 768 atomics
+// on 768 addresses, 190 us per step), then one atomic per column into the position row and the token-type row.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ d, const int64_t* __restrict__ ids,
                                                         int rows_per_seq, float* __restrict__ gword, float* __restrict__ gpos,
                                                         float* __restrict__ gtype, int rows, int pos_wrap) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int64_t tok = ids[row];
-  int pos = row % rows_per_seq;
+  if (row < rows) {
+    const int64_t tok = ids[row];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i * 256 + lane * 4;
+      const f32x4 v = *(const f32x4*)(d + (size_t)row * D768 + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(gword + (size_t)tok * D768 + c + e, v[e]);
+    }
+    return;
+  }
+  const int r = row - rows;
+  if (r >= rows_per_seq) return;
+  int pos = r;
   if (pos_wrap > 0 && pos >= pos_wrap) pos = pos - pos_wrap + 1;     // probe rows: [MASK] at positions 1, 2, ...
+  const int nseq = rows / rows_per_seq;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * 256 + lane * 4;
-    const f32x4 v = *(const f32x4*)(d + (size_t)row * D768 + c);
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nseq; ++b) a += *(const f32x4*)(d + ((size_t)b * rows_per_seq + r) * D768 + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(gword + (size_t)tok * D768 + c + e, v[e]);
-      atomicAdd(gpos + (size_t)pos * D768 + c + e, v[e]);
-      atomicAdd(gtype + c + e, v[e]);
+      atomicAdd(gpos + (size_t)pos * D768 + c + e, a[e]);
+      atomicAdd(gtype + c + e, a[e]);
     }
   }
 }
@@ -611,8 +626,9 @@ extern "C" int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream)
 
 extern "C" int vitcap_embed_bwd(const float* d, const int64_t* ids, int rows_per_seq, float* gword, float* gpos, float* gtype,
                                 int rows, int pos_wrap, void* stream) {
-  VC_REQUIRE(d && ids && gword && gpos && gtype && rows > 0, "embed_bwd: bad arguments");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, ids, rows_per_seq, gword,
+  VC_REQUIRE(d && ids && gword && gpos && gtype && rows > 0 && rows_per_seq > 0 && rows % rows_per_seq == 0,
+             "embed_bwd: bad arguments (rows %d must be whole sequences of %d)", rows, rows_per_seq);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + rows_per_seq + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, ids, rows_per_seq, gword,
                      gpos, gtype, rows, pos_wrap);
   VC_LAUNCH_CHECK("embed_bwd");
   return VITCAP_OK;
