@@ -384,48 +384,54 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
   }
 }
 
-// sigmoid + top-k (k <= 64), one 1024-thread workgroup per row; each thread keeps up to 32 candidates.
+// sigmoid + top-k (k <= 64), one 1024-thread workgroup per row; each thread keeps up to 32 candidates as sortable 64-bit keys
+// (tk_key below: larger value first, lower index on ties -- torch.topk's CPU order) and its own running maximum, so a round is
+// one workgroup-wide max over 1024 cached values behind ONE barrier and a 32-element rescan by the one thread whose candidate was
+// taken (k rescans of every thread's 32 values behind two barriers were 122 us per batch of 64 rows).
 constexpr int TK_PER_THREAD = 32;
+__device__ __forceinline__ unsigned long long tk_key(float f, int i);
+__device__ __forceinline__ float tk_val(unsigned long long k);
+__device__ __forceinline__ int tk_idx(unsigned long long k);
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long a);
 __global__ __launch_bounds__(1024) void sigmoid_topk_kernel(const float* __restrict__ logits, int ldl, int V, int k,
                                                             float thresh, int64_t* __restrict__ out_ids,
                                                             float* __restrict__ out_prob,
                                                             int64_t* __restrict__ out_len) {
-  __shared__ ArgMax s_am[16];
-  __shared__ ArgMax s_best;
+  __shared__ unsigned long long s_wmax[2][16];      // double-buffered by round: ONE barrier per round (a wave can be at most one round ahead)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* row = logits + (size_t)b * ldl;
-  float pv[TK_PER_THREAD];
+  unsigned long long key[TK_PER_THREAD];
+  unsigned long long tmax = 0ull;                                   // below every real key (sigmoid > 0 maps above 2^63)
 #pragma unroll
   for (int j = 0; j < TK_PER_THREAD; ++j) {
     const int i = tid + j * 1024;
-    pv[j] = i < V ? 1.0f / (1.0f + expf(-row[i])) : -1.0f;   // sigmoid in (0,1); -1 = absent/taken
+    key[j] = i < V ? tk_key(1.0f / (1.0f + expf(-row[i])), i) : 0ull;   // sigmoid in (0,1); 0 = absent / taken
+    tmax = key[j] > tmax ? key[j] : tmax;
   }
   int nlen = 0;
   for (int r = 0; r < k; ++r) {
-    ArgMax best{-2.0f, 0x7fffffff};
-#pragma unroll
-    for (int j = 0; j < TK_PER_THREAD; ++j) {
-      ArgMax c{pv[j], tid + j * 1024};
-      best = am_better(best, c);
-    }
-    best = wave_argmax(best);
-    if (lane == 0) s_am[w] = best;
+    const unsigned long long wm = wave_max_u64(tmax);
+    if (lane == 0) s_wmax[r & 1][w] = wm;
     __syncthreads();
+    unsigned long long best = s_wmax[r & 1][0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+      const unsigned long long c = s_wmax[r & 1][q];
+      best = c > best ? c : best;
+    }
     if (tid == 0) {
-      ArgMax bb = s_am[0];
-      for (int q = 1; q < 16; ++q) bb = am_better(bb, s_am[q]);
-      s_best = bb;
-      out_ids[(size_t)b * k + r] = bb.i;
-      out_prob[(size_t)b * k + r] = bb.v;
-      if (bb.v >= thresh) ++nlen;
+      const float pv = tk_val(best);
+      out_ids[(size_t)b * k + r] = tk_idx(best);
+      out_prob[(size_t)b * k + r] = pv;
+      if (pv >= thresh) ++nlen;
     }
-    __syncthreads();
-    const int wi = s_best.i;
-    if ((wi & 1023) == tid) {
-      const int jj = wi >> 10;
+    if (tmax == best) {                 // keys are unique (they carry the index): exactly one thread owns the winner
+      tmax = 0ull;
 #pragma unroll
-      for (int j = 0; j < TK_PER_THREAD; ++j)
-        if (j == jj) pv[j] = -1.0f;
+      for (int j = 0; j < TK_PER_THREAD; ++j) {
+        if (key[j] == best) key[j] = 0ull;
+        tmax = key[j] > tmax ? key[j] : tmax;
+      }
     }
   }
   if (tid == 0) out_len[b] = nlen;
