@@ -337,9 +337,8 @@ int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int
   return gemm_desc(A, W, nullptr, nullptr, partials, d, s);
 }
 
-// Decode-step GEMMs with few rows (M <= 256): the "resident" kernel form requests the whole 768-long k range of a tile at
-// once (one memory round trip instead of four dependent ones: 9.3 -> ~5.5 us per launch at M = 128).  Returns the number of
-// fp32 partial slabs written (K / 768) when `partials` is used, 0 for a finished output.
+// Decode-step GEMMs with few rows (M <= 256).  `hint` 20 / 21 / 22 name the "resident" kernel form (the whole 768-long k range of a
+// tile requested at once); see below for which form actually runs.
 int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M, int N, int K, int act, int out,
                int hint, void* s) {
   vitcap_gemm_desc d;
@@ -348,6 +347,11 @@ int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C
   d.lda = lda; d.ldw = K; d.ldc = ldc;
   d.act = act; d.out_dtype = out;
   d.tile_hint = hint;
+  // K = 768: the 4-stage LDS-DMA ring on 64x32 (32x32 for a handful of rows) tiles.  Round 2 used the resident whole-K form here
+  // too -- a workaround for the ring's counted waits having silently become vmcnt(0) (DESIGN.md 4.2 i); with the waits real the
+  // ring wins at every batch size: decode phase 5.54 -> 5.28 ms at 64 images, 3.84 -> 3.59 at one, 8.65 -> 7.78 at 128.
+  // K = 3072 keeps the resident form (its contract is different: raw fp32 slabs per 768-long k range).
+  if (K == 768 && hint >= 20 && hint <= 22) d.tile_hint = M <= 32 ? 14 : 13;
   return gemm_desc(A, W, bias, nullptr, C, d, s);
 }
 
