@@ -72,7 +72,11 @@ typedef struct {
                     stream's kernels fill the partial last round, and CU-time, not the launch's length, is what counts);
                     33 = the same with 192- or 128-row tiles for the rows behind the last whole round of the chip's CUs where
                     that shortens the launch (vitcap_gemm_tile_plan; auto picks it for M >= 2048 on an otherwise idle GPU);
-                    30 / 31 = every tile 192 / 128 rows (measurements, tests); 12 = 256x256 persistent workgroups.
+                    30 / 31 = every tile 192 / 128 rows (measurements, tests); 12 = 256x256 persistent workgroups;
+                    13 / 14 / 15 = 64x32 / 32x32 / 32x64 tiles on the 4-stage ring (decode-step shapes); 23 / 24 = 64x32 / 32x32
+                    ring tiles writing K/768 raw fp32 slabs C[K/768][M][ldc] (K a multiple of 768 above it, no bias /
+                    residual / activation: the consumer sums them, vitcap_sum_layernorm); 20 / 21 / 22 = the whole-K
+                    "resident" forms of the same (finished output at K = 768, slabs above).
                     Tile shape never changes a result bit. */
   int split_k;   /* > 1: C is fp32 [split_k][M][ldc] partial slabs (no bias/act/residual applied); the consumer
                     (vitcap_sum_layernorm) reduces them.  K must be a multiple of 128*split_k. */

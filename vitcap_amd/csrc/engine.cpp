@@ -350,8 +350,10 @@ int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C
   // K = 768: the 4-stage LDS-DMA ring on 64x32 (32x32 for a handful of rows) tiles.  Round 2 used the resident whole-K form here
   // too -- a workaround for the ring's counted waits having silently become vmcnt(0) (DESIGN.md 4.2 i); with the waits real the
   // ring wins at every batch size: decode phase 5.54 -> 5.28 ms at 64 images, 3.84 -> 3.59 at one, 8.65 -> 7.78 at 128.
-  // K = 3072 keeps the resident form (its contract is different: raw fp32 slabs per 768-long k range).
   if (K == 768 && hint >= 20 && hint <= 22) d.tile_hint = M <= 32 ? 14 : 13;
+  // K = 3072 (`output.dense`): the same ring with one raw fp32 slab per 768-long k range (hints 23 / 24 = the resident form's
+  // contract): decode phase 5.24 -> 5.13 ms at 64 images, 3.58 -> 3.48 at one
+  if (K > 768 && K % 768 == 0 && hint >= 20 && hint <= 22) d.tile_hint = M <= 32 ? 24 : 23;
   return gemm_desc(A, W, bias, nullptr, C, d, s);
 }
 

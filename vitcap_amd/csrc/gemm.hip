@@ -1598,6 +1598,8 @@ int launch_rowstat_t(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_rowstat(const GemmArgs& a, hipStream_t s) {
+  // re-measured with the ring's counted waits working (DESIGN.md 4.2 x): 3 / 6 / 8 stages and 64x128 tiles are all slower than
+  // 64x64 x 4 stages in the decode loop (decode phase 5.10-5.18 ms against 5.17-5.26)
   return a.M <= 256 ? launch_rowstat_t<2, 2, 4>(a, s) : launch_rowstat_t<4, 4, 2>(a, s);
 }
 
@@ -1697,6 +1699,17 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
                    (!aux_bf16 || ldaux % 8 == 0) && (!zout_bf16 || ldz % 8 == 0) && d->act != VITCAP_ACT_TANH,
                "gemm(colsum): needs bf16 output, no residual / row remap / split-K, M >= 2048, N, ldc (ldaux, ldz) multiples of 8");
     return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);
+  }
+  if (hint == 23 || hint == 24) {
+    // the resident form's contract on the 4-stage ring: K > 768 -> K/768 raw fp32 partial slabs in C = [K/768][M][ldc], one per
+    // 768-long k range (blockIdx.y); 64x32 (23) or 32x32 (24) tiles
+    VC_REQUIRE(d->K % 768 == 0 && d->K > 768 && plain_rows && !aux_bf16 && !zout_bf16 && d->out_dtype == VITCAP_OUT_F32 && !bias && !residual &&
+                   d->act == VITCAP_ACT_NONE,
+               "gemm(ring slabs): needs K a multiple of 768 above it, plain rows, raw fp32 slabs (no bias / residual / activation)");
+    a.split_k = d->K / 768;
+    a.kt_per_split = 12;
+    a.slab = (size_t)d->M * d->ldc;
+    return hint == 23 ? dispatch<2, 1>(a, VITCAP_ACT_NONE, 1, s) : dispatch<1, 1>(a, VITCAP_ACT_NONE, 1, s);
   }
   if (hint == 20 || hint == 21 || hint == 22) {
     // resident whole-K form (decode-step shapes); K > 768 -> K/768 fp32 partial slabs in C = [K/768][M][ldc]
