@@ -337,7 +337,7 @@ int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int
   return gemm_desc(A, W, nullptr, nullptr, partials, d, s);
 }
 
-// Decode-step GEMMs with few rows (M <= 256).  `hint` 20 / 21 / 22 name the "resident" kernel form (the whole 768-long k range of a
+// Decode-step GEMMs with few rows (M <= 1024).  `hint` 20 / 21 / 22 name the "resident" kernel form (the whole 768-long k range of a
 // tile requested at once); see below for which form actually runs.
 int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M, int N, int K, int act, int out,
                int hint, void* s) {
@@ -862,9 +862,11 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
     CK(vitcap_embed_step(ids, L, t, o.mask_token_id, w.word_emb, w.pos_emb, w.type_emb, w.emb_ln_g, w.emb_ln_b, 1e-12f, xs_f, xs_b,
                          ns, s));
   static const int force_old = [] { const char* e = getenv("VITCAP_DECODE_SPLITK"); return e ? atoi(e) : 0; }();   // A/B measurements
-  // resident whole-K kernels for greedy / sampling batches; beams keep the split-K path.  The choice follows the WHOLE batch, so
-  // that a sequence's arithmetic does not depend on how the batch is sliced.
-  const bool small = 2 * NS <= 256 && !force_old;
+  // small-tile LDS-DMA ring kernels (gemm_small) for batches of few rows; larger ones take the big-tile / split-K path.  The choice
+  // follows the WHOLE batch, so that a sequence's arithmetic does not depend on how the batch is sliced.
+  // up to 1024 rows (512 sequences) the small-tile ring forms of gemm_small win (decode phase 13.2 -> 11.9 ms at 256 images,
+  // 20.4 -> 19.9 at 512); at 2560 rows (5 beams x 256 images) the 128x128 / 256x256 tiles do (21.4 against 23.8 ms)
+  const bool small = 2 * NS <= 1024 && !force_old;
   static const int no_beam_attn = [] { const char* e = getenv("VITCAP_BEAM_ATTN_VALU"); return e ? atoi(e) : 0; }();   // A/B measurements
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
