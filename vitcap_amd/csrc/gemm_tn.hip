@@ -24,6 +24,9 @@ namespace {
 constexpr int TBN = 256, TBK = 256, TBM = 64;
 constexpr int ROW_B = 512;                       // bytes per tile row (256 bf16)
 constexpr int OP_BYTES = TBM * ROW_B;            // 32 KiB per operand per stage
+#ifndef VC_TN_RING4
+#define VC_TN_RING4 1
+#endif
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 
 struct TnArgs {
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   // The MFMAs are already hidden; the critical path is LDS-DMA in (25 B/clk/CU, the same ceiling the NT kernel sees) PLUS
   // the transpose reads out, which do not overlap each other.  Tried and measured, both slower or equal, both reverted:
   // the two n-halves one phase apart as in gemm_nt_256_kernel (+3 %), and a ring of four 32-row stages with the request
-  // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242); register-staged tiles (global_load -> VGPR ->
+  // issued three stages ahead (DMA-only 127 -> 104 us, but full 200 -> 242 -- with the waits of that time, see below: round 3
+  // built it again on counted waits and it is the shipped form, VC_TN_RING4); register-staged tiles (global_load -> VGPR ->
   // ds_write_b128) instead of LDS-DMA: 195 -> 499 us.  SQ counters: no LDS bank conflicts, 67 % of wave cycles in
   // s_waitcnt/barriers, MFMA pipe 33 % busy.
   // Round 2, measured and reverted: the bias gradient (column sums of Y) as extra MFMAs against an all-ones fragment inside this
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) yaddr[i] = lane_base + (uint32_t)(((wn * 8 + i) ^ fsw) * 32);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xaddr[j] = lane_base + (uint32_t)OP_BYTES + (uint32_t)(((wk * 4 + j) ^ fsw) * 32);
+    for (int j = 0; j < 4; ++j) xaddr[j] = lane_base + (uint32_t)(VC_TN_RING4 ? OP_BYTES / 2 : OP_BYTES) + (uint32_t)(((wk * 4 + j) ^ fsw) * 32);
   }
   const uint32_t lds0 = lds_addr(smem);
 #define TN_STEP(MS_)                                                                                                  \
@@ -151,6 +155,40 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(xl[j], xh[j]), tr_pair(yl[i], yh[i]), acc[i][j], 0, 0, 0); \
   } while (0)
 
+#if VC_TN_RING4
+  // ring of FOUR 32-row stages, requests three stages ahead: more bytes in flight per CU than the two 64-row buffers (the kernel
+  // is bound by LDS-DMA throughput in), one barrier per 32-row step.  Round 2 measured this form slower -- with the transpose-read
+  // intrinsic every step waited for vmcnt(0), which four short stages pay twice as often; with the asm reads the counted wait holds.
+  const int s32_begin = 2 * s_begin, nst32 = 2 * nst;
+#define STAGE32(buf_, st_)                                                                          \
+  do {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+      const int r_ = w * 4 + i * 2 + drow;           /* stage row 0..31 */                          \
+      const int lc_ = dchunk ^ (swz(r_) << 1);                                                      \
+      const int m_ = (st_) * 32 + r_;                                                               \
+      const bf16_t* ys_ = m_ < p.M ? p.Y + (size_t)m_ * p.ldy + n0 + lc_ * 8 : p.zeros + lc_ * 8;   \
+      const bf16_t* xs_ = m_ < p.M ? p.X + (size_t)m_ * p.ldx + k0 + lc_ * 8 : p.zeros + lc_ * 8;   \
+      char* dst_ = smem + (buf_) * (STAGE_BYTES / 2) + (w * 4 + i * 2) * ROW_B;                     \
+      glds16(ys_, dst_);                                                                            \
+      glds16(xs_, dst_ + OP_BYTES / 2);                                                             \
+    }                                                                                               \
+  } while (0)
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q < nst32) STAGE32(q, s32_begin + q);
+  for (int t = 0; t < nst32; ++t) {
+    // stage t has landed when at most the requests of stages t+1, t+2 (4 per wave each) are outstanding
+    const int newer = nst32 - 1 - t;
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // stage t visible to all waves; every wave is done reading stage t-1 ...
+    if (t + 3 < nst32) STAGE32((t + 3) & 3, s32_begin + t + 3);      // ... whose buffer the request for stage t+3 refills
+    const uint32_t sb = lds0 + (uint32_t)((t & 3) * (STAGE_BYTES / 2));
+    TN_STEP(0);
+  }
+#undef STAGE32
+#else
   if (nst > 0) STAGE(0, s_begin);
   for (int t = 0; t < nst; ++t) {
     const int buf = t & 1;
@@ -169,6 +207,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
     TN_STEP(1);
     __builtin_amdgcn_s_barrier();                          // everyone done reading `buf` before it is refilled
   }
+#endif
 #undef TN_STEP
 #undef STAGE
 
