@@ -24,6 +24,9 @@ namespace {
 constexpr int TBN = 256, TBK = 256, TBM = 64;
 constexpr int ROW_B = 512;                       // bytes per tile row (256 bf16)
 constexpr int OP_BYTES = TBM * ROW_B;            // 32 KiB per operand per stage
+#ifndef VC_TN_ALTERNATE     // 1: the two wave groups one segment apart (needs VC_TN_RING4)
+#define VC_TN_ALTERNATE 1
+#endif
 #ifndef VC_TN_RING4
 #define VC_TN_RING4 1
 #endif
@@ -173,20 +176,86 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
       glds16(xs_, dst_ + OP_BYTES / 2);                                                             \
     }                                                                                               \
   } while (0)
+  // stage T_ has landed for this wave when at most the requests of the two younger stages (4 per wave each) are outstanding
+#define WAIT_STAGE(T_)                                                          \
+  do {                                                                          \
+    const int newer_ = nst32 - 1 - (T_);                                        \
+    if (newer_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           \
+    else if (newer_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+  } while (0)
 #pragma unroll
   for (int q = 0; q < 3; ++q)
     if (q < nst32) STAGE32(q, s32_begin + q);
+#if VC_TN_ALTERNATE
+  // The two wave groups (wn = 0 / 1: waves w and w + 4 share a SIMD) run one segment apart, as in gemm_nt_256_kernel: a step is a
+  // LOAD segment (24 transpose reads) and an MFMA segment (32 MFMAs), each closed by a barrier, and while one wave of a SIMD
+  // multiplies, the other reads.  Barrier 2t opens L_A(t) (stage t landed for everyone: every wave waited for its own pieces
+  // before it) and M_B(t-1); barrier 2t+1 opens M_A(t) and L_B(t).  The buffer of stage t-1 was last read in L_B(t-1), which
+  // barrier 2t closes, so either group requests stage t+3 right behind that barrier.
+  s16x4 xl[4], xh[4], yl[8], yh[8];
+#define TN_LOAD()                                                                                                     \
+  do {                                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+      xl[j] = lds_tr_read<0>(sb + xaddr[j]);                                                                          \
+      xh[j] = lds_tr_read<4 * ROW_B>(sb + xaddr[j]);                                                                  \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+      yl[i] = lds_tr_read<0>(sb + yaddr[i]);                                                                          \
+      yh[i] = lds_tr_read<4 * ROW_B>(sb + yaddr[i]);                                                                  \
+    }                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+                 : "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]), "+v"(xh[2]), "+v"(xl[3]), "+v"(xh[3]), \
+                   "+v"(yl[0]), "+v"(yh[0]), "+v"(yl[1]), "+v"(yh[1]), "+v"(yl[2]), "+v"(yh[2]), "+v"(yl[3]), "+v"(yh[3]), \
+                   "+v"(yl[4]), "+v"(yh[4]), "+v"(yl[5]), "+v"(yh[5]), "+v"(yl[6]), "+v"(yh[6]), "+v"(yl[7]), "+v"(yh[7])); \
+  } while (0)
+#define TN_MFMA()                                                                                                     \
+  do {                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(xl[j], xh[j]), tr_pair(yl[i], yh[i]), acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
+  } while (0)
+  if (wn == 0) {
+    for (int t = 0; t < nst32; ++t) {
+      WAIT_STAGE(t);
+      __builtin_amdgcn_s_barrier();                                           // 2t
+      if (t + 3 < nst32) STAGE32((t + 3) & 3, s32_begin + t + 3);
+      const uint32_t sb = lds0 + (uint32_t)((t & 3) * (STAGE_BYTES / 2));
+      TN_LOAD();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                           // 2t + 1
+      TN_MFMA();
+    }
+    __builtin_amdgcn_s_barrier();                                             // 2 nst32: group B's last
+  } else {
+    if (nst32 > 0) WAIT_STAGE(0);
+    __builtin_amdgcn_s_barrier();                                             // 0
+    if (3 < nst32) STAGE32(3, s32_begin + 3);
+    for (int t = 0; t < nst32; ++t) {
+      __builtin_amdgcn_s_barrier();                                           // 2t + 1
+      const uint32_t sb = lds0 + (uint32_t)((t & 3) * (STAGE_BYTES / 2));
+      TN_LOAD();
+      if (t + 1 < nst32) WAIT_STAGE(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                           // 2t + 2
+      if (t + 4 < nst32) STAGE32((t + 4) & 3, s32_begin + t + 4);
+      TN_MFMA();
+    }
+  }
+#undef TN_LOAD
+#undef TN_MFMA
+#else
   for (int t = 0; t < nst32; ++t) {
-    // stage t has landed when at most the requests of stages t+1, t+2 (4 per wave each) are outstanding
-    const int newer = nst32 - 1 - t;
-    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_STAGE(t);
     __builtin_amdgcn_s_barrier();            // stage t visible to all waves; every wave is done reading stage t-1 ...
     if (t + 3 < nst32) STAGE32((t + 3) & 3, s32_begin + t + 3);      // ... whose buffer the request for stage t+3 refills
     const uint32_t sb = lds0 + (uint32_t)((t & 3) * (STAGE_BYTES / 2));
     TN_STEP(0);
   }
+#endif
+#undef WAIT_STAGE
 #undef STAGE32
 #else
   if (nst > 0) STAGE(0, s_begin);
