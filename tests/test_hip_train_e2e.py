@@ -681,7 +681,7 @@ def test_pipeline_trains_on_tsv_data(tmp_path, monkeypatch, scst):
     tsv_writer(img_rows, str(d / 'train.tsv'))
     tsv_writer(cap_rows, str(d / 'train.caption.tsv'))
     tsv_writer(lab_rows, str(d / 'train.label.vvinvl.tsv'))
-    param = {'full_expid': 'R', 'max_iter': 3, 'drop_out': 0, 'effective_batch_size': 4, 'init_recipe_seed': 0, 'log_step': 1, 'data': 'toy',
+    param = {'full_expid': 'R', 'max_iter': '1e', 'drop_out': 0, 'effective_batch_size': 4, 'init_recipe_seed': 0, 'log_step': 1, 'data': 'toy',
              'text_encoder_type': str(enc), 'tagemb': 'cls', 'lr_multiplier': 0.1, 'force_train': True, 'max_seq_a_length': 20,
              'train_label_version': 'vinvl', 'encode': 'bert', 'input_small_scale': 0.08, 'num_workers': 2, 'random_seed': 5,
              'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}

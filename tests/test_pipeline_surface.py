@@ -98,3 +98,24 @@ def test_unbuilt_model_variants_are_refused():
     with pytest.raises(NotImplementedError, match='drop_out'):
         CaptionUniPipeline(drop_out=0.1, init_recipe_seed=0).ensure_train()
     check_model_config(CaptionUniPipeline(drop_out=0.1).cfg, training=False)      # inference: dropout is inactive
+
+
+def test_max_iter_in_epochs(tmp_path, monkeypatch):
+    """`max_iter: 30e` (the shipped YAML): epochs are converted with the number of (image, caption) pairs of the training split,
+    int(x * n / effective_batch_size) as uni_pipeline.py:253-261 does, and the final snapshot's name follows; without a training
+    set the epoch form is refused with a message instead of int('30e')."""
+    import json
+    import pytest
+    from vitcap_amd.pipeline import CaptionUniPipeline
+    from vitcap_amd.tsv import tsv_writer
+    monkeypatch.chdir(tmp_path)
+    d = tmp_path / 'data' / 'toy'
+    d.mkdir(parents=True)
+    rows = [('k%d' % i, json.dumps([{'caption': 'a b'}] * (1 + i % 3))) for i in range(10)]      # 1+2+3+1+2+3+1+2+3+1 = 19 pairs
+    tsv_writer(rows, str(d / 'train.caption.tsv'))
+    p = CaptionUniPipeline(data='toy', max_iter='30e', effective_batch_size=4, full_expid='E')
+    assert p.parse_iter('30e') == int(30 * 19 / 4) == 142 and p.parse_iter(7) == 7 and p.parse_iter('7') == 7
+    assert p.parse_iter('0.5e') == 2
+    assert p.get_checkpoint_file().endswith('output/E/snapshot/model_iter_0000142.pt')
+    with pytest.raises(ValueError, match='training set'):
+        CaptionUniPipeline(max_iter='30e').parse_iter('30e')

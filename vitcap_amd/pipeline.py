@@ -111,6 +111,7 @@ class CaptionUniPipeline(object):
         self.rank, self.world, self.local_rank = D.env_rank_world()
         self._tokenizer = None
         self._initialized = False
+        self._n_train = None
 
     # ------------------------------------------------------------------ naming (uni_pipeline.py:150-170)
     @property
@@ -125,15 +126,26 @@ class CaptionUniPipeline(object):
     def get_snapshot_dir(self):
         return op.join(self.output_folder, 'snapshot')
 
+    def parse_iter(self, i):
+        """uni_pipeline.py:253-261: an integer, or '<x>e' = x epochs = int(x * number of training samples / effective_batch_size);
+        the samples are the (image, caption) pairs of the training split's caption index (CaptionIdxTSVDataset).  The shipped
+        YAML trains for `max_iter: 30e`."""
+        if isinstance(i, str) and i.endswith('e'):
+            if not self.cfg.data or self.cfg.data == 'synthetic':
+                raise ValueError("max_iter given in epochs ('%s') needs a training set (`data: <name>`); use an integer with synthetic data" % i)
+            if self._n_train is None:
+                from .dataset import CaptionIdx
+                self._n_train = len(CaptionIdx(self.cfg.data_root or 'data', self.cfg.data, 'train', self.cfg.train_version))
+            return int(float(i[:-1]) * (1. * self._n_train / int(self.cfg.effective_batch_size)))
+        return int(i)
+
     def get_checkpoint_file(self, iteration=None):
         """uni_pipeline.py:614-622: `model_file` if given (and no iteration asked for), else snapshot/model_iter_<max_iter>.pt.
         `basemodel` is the training INIT only (..._bertemb.py:259-267) and never the file that is evaluated."""
         if iteration is None and self.cfg.model_file is not None:
             return self.cfg.model_file
-        it = self.cfg.max_iter if iteration is None else iteration
-        if isinstance(it, str):
-            raise ValueError("max_iter given in epochs ('%s') needs the training set; use an integer" % it)
-        return op.join(self.get_snapshot_dir(), 'model_iter_{:07d}.pt'.format(int(it)))
+        it = self.parse_iter(self.cfg.max_iter if iteration is None else iteration)
+        return op.join(self.get_snapshot_dir(), 'model_iter_{:07d}.pt'.format(it))
 
     def is_train_finished(self):
         return op.isfile(self.get_checkpoint_file())
@@ -277,7 +289,7 @@ class CaptionUniPipeline(object):
             model.load_recipe(int(self.cfg.init_recipe_seed))
         else:
             raise FileNotFoundError('basemodel not found: {}'.format(self.cfg.basemodel))
-        max_iter = int(self.cfg.max_iter)
+        max_iter = self.parse_iter(self.cfg.max_iter)
         dist = None
         if self.world > 1:
             import torch.distributed as dist
