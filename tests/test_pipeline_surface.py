@@ -90,7 +90,7 @@ def test_unbuilt_model_variants_are_refused():
     check_model_config(CaptionUniPipeline().cfg, training=False)                  # an empty config is the built model
     for bad in ({'split_blocks': 2}, {'topk': 20}, {'topk': None}, {'image_encoder_type': 'VitEmb_vit_large_patch16_384'},
                 {'tie_tag_weights': True}, {'mask_type': 'bidirectional'}, {'optimizer_type': 'LAMB'}, {'scheduler_type': 'cosine'},
-                {'use_img_layernorm': True}, {'ln_no_weight_decay': False}, {'use_amp': True}):
+                {'use_img_layernorm': True}, {'ln_no_weight_decay': False}, {'category': 'vinvl'}, {'train_transform': 'inception'}, {'use_amp': True}):
         with pytest.raises(NotImplementedError, match=list(bad)[0]):
             check_model_config(CaptionUniPipeline(**dict(shipped, **bad)).cfg, training=False)
     with pytest.raises(NotImplementedError, match='drop_out'):

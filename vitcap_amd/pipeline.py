@@ -53,6 +53,8 @@ _BUILT_FOR = (
     ('use_img_layernorm', (False, 0), 'LayerNorm on the image features (config.use_img_layernorm)'),
     ('tie_tag_weights', (False, 0), 'tag head tied to the word embeddings (modeling_bert.py:724-726)'),
     ('mask_type', ('seq2seq',), 'attention mask family (dataset.py:377-417)'),
+    ('category', ('bert',), "tag vocabulary: 'vinvl' maps tags through tokenizer_file into another label space (config.category)"),
+    ('train_transform', ('vit',), 'training image transform family (get_transform, ..._bertemb.py:373-518)'),
     ('scheduler_type', ('linear',), 'LR schedule (..._bertemb.py:358-371)'),
     ('optimizer_type', ('MAdamW',), 'optimizer (..._bertemb.py:346-356)'),
     ('bias_no_weight_decay', (True, 1), 'parameter groups (..._bertemb.py:280-322)'),
