@@ -83,9 +83,13 @@ class TagLabelTensorizer(object):
                         v[self._id(t)] = 1
         if caption is not None:
             if self.encode == 'nltk':
-                if self.pos_tagger is None:
-                    raise RuntimeError("encode='nltk' needs nltk.word_tokenize + nltk.pos_tag, which are not installed here: "
-                                       "pass pos_tagger=callable(caption) -> [(word, tag)] or set encode: bert")
+                if self.pos_tagger is None:          # the reference's own tagger where it is installed (dataset.py:801-804)
+                    try:
+                        import nltk
+                        self.pos_tagger = lambda c: nltk.pos_tag(nltk.word_tokenize(c))
+                    except ImportError:
+                        raise RuntimeError("encode='nltk' needs nltk.word_tokenize + nltk.pos_tag, which are not installed here: "
+                                           "pass pos_tagger=callable(caption) -> [(word, tag)] or set encode: bert")
                 for word, pos in self.pos_tagger(caption):
                     if pos in ('JJ', 'NN', 'NNP'):
                         for t in word.split(' '):
