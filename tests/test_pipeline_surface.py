@@ -100,6 +100,24 @@ def test_unbuilt_model_variants_are_refused():
     check_model_config(CaptionUniPipeline(drop_out=0.1).cfg, training=False)      # inference: dropout is inactive
 
 
+def test_text_encoder_config_is_checked(tmp_path):
+    """<text_encoder_type>/config.json with another BERT geometry is refused; the shipped VILT-L12-H784 values pass (its
+    num_hidden_layers = 12 is overridden to 4 by the reference itself)."""
+    import json
+    import pytest
+    from vitcap_amd.pipeline import check_text_encoder_config
+    good = {'attention_probs_dropout_prob': 0.1, 'hidden_act': 'gelu', 'hidden_dropout_prob': 0.1, 'hidden_size': 768, 'intermediate_size': 3072,
+            'layer_norm_eps': 1e-12, 'max_position_embeddings': 512, 'num_attention_heads': 12, 'num_hidden_layers': 12, 'type_vocab_size': 2,
+            'vocab_size': 30522}
+    (tmp_path / 'config.json').write_text(json.dumps(good))
+    check_text_encoder_config(str(tmp_path))
+    check_text_encoder_config(str(tmp_path / 'missing'))           # no config.json: nothing to check
+    for bad in ({'hidden_size': 1024}, {'vocab_size': 28996}, {'hidden_act': 'relu'}, {'num_attention_heads': 16}):
+        (tmp_path / 'config.json').write_text(json.dumps(dict(good, **bad)))
+        with pytest.raises(NotImplementedError, match=list(bad)[0]):
+            check_text_encoder_config(str(tmp_path))
+
+
 def test_max_iter_in_epochs(tmp_path, monkeypatch):
     """`max_iter: 30e` (the shipped YAML): epochs are converted with the number of (image, caption) pairs of the training split,
     int(x * n / effective_batch_size) as uni_pipeline.py:253-261 does, and the final snapshot's name follows; without a training

@@ -73,6 +73,7 @@ def check_model_config(cfg, training):
     additionally needs `drop_out: 0` as in the shipped YAML: cfg.drop_out becomes BertConfig.hidden_dropout_prob
     (..._bertemb.py:535; the pipeline's own default is 0.1) and hidden-state dropout is not built -- only the decoder's attention
     dropout (attention_probs_dropout_prob) is."""
+    check_text_encoder_config(cfg.text_encoder_type)
     given = cfg.overwrite
     for key, ok, what in _BUILT_FOR:
         if key in given and given[key] not in ok:
@@ -80,6 +81,26 @@ def check_model_config(cfg, training):
     if training and float(cfg.drop_out or 0) != 0:
         raise NotImplementedError('drop_out: %r -- hidden-state dropout (BertConfig.hidden_dropout_prob, ..._bertemb.py:535) is not built; '
                                   'the shipped YAML trains with drop_out: 0 (the pipeline\'s own default is 0.1)' % (cfg.drop_out,))
+
+
+_BERT_CONFIG_BUILT = {   # BertConfig fields of <text_encoder_type>/config.json the kernels are sized for (the shipped VILT-L12-H784 values)
+    'hidden_size': 768, 'num_attention_heads': 12, 'intermediate_size': 3072, 'vocab_size': 30522, 'max_position_embeddings': 512,
+    'type_vocab_size': 2, 'layer_norm_eps': 1e-12, 'hidden_act': 'gelu',
+}
+
+
+def check_text_encoder_config(text_encoder_type):
+    """<text_encoder_type>/config.json, when present, must describe the BERT geometry this build implements (num_hidden_layers is
+    overridden to 4 by the reference itself, modeling_bert.py:1342-1346); another geometry is refused, not mis-run."""
+    import json
+    cj = op.join(text_encoder_type or '.', 'config.json')
+    if not op.isfile(cj):
+        return
+    with open(cj) as fp:
+        cfg = json.load(fp)
+    for k, want in _BERT_CONFIG_BUILT.items():
+        if k in cfg and cfg[k] != want:
+            raise NotImplementedError('%s: %s = %r, this build implements %r' % (cj, k, cfg[k], want))
 
 
 class _EngineState(object):
