@@ -61,6 +61,71 @@ def install_shims():
     sys.path.insert(0, REF)
 
 
+class _StubModule(types.ModuleType):
+    """A module whose every attribute is an inert class: stands in for packages the reference's pipeline module imports at the
+    top of the file and never touches on the path driven here (image transforms, tokenisers for tags, progress bars)."""
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        v = type(name, (), {'__init__': lambda self, *a, **k: None, '__call__': lambda self, *a, **k: None})
+        setattr(self, name, v)
+        return v
+
+
+def install_pipeline_shims():
+    """On top of install_shims(): whatever ``src.pipelines.tagger_caption_uni_pipeline_expanding_bertemb`` needs to IMPORT in
+    this container, so that the reference's own ``ImageCaptioning`` wrapper (construct_attn_mask :57-85, forward :87-184), its
+    ``InputAsDict`` and its ``CaptionTensorizer`` run as written.  Stubbed (absent here, unused on this path): torchvision, cv2,
+    nltk, future, progressbar, anytree, pathos, deprecated, pycocotools; torch.utils.model_zoo lost the private names
+    checkpoint.py:11 imports."""
+    install_shims()
+    for name in ('torchvision', 'torchvision.transforms', 'torchvision.transforms.transforms', 'torchvision.transforms.functional',
+                 'torchvision.datasets', 'torchvision.datasets.folder', 'cv2', 'nltk', 'future', 'future.utils', 'progressbar',
+                 'anytree', 'pathos', 'pathos.multiprocessing', 'deprecated', 'pycocotools', 'pycocotools.coco',
+                 'pycocotools.cocoeval'):
+        parts = name.split('.')
+        for i in range(1, len(parts) + 1):
+            n = '.'.join(parts[:i])
+            if n not in sys.modules:
+                m = _StubModule(n)
+                m.__path__ = []
+                sys.modules[n] = m
+                if i > 1:
+                    setattr(sys.modules['.'.join(parts[:i - 1])], parts[i - 1], m)
+    import torch.utils.model_zoo as mz
+    for n in ('_download_url_to_file', 'urlparse', 'HASH_REGEX'):
+        if not hasattr(mz, n):
+            setattr(mz, n, None)
+
+
+def build_wrapper(model, enc, num_beams=1, **over):
+    """The reference's own inference model as CaptionUniPipeline.get_raw_model(is_train=False) assembles it
+    (..._bertemb.py:566-618, image encoder :750-778): ImageCaptioning(ViTCAP, test_extra_input, InputAsDict(timm ViT))."""
+    from src.pipelines.tagger_caption_uni_pipeline_expanding_bertemb import ImageCaptioning
+    from src.tools.torch_common import InputAsDict
+    from src.layers.bert.tokenization_bert import BertTokenizer
+    tok = BertTokenizer(os.path.join(REF, 'yaml', 'VILT-L12-H784-uncased_16_384', 'vocab.txt'), do_lower_case=True)
+    cls_id, sep_id, pad_id, mask_id = tok.convert_tokens_to_ids([tok.cls_token, tok.sep_token, tok.pad_token, tok.mask_token])
+    cfg = types.SimpleNamespace(mask_type='seq2seq', use_cbs=False, pert_img_prob=None, category='bert', gt_tag_train=False,
+                                pred_tag_train=False, gen_tag_ratio=None, max_iter=1)
+    extra = {'is_decode': True, 'do_sample': False, 'bos_token_id': cls_id, 'pad_token_id': pad_id, 'eos_token_ids': [sep_id],
+             'mask_token_id': mask_id, 'add_od_labels': True, 'od_labels_start_posid': 20, 'max_length': 20,
+             'num_beams': num_beams, 'temperature': 1, 'top_k': 0, 'top_p': 1, 'repetition_penalty': 1, 'length_penalty': 1,
+             'num_return_sequences': 1, 'num_keep_best': 1}
+    extra.update(over)
+    wrap = ImageCaptioning(model, extra, tokenizer=tok, bert_tokenizer=tok, image_encoder=InputAsDict(enc), cfg=cfg)
+    return wrap.eval(), tok          # the pipeline evaluates under .eval() (uni_pipeline.py:759-769)
+
+
+def reference_tensorizer(tok, is_train, **kw):
+    """The reference's CaptionTensorizer (src/data_layer/dataset.py:158-417) with the shipped YAML's lengths (max_seq_a_length 20 =
+    max_gen_length at test time, od label span 50: ..._bertemb.py:423-470)."""
+    from src.data_layer.dataset import CaptionTensorizer
+    return CaptionTensorizer(tok, max_img_seq_length=0, max_seq_length=70, max_seq_a_length=20, is_train=is_train,
+                             mask_type='seq2seq', **kw)
+
+
 def build_reference(tagemb='cls', tie_weights=True):
     from src.layers.bert import BertConfig, ViTCAP
     from src.pytorch_image_models.timm.models import vision_transformer as vt

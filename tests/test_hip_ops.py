@@ -135,6 +135,51 @@ def test_gemm_256_tile_heights_bit_identical(ops, variant):
         assert torch.equal(outs[hint], outs[32]), 'tile_hint %d differs from 256-row tiles (%s)' % (hint, variant)
 
 
+@pytest.mark.parametrize('variant', ['bias_bf16', 'gelu_bf16', 'res_f32', 'rowmap_res_f32', 'bias_f32', 'res_bf16', 'k128', 'k3072_res_f32',
+                                     'ragged_n', 'strided'])
+def test_gemm_4wave_bit_identical(ops, variant):
+    """The 4-wave / 512-register 256x256 kernel (tile_hint 40 / 41 / 42, csrc/gemm4w.hip) against the 8-wave one (tile_hint 32): same LDS image,
+    same MFMA, same k order per output element and the same epilogue arithmetic, so every bit must agree; hint 32 itself is checked
+    against fp32 torch by test_gemm_256_tile_heights_bit_identical."""
+    from vitcap_amd import _lib as L
+    M, N, K = {'bias_bf16': (9232, 2304, 768), 'gelu_bf16': (4099, 3072, 768), 'res_f32': (10386, 768, 768), 'rowmap_res_f32': (16 * 576, 768, 768),
+               'bias_f32': (2500, 1024, 256), 'res_bf16': (3000, 768, 768), 'k128': (2048, 512, 128), 'k3072_res_f32': (5000, 768, 3072),
+               'ragged_n': (2300, 2304 - 64, 768), 'strided': (4096, 768, 768)}[variant]
+    a = _bf(_rand((M, K), 81)).cuda()
+    w = _bf(_rand((N, K), 82, 0.05)).cuda()
+    bias = _rand((N,), 83, 0.1).cuda()
+    outs = {}
+    for hint in (32, 40, 41, 42):
+        if variant in ('bias_bf16', 'k128', 'ragged_n'):
+            outs[hint] = ops.gemm_bias_act(a, w, bias, tile_hint=hint)
+        elif variant == 'gelu_bf16':
+            outs[hint] = ops.gemm_bias_act(a, w, bias, act=L.ACT_GELU_ERF, tile_hint=hint)
+        elif variant == 'bias_f32':
+            outs[hint] = ops.gemm_bias_act(a, w, bias, out_dtype=torch.float32, tile_hint=hint)
+        elif variant in ('res_f32', 'k3072_res_f32'):
+            x = _rand((M, N), 84).cuda()
+            outs[hint] = ops.gemm_bias_act(a, w, bias, residual=x, out=x.clone(), tile_hint=hint)
+        elif variant == 'res_bf16':
+            x = _rand((M, N), 84).cuda()
+            outs[hint] = ops.gemm_bias_act(a, w, bias, residual=x, out_dtype=torch.bfloat16, tile_hint=hint)
+        elif variant == 'strided':       # the output is a column slice of a wider buffer (ldc > N)
+            big = torch.zeros(M, 2 * N, device='cuda', dtype=torch.bfloat16)
+            outs[hint] = ops.gemm_bias_act(a, w, bias, out=big[:, N:], tile_hint=hint).clone()
+        else:
+            pos = _rand((577, N), 75).cuda()
+            out = torch.zeros(16 * 577, N, device='cuda')
+            outs[hint] = ops.gemm_bias_act(a, w, bias, residual=pos[1:], out=out, row_group=576, out_group_rows=577,
+                                           out_row_off=1, res_periodic=1, tile_hint=hint)
+    torch.cuda.synchronize()
+    if variant in ('bias_bf16', 'bias_f32', 'k128', 'ragged_n'):
+        z = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+        tol = (2 ** -7, 2e-3) if outs[40].dtype == torch.bfloat16 else (1e-4, 1e-4)
+        _close(outs[40], z, tol[0], tol[1], 'hint 40 vs torch (%s)' % variant)
+    for hint in (40, 41, 42):     # LDS epilogue / register epilogue / persistent pipeline
+        assert torch.equal(outs[hint], outs[32]), 'tile_hint %d differs from the 8-wave 256x256 kernel (%s): max |d| %g' % (
+            hint, variant, float((outs[hint].float() - outs[32].float()).abs().max()))
+
+
 @pytest.mark.parametrize('M,N,K,split', [(128, 768, 768, 6), (128, 768, 3072, 12), (64, 768, 768, 6), (128, 2304, 768, 1),
                                           (64, 30592, 768, 1), (100, 3072, 768, 1), (256, 768, 3072, 4)])
 def test_gemm_skinny_splitk(ops, M, N, K, split):

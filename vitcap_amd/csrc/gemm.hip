@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include <hip/hip_ext.h>
+#include "gemm_args.h"
 
 #include <algorithm>
 #include <mutex>
@@ -25,44 +25,6 @@
 #include <vector>
 
 namespace {
-
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* W;
-  const float* bias;
-  const float* res;
-  void* C;
-  int M, N, K;
-  int lda, ldw, ldc, ldr;
-  int row_group, out_group_rows, out_row_off, res_periodic;
-  int tiles_m, tiles_n;
-  int n_big, tiles_m_small;     // mixed launch of the 256-wide kernel: workgroups [0, n_big) own 256-row tiles, the rest short ones
-  // training extras
-  float* colsum;       // training: colsum[n] += sum over rows of the finished bf16 outputs (bias gradient of the layer whose
-                       // output gradient this GEMM produces); fp32 [N], atomics; 256x256 kernel, bf16 output, plain rows
-  const bf16_t* aux;   // epilogue multiplies by aux (the stored gelu' factor: backward of the MLP activation); bf16 [M][ldaux]
-  int ldaux;
-  bf16_t* zout;        // gelu'(pre-activation) for the backward (act == GELU only; the factor a later launch takes as `aux`); bf16 [M][ldz]
-  int ldz;
-  int direct_epilogue; // 256x256 kernels: register-transpose epilogue (1) or the LDS-staged one (0)
-  int split_k;         // > 1: blockIdx.y = split, ragged k-tile ranges, fp32 partial slabs, no epilogue
-  int kt_per_split;
-  size_t slab;
-  int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
-  const int32_t* live;         // decode loop: return at entry once *live == 0 (vitcap_gemm_desc.live)
-  float* rowstat;              // ROWSTAT kernels: per (row, 32-column piece) {max, argmax column, sum exp(x - max), 0}
-};
-
-// launch of a large-tile GEMM: with kernel-bound timing events when the engine's timing run asked for them (common.h)
-#define VC_LAUNCH_GEMM(kern, grid, block, smem, s, p)                                                              \
-  do {                                                                                                             \
-    if (vc_tls_kev_start) {                                                                                        \
-      hipExtLaunchKernelGGL(kern, grid, block, smem, s, vc_tls_kev_start, vc_tls_kev_stop, 0, p);                 \
-      vc_tls_kev_used = true;                                                                                      \
-    } else {                                                                                                       \
-      hipLaunchKernelGGL(kern, grid, block, smem, s, p);                                                           \
-    }                                                                                                              \
-  } while (0)
 
 // width (in 256-column tiles) of the column groups the 256x256 kernels walk; VITCAP_GEMM_GROUP_N overrides (experiments)
 int tile_group_n(int tiles_n) {
@@ -73,6 +35,10 @@ int tile_group_n(int tiles_n) {
   int g = env_gn > 0 ? env_gn : (tiles_n > 9 ? 3 : tiles_n);
   return g > tiles_n ? tiles_n : g;
 }
+
+}  // namespace
+int vc_tile_group_n(int tiles_n) { return tile_group_n(tiles_n); }
+namespace {
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1767,6 +1733,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // the persistent kernel's bf16 epilogue stores 8 columns (16 bytes) per lane
   const bool wide_ok = d->out_dtype == VITCAP_OUT_F32 || residual || (d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)C & 15) == 0);
   if (hint == 12 && wide_ok) return dispatch_256p(a, d->act, d->out_dtype, s);
+  if (hint >= 40 && hint <= 42) return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent
   if (hint == 30) return dispatch_256<4>(a, d->act, d->out_dtype, s, 3);    // every tile 192 x 256 (tile-cost measurement)
   if (hint == 31) return dispatch_256<4>(a, d->act, d->out_dtype, s, 2);    // every tile 128 x 256
   if (hint == 5 || hint == 32) return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);    // 256 x 256 tiles only (no short tail tiles)

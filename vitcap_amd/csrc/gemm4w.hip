@@ -1,0 +1,754 @@
+// bf16 NT GEMM, 256 x 256 x 64 tiles, FOUR waves of 128 x 128 each (one wave per SIMD, 512 registers per lane):
+//   C = act(A . W^T + bias) (+ residual),  A[M][K], W[N][K] both K-contiguous.
+//
+// Why this form (round 4): the 8-wave kernel of gemm.hip (two waves per SIMD, 128 x 64 per wave) issues
+// 24 ds_read_b128 per 64 MFMAs and pays two s_barriers per 16 MFMAs to alternate its wave pairs; its instruction stream is 29 %
+// MFMA.  With ONE wave per SIMD the 128 x 128 wave tile keeps its 256 accumulator registers in the AGPR half of the unified
+// 512-entry file and both k-halves' fragments (2 x 16 x 4 VGPRs) in the VGPR half:
+//   * 32 ds_read_b128 + 16 LDS-DMA pieces per 128 MFMAs (0.375 memory instructions per MFMA instead of 0.5),
+//   * ONE s_barrier per k-tile (at its middle: the k-half-1 fragments of tile t have been read, tile t+1 has landed),
+//   * the wave's own MFMAs cover its own loads: each memory instruction sits behind an MFMA that is busy for 16 cycles.
+// hipcc cannot keep 256 loop-carried accumulators in place (it rotates them through VGPRs: 250 v_accvgpr moves per k-tile,
+// measured in the ISA) and schedules the loads in clumps, so the main loop is written as ordered `asm volatile` statements
+// (cdna guide section 5.7): MFMAs with the accumulator tied ("+a"), fragment reads as asm ds_read_b128 fenced by explicit
+// lgkmcnt waits, LDS-DMA as `s_mov m0` + `buffer_load_dwordx4 ... offen lds` with per-piece scalar offsets (no per-lane address
+// arithmetic in the loop at all).  The compiler only allocates registers.
+//
+// Same tile walk (XCD-contiguous chunks, column groups), same LDS image (128-byte rows, 16-byte chunks XOR-swizzled by row & 7)
+// and the SAME summation order per output element as gemm.hip's 256 x 256 kernel (k-tiles ascending, two 32-deep MFMAs per
+// tile, same operand roles), so results are bit-identical to it (tests/test_hip_ops.py::test_gemm_4wave_bit_identical).
+#include "common.h"
+#include "gemm_args.h"
+
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int A_BYTES = 256 * 128;        // one operand's k-tile: 256 rows x 64 bf16
+constexpr int BUF_BYTES = 2 * A_BYTES;    // A tile + W tile
+constexpr int EP_ROWB = 272;              // epilogue staging row: 64 fp32 + 16 B pad (conflict-free ds_write_b128)
+constexpr int EP_WAVE = 128 * EP_ROWB;    // one wave's 128 x 64 fp32 patch
+constexpr int SMEM_4W = 4 * EP_WAVE > 2 * BUF_BYTES ? 4 * EP_WAVE : 2 * BUF_BYTES;
+constexpr int PATCH_BYTES = 16 * 512;    // register epilogue, fp32 path: one wave's m-tile (16 rows x 128 fp32) behind the k-tile buffers
+constexpr int SMEM_4WP = 2 * BUF_BYTES + 4 * PATCH_BYTES;   // = 160 KiB, the whole LDS of a CU
+
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_zero(f32x4& c, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(a));
+}
+template <int OFF>
+__device__ __forceinline__ void ds_read16(bf16x8& d, uint32_t addr) {
+#if defined(VC_LOOP_ABL) && (VC_LOOP_ABL & 2)     // probe ablation: no fragment reads in the loop (wrong results)
+  asm volatile("" : "+v"(d));
+  return;
+#endif
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// one LDS-DMA piece: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS byte address `lds`; global address = rsrc base + voff + soff
+__device__ __forceinline__ void dma16(uint32_t lds, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
+#if defined(VC_LOOP_ABL) && (VC_LOOP_ABL & 1)     // probe ablation: no LDS-DMA (wrong results)
+  if (soff != 0xffffffffu) return;
+#endif
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// probe builds only (tools/probes/g4w_probe.hip defines VC_4W_STAMP): wave 0 of every workgroup records the shader clock at four
+// points into p.rowstat (reused as a uint64 buffer): start, main loop entry, main loop exit, end
+#ifdef VC_4W_STAMP
+#define STAMP(i_)                                                                                        \
+  if (w == 0 && lane == 0 && p.rowstat) ((unsigned long long*)p.rowstat)[blockIdx.x * 4 + (i_)] = __builtin_readcyclecounter()
+#define STAMP_AT(slot_, i_)                                                                              \
+  if (w == 0 && lane == 0 && p.rowstat) ((unsigned long long*)p.rowstat)[(slot_) * 4 + (i_)] = __builtin_readcyclecounter()
+#else
+#define STAMP(i_)
+#define STAMP_AT(slot_, i_)
+#endif
+
+struct Frags {
+  bf16x8 a[2][8];   // [k-half][m-tile]
+  bf16x8 w[2][8];   // [k-half][n-tile]
+};
+
+// addresses the main loop needs (all wave-uniform values live in SGPRs)
+struct Loop {
+  uint32_t a_rd[2], w_rd[2];      // per-lane LDS read addresses of k-half 0 / 1 in buffer 0 (row base + swizzled chunk)
+  uint32_t lds_a, lds_w;          // wave's first DMA destination (buffer 0)
+  uint32_t voff_a, voff_w;        // per-lane global byte offset inside a piece
+  uint32_t soff_a, soff_w;        // wave's first piece (scalar byte offset)
+  uint32_t pstep_a, pstep_w;      // 8 rows
+};
+// buffer descriptors of one output tile's operand panels (base = the tile's first row, range-checked to the matrix end: rows past
+// M / N read as out-of-range -- no fault, and their outputs are never stored)
+struct Src {
+  i32x4 ra, rw;
+};
+__device__ __forceinline__ Src make_src(const GemmArgs& p, int m0, int n0) {
+  const bf16_t* abase = p.A + (size_t)m0 * p.lda;
+  const bf16_t* wbase = p.W + (size_t)n0 * p.ldw;
+  const long long arem = ((long long)(p.M - m0 - 1) * p.lda + p.K) * 2, wrem = ((long long)(p.N - n0 - 1) * p.ldw + p.K) * 2;
+  const uint32_t arec = arem > 0xffffffffll ? 0xffffffffu : (uint32_t)arem, wrec = wrem > 0xffffffffll ? 0xffffffffu : (uint32_t)wrem;
+  const uint64_t ab = (uint64_t)abase, wb = (uint64_t)wbase;
+  Src r;
+  r.ra = i32x4{(int)(uint32_t)ab, (int)(uint32_t)(ab >> 32), (int)arec, 0x00020000};
+  r.rw = i32x4{(int)(uint32_t)wb, (int)(uint32_t)(wb >> 32), (int)wrec, 0x00020000};
+  return r;
+}
+template <int MI>
+__device__ __forceinline__ Loop make_loop(const GemmArgs& p, uint32_t smem_base, int lane, int w) {
+  Loop L;
+  // LDS-DMA piece: 8 rows x 128 B; lane -> row lane >> 3, LDS chunk position lane & 7, which holds source chunk (lane & 7) ^ (row & 7)
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  L.voff_a = (uint32_t)(srow * p.lda * 2 + schunk * 16);
+  L.voff_w = (uint32_t)(srow * p.ldw * 2 + schunk * 16);
+  const int a_row0 = w * (8 * MI), w_row0 = w * 64;
+  L.soff_a = (uint32_t)(a_row0 * p.lda * 2);
+  L.soff_w = (uint32_t)(w_row0 * p.ldw * 2);
+  L.pstep_a = (uint32_t)(8 * p.lda * 2);
+  L.pstep_w = (uint32_t)(8 * p.ldw * 2);
+  L.lds_a = smem_base + a_row0 * 128;
+  L.lds_w = smem_base + A_BYTES + w_row0 * 128;
+  const int wm = w >> 1, wn = w & 1, frow = lane & 15, fk = lane >> 4;
+  const uint32_t arow = smem_base + (wm * 16 * MI + frow) * 128, wrow = smem_base + A_BYTES + (wn * 128 + frow) * 128;
+  L.a_rd[0] = arow + ((0 * 4 + fk) ^ (frow & 7)) * 16;
+  L.a_rd[1] = arow + ((1 * 4 + fk) ^ (frow & 7)) * 16;
+  L.w_rd[0] = wrow + ((0 * 4 + fk) ^ (frow & 7)) * 16;
+  L.w_rd[1] = wrow + ((1 * 4 + fk) ^ (frow & 7)) * 16;
+  return L;
+}
+
+template <int MI, int Q>
+__device__ __forceinline__ void dma_piece(const Loop& L, const Src& src, uint32_t bufoff, uint32_t kb) {
+  // piece Q of a k-tile: Q < MI -> 8 rows of A, else 8 rows of W
+  if constexpr (Q < MI) dma16(L.lds_a + bufoff + Q * 1024, L.voff_a, src.ra, L.soff_a + Q * L.pstep_a + kb);
+  else dma16(L.lds_w + bufoff + (Q - MI) * 1024, L.voff_w, src.rw, L.soff_w + (Q - MI) * L.pstep_w + kb);
+}
+template <int MI, int... Q>
+__device__ __forceinline__ void dma_tile(const Loop& L, const Src& src, uint32_t bufoff, uint32_t kb, std::integer_sequence<int, Q...>) {
+  (dma_piece<MI, Q>(L, src, bufoff, kb), ...);
+}
+
+template <int MI, int H, int R>
+__device__ __forceinline__ void read_frag(Frags& f, uint32_t a_addr, uint32_t w_addr) {
+  // fragment R of k-half H: W fragments first (the first MFMAs of a half need all eight), then the A fragments
+  if constexpr (R < 8) ds_read16<R * 2048>(f.w[H][R], w_addr);
+  else ds_read16<(R - 8) * 2048>(f.a[H][R - 8], a_addr);
+}
+template <int MI, int H, int... R>
+__device__ __forceinline__ void read_frags(Frags& f, uint32_t a_addr, uint32_t w_addr, std::integer_sequence<int, R...>) {
+  (read_frag<MI, H, R>(f, a_addr, w_addr), ...);
+}
+
+// One MFMA step S of a half (m-tile S / 8, n-tile S % 8) and the memory instructions scheduled behind it.
+//   MODE 0: k-half 0 of a tile: reads the k-half-1 fragments of the same tile (buffer `cur`)
+//   MODE 1: k-half 1: DMA of tile t+2 into `cur` (free since the mid-tile barrier) + k-half-0 fragments of tile t+1
+//   MODE 2: k-half 1, no DMA (second-to-last tile)     MODE 3: k-half 1, nothing (last tile)
+//   MODE 4: k-half 1 with the DMA but without fragment reads (persistent kernel, last k-tile of an output tile: the next tile's
+//           fragments are read after the epilogue, so that no fragment register is live across it)
+template <int MI, int MODE, bool FIRST, int S>
+__device__ __forceinline__ void half_step(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t rd_a, uint32_t rd_w,
+                                          uint32_t bufoff, uint32_t kb) {
+  constexpr int H = MODE == 0 ? 0 : 1;
+  constexpr int STEPS = MI * 8, NOPS = MI + 8;
+  constexpr int STRIDE = (STEPS * 3 / 4) / NOPS > 0 ? (STEPS * 3 / 4) / NOPS : 1;
+  if constexpr (FIRST) mfma_zero(acc[S / 8][S % 8], f.w[H][S % 8], f.a[H][S / 8]);
+  else mfma_acc(acc[S / 8][S % 8], f.w[H][S % 8], f.a[H][S / 8]);
+  if constexpr (MODE == 1 || MODE == 4) {
+    if constexpr (S % STRIDE == 0 && S / STRIDE < NOPS) dma_piece<MI, S / STRIDE>(L, src, bufoff, kb);
+  }
+  if constexpr (MODE != 3 && MODE != 4) {
+    constexpr int PH = STRIDE > 1 ? 1 : 0;
+    if constexpr (S % STRIDE == PH && S / STRIDE < NOPS) {
+      read_frag<MI, 1 - H, S / STRIDE>(f, rd_a, rd_w);
+    }
+  }
+}
+template <int MI, int MODE, bool FIRST, int... S>
+__device__ __forceinline__ void half_steps(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t rd_a, uint32_t rd_w, uint32_t bufoff,
+                                           uint32_t kb, std::integer_sequence<int, S...>) {
+  (half_step<MI, MODE, FIRST, S>(acc, f, L, src, rd_a, rd_w, bufoff, kb), ...);
+}
+
+// One k-tile t (cur = its buffer's byte offset): k-half 0, the mid-tile rendezvous, k-half 1 (whose DMA, MODE1 == 1, requests the
+// k-tile at byte offset kb2 of the panels `src` -- two k-tiles ahead in the stream, possibly the NEXT output tile's -- into `cur`).
+template <int MI, int MODE1, bool FIRST>
+__device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2) {
+  const uint32_t nxt = BUF_BYTES - cur;
+  half_steps<MI, 0, FIRST>(acc, f, L, src, L.a_rd[1] + cur, L.w_rd[1] + cur, 0, 0, std::make_integer_sequence<int, MI * 8>{});
+  // every wave has read the whole of buffer `cur` (lgkmcnt) and its own pieces of tile t+1 have landed (vmcnt): after the barrier
+  // `cur` may be overwritten and buffer `nxt` may be read
+#if defined(VC_LOOP_ABL) && (VC_LOOP_ABL & 4)     // probe ablation: no mid-tile barrier (wrong results)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+  half_steps<MI, MODE1, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
+  if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// The accumulators' last writers are asm MFMAs whose result latency hipcc does not know: a v_accvgpr_read it schedules right behind
+// the asm statement that last wrote a register (long before the final s_nop) returns the rows of the MFMA's last pass stale -- seen
+// as NaN / old sums in lanes 12-15 and 44-47 of two n-tiles.  After the final MFMA: 24 wait states, then every accumulator passes
+// through an (empty) asm statement, so that each compiler read is ordered behind the wait.
+template <int MI>
+__device__ __forceinline__ void fence_accumulators(f32x4 (&acc)[MI][8]) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+}
+
+#define ROWS_OF(m_, orow_, rrow_)                                             \
+  int orow_ = (m_), rrow_ = (m_);                                             \
+  if (p.row_group > 0) {                                                      \
+    const int g_ = (m_) / p.row_group, in_ = (m_) - g_ * p.row_group;         \
+    orow_ = g_ * p.out_group_rows + p.out_row_off + in_;                      \
+    rrow_ = p.res_periodic ? in_ : orow_;                                     \
+  }
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+// ---- epilogue straight from the accumulators (no LDS: in the persistent kernel the k-tile buffers already hold the next tile's
+// first k-tiles).  After the operand-swapped MFMAs a lane (frow = lane & 15, fk = lane >> 4) holds, of m-tile i and n-tile j, the four
+// columns j*16 + fk*4 .. +3 of row i*16 + frow:
+//   fp32 output: that is one 16-byte store; the four lane groups cover 64 contiguous bytes of the row, the residual arrives by the
+//                same pattern, requested one m-tile (8 loads) ahead;
+//   bf16 output: two n-tiles (je, jo = je + 1) are packed and exchanged between neighbouring lane groups (v_permlane16_swap: group
+//                fk = 1 / 3 gives its je values to group 0 / 2 and takes their jo values), after which group 0 / 2 holds columns
+//                0..7 / 8..15 of tile je and group 1 / 3 those of tile jo: one 16-byte store per lane, 64 contiguous bytes per row.
+// bias -> activation -> residual -> rounding in gemm.hip's order on the same values: bit-identical outputs.
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[MI][8], const GemmArgs& p, const int row_w, const int col_w, const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 bias4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = col_w + j * 16 + fk * 4;
+    bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 rres[2][8];
+#define ISSUE_RES_R(i_)                                                                                            \
+  if (HAS_RES) {                                                                                                   \
+    const int m_ = row_w + (i_) * 16 + frow;                                                                       \
+    ROWS_OF(m_, o_, r_);                                                                                           \
+    (void)o_;                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+      const int n_ = col_w + j * 16 + fk * 4;                                                                      \
+      rres[(i_) & 1][j] = (m_ < p.M && n_ < p.N) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + n_)                \
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
+    }                                                                                                              \
+  }
+  ISSUE_RES_R(0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (i + 1 < MI) { ISSUE_RES_R(i + 1); }
+    const int m = row_w + i * 16 + frow;
+    ROWS_OF(m, orow, rrow);
+    (void)rrow;
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = acc[i][j] + bias4[j];
+      if (ACT == VITCAP_ACT_GELU_ERF) v[j] = gelu_erf4(v[j]);
+      if (HAS_RES) v[j] += rres[i & 1][j];
+    }
+    if constexpr (OUT_F32) {
+      float* dst = (float*)p.C + (size_t)orow * p.ldc + col_w + fk * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (m < p.M && col_w + j * 16 + fk * 4 < p.N) *(f32x4*)(dst + j * 16) = v[j];
+    } else {
+      bf16_t* dst = (bf16_t*)p.C + (size_t)orow * p.ldc + col_w + (fk & 1) * 16 + (fk >> 1) * 8;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pack2bf(v[2 * jj][0], v[2 * jj][1]), pack2bf(v[2 * jj + 1][0], v[2 * jj + 1][1]), false, false);
+        const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pack2bf(v[2 * jj][2], v[2 * jj][3]), pack2bf(v[2 * jj + 1][2], v[2 * jj + 1][3]), false, false);
+        uint4 o;
+        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+        if (m < p.M && col_w + jj * 32 + (fk & 1) * 16 + (fk >> 1) * 8 < p.N) *(uint4*)(dst + jj * 32) = o;
+      }
+    }
+  }
+#undef ISSUE_RES_R
+}
+
+// ---- the persistent kernel's epilogues (plain rows, N a multiple of 256).  With ONE wave per SIMD every instruction of the
+// epilogue costs its full issue time (nothing else runs on the SIMD): the general forms above spend 9.8k cycles on a 128 x 128 bf16
+// wave tile (stamped), two thirds of it on per-store predicates (compare, exec save / branch / restore) and 64-bit address
+// arithmetic.  Here rows and columns are addressed through a buffer descriptor whose range ends behind row M - 1 (rows past M are
+// dropped by the range check, no predicate), one 32-bit per-lane offset serves the whole tile, the m-tile's row offset rides in
+// the scalar offset and the n-tile's in the immediate.  Same arithmetic per element.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, long long bytes) {
+  const unsigned rec = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec, 0x00020000);
+}
+
+template <int ACT, int MI>
+__device__ __forceinline__ void epilogue_regs_fast(f32x4 (&acc)[MI][8], const GemmArgs& p, const int row_w, const int col_w, const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 bias4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias4[j] = p.bias ? *(const f32x4*)(p.bias + col_w + j * 16 + fk * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rc = rows_rsrc((const bf16_t*)p.C + (size_t)row_w * p.ldc, (long long)(p.M - row_w) * p.ldc * 2);
+  // The m-tile's row offset rides in the VECTOR offset, the scalar offset stays the constant 0: with a REGISTER soffset hipcc omits
+  // the wait state between a 16-byte buffer store and a VALU write to its data registers (LLVM's hazard table says the hazard only
+  // exists without one) -- on gfx950 it exists all the same: the next v_pk_add overwrote the store's last data dword in lanes
+  // 12-15 / 44-47 (found as 32 wrong elements per wave tile, always the same ones).
+  unsigned voff = (unsigned)(frow * p.ldc + col_w + (fk & 1) * 16 + (fk >> 1) * 8) * 2u;
+  const unsigned istep = 16u * p.ldc * 2u;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      f32x4 ve = acc[i][2 * jj] + bias4[2 * jj], vo = acc[i][2 * jj + 1] + bias4[2 * jj + 1];
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+        ve = gelu_erf4(ve);
+        vo = gelu_erf4(vo);
+      }
+#if defined(VC_EPI_ABL) && (VC_EPI_ABL & 2)       // probe ablation: no lane exchange (wrong results)
+      const u32x2_t s0 = u32x2_t{pack2bf(ve[0], ve[1]), pack2bf(vo[0], vo[1])};
+      const u32x2_t s1 = u32x2_t{pack2bf(ve[2], ve[3]), pack2bf(vo[2], vo[3])};
+#else
+      const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[0], ve[1]), pack2bf(vo[0], vo[1]), false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[2], ve[3]), pack2bf(vo[2], vo[3]), false, false);
+#endif
+#if defined(VC_EPI_ABL) && (VC_EPI_ABL & 1)       // probe ablation: values kept alive, no store
+      asm volatile("" ::"v"(s0), "v"(s1));
+#else
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{s0[0], s1[0], s0[1], s1[1]}, rc, voff + jj * 64, 0, 0);
+#endif
+    }
+    voff += istep;
+  }
+}
+
+// fp32 output and / or residual: each m-tile through the wave's 8 KiB LDS patch (see epilogue_patch), loads and stores by buffer
+// instructions: lane -> columns (lane & 31) * 4 .. +3 of row 2 * it + (lane >> 5), two rows of 512 contiguous bytes per instruction
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+__device__ __forceinline__ void epilogue_patch_fast(f32x4 (&acc)[MI][8], const GemmArgs& p, char* patch, const int row_w, const int col_w,
+                                                    const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  const int rr = lane >> 5, rcx = lane & 31;
+  const f32x4 bias4 = p.bias ? *(const f32x4*)(p.bias + col_w + rcx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int CB = OUT_F32 ? 4 : 2;
+  const __amdgpu_buffer_rsrc_t rc = rows_rsrc((const char*)p.C + (size_t)row_w * p.ldc * CB, (long long)(p.M - row_w) * p.ldc * CB);
+  const __amdgpu_buffer_rsrc_t rs = rows_rsrc(HAS_RES ? p.res + (size_t)row_w * p.ldr : nullptr, HAS_RES ? (long long)(p.M - row_w) * p.ldr * 4 : 0);
+  unsigned voff_c = (unsigned)(rr * p.ldc + col_w + rcx * 4) * CB;     // stores: row steps in the vector offset, soffset constant (see epilogue_regs_fast)
+  const unsigned voff_r = (unsigned)(rr * p.ldr + col_w + rcx * 4) * 4u;
+  const unsigned cstep = 2u * p.ldc * CB, rstep = 2u * p.ldr * 4u;     // two rows
+  char* wr = patch + frow * 512;
+  f32x4 rres[2][8];
+  unsigned so_r = 0;                       // loads: running scalar offset (two rows per step), opaque: not hoisted across tiles
+  asm volatile("" : "+s"(so_r));
+#define ISSUE_RES_F(i_)                                                                                                           \
+  if (HAS_RES) {                                                                                                                  \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                                            \
+      rres[(i_) & 1][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_r, so_r, 0));                 \
+      so_r += rstep;                                                                                                              \
+    }                                                                                                                             \
+  }
+  ISSUE_RES_F(0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (i + 1 < MI) { ISSUE_RES_F(i + 1); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(f32x4*)(wr + (((j * 4 + fk) ^ (frow & 7)) * 16)) = acc[i][j];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 2 + rr;
+      f32x4 v = *(const f32x4*)(patch + rl * 512 + ((rcx ^ (rl & 7)) * 16));
+      v += bias4;
+      if (ACT == VITCAP_ACT_GELU_ERF) v = gelu_erf4(v);
+      if (HAS_RES) v += rres[i & 1][it];
+      if (OUT_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc, voff_c, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}, rc, voff_c, 0, 0);
+      voff_c += cstep;
+    }
+  }
+#undef ISSUE_RES_F
+}
+
+// ---- fp32 outputs and residual adds: 16-byte pieces of 16 different rows per store instruction (what the register layout gives:
+// 64 contiguous bytes per row) cost 50k cycles per tile against 30-35k for row-major stores (stamped, proj / fc2) -- the output and
+// residual streams want whole rows.  Each wave therefore turns ONE m-tile (16 rows x 128 columns fp32 = 8 KiB) at a time through a
+// private patch in the 32 KiB of LDS behind the two k-tile buffers (which, in the persistent kernel, already hold the next tile's
+// first k-tiles): written in the MFMA layout (16-byte chunks XOR-swizzled by row & 7: conflict-free both ways), read back row-major
+// -- a lane gets columns (lane & 31) * 4 .. +3 of row 2 * it + (lane >> 5) -- so every residual load and every store covers two rows
+// of 512 contiguous bytes.  Wave-private: LDS operations of one wave execute in order, no barrier.  Same arithmetic per element.
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+__device__ __forceinline__ void epilogue_patch(f32x4 (&acc)[MI][8], const GemmArgs& p, char* patch, const int row_w, const int col_w, const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  const int rr = lane >> 5, rc = lane & 31;           // read-back: row within a pair, 16-byte chunk of the row
+  const int ncol = col_w + rc * 4;
+  const bool col_ok = ncol < p.N;
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_ok) bias4 = *(const f32x4*)(p.bias + ncol);
+  char* wr = patch + frow * 512;
+  f32x4 rres[2][8];
+#define ISSUE_RES_P(i_)                                                                                            \
+  if (HAS_RES) {                                                                                                   \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                             \
+      const int m_ = row_w + (i_) * 16 + it * 2 + rr;                                                              \
+      ROWS_OF(m_, o_, r_);                                                                                         \
+      (void)o_;                                                                                                    \
+      rres[(i_) & 1][it] = (m_ < p.M && col_ok) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + ncol)               \
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};                                       \
+    }                                                                                                              \
+  }
+  ISSUE_RES_P(0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (i + 1 < MI) { ISSUE_RES_P(i + 1); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(f32x4*)(wr + (((j * 4 + fk) ^ (frow & 7)) * 16)) = acc[i][j];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 2 + rr;
+      f32x4 v = *(const f32x4*)(patch + rl * 512 + ((rc ^ (rl & 7)) * 16));
+      const int m = row_w + i * 16 + rl;
+      ROWS_OF(m, orow, rrow);
+      (void)rrow;
+      v += bias4;
+      if (ACT == VITCAP_ACT_GELU_ERF) v = gelu_erf4(v);
+      if (HAS_RES) v += rres[i & 1][it];
+      if (m < p.M && col_ok) {
+        if (OUT_F32) {
+          *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+        } else {
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+        }
+      }
+    }
+  }
+#undef ISSUE_RES_P
+}
+
+// ---- epilogue through LDS (one-tile-per-workgroup kernel only: nobody reads the k-tile buffers after the last tile's mid barrier):
+// each wave parks one 64-column half of its tile (fp32) in a private 128 x 64 patch, reads it back row-major: 16 lanes cover one
+// 64-column row segment (256 B fp32 / 128 B bf16).  Handles every column alignment vitcap_gemm_ex admits (N % 4 == 0).
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[MI][8], const GemmArgs& p, char* ep, const int row_w, const int col_w, const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  const int er = lane >> 4, ec = (lane & 15) * 4;    // read-back: row within a group of 4, first of 4 columns
+  constexpr int CH = 2 * MI;                          // rows of a chunk = 4 * CH: the residual is requested one chunk ahead
+  f32x4 rres[2][CH];
+#define ISSUE_RES(hn_, c_, slot_)                                                                            \
+  if (HAS_RES) {                                                                                             \
+    const int nc_ = col_w + (hn_) * 64 + ec;                                                                 \
+    _Pragma("unroll") for (int it = 0; it < CH; ++it) {                                                      \
+      const int m_ = row_w + (c_) * (4 * CH) + it * 4 + er;                                                  \
+      ROWS_OF(m_, o_, r_);                                                                                   \
+      (void)o_;                                                                                              \
+      rres[slot_][it] = (m_ < p.M && nc_ < p.N) ? *(const f32x4*)(p.res + (size_t)r_ * p.ldr + nc_)          \
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};                                 \
+    }                                                                                                        \
+  }
+  ISSUE_RES(0, 0, 0);
+#pragma unroll
+  for (int hn = 0; hn < 2; ++hn) {
+    const int ncol = col_w + hn * 64 + ec;
+    const bool col_ok = ncol < p.N;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col_ok) bias4 = *(const f32x4*)(p.bias + ncol);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(ep + (i * 16 + frow) * EP_ROWB + (j * 16 + fk * 4) * 4) = acc[i][hn * 4 + j];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {           // two chunks of 8 * MI rows
+      const int g = hn * 2 + c;
+      if (g + 1 < 4) { ISSUE_RES((g + 1) >> 1, (g + 1) & 1, (g + 1) & 1); }
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const int rl = c * (4 * CH) + it * 4 + er;
+        f32x4 v = *(const f32x4*)(ep + rl * EP_ROWB + ec * 4);
+        const int m = row_w + rl;
+        const bool ok = m < p.M && col_ok;
+        ROWS_OF(m, orow, rrow);
+        (void)rrow;
+        v += bias4;
+        if (ACT == VITCAP_ACT_GELU_ERF) v = gelu_erf4(v);
+        if (HAS_RES) v += rres[g & 1][it];
+        if (ok) {
+          if (OUT_F32) {
+            *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+          } else {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.C + (size_t)orow * p.ldc + ncol) = o;
+          }
+        }
+      }
+    }
+  }
+#undef ISSUE_RES
+}
+#undef ROWS_OF
+
+// tile list position -> tile coordinates: column groups of group_n tiles (the tiles an XCD runs at once span few W tiles, which stay
+// in its L2 for the walk down M, and each A tile is fetched once for group_n consumers)
+__device__ __forceinline__ void tile_of(const GemmArgs& p, int pos, int& tm, int& tn) {
+  const int per_g = p.tiles_m * p.group_n;
+  const int gi = pos / per_g, rem = pos - gi * per_g;
+  const int gleft = p.tiles_n - gi * p.group_n;
+  const int gw = gleft < p.group_n ? gleft : p.group_n;
+  tm = rem / gw;
+  tn = gi * p.group_n + rem - tm * gw;
+}
+
+// ---- one tile per workgroup (EPI: 0 = LDS epilogue, 1 = register epilogue)
+template <int ACT, int OUT_F32, bool HAS_RES, int EPI, int MI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_4w_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  {
+    // XCD-aware, bijective remap: the blocks of one XCD (block b runs on XCD b % 8) get a contiguous chunk of the tile list
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  tile_of(p, bid, tm, tn);
+  const int m0 = tm * (32 * MI), n0 = tn * 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Loop L = make_loop<MI>(p, lds_addr(smem), lane, w);
+  const Src src = make_src(p, m0, n0);
+  f32x4 acc[MI][8];
+  Frags f;
+  const int nk = p.K / 64;      // >= 2 (launcher)
+  constexpr auto PIECES = std::make_integer_sequence<int, MI + 8>{};
+
+  STAMP(0);
+  // prologue: k-tiles 0 and 1 requested, tile 0 awaited, its k-half-0 fragments read
+  dma_tile<MI>(L, src, 0, 0, PIECES);
+  dma_tile<MI>(L, src, BUF_BYTES, 128, PIECES);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
+  read_frags<MI, 0>(f, L.a_rd[0], L.w_rd[0], PIECES);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  STAMP(1);
+  uint32_t cur = BUF_BYTES;        // buffer of the tile about to run (after tile 0)
+  if (nk == 2) {
+    k_tile<MI, 2, true>(acc, f, L, src, 0, 0);
+  } else {
+    k_tile<MI, 1, true>(acc, f, L, src, 0, 2 * 128);
+    for (int t = 1; t < nk - 2; ++t) {
+      k_tile<MI, 1, false>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128);
+      cur = BUF_BYTES - cur;
+    }
+    k_tile<MI, 2, false>(acc, f, L, src, cur, 0);
+    cur = BUF_BYTES - cur;
+  }
+  k_tile<MI, 3, false>(acc, f, L, src, cur, 0);
+  fence_accumulators<MI>(acc);
+  STAMP(2);
+  const int row_w = m0 + (w >> 1) * (16 * MI), col_w = n0 + (w & 1) * 128;
+  if constexpr (EPI == 1) {
+    if constexpr (OUT_F32 || HAS_RES) epilogue_patch<ACT, OUT_F32, HAS_RES, MI>(acc, p, smem + 2 * BUF_BYTES + w * PATCH_BYTES, row_w, col_w, lane);
+    else epilogue_regs<ACT, OUT_F32, HAS_RES, MI>(acc, p, row_w, col_w, lane);
+  }
+  else epilogue_lds<ACT, OUT_F32, HAS_RES, MI>(acc, p, smem + w * EP_WAVE, row_w, col_w, lane);
+  STAMP(3);
+}
+
+// ---- persistent form: one workgroup per CU walks its share of the tile list as ONE continuous software pipeline.  The k-tile
+// stream does not stop at an output tile's end: the last two k-tiles of a tile already request the first two k-tiles of the NEXT
+// tile (buffers keep alternating with the stream position), the register epilogue sits between two k-tiles, and the next tile's
+// k-half-0 fragments were read before it started -- no per-tile prologue (3-7k cycles of exposed DMA latency per tile in the
+// one-tile kernel, stamped), and the epilogue's stores drain behind the next tile's first MFMAs.
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_4wp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this workgroup's positions: XCD x = blockIdx % 8 owns the contiguous chunk [c0, c1) of the tile list; its workgroups (slot =
+  // blockIdx / 8 of nslot) take c0 + slot, c0 + slot + nslot, ...: at any time an XCD's CUs work on neighbouring tiles
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+  const int c0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int c1 = c0 + q + (xcd < r ? 1 : 0);
+  const int nslot = ((int)gridDim.x - xcd + 7) >> 3;
+  int pos = c0 + ((int)blockIdx.x >> 3);
+  if (pos >= c1) return;
+#ifdef VC_4W_STAMP
+  // probe: start the XCDs a fraction of a tile period apart (p.direct_epilogue = units of 64 cycles per XCD step)
+  for (int i = 0; i < ((int)blockIdx.x >> 3) * p.direct_epilogue; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
+  const Loop L = make_loop<MI>(p, lds_addr(smem), lane, w);
+  int tm, tn;
+  tile_of(p, pos, tm, tn);
+  Src src = make_src(p, tm * (32 * MI), tn * 256);
+  f32x4 acc[MI][8];
+  Frags f;
+  const int nk = p.K / 64;      // >= 2 (launcher)
+  constexpr auto PIECES = std::make_integer_sequence<int, MI + 8>{};
+  // the only prologue: k-tiles 0 and 1 of the first tile
+  dma_tile<MI>(L, src, 0, 0, PIECES);
+  dma_tile<MI>(L, src, BUF_BYTES, 128, PIECES);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
+  read_frags<MI, 0>(f, L.a_rd[0], L.w_rd[0], PIECES);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  uint32_t cur = 0;
+  // ONE straight-line body per output tile (no branch around any accumulator update: hipcc merges accumulators that are defined on
+  // two paths through VGPR copies and scratch -- measured: 750-1150 spilled registers in a version that branched on `more`).  A
+  // workgroup's last tile requests its two look-ahead k-tiles through a descriptor of zero records: every lane is out of range,
+  // nothing is fetched, and the (unused) LDS image is whatever the range check returns.
+  while (true) {
+    const int m0 = tm * (32 * MI), n0 = tn * 256;
+    const int npos = pos + nslot;
+    const bool more = npos < c1;
+    tile_of(p, more ? npos : pos, tm, tn);
+    Src nsrc = make_src(p, tm * (32 * MI), tn * 256);
+    if (!more) {
+      nsrc.ra[2] = 0;
+      nsrc.rw[2] = 0;
+    }
+    // k-tiles 0 .. nk-3 request k-tiles 2 .. nk-1 of this tile; k-tiles nk-2, nk-1 request k-tiles 0, 1 of the next tile (nk >= 3)
+    STAMP_AT(pos, 0);
+    k_tile<MI, 1, true>(acc, f, L, src, cur, 2 * 128);
+    cur = BUF_BYTES - cur;
+    STAMP_AT(pos, 1);
+    for (int t = 1; t < nk - 2; ++t) {
+      k_tile<MI, 1, false>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128);
+      cur = BUF_BYTES - cur;
+    }
+    k_tile<MI, 1, false>(acc, f, L, nsrc, cur, 0);
+    cur = BUF_BYTES - cur;
+    k_tile<MI, 4, false>(acc, f, L, nsrc, cur, 128);
+    cur = BUF_BYTES - cur;
+    fence_accumulators<MI>(acc);
+    STAMP_AT(pos, 2);
+#ifdef VC_4W_GENERAL_EPI
+    if constexpr (OUT_F32 || HAS_RES)
+      epilogue_patch<ACT, OUT_F32, HAS_RES, MI>(acc, p, smem + 2 * BUF_BYTES + w * PATCH_BYTES, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+    else
+      epilogue_regs<ACT, OUT_F32, HAS_RES, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+#else
+    if constexpr (OUT_F32 || HAS_RES)
+      epilogue_patch_fast<ACT, OUT_F32, HAS_RES, MI>(acc, p, smem + 2 * BUF_BYTES + w * PATCH_BYTES, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+    else
+      epilogue_regs_fast<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+#endif
+    STAMP_AT(pos, 3);
+    if (!more) break;
+    pos = npos;
+    src = nsrc;
+    // the next tile's k-tile 0 landed before the last mid-tile barrier: its k-half-0 fragments
+    read_frags<MI, 0>(f, L.a_rd[0] + cur, L.w_rd[0] + cur, PIECES);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// Tile height by launch: a launch of T equal tiles on C CUs costs ceil(T / C) tile times, and a (32 * MI)-row tile costs about
+// (fixed + MI) units -- 435 tiles of 256 rows (M = 36928, N = 768) pay 2 rounds for 1.7 rounds of work, 495 tiles of 224 rows pay
+// 2 rounds of 7/8 the length; 1305 (N = 2304) pay 6, 1485 of 224 rows pay 6 x 7/8.  The kernel is the same code for every MI (the
+// wave tile is MI x 8 MFMA tiles, k order per output element unchanged: bit-identical results whatever the height).
+int pick_mi(int M, int tiles_n, int form) {
+  static const int env_mi = [] { const char* e = getenv("VITCAP_GEMM4W_MI"); return e ? atoi(e) : 0; }();
+  if (env_mi >= 6 && env_mi <= 8) return env_mi;
+  static const int n_cu = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      return prop.multiProcessorCount;
+    return 256;
+  }();
+  const float fixed = form == 2 ? 0.3f : 0.9f;       // per-tile cost that does not shrink with the tile: pipeline fill, barriers' skew, W traffic
+  int best = 8;
+  float best_c = 1e30f;
+  for (int mi = 8; mi >= 6; --mi) {
+    const long long tiles = (long long)((M + 32 * mi - 1) / (32 * mi)) * tiles_n;
+    const float c = (float)((tiles + n_cu - 1) / n_cu) * (fixed + (float)mi);
+    if (c < best_c * 0.985f) { best_c = c; best = mi; }      // a shorter tile must win 1.5 % to be taken
+  }
+  return best;
+}
+
+// form: 0 = one tile per workgroup + LDS epilogue, 1 = one tile per workgroup + register epilogue, 2 = persistent
+template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
+  p.tiles_m = (p.M + 32 * MI - 1) / (32 * MI);
+  p.n_big = p.tiles_m * p.tiles_n;
+  if (form == 2) {
+    static const int n_cu = [] {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        return prop.multiProcessorCount;
+      return 256;
+    }();
+    auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
+    constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
+    VC_FUNC_SMEM(kern, smem);
+    const int grid = p.n_big < n_cu ? p.n_big : n_cu;
+    VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
+  } else {
+    auto kern = gemm_nt_4w_kernel<ACT, OUT_F32, HAS_RES, 1, MI>;
+    constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
+    VC_FUNC_SMEM(kern, smem);
+    VC_LAUNCH_GEMM(kern, dim3(p.n_big), dim3(256), smem, s, p);
+  }
+  VC_LAUNCH_CHECK("gemm_nt_4w");
+  return VITCAP_OK;
+}
+
+template <int ACT, int OUT_F32, bool HAS_RES>
+int launch_4w(const GemmArgs& a, hipStream_t s, int form) {
+  GemmArgs p = a;
+  p.tiles_n = (a.N + 255) / 256;
+  p.group_n = vc_tile_group_n(p.tiles_n);
+  p.tiles_m_small = 0;
+  // the register epilogue's bf16 stores are 16 bytes wide
+  const bool regs_ok = OUT_F32 || HAS_RES || ((a.N & 7) == 0 && (a.ldc & 7) == 0);
+  if (form != 0 && !regs_ok) form = 0;
+  // the persistent pipeline's tile body needs three k-tiles; its epilogues address plain rows of whole 256-column tiles
+  if (form == 2 && (a.K < 192 || (a.N & 255) != 0 || a.row_group != 0 || (!OUT_F32 && (a.ldc & 7) != 0))) form = 1;
+  if (form == 0) {
+    p.tiles_m = (a.M + 255) / 256;
+    p.n_big = p.tiles_m * p.tiles_n;
+    auto kern = gemm_nt_4w_kernel<ACT, OUT_F32, HAS_RES, 0, 8>;
+    VC_FUNC_SMEM(kern, SMEM_4W);
+    VC_LAUNCH_GEMM(kern, dim3(p.n_big), dim3(256), SMEM_4W, s, p);
+    VC_LAUNCH_CHECK("gemm_nt_4w");
+    return VITCAP_OK;
+  }
+  switch (pick_mi(a.M, p.tiles_n, form)) {
+    case 7: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 7>(p, s, form);
+    case 6: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 6>(p, s, form);
+    default: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 8>(p, s, form);
+  }
+}
+
+}  // namespace
+
+bool vc_4w_supports(const GemmArgs& a, int act) {
+#ifdef VC_4W_STAMP
+  if (a.rowstat) return true;
+#endif
+  return !a.aux && !a.zout && !a.colsum && !a.rowstat && a.split_k <= 1 && a.K >= 128 && (act == VITCAP_ACT_NONE || act == VITCAP_ACT_GELU_ERF);
+}
+
+int vc_dispatch_4w(const GemmArgs& a, int act, int out_f32, hipStream_t s, int form) {
+  VC_REQUIRE(vc_4w_supports(a, act), "gemm(4-wave): unsupported options (training extras / split-K / activation %d / K < 128)", act);
+  const bool res = a.res != nullptr;
+#define CASE(ACT_, OUT_)              \
+  if (act == ACT_ && out_f32 == OUT_) \
+    return res ? launch_4w<ACT_, OUT_, true>(a, s, form) : launch_4w<ACT_, OUT_, false>(a, s, form);
+  CASE(VITCAP_ACT_NONE, 0)
+  CASE(VITCAP_ACT_NONE, 1)
+  CASE(VITCAP_ACT_GELU_ERF, 0)
+  CASE(VITCAP_ACT_GELU_ERF, 1)
+#undef CASE
+  vitcap_set_error("gemm(4-wave): unsupported act %d / out %d", act, out_f32);
+  return VITCAP_EINVAL;
+}
