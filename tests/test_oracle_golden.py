@@ -306,3 +306,58 @@ def test_image_dependent_family_pins_the_oracle(sd_t):
         ids, lp = O.greedy_incremental(sd_t, img, emulate_bf16=False, eos=eos)
     np.testing.assert_array_equal(ids.numpy(), vec['multi_eos_ids'])
     np.testing.assert_allclose(lp.numpy(), vec['multi_eos_logprobs'], rtol=0, atol=2e-4)
+
+
+def _unpack(vec, name):
+    shape = tuple(int(x) for x in vec[name + '_shape'])
+    n = int(np.prod(shape))
+    return np.unpackbits(vec[name + '_bits'])[:n].reshape(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize('n_tag', [0, 7, 50])
+def test_construct_attn_mask_equals_reference(n_tag):
+    """a8 pinned to the reference's OWN code: tests/golden/reference_wrapper.npz holds the 70 x 70 mask of the reference's
+    CaptionTensorizer.tensorize_ab (dataset.py:206-417, test mode, text_b of n_tag slots) and the 647 x 647 joint mask of the
+    reference's ImageCaptioning.construct_attn_mask (..._bertemb.py:57-85), both produced by running those functions
+    (tests/golden/make_golden_wrapper.py).  The oracle's restatements -- which every other generator and every device test feed
+    to both sides -- must reproduce them exactly, and so must the reference tensorizer's input ids."""
+    from oracle import vitcap_oracle as O
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_wrapper.npz'))
+    ids, am = O.test_text_inputs(2, n_tag_visible=n_tag)
+    want70 = _unpack(vec, 'test_n%d_mask70' % n_tag)
+    assert np.array_equal(am[0].numpy(), want70) and np.array_equal(am[1].numpy(), want70)
+    full = O.construct_attn_mask(am, 577)
+    assert tuple(full.shape) == (2, 647, 647)
+    assert np.array_equal(full[1].numpy(), _unpack(vec, 'test_n%d_full' % n_tag))
+    if n_tag == 0:
+        assert np.array_equal(ids[0].numpy(), vec['test_n0_input_ids'])
+    else:       # text_b tokens sit in the tag slots of the reference's ids; the model overwrites those rows' embeddings (modeling_bert.py:1449-1489)
+        assert np.array_equal(ids[0].numpy()[:20], vec['test_n%d_input_ids' % n_tag][:20])
+
+
+def test_construct_attn_mask_train_equals_reference():
+    """Training mask with a 13-token caption: the reference's tensorize_ab (train mode, seed 1313) + construct_attn_mask."""
+    from oracle import vitcap_oracle as O
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_wrapper.npz'))
+    m70 = _unpack(vec, 'train13_mask70')
+    ids = vec['train13_input_ids']
+    n_tok = int((ids != 0).sum())
+    assert n_tok == 15 and int(vec['train13_masked_pos'].sum()) >= 1
+    # structure the trainer assumes (vitcap_amd/train.py check_text_inputs): causal over the caption's tokens, nothing else visible
+    want = np.zeros((70, 70), dtype=np.float32)
+    want[:n_tok, :n_tok] = np.tril(np.ones((n_tok, n_tok), dtype=np.float32))
+    assert np.array_equal(m70, want)
+    full = O.construct_attn_mask(torch.from_numpy(m70)[None], 577)
+    assert np.array_equal(full[0].numpy(), _unpack(vec, 'train13_full'))
+
+
+def test_wrapper_forward_reproduced_the_goldens():
+    """a16: greedy_b4, greedy_tags50_b2 and the training loss were produced a second time THROUGH the reference's
+    ImageCaptioning.forward (mask by its own construct_attn_mask, inputs by its own tensorizer): same ids / log-probs / loss bit for bit
+    as the goldens the oracle-built inputs gave (asserted in the generator; the wrapper's outputs are stored and compared here)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    w, g, t = (np.load(os.path.join(here, f)) for f in ('reference_wrapper.npz', 'reference_vectors.npz', 'reference_train.npz'))
+    for name in ('greedy_b4', 'greedy_tags50_b2'):
+        assert np.array_equal(w['wrapper_%s_ids' % name], g[name + '_ids'])
+        assert np.array_equal(w['wrapper_%s_logprobs' % name], g[name + '_logprobs'])
+    assert float(w['wrapper_train_masked_loss']) == float(t['masked_loss'])

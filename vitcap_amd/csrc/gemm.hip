@@ -18,6 +18,8 @@
 
 #include "common.h"
 #include "gemm_args.h"
+#include <string.h>
+
 
 #include <algorithm>
 #include <mutex>
@@ -1733,6 +1735,23 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   // the persistent kernel's bf16 epilogue stores 8 columns (16 bytes) per lane
   const bool wide_ok = d->out_dtype == VITCAP_OUT_F32 || residual || (d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)C & 15) == 0);
   if (hint == 12 && wide_ok) return dispatch_256p(a, d->act, d->out_dtype, s);
+  {
+    // The 4-wave kernel (gemm4w.hip) behind the two production hints, measured end to end:
+    //   auto (one stream): its persistent form, +1.8 % images/s at B = 64 and B = 512 against the 8-wave kernel + planned tile mix;
+    //   tile_hint 5 (the 2-slot pipeline: another stream's small kernels must slip in between tiles): the 8-wave kernel stays while a
+    //   launch is a few rounds of the CUs (B = 64: 3802 vs 3703 img/s one-tile 4-wave, 3517 persistent -- a persistent grid owns
+    //   every CU for the whole GEMM, and a 512-register workgroup leaves no room for a co-resident decode wave); from 8 rounds on
+    //   (B = 512) the persistent form wins there too (+1.3 %).
+    // VITCAP_GEMM_4W = "<form for tile_hint 5>,<form for auto>" overrides (-1 = 8-wave kernel, 0..2 = form; experiments).
+    static const int env_set = getenv("VITCAP_GEMM_4W") != nullptr;
+    static const int env_tiles = [] { const char* e = getenv("VITCAP_GEMM_4W"); return e ? atoi(e) : -1; }();
+    static const int env_auto = [] { const char* e = getenv("VITCAP_GEMM_4W"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : (e ? atoi(e) : -1); }();
+    const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    int form = -1;
+    if (hint == 5) form = env_set ? env_tiles : (tiles256 >= 8 * 256 ? 2 : -1);
+    else if (hint == 0) form = env_set ? env_auto : 2;
+    if (form >= 0 && form <= 2 && d->M >= 2048 && vc_4w_supports(a, d->act)) return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);
+  }
   if (hint >= 40 && hint <= 42) return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent
   if (hint == 30) return dispatch_256<4>(a, d->act, d->out_dtype, s, 3);    // every tile 192 x 256 (tile-cost measurement)
   if (hint == 31) return dispatch_256<4>(a, d->act, d->out_dtype, s, 2);    // every tile 128 x 256

@@ -282,6 +282,9 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[MI][8], const GemmArg
 // dropped by the range check, no predicate), one 32-bit per-lane offset serves the whole tile, the m-tile's row offset rides in
 // the scalar offset and the n-tile's in the immediate.  Same arithmetic per element.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+#ifndef VC_4W_STORE_AUX
+#define VC_4W_STORE_AUX 0      // cache policy of the output stores (2 = nt)
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, long long bytes) {
   const unsigned rec = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec, 0x00020000);
@@ -319,7 +322,7 @@ __device__ __forceinline__ void epilogue_regs_fast(f32x4 (&acc)[MI][8], const Ge
 #if defined(VC_EPI_ABL) && (VC_EPI_ABL & 1)       // probe ablation: values kept alive, no store
       asm volatile("" ::"v"(s0), "v"(s1));
 #else
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{s0[0], s1[0], s0[1], s1[1]}, rc, voff + jj * 64, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{s0[0], s1[0], s0[1], s1[1]}, rc, voff + jj * 64, 0, VC_4W_STORE_AUX);
 #endif
     }
     voff += istep;
@@ -364,7 +367,7 @@ __device__ __forceinline__ void epilogue_patch_fast(f32x4 (&acc)[MI][8], const G
       v += bias4;
       if (ACT == VITCAP_ACT_GELU_ERF) v = gelu_erf4(v);
       if (HAS_RES) v += rres[i & 1][it];
-      if (OUT_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc, voff_c, 0, 0);
+      if (OUT_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc, voff_c, 0, VC_4W_STORE_AUX);
       else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}, rc, voff_c, 0, 0);
       voff_c += cstep;
     }
