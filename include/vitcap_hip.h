@@ -43,6 +43,12 @@ extern "C" {
 #define VITCAP_OUT_F32 1
 
 const char* vitcap_last_error(void);
+/* ABI version of this header: bumped whenever a struct layout or a function signature changes (3: `abi` heads vitcap_gemm_desc and
+ * vitcap_gen_opts; 2 -> 3 also covers round 3's additions: gemm_desc.colsum, gen_opts.eos_extra / tag_pos0, vitcap_tag_embed's pos0,
+ * vitcap_layernorm_bwd's extra pointer, zout / aux carrying gelu').  vitcap_version() returns the library's value: a binding checks
+ * the two for equality at load time, and every call that takes one of the two option structs rejects a struct whose first field is
+ * not VITCAP_ABI_VERSION (a caller built against an older header passes a shorter struct: its fields would be misread). */
+#define VITCAP_ABI_VERSION 3
 int vitcap_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -62,6 +68,7 @@ int vitcap_version(void);
  *     else out_row = res_row = r.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
+  int abi;       /* VITCAP_ABI_VERSION (checked by every entry point that takes this struct) */
   int M, N, K;
   int lda, ldw, ldc, ldr;
   int act;
@@ -99,6 +106,10 @@ int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const 
  * plan[0] = number of 256-row m-tiles, plan[1] = height class of the tiles behind them (0 = none, 3 = 192 rows, 2 = 128 rows),
  * plan[2] = number of those m-tiles. */
 int vitcap_gemm_tile_plan(int M, int N, int K, int* plan3);
+/* Which kernel family runs an M x N x K GEMM with M >= 2048 under `tile_hint` (0 = auto, 5) on the current device (host-side query):
+ * -1 = the 8-wave 256x256 kernel (gemm.hip); otherwise form + 10 * MI of the 4-wave kernel (gemm4w.hip): form 1 = one tile per
+ * workgroup, 2 = persistent pipeline; MI = 8 / 7 / 6 -> 256- / 224- / 192-row tiles.  Results do not depend on the choice. */
+int vitcap_gemm_large_form(int M, int N, int K, int tile_hint);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (768): y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 statistics.
@@ -421,6 +432,7 @@ int vitcap_engine_bind_weights(vitcap_engine* e, const vitcap_weights* w);
 #define VITCAP_GEMM_AUTO 0       /* large GEMMs as persistent workgroups where that wins (the GEMM has the GPU to itself) */
 #define VITCAP_GEMM_TILES 1      /* one tile per workgroup: a second stream's small kernels interleave (batch pipeline) */
 typedef struct vitcap_gen_opts {
+  int32_t abi;                /* VITCAP_ABI_VERSION: set by vitcap_gen_opts_init, checked by vitcap_gen_opts_check and every engine call */
   int32_t num_beams;          /* 1 = greedy / sampling (_generate_no_beam_search); 2..8 = beam search                  */
   int32_t seqs_per_image;     /* num_return_sequences, 1..8; > 1 needs num_beams == 1 (inputs expanded,
                                  modeling_bert.py:976-994; the copies share the image's encoder output and visual K/V)  */
@@ -585,6 +597,10 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */
 int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches);
+/* time only every stride-th eligible launch from the next timing_begin on (default 1 = all): four event records per timed launch cost
+ * 2.6 % of a pipelined B = 64 step when every launch is timed (bench.py `unarmed_ms_per_step`); a stride co-prime with the number of
+ * GEMM variants samples all of them evenly */
+int vitcap_engine_timing_sample(vitcap_engine* e, int stride);
 int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, int* launches12);
 /* the same plus busy_ms12: per variant the length of the union of its launches' [start, stop] intervals (launches of one kernel
  * overlap when several chains are in flight; their summed durations count that time twice) */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of BASELINE configs[1..4], rocprof summaries, PMC traffic.
 # Usage: bash scripts_gpu_round.sh [tag] [notests]
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
@@ -12,6 +12,8 @@ python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python bench.py --steps 50 --warmup 3 --pipeline 0 --no-cpu-baseline > gpurun_out/bench_seq_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 20 --warmup 2 --beams 5 --batch 256 --graph 1 --no-cpu-baseline > gpurun_out/bench_beam5_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 30 --warmup 3 --mode train > gpurun_out/bench_train_$TAG.json 2>> gpurun_out/bench_$TAG.err
+# the launcher + RCCL path on the one GPU of this box: a process group of ONE rank, the gradient exchange forced (VITCAP_DP_FORCE)
+VITCAP_DP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --mode train > gpurun_out/bench_train_rccl1_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err

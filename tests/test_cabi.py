@@ -43,6 +43,27 @@ def test_argument_validation_without_gpu(L):
     assert L.lib.vitcap_sigmoid_topk(a, 30592, 30522, 65, 0.2, a, a, a, 1, None) == -1      # k > 64
 
 
+def test_abi_version_is_checked(L):
+    """a struct or signature change bumps VITCAP_ABI_VERSION; the binding refuses a library of another version at load
+    time, and the two option structs carry the version in their first field -- a caller built against an older header is rejected
+    instead of having its (shorter / shifted) struct misread."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'vitcap_hip.h')).read()
+    want = int(re.search(r'#define VITCAP_ABI_VERSION (\d+)', hdr).group(1))
+    assert L.lib.vitcap_version() == want == L.ABI_VERSION
+    buf = (C.c_char * 4096)()
+    a = C.c_void_p((C.addressof(buf) + 255) & ~255)
+    d = L.GemmDesc(M=8, N=16, K=64, lda=64, ldw=64, ldc=16)
+    assert d.abi == want
+    d.abi = want - 1
+    assert L.lib.vitcap_gemm_bias_act(a, a, None, None, a, C.byref(d), None) == -1 and b'ABI' in L.lib.vitcap_last_error()
+    o = L.gen_opts()
+    assert o.abi == want and L.lib.vitcap_gen_opts_check(C.byref(o)) == 0
+    stale = L.GenOpts()                 # zero-initialised, as a caller that never heard of the field would leave it
+    assert L.lib.vitcap_gen_opts_check(C.byref(stale)) == -1 and b'ABI' in L.lib.vitcap_last_error()
+    assert L.lib.vitcap_engine_workspace_bytes(1, C.byref(stale)) == 0
+
+
 def test_gemm_tile_plan_host_logic(L):
     """vitcap_gemm_tile_plan (host only): the 256-row tiles plus the short tiles behind them cover every row exactly once,
     the 256-row region ends on a tile boundary, and the hot B = 64 shapes whose plain grids waste a partial round get a mix."""
@@ -93,8 +114,8 @@ def test_struct_sizes_match_header(L):
     # every field is one pointer: 12/12/6 per block struct, total as laid out in vitcap_hip.h
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
-    assert C.sizeof(L.GemmDesc) == 16 * 4 + 24          # 15 ints, padding, three pointers (live, rowstat, colsum)
-    assert C.sizeof(L.GenOpts) == 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4
+    assert C.sizeof(L.GemmDesc) == 16 * 4 + 24          # abi + 15 ints, three pointers (live, rowstat, colsum)
+    assert C.sizeof(L.GenOpts) == 4 + 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4
 
 
 def test_model_surface(L, sd_np):

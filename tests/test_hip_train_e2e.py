@@ -370,6 +370,74 @@ def test_two_process_data_parallel_step(tmp_path, path):
     assert float(d.mean()) < 2e-6, float(d.mean())          # Adam's sign-like first step: near-zero gradients may flip
 
 
+def _rccl_one_rank_worker(port, out, tmp, algo):
+    import os
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VITCAP_DP_REDUCE=algo)
+    import torch
+    from vitcap_amd import dist_util as D
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    from vitcap_amd.dist_util import BucketedAllReduce
+    torch.cuda.set_device(0)
+    dist = D.init('nccl', torch.device('cuda', 0))           # RCCL communicator of one rank, bound to the device as bench.py does
+    assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda:0', max_iter=10, attn_dropout=0.0, dist=dist)
+    eng.reducer = BucketedAllReduce(eng.G, eng.reducer.buckets, eng.reducer.stages, dist, algo=algo, force_exchange=True)
+    assert eng.reducer.exchange and eng.reducer.comm is not None and eng.reducer._native_rs
+    b = {k: v.cuda() for k, v in synthetic_train_inputs(2).items()}
+    b['image'] = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+    res = eng.train_step(b)
+    torch.cuda.synchronize()
+    t = torch.ones(1, device='cuda')
+    dist.all_reduce(t)                                        # the bench's barrier / max-over-ranks primitives on RCCL
+    dist.barrier()
+    torch.save(eng.P.cpu(), '%s/p_%s.pt' % (tmp, algo))
+    out.put((float(res['masked_loss']), eng.grad_norm(), eng.reducer.launched_bytes, float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag'])
+def test_rccl_exchange_one_rank_group(tmp_path, algo):
+    """The `nccl` (= RCCL) branch of the gradient exchange on the one GPU a test box has: a process group of ONE rank, the exchange
+    forced (BucketedAllReduce(force_exchange=True)): communicator creation with device_id, every bucket's collective enqueued on the
+    side stream behind the backward pass (all_reduce, or reduce_scatter_tensor in place + all_gather_into_tensor), the 1/world
+    scaling, finish()'s stream join -- inside a real train_step.  With one rank every collective is an identity and the scaling a
+    multiplication by 1.0, so the step must reproduce the no-dist step to within the training kernels' own run-to-run variation
+    (loss / column-sum reductions use fp32 atomics: the loss differs in the 7th digit between two processes, and Adam's first step
+    is sign-like) -- the tolerances of test_two_process_data_parallel_step."""
+    import socket
+    import torch.multiprocessing as mp
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q, str(tmp_path), algo))
+    p.start()
+    loss, gnorm, nbytes, one = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert one == 1.0 and nbytes > 600e6                      # every gradient bucket went through the collective path
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    b = {k: v.cuda() for k, v in synthetic_train_inputs(2).items()}
+    b['image'] = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+    want = eng.train_step(b)
+    torch.cuda.synchronize()
+    assert abs(loss - float(want['masked_loss'])) < 1e-5
+    assert abs(gnorm - eng.grad_norm()) < 1e-3 * gnorm
+    got = torch.load(str(tmp_path / ('p_%s.pt' % algo)))
+    d = (eng.P.cpu() - got).abs()
+    assert float(d.mean()) < 2e-6, float(d.mean())
+
+
 def test_scst_logprob_gradient_vs_oracle(sd_t):
     """Self-critical step (BASELINE config 5): loss = -mean_s(reward_s * mean_t log p(sampled token)) and its gradient.
     Device: ONE pass over [578 visual | 20 token rows | 19 [MASK] probe rows]; oracle: the generator's 19 full forwards

@@ -1,0 +1,119 @@
+"""Input side, measured once (GPU box): `run.py pipeline_eval_multi` from a TSV of base64 JPEGs on disk, next to the resident-HBM
+bench figure.  Builds a synthetic test set (N JPEGs of mixed COCO-like sizes), then reports
+  * decode-only images/s of the host (base64 + Pillow/libjpeg -> RGB) by number of threads, and the cost per image,
+  * end-to-end images/s of the pipeline (TSV -> decode threads -> HIP resize/crop/normalise -> 2-slot caption pipeline -> predict TSV)
+    by `num_workers`, batch size 64.
+Usage: python tools/input_side_bench.py [N=4096] [out.json]"""
+import base64
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+SIZES = [(480, 640), (375, 500), (640, 480), (427, 640), (768, 1024), (333, 500), (500, 375), (600, 800)]
+
+
+def synth_jpeg(i):
+    from PIL import Image
+    h, w = SIZES[i % len(SIZES)]
+    g = np.random.default_rng(1000 + i)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([127 + 100 * np.sin(xx / (17 + i % 13) + c) * np.cos(yy / (23 + i % 7) - c) for c in range(3)], -1)
+    img += g.normal(0, 12, img.shape)                     # texture: keeps the entropy decoder honest (about 100-200 KB per image)
+    buf = io.BytesIO()
+    Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), 'RGB').save(buf, format='JPEG', quality=90)
+    return buf.getvalue()
+
+
+def main():
+    import run
+    from vitcap_amd.imageio import decode_image
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.tsv import TSVFile, tsv_writer
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    tmp = tempfile.mkdtemp(prefix='vitcap_input_')
+    os.chdir(tmp)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(32) as pool:
+        jpegs = list(pool.map(synth_jpeg, range(min(N, 256))))       # 256 distinct images, repeated: the decoder does not care
+    rows = [('img%d' % i, base64.b64encode(jpegs[i % len(jpegs)])) for i in range(N)]
+    tsv_writer(rows, os.path.join(tmp, 'data', 'toy', 'test.tsv'))
+    res = {'images': N, 'mean_jpeg_bytes': int(np.mean([len(j) for j in jpegs])), 'sizes': SIZES, 'host_cores': os.cpu_count(),
+           'build_s': round(time.perf_counter() - t0, 1)}
+    # ---- decode only
+    t = TSVFile(os.path.join(tmp, 'data', 'toy', 'test.tsv'))
+    recs = [t[i][1] for i in range(min(N, 1024))]
+    dec = {}
+    for th in (1, 8, 16, 32, 64):
+        with ThreadPoolExecutor(th) as pool:
+            list(pool.map(decode_image, recs[:64]))
+            t0 = time.perf_counter()
+            list(pool.map(decode_image, recs))
+            dec[th] = round(len(recs) / (time.perf_counter() - t0), 1)
+    res['decode_only_images_per_s_by_threads'] = dec
+    res['decode_ms_per_image_one_thread'] = round(1e3 / dec[1], 2)
+    # ---- the pipeline from disk
+    enc = os.path.join(tmp, 'enc')
+    os.makedirs(enc)
+    toks = ['[PAD]'] + ['w%d' % i for i in range(1, 30522)]
+    toks[100], toks[101], toks[102], toks[103] = '[UNK]', '[CLS]', '[SEP]', '[MASK]'
+    open(os.path.join(enc, 'vocab.txt'), 'w').write('\n'.join(toks) + '\n')
+    sd = ImageCaptioning().load_recipe(0).state_dict()
+    ck = os.path.join(tmp, 'base.pt')
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'iteration': 0}, ck)
+    # decode only, worker processes (what the loader uses)
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from vitcap_amd.jpegdec import decode_many
+    decp = {}
+    for th in (8, 16, 32):
+        with ProcessPoolExecutor(th, mp_context=mp.get_context('spawn')) as pool:
+            chunks = [recs[c:c + 8] for c in range(0, len(recs), 8)]
+            list(pool.map(decode_many, chunks[:th]))
+            t0 = time.perf_counter()
+            list(pool.map(decode_many, chunks))
+            decp[th] = round(len(recs) / (time.perf_counter() - t0), 1)
+    res['decode_only_images_per_s_by_worker_processes'] = decp
+    # the pipeline: run.py pipeline_eval_multi over the N rows; steady-state images/s as CaptionUniPipeline.predict measures it (from the
+    # second batch's captions to the last row: model load, weight packing and worker start-up are outside)
+    from vitcap_amd import pipeline as P
+    e2e = {}
+
+    def run_once(name, workers, threads):
+        cfg = {'type': 'pipeline_eval_multi', 'all_test_data': [{'test_data': 'toy', 'test_split': 'test'}],
+               'param': {'full_expid': name, 'max_iter': 10, 'model_file': ck, 'text_encoder_type': enc, 'tagemb': 'cls',
+                         'test_batch_size': 64, 'force_predict': True, 'crop_pct': 1.0, 'test_crop_size': 384, 'num_workers': workers,
+                         'loader_threads': threads, 'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+        yf = os.path.join(tmp, name + '.yaml')
+        open(yf, 'w').write(yaml.safe_dump(cfg))
+        kw = run.parse_general_args(['-c', yf])
+        P.LAST_PREDICT_STATS.clear()
+        t0 = time.perf_counter()
+        getattr(run, kw.pop('type'))(**kw)
+        torch.cuda.synchronize()
+        return dict(P.LAST_PREDICT_STATS), time.perf_counter() - t0
+    for workers, threads in ((8, True), (8, False), (16, False), (32, False), (64, False)):
+        st, wall = run_once('w%d%d' % (workers, threads), workers, threads)
+        e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
+        print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s)' % (
+            workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall), flush=True)
+    res['pipeline_from_tsv_images_per_s'] = e2e
+    res['note'] = ('run.py pipeline_eval_multi, batch 64, 2-slot caption pipeline, predictions written as the reference\'s predict TSV; '
+                   'steady state = from the second batch\'s captions to the last row')
+    print(json.dumps(res))
+    if out_path:
+        json.dump(res, open(os.path.join(REPO, out_path) if not os.path.isabs(out_path) else out_path, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

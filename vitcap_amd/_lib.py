@@ -23,10 +23,17 @@ OUT_BF16, OUT_F32 = 0, 1
 vp = C.c_void_p
 
 
+ABI_VERSION = 3          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
+
+
 class GemmDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
+    _fields_ = [(n, C.c_int) for n in ('abi', 'M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
                                        'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')] \
         + [('live', C.c_void_p), ('rowstat', C.c_void_p), ('colsum', C.c_void_p)]
+
+    def __init__(self, *a, **kw):
+        kw.setdefault('abi', ABI_VERSION)
+        super().__init__(*a, **kw)
 
 
 class CtItem(C.Structure):
@@ -46,7 +53,7 @@ class SampleParams(C.Structure):
 
 class GenOpts(C.Structure):
     """vitcap_gen_opts: the kwargs of ViTCAP.generate (modeling_bert.py:928-933) + launch form, passed per call."""
-    _fields_ = [('num_beams', C.c_int32), ('seqs_per_image', C.c_int32), ('num_keep_best', C.c_int32),
+    _fields_ = [('abi', C.c_int32), ('num_beams', C.c_int32), ('seqs_per_image', C.c_int32), ('num_keep_best', C.c_int32),
                 ('max_length', C.c_int32), ('bos_token_id', C.c_int32), ('eos_token_id', C.c_int32),
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
@@ -93,6 +100,7 @@ _SIGS = {
     'vitcap_version': (C.c_int, []),
     'vitcap_gemm_bias_act': (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(GemmDesc), vp]),
     'vitcap_gemm_tile_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_gemm_large_form': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'vitcap_layernorm_fwd': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_sum_layernorm': (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp,
                                        C.c_int, C.c_int, vp]),
@@ -183,6 +191,7 @@ _SIGS = {
     'vitcap_engine_tap': (vp, [vp, C.c_char_p, vp, C.c_int, C.POINTER(GenOpts)]),
     'vitcap_repetition_penalty': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     'vitcap_engine_timing_begin': (C.c_int, [vp, C.c_int]),
+    'vitcap_engine_timing_sample': (C.c_int, [vp, C.c_int]),
     'vitcap_engine_timing_end': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'vitcap_engine_timing_end_ex': (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                               C.POINTER(C.c_double)]),
@@ -207,6 +216,10 @@ def _load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    got = lib.vitcap_version()
+    if got != ABI_VERSION:         # a stale .so (or binding): struct layouts / signatures differ, every call would be misread
+        raise ImportError('libvitcap_hip.so reports ABI version %d, this binding is written for %d: rebuild (make -C vitcap_amd/csrc)'
+                          % (got, ABI_VERSION))
     return lib
 
 

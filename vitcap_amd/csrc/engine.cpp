@@ -56,6 +56,8 @@ struct vitcap_engine {
   vitcap_weights w;
   bool bound = false;
   bool timing = false;
+  int timing_stride = 1;      // every timing_stride-th eligible launch is timed (vitcap_engine_timing_sample)
+  long long timing_seen = 0;  // eligible launches since timing_begin
   // one enqueue at a time per engine: the side stream / fork-join events and the graph cache are shared by all callers
   std::mutex mu;
   // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
@@ -87,6 +89,7 @@ constexpr int SPLIT_AO = 6, SPLIT_FC2 = 12, SPLIT_MAX = 12;   // split-K of the 
 vitcap_gen_opts default_opts() {
   vitcap_gen_opts o;
   memset(&o, 0, sizeof(o));
+  o.abi = VITCAP_ABI_VERSION;
   o.num_beams = 1;
   o.seqs_per_image = 1;
   o.num_keep_best = 1;
@@ -109,6 +112,7 @@ vitcap_gen_opts default_opts() {
 
 int check_opts(const vitcap_gen_opts& o) {
 #define OPT_REQ(cond, ...) do { if (!(cond)) { vitcap_set_error(__VA_ARGS__); return VITCAP_EINVAL; } } while (0)
+  OPT_REQ(o.abi == VITCAP_ABI_VERSION, "gen_opts: built against ABI %d, this library is ABI %d (use vitcap_gen_opts_init)", o.abi, VITCAP_ABI_VERSION);
   OPT_REQ(o.num_beams >= 1 && o.num_beams <= 8, "gen_opts: num_beams must be 1..8 (got %d)", o.num_beams);
   OPT_REQ(o.seqs_per_image >= 1 && o.seqs_per_image <= 8, "gen_opts: seqs_per_image must be 1..8 (got %d)", o.seqs_per_image);
   OPT_REQ(o.num_keep_best >= 1 && o.num_keep_best <= 8, "gen_opts: num_keep_best must be 1..8 (got %d)", o.num_keep_best);
@@ -295,7 +299,8 @@ struct CallScope {
 
 int gemm_desc(const void* A, const void* W, const float* bias, const float* res, void* C, vitcap_gemm_desc d, void* s) {
   vitcap_engine* e = g_cur;
-  const bool timed = e && e->timing && d.M > 256 && e->used < e->pool.size();
+  const bool eligible = e && e->timing && d.M > 256;
+  const bool timed = eligible && (e->timing_seen++ % e->timing_stride) == 0 && e->used < e->pool.size();
   GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
   // one tile per workgroup for the large GEMMs when the caller overlaps a second stream (vitcap_gen_opts.gemm_mode)
   if (d.tile_hint == 0 && g_gemm_mode == VITCAP_GEMM_TILES && d.M >= 2048 && d.act != VITCAP_ACT_TANH && d.split_k <= 1) d.tile_hint = 5;
@@ -321,6 +326,7 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
          int N, int K, int act, int out, void* s) {
   vitcap_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
   d.M = M; d.N = N; d.K = K;
   d.lda = lda; d.ldw = K; d.ldc = ldc; d.ldr = ldr;
   d.act = act; d.out_dtype = out;
@@ -330,6 +336,7 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
 int gemm_split(const void* A, int lda, const void* W, void* partials, int M, int N, int K, int split, void* s) {
   vitcap_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
   d.M = M; d.N = N; d.K = K;
   d.lda = lda; d.ldw = K; d.ldc = N;
   d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
@@ -343,6 +350,7 @@ int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C
                int hint, void* s) {
   vitcap_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
   d.M = M; d.N = N; d.K = K;
   d.lda = lda; d.ldw = K; d.ldc = ldc;
   d.act = act; d.out_dtype = out;
@@ -441,7 +449,15 @@ extern "C" int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches) {
     e->pool.push_back(t);
   }
   e->used = 0;
+  e->timing_seen = 0;
   e->timing = max_launches > 0;
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_engine_timing_sample(vitcap_engine* e, int stride) {
+  if (!e || stride < 1) return VITCAP_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->timing_stride = stride;
   return VITCAP_OK;
 }
 
@@ -601,6 +617,7 @@ static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, i
   {
     vitcap_gemm_desc d;
     memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
     d.M = B * 576; d.N = D; d.K = D;
     d.lda = D; d.ldw = D; d.ldc = D; d.ldr = D;
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
@@ -927,6 +944,7 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
     // moves them at 3.8 TB/s against 2.3 TB/s for the 32x32 tiles the small-M dispatch would pick (12.5 vs 20.8 us at NS = 64)
     vitcap_gemm_desc d;
     memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
     d.M = ns; d.N = VP; d.K = D;
     d.lda = D; d.ldw = D; d.ldc = VP;
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;

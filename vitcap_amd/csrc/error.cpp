@@ -20,4 +20,4 @@ void vitcap_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vitcap_last_error(void) { return g_err; }
-extern "C" int vitcap_version(void) { return 2; }
+extern "C" int vitcap_version(void) { return VITCAP_ABI_VERSION; }

@@ -1590,6 +1590,26 @@ int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 
 }  // namespace
 
+// which kernel family runs a large GEMM under tile_hint `hint` (0 = auto, 5 = one tile per workgroup): -1 = the 8-wave kernel of this
+// file, 0..2 = a form of the 4-wave kernel (gemm4w.hip); see the measurements at the call site in vitcap_gemm_ex
+static int large_gemm_form(int M, int N, int hint) {
+  static const int env_set = getenv("VITCAP_GEMM_4W") != nullptr;
+  static const int env_tiles = [] { const char* e = getenv("VITCAP_GEMM_4W"); return e ? atoi(e) : -1; }();
+  static const int env_auto = [] { const char* e = getenv("VITCAP_GEMM_4W"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : (e ? atoi(e) : -1); }();
+  const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (M < 2048) return -1;
+  if (hint == 5) return env_set ? env_tiles : (tiles256 >= 8 * 256 ? 2 : -1);
+  if (hint == 0) return env_set ? env_auto : 2;
+  return -1;
+}
+
+extern "C" int vitcap_gemm_large_form(int M, int N, int K, int tile_hint) {
+  (void)K;
+  const int form = large_gemm_form(M, N, tile_hint);
+  if (form < 0 || form > 2) return -1;
+  return form + 10 * vc_4w_pick_mi(M, (N + 255) / 256, form);
+}
+
 extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
                               const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
                               void* stream);
@@ -1617,6 +1637,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
                               const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz,
                               void* stream) {
   VC_REQUIRE(A && W && C && d, "gemm: null pointer");
+  VC_REQUIRE(d->abi == VITCAP_ABI_VERSION, "gemm: descriptor built against ABI %d, this library is ABI %d", d->abi, VITCAP_ABI_VERSION);
   VC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
   VC_REQUIRE(d->K % 64 == 0, "gemm: K=%d must be a multiple of 64", d->K);
   VC_REQUIRE(d->N % 4 == 0 && d->ldc % 4 == 0, "gemm: N=%d and ldc=%d must be multiples of 4", d->N, d->ldc);
@@ -1743,13 +1764,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     //   every CU for the whole GEMM, and a 512-register workgroup leaves no room for a co-resident decode wave); from 8 rounds on
     //   (B = 512) the persistent form wins there too (+1.3 %).
     // VITCAP_GEMM_4W = "<form for tile_hint 5>,<form for auto>" overrides (-1 = 8-wave kernel, 0..2 = form; experiments).
-    static const int env_set = getenv("VITCAP_GEMM_4W") != nullptr;
-    static const int env_tiles = [] { const char* e = getenv("VITCAP_GEMM_4W"); return e ? atoi(e) : -1; }();
-    static const int env_auto = [] { const char* e = getenv("VITCAP_GEMM_4W"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : (e ? atoi(e) : -1); }();
-    const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    int form = -1;
-    if (hint == 5) form = env_set ? env_tiles : (tiles256 >= 8 * 256 ? 2 : -1);
-    else if (hint == 0) form = env_set ? env_auto : 2;
+    const int form = large_gemm_form(d->M, d->N, hint);
     if (form >= 0 && form <= 2 && d->M >= 2048 && vc_4w_supports(a, d->act)) return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);
   }
   if (hint >= 40 && hint <= 42) return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent

@@ -734,6 +734,8 @@ int launch_4w(const GemmArgs& a, hipStream_t s, int form) {
 
 }  // namespace
 
+int vc_4w_pick_mi(int M, int tiles_n, int form) { return form == 0 ? 8 : pick_mi(M, tiles_n, form); }
+
 bool vc_4w_supports(const GemmArgs& a, int act) {
 #ifdef VC_4W_STAMP
   if (a.rowstat) return true;

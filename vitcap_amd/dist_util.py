@@ -63,18 +63,28 @@ class BucketedAllReduce(object):
                     only, all-gather of the slices (what a ring all-reduce does internally, made explicit so that
                     the two halves of consecutive buckets overlap on xGMI's point-to-point links and the scaling touches
                     1/world of the bytes).  Range tails that do not divide by world go through a small all-reduce.
-    Both give the same mean (bit-identical on 2 ranks; summation order may differ with more)."""
+    Both give the same mean (bit-identical on 2 ranks; summation order may differ with more).
 
-    def __init__(self, flat, buckets, stages, dist, algo=None):
+    `force_exchange` (default from VITCAP_DP_FORCE=1): run the exchange also in a process group of ONE rank -- every collective is
+    then an identity and the scaling a multiplication by 1.0, so the step's parameters equal the no-dist step bit for bit, while the
+    whole RCCL code path (communicator on `device_id`, collectives enqueued on the side stream behind an event, the in-place
+    reduce-scatter's aliasing, finish()'s stream join) executes on the one GPU a test box has."""
+
+    def __init__(self, flat, buckets, stages, dist, algo=None, force_exchange=None):
         self.flat, self.buckets, self.stages, self.dist = flat, buckets, list(stages), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        if force_exchange is None:
+            force_exchange = os.environ.get('VITCAP_DP_FORCE', '0') == '1'
+        self.exchange = self.world > 1 or (bool(force_exchange) and dist is not None and dist.is_initialized())
+        self.rank = dist.get_rank() if self.exchange else 0
         self.cuda = flat.is_cuda
-        self.comm = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
+        # high priority: the collective's few workgroups (RCCL channels) must not queue behind GEMM grids that fill every CU --
+        # the dispatcher serves a higher-priority queue first whenever a workgroup slot frees (DESIGN.md section 7)
+        self.comm = torch.cuda.Stream(device=flat.device, priority=-1) if (self.cuda and self.exchange) else None
         self.algo = algo or os.environ.get('VITCAP_DP_REDUCE', 'all_reduce')
         if self.algo not in ('all_reduce', 'rs_ag'):
             raise ValueError('unknown gradient exchange %r (all_reduce | rs_ag)' % self.algo)
-        self._native_rs = self.world > 1 and dist.get_backend() == 'nccl'     # gloo has no reduce_scatter: emulate per slice
+        self._native_rs = self.exchange and dist.get_backend() == 'nccl'     # gloo has no reduce_scatter: emulate per slice
         self._works = []
         self._done = set()
         self.launched_bytes = 0
@@ -123,7 +133,7 @@ class BucketedAllReduce(object):
         if stage != expect:
             raise RuntimeError('backward stages out of order: got %s, expected %s' % (stage, expect))
         self._done.add(stage)
-        if self.world == 1:
+        if not self.exchange:
             return
         scale = 1.0 / self.world
         if self.cuda:
@@ -145,10 +155,10 @@ class BucketedAllReduce(object):
                 self.launched_bytes += (b - a) * self.flat.element_size()
 
     def finish(self):
-        if len(self._done) != len(self.stages) and self.world > 1:
+        if len(self._done) != len(self.stages) and self.exchange:
             missing = [s for s in self.stages if s not in self._done]
             raise RuntimeError('finish() before stages %s completed' % missing)
-        if self.world == 1:
+        if not self.exchange:
             return
         if self.cuda:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)

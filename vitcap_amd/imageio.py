@@ -17,17 +17,7 @@ from ._lib import TrainAug as _TrainAug
 from ._lib import check, lib
 
 
-def decode_image(data):
-    """base64 str/bytes or raw JPEG/PNG bytes -> uint8 (H,W,3) RGB."""
-    from PIL import Image
-    if isinstance(data, str):
-        data = base64.b64decode(data)
-    elif isinstance(data, (bytes, bytearray)) and not (data[:2] == b'\xff\xd8' or data[:4] == b'\x89PNG'):
-        data = base64.b64decode(data)
-    img = Image.open(io.BytesIO(data))
-    if img.mode != 'RGB':
-        img = img.convert('RGB')         # cv2.IMREAD_COLOR also yields 3 channels for grey / palette / alpha inputs
-    return np.asarray(img)
+from .jpegdec import decode_image      # noqa: E402,F401  (kept importable from here; the loader's worker processes import jpegdec alone)
 
 
 class ImagePreprocessor(object):
@@ -48,7 +38,10 @@ class ImagePreprocessor(object):
         for i, im in enumerate(images):
             if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
                 raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
-            t = torch.from_numpy(np.array(im, copy=True, order='C')).to(self.dev, non_blocking=True)
+            # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
+            # loader's shared-memory slabs -- goes to the device as it is
+            src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')
+            t = torch.from_numpy(src).to(self.dev, non_blocking=True)
             dev_imgs.append(t)
             desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
         need = lib.vitcap_image_preproc_workspace_bytes(desc, B, self.resize_short, self.crop)
@@ -83,7 +76,10 @@ class TrainImagePreprocessor(object):
         for i, (im, pr) in enumerate(zip(images, params)):
             if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
                 raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
-            t = torch.from_numpy(np.array(im, copy=True, order='C')).to(self.dev, non_blocking=True)
+            # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
+            # loader's shared-memory slabs -- goes to the device as it is
+            src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')
+            t = torch.from_numpy(src).to(self.dev, non_blocking=True)
             dev_imgs.append(t)
             desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
             top, left, h, w = pr['box']

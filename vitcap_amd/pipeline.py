@@ -24,6 +24,43 @@ import os.path as op
 import torch
 
 from . import dist_util as D
+
+
+
+def _prefetched(gen, device, depth=2):
+    """Runs the batch generator in a background thread, `depth` batches ahead: reading the TSV rows, handing them to the decode workers,
+    the host -> device copies and the launch of the transform kernel no longer sit between two caption launches of the consumer
+    (measured: the consumer thread was the limit at 26 ms per batch of 64, the GPU needs 17).  A batch is handed over after the producer's
+    stream has been synchronised, so the consumer may use it on any stream."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(1, depth))
+    END = object()
+
+    def work():
+        try:
+            if device.type == 'cuda':
+                torch.cuda.set_device(device)
+            for b in gen:
+                if device.type == 'cuda':
+                    torch.cuda.current_stream(device).synchronize()
+                q.put(b)
+            q.put(END)
+        except BaseException as e:          # surfaces in the consumer
+            q.put(e)
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        b = q.get()
+        if b is END:
+            break
+        if isinstance(b, BaseException):
+            raise b
+        yield b
+    t.join()
+
+
+LAST_PREDICT_STATS = {}     # filled by CaptionUniPipeline.predict: rows, steady-state images/sec of this rank (tools/input_side_bench.py)
 from .checkpoint import Checkpointer
 from .config import Config
 
@@ -391,9 +428,80 @@ class CaptionUniPipeline(object):
                                     float(self.cfg.crop_pct or 1.0))
             bs = int(self.cfg.test_batch_size)
             mine = list(range(self.rank, len(rows), self.world))
-            for i in range(0, len(mine), bs):
-                recs = [rows[j] for j in mine[i:i + bs]]
-                yield {'image': pre([decode_image(r[-1]) for r in recs]), 'key': [r[0] for r in recs]}
+            # JPEG decoding is host work: `num_workers` worker PROCESSES (the reference's DataLoader(num_workers),
+            # uni_pipeline.py:333-339) decode the images of the next batches while the GPU captions the current one.  Measured on the
+            # GPU box (tools/input_side_bench.py, profiles/r04_input_side.json): one core decodes 600 images/s, threads of one process
+            # top out near 2 000 (GIL), a GPU captions 3 700.  The workers are SPAWNED (never forked: this process owns a GPU
+            # context) and import vitcap_amd.jpegdec only.  `loader_threads: true` keeps the decode in threads of this process.
+            # Rows are read by the consumer (the TSV handle is not shared), batches come back in order.
+            from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+            from .jpegdec import decode_into, decode_many
+            import numpy as np
+            workers = max(1, int(self.cfg.num_workers or 1))
+            chunk = 8                                                  # images per worker task
+            per_batch = (bs + chunk - 1) // chunk
+            ahead = max(2, (2 * workers + per_batch - 1) // per_batch + 1)   # batches in flight: two tasks per worker
+            starts = list(range(0, len(mine), bs))
+            slabs, free = [], []
+            if self.cfg.loader_threads:
+                pool = ThreadPoolExecutor(max_workers=workers)
+            else:
+                import multiprocessing as mp
+                from multiprocessing import shared_memory
+                pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))
+                # decoded pixels come back through shared memory (vitcap_amd/jpegdec.py); a slab holds one task's images and is reused
+                # two batches after the batch that read it went to the GPU
+                slab_bytes = int(self.cfg.loader_slab_mb or 24) << 20
+                slabs = [shared_memory.SharedMemory(create=True, size=slab_bytes) for _ in range((ahead + 3) * per_batch)]
+                free = list(range(len(slabs)))
+            retired = []                                               # slab ids of the last batches handed to the GPU
+            try:
+                with pool:
+                    inflight = []
+
+                    def submit(k):
+                        recs = [rows[j] for j in mine[starts[k]:starts[k] + bs]]
+                        blobs = [r[-1] for r in recs]
+                        tasks = []
+                        for c in range(0, len(blobs), chunk):
+                            if slabs:
+                                sid = free.pop()
+                                tasks.append((sid, pool.submit(decode_into, slabs[sid].name, blobs[c:c + chunk])))
+                            else:
+                                tasks.append((None, pool.submit(decode_many, blobs[c:c + chunk])))
+                        inflight.append(([r[0] for r in recs], tasks))
+                    nxt = 0
+                    while nxt < len(starts) and len(inflight) < ahead:
+                        submit(nxt)
+                        nxt += 1
+                    while inflight:
+                        keys, tasks = inflight.pop(0)
+                        imgs, used = [], []
+                        for sid, f in tasks:
+                            for item in f.result():
+                                if sid is not None and isinstance(item, tuple):
+                                    off, h, w = item
+                                    imgs.append(np.ndarray((h, w, 3), dtype=np.uint8, buffer=slabs[sid].buf, offset=off))
+                                else:
+                                    imgs.append(item)
+                            if sid is not None:
+                                used.append(sid)
+                        batch = {'image': pre(imgs), 'key': keys}       # host -> device copies of pageable memory return once staged
+                        del imgs
+                        retired.append(used)
+                        if len(retired) > 2:
+                            free.extend(retired.pop(0))
+                        if nxt < len(starts):
+                            submit(nxt)
+                            nxt += 1
+                        yield batch
+            finally:
+                for shm in slabs:
+                    try:
+                        shm.close()
+                        shm.unlink()
+                    except Exception:
+                        pass
             return
         from . import weights as W
         n = int(self.cfg.synthetic_num_images or 8)
@@ -460,7 +568,7 @@ class CaptionUniPipeline(object):
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
             n_seen = None                         # visible tag slots of the first batch whose text tensors live on the device
             with torch.no_grad():
-                for batch in self.iter_test_batches():
+                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or 2)):
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
                     flag = None
@@ -486,7 +594,23 @@ class CaptionUniPipeline(object):
                 for entry in pending:
                     for key, js in collect(entry):
                         yield key, js
-        tsv_writer(gen_rows(), sub)                 # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
+        import time
+        stats = {'rows': 0, 't_first': None, 'rows_first': 0}
+
+        def timed_rows():
+            # images/s of the steady state: from the moment the first two batches' captions have come back (model warm, loader
+            # workers running) to the last row -- the figure the reference's trainer logs as images/sec (trainer.py:155-170)
+            for row in gen_rows():
+                stats['rows'] += 1
+                if stats['t_first'] is None and stats['rows'] >= 2 * int(self.cfg.test_batch_size):
+                    stats['t_first'], stats['rows_first'] = time.perf_counter(), stats['rows']
+                yield row
+        tsv_writer(timed_rows(), sub)               # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
+        if stats['t_first'] is not None and stats['rows'] > stats['rows_first']:
+            dt = time.perf_counter() - stats['t_first']
+            LAST_PREDICT_STATS.update(rows=stats['rows'], steady_rows=stats['rows'] - stats['rows_first'], steady_seconds=dt,
+                                      images_per_sec=(stats['rows'] - stats['rows_first']) / dt)
+            logging.info('predict: %d rows, steady state %.1f images/sec on rank %d', stats['rows'], LAST_PREDICT_STATS['images_per_sec'], self.rank)
         if self.world > 1:
             import torch.distributed as dist
             dist.barrier()
