@@ -6,9 +6,11 @@ R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
 python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/tests_$TAG.log
+python -m pytest tests/test_hip_e2e.py -m gpu -q -s -k population 2>&1 | grep "population" > gpurun_out/population_$TAG.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 fi
-python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+python bench.py --steps 200 --warmup 5 --no-cpu-baseline > gpurun_out/bench_long_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 50 --warmup 3 --pipeline 0 --no-cpu-baseline > gpurun_out/bench_seq_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 20 --warmup 2 --beams 5 --batch 256 --graph 1 --no-cpu-baseline > gpurun_out/bench_beam5_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 30 --warmup 3 --mode train > gpurun_out/bench_train_$TAG.json 2>> gpurun_out/bench_$TAG.err
@@ -18,17 +20,22 @@ python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.j
 python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
 (python tools/library_yardstick.py; python tools/library_yardstick.py 295424) 2>&1 | grep -v amdgpu.ids > gpurun_out/library_yardstick_$TAG.txt
+(for f in 1 2; do for m in 36928 295424; do tools/probes/_bin/g4w_probe $m $f; done; done) 2>&1 | cut -c1-260 > gpurun_out/g4w_probe_$TAG.txt
+python tools/exact_rate.py 2>&1 | grep EXACT > gpurun_out/exact_rate_$TAG.txt
+python tools/input_side_bench.py 8192 gpurun_out/input_side_$TAG.json > gpurun_out/input_side_$TAG.log 2>&1
 bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
+bash tools/pmc_traffic.sh ${TAG}_b512 "--batch 512" > gpurun_out/traffic_${TAG}_b512.log 2>&1
 bash tools/pmc_hot.sh $TAG > gpurun_out/pmc_hot_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline --single-region > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline --single-region >> $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o train -- python3 $R/bench.py --steps 3 --warmup 1 --mode train >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o b512 -- python3 $R/bench.py --steps 6 --warmup 2 --batch 512 --isolated 0 --no-cpu-baseline --single-region >> $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
-for k in pipe seq train; do
+for k in pipe seq train b512; do
 DB=$(find gpurun_out/prof_$TAG -name "${k}_results.db" | head -1)
-python tools/rocprof_summary.py "$DB" "bench.py ($k), B=64" > gpurun_out/prof_${TAG}_${k}.md 2>&1 || true
+python tools/rocprof_summary.py "$DB" "bench.py ($k)" > gpurun_out/prof_${TAG}_${k}.md 2>&1 || true
 done
 # raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
-rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_$TAG gpurun_out/traffic_${TAG}_FETCH_SIZE gpurun_out/traffic_${TAG}_WRITE_SIZE
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_$TAG gpurun_out/traffic_${TAG}_FETCH_SIZE gpurun_out/traffic_${TAG}_WRITE_SIZE gpurun_out/traffic_${TAG}_b512_FETCH_SIZE gpurun_out/traffic_${TAG}_b512_WRITE_SIZE
 du -sh gpurun_out | tail -1

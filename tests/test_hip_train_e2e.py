@@ -61,6 +61,48 @@ def test_gradients_per_tensor(run):
     assert not bad, bad[:5]
 
 
+def test_loss_trajectory_five_steps(sd_t):
+    """not one step but a trajectory.  Five cross-entropy steps (B = 2, five different synthetic batches, dropout
+    off, max_iter 10: the learning rate decays every step) on the device against the oracle's trainer restatement
+    (O.train_step_as_written carrying its AdamW state: trainer.py:95-142, solver AdamW, WarmupLinearSchedule) started from the same
+    weights.  Asserted: the loss of every step within 5e-3 of the oracle's (bf16 forward vs fp32; the first step's own tolerance is
+    2e-3) and the loss CHANGES from step to step within 30 % of the oracle's changes where those exceed the noise -- i.e. the updates
+    move the model the way the reference's optimizer does, not merely the first forward pass."""
+    from oracle import vitcap_oracle as O
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.train import TrainEngine
+    B, steps = 2, 5
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    sd = {k: v.clone() for k, v in sd_t.items()}
+    state = None
+    ref_losses, dev_losses = [], []
+    for it in range(1, steps + 1):
+        img = torch.from_numpy(W.gen_image_batch(B, 5000 + it))
+        batch = O.synthetic_train_inputs(B, seed=100 + it)
+        ref = O.train_step_as_written(sd, img, batch, step=it, max_iter=10, state=state)
+        state = ref['state']
+        # the oracle ties the LM head to the word embedding by object identity: keep that while carrying the parameters over
+        new, seen = {}, {}
+        for k, t in sd.items():
+            if id(t) not in seen:
+                seen[id(t)] = ref['params'][k]
+            new[k] = seen[id(t)]
+        sd = new
+        ref_losses.append(ref['loss'])
+        db = {k: v.cuda() for k, v in batch.items()}
+        db['image'] = img.cuda()
+        dev_losses.append(float(eng.train_step(db)['masked_loss']))
+    torch.cuda.synchronize()
+    print('loss trajectory  oracle:', ['%.4f' % x for x in ref_losses], ' device:', ['%.4f' % x for x in dev_losses])
+    for it, (a, b) in enumerate(zip(dev_losses, ref_losses)):
+        assert abs(a - b) < 5e-3, (it, a, b)
+    for it in range(1, steps):
+        d_ref, d_dev = ref_losses[it] - ref_losses[it - 1], dev_losses[it] - dev_losses[it - 1]
+        if abs(d_ref) > 2e-2:
+            assert abs(d_dev - d_ref) < 0.3 * abs(d_ref) + 5e-3, (it, d_dev, d_ref)
+
+
 def test_parameter_update(run):
     """Adam's first step is lr*sign(g) wherever |g| >> eps, so comparing updates computed from two slightly different
     gradients is ill-conditioned (e.g. key biases have a mathematically zero gradient).  The update rule and the

@@ -42,7 +42,7 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if res else torch.bfloat16)
         gf = 2.0 * M * N * K / 1e9
         rows = []
-        for label, hint in (('ours 256-row tiles', 5), ('ours planned mix', 33)):
+        for label, hint in (('ours 8-wave 256-row tiles', 32), ('ours 8-wave planned mix', 33), ('ours 4-wave one tile', 41), ('ours 4-wave persistent', 42)):
             us = timed(lambda: ops.gemm_bias_act(a, w, bias, residual=r, act=act, out=out, tile_hint=hint))
             rows.append('%s %.1f us %.0f TF' % (label, us, gf / us * 1e3))
         o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

@@ -157,7 +157,11 @@ __device__ __forceinline__ void half_step(f32x4 (&acc)[MI][8], Frags& f, const L
   if constexpr (FIRST) mfma_zero(acc[S / 8][S % 8], f.w[H][S % 8], f.a[H][S / 8]);
   else mfma_acc(acc[S / 8][S % 8], f.w[H][S % 8], f.a[H][S / 8]);
   if constexpr (MODE == 1 || MODE == 4) {
+#ifdef VC_4W_DMA_DENSE          // probe: the tile's pieces behind the first MFMAs of the half (one per VC_4W_DMA_DENSE MFMAs) instead of spread over it
+    if constexpr (S % VC_4W_DMA_DENSE == 0 && S / VC_4W_DMA_DENSE < NOPS) dma_piece<MI, S / VC_4W_DMA_DENSE>(L, src, bufoff, kb);
+#else
     if constexpr (S % STRIDE == 0 && S / STRIDE < NOPS) dma_piece<MI, S / STRIDE>(L, src, bufoff, kb);
+#endif
   }
   if constexpr (MODE != 3 && MODE != 4) {
     constexpr int PH = STRIDE > 1 ? 1 : 0;

@@ -83,13 +83,8 @@ class TagLabelTensorizer(object):
                         v[self._id(t)] = 1
         if caption is not None:
             if self.encode == 'nltk':
-                if self.pos_tagger is None:          # the reference's own tagger where it is installed (dataset.py:801-804)
-                    try:
-                        import nltk
-                        self.pos_tagger = lambda c: nltk.pos_tag(nltk.word_tokenize(c))
-                    except ImportError:
-                        raise RuntimeError("encode='nltk' needs nltk.word_tokenize + nltk.pos_tag, which are not installed here: "
-                                           "pass pos_tagger=callable(caption) -> [(word, tag)] or set encode: bert")
+                if self.pos_tagger is None:
+                    self.pos_tagger = resolve_nltk_tagger()
                 for word, pos in self.pos_tagger(caption):
                     if pos in ('JJ', 'NN', 'NNP'):
                         for t in word.split(' '):
@@ -98,6 +93,26 @@ class TagLabelTensorizer(object):
                 for i in self.tok.convert_tokens_to_ids(self.tok.tokenize(caption)):
                     v[i] = 1
         return {'label': v}
+
+
+def nltk_pos_tag(caption):
+    """The reference's own tagger (dataset.py:801-804).  A module-level function: the tensorizer stays picklable (spawned loader
+    workers, copy.deepcopy)."""
+    import nltk
+    return nltk.pos_tag(nltk.word_tokenize(caption))
+
+
+def resolve_nltk_tagger():
+    """encode='nltk': nltk AND its punkt / averaged_perceptron_tagger data must be there -- probed once on a dummy caption, so that a
+    missing package (ImportError) or missing data (LookupError, raised inside the loader thread on the first caption otherwise)
+    both give the same explanation."""
+    try:
+        nltk_pos_tag('a dog on a bench')
+    except (ImportError, LookupError) as e:
+        raise RuntimeError("encode='nltk' needs nltk.word_tokenize + nltk.pos_tag and their data (punkt, averaged_perceptron_tagger), "
+                           "which are not usable here (%s: %s): pass pos_tagger=callable(caption) -> [(word, tag)] or set encode: bert"
+                           % (type(e).__name__, str(e).strip().splitlines()[0] if str(e).strip() else ''))
+    return nltk_pos_tag
 
 
 class CaptionTrainSet(object):

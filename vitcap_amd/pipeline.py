@@ -402,10 +402,12 @@ class CaptionUniPipeline(object):
                              self.world * n * per_gpu / dt)
                 t0 = time.time()
             if it % int(self.cfg.snapshot_steps) == 0 or it == max_iter:
+                eng.flush_text_check()          # no snapshot from steps trained on a mask the kernels do not implement
                 ckpt.save('model_iter_{:07d}'.format(it), iteration=it)
             if self.cfg.stop_after_iter is not None and it >= int(self.cfg.stop_after_iter):
                 logging.info('stop_after_iter=%s: leaving the training loop early (resume test / pre-emption drill)', self.cfg.stop_after_iter)
                 break
+        eng.flush_text_check()                  # the steps since the last periodic read
         if dist is not None:
             dist.barrier()      # uni_pipeline.py:376 synchronize(): no rank may reach ensure_predict before rank 0's final snapshot exists
         return self.get_checkpoint_file(iteration=max_iter)
@@ -556,17 +558,26 @@ class CaptionUniPipeline(object):
                 popts[n_tag] = base if n_tag == base.tag_visible else model.gen_options(gemm_mode=1, tag_visible=n_tag)
             return popts[n_tag]
 
+        seen = {'n': None}                        # visible tag slots of the last batch whose text tensors live on the device
+
         def collect(entry):
             b, out, flag = entry
             out = out.result() if overlap else out          # synchronises with the batch's decode stream
             if flag is not None and not bool(flag):
-                raise NotImplementedError('a batch\'s attention_mask / token_type_ids on the device do not describe the mask structure '
-                                          'the HIP engine implements (ImageCaptioning.check_text_inputs)')
+                # the device-side comparison against the count of the earlier batches failed: either this batch's (valid) mask shows
+                # another number of visible tag slots -- then it is decoded again with the options of ITS count, as a host-resident
+                # batch would have been from the start -- or the mask is not one the engine implements
+                n_tag = model.check_text_inputs(b, base.max_length)         # raises NotImplementedError for an unsupported mask
+                if n_tag == seen['n']:
+                    raise NotImplementedError('a batch\'s attention_mask / token_type_ids on the device do not describe the mask structure '
+                                              'the HIP engine implements (ImageCaptioning.check_text_inputs)')
+                logging.info('visible tag slots changed from %s to %d: batch decoded again with its own options', seen['n'], n_tag)
+                seen['n'] = n_tag
+                out = model.generate_async(b['image'], opts=opts_for(n_tag)).result()
             return self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu()))
 
         def gen_rows():
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
-            n_seen = None                         # visible tag slots of the first batch whose text tensors live on the device
             with torch.no_grad():
                 for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or 2)):
                     batch = dict(batch)
@@ -578,12 +589,12 @@ class CaptionUniPipeline(object):
                         # their stream and the verdict is read when the batch's captions are collected -- nothing stalls the
                         # 2-slot pipeline
                         am = batch.get('attention_mask')
-                        if am is not None and am.is_cuda and n_seen is not None:
-                            n_tag, flag = model.check_text_inputs(batch, base.max_length, expect_n_tag=n_seen)
+                        if am is not None and am.is_cuda and seen['n'] is not None:
+                            n_tag, flag = model.check_text_inputs(batch, base.max_length, expect_n_tag=seen['n'])
                         else:
                             n_tag = model.check_text_inputs(batch, base.max_length)
                             if am is not None and am.is_cuda:
-                                n_seen = n_tag
+                                seen['n'] = n_tag
                         out = model.generate_async(batch['image'], opts=opts_for(n_tag))
                     else:
                         out = model(batch)

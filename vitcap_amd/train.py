@@ -293,8 +293,17 @@ class TrainEngine(object):
         if getattr(self, '_text_bad', None) is None:
             self._text_bad = torch.zeros((), dtype=torch.int32, device=ok.device)
         self._text_bad += (~ok).to(torch.int32)
-        if self.step_no % 50 == 49 and int(self._text_bad) != 0:
-            raise NotImplementedError('a training batch of the last 50 steps carried an attention_mask / masked_pos the HIP '
+        if self.step_no % 50 == 49:
+            self.flush_text_check()
+
+    def flush_text_check(self):
+        """Reads the device-side counter of batches whose text tensors the kernels do not implement (one host synchronisation).
+        Called every 50 steps, and by the pipeline before every checkpoint it saves and after the last step (otherwise a
+        snapshot could be written from up to 49 steps trained on the hard-wired mask, and the final steps were never reported)."""
+        bad = getattr(self, '_text_bad', None)
+        if bad is not None and int(bad) != 0:
+            self._text_bad = None
+            raise NotImplementedError('a training batch since the last check carried an attention_mask / masked_pos the HIP '
                                       'training kernels do not implement (TrainEngine.check_text_inputs)')
 
     # ------------------------------------------------------------------ views
