@@ -537,6 +537,13 @@ int vitcap_layernorm_bwd(const float* x, int ldx, const void* dy, int dy_is_f32,
  * output gradient dx is; what vitcap_colsum_bf16(dx_bf16) would add). */
 int vitcap_reduce_slabs(const float* slabs, size_t slab_stride, int S, float* out, size_t n, int accumulate, void* stream);
 int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream);
+/* Hidden-state dropout of the BERT parts in training mode -- nn.Dropout(config.hidden_dropout_prob) in BertEmbeddings
+ * (modeling_bert.py:236), BertSelfOutput (:355) and BertOutput (:417); the pipeline's `drop_out`:
+ *   out[m][d] = x[m][d] * keep / (1 - p) (+ residual[m][d]); keep is a counter-based function of (seed, m / rows_per_seq,
+ *   row0 + m % rows_per_seq, d), recomputed (not stored) by the backward pass, which is the same call on the gradient: dx = dy * keep / (1 - p).
+ * x, residual (or NULL), out: fp32 [M][768]; out may alias x. */
+int vitcap_hidden_dropout(const float* x, const float* residual, float* out, int M, int D, int rows_per_seq, int row0,
+                          uint32_t seed, float p, void* stream);
 /* the same over [M][768] rows, with colsum[c] += sum over rows of the ROUNDED values (cast + vitcap_colsum_bf16 in one pass) */
 int vitcap_cast_bf16_colsum(const float* x, void* y, float* colsum, int M, int D, void* stream);
 /* BertEmbeddings backward: scatter-add into word / position / token-type gradient tables (modeling_bert.py:230-234) */

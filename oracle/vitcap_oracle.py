@@ -164,9 +164,11 @@ def encode_tag_to_embedding(sd, pred_topk, cls_emb_weight=None, caption_len=20):
 # --------------------------------------------------------------------------------------------
 # a9  post-LN BERT layer   (modeling_bert.py:275-437)
 # --------------------------------------------------------------------------------------------
-def bert_layer(sd, p, x, ext_mask, keep=None, p_drop=0.0):
+def bert_layer(sd, p, x, ext_mask, keep=None, p_drop=0.0, hid=None, p_hid=0.0):
     """``keep`` (B,12,S,S) bool + ``p_drop``: the training-mode dropout on the attention probabilities
-    (modeling_bert.py:330-333) with the keep decisions made explicit."""
+    (modeling_bert.py:330-333) with the keep decisions made explicit.  ``hid`` = (m_attention_output, m_output), each a (B,S,768)
+    multiplier (keep / (1 - p), hidden_keep_joint): nn.Dropout(hidden_dropout_prob) on the two dense outputs (BertSelfOutput :355,
+    BertOutput :417)."""
     B, S, _ = x.shape
 
     def heads(t):
@@ -180,9 +182,15 @@ def bert_layer(sd, p, x, ext_mask, keep=None, p_drop=0.0):
     if keep is not None:
         pr = pr * keep.to(pr.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p_drop)))
     ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).contiguous().view(B, S, HID)
-    a = _ln(sd, p + '.attention.output.LayerNorm', _lin(sd, p + '.attention.output.dense', ctx) + x, 1e-12)
+    ao = _lin(sd, p + '.attention.output.dense', ctx)
+    if hid is not None:
+        ao = ao * hid[0].to(ao.dtype)
+    a = _ln(sd, p + '.attention.output.LayerNorm', ao + x, 1e-12)
     i = gelu_erf(_lin(sd, p + '.intermediate.dense', a))
-    return _ln(sd, p + '.output.LayerNorm', _lin(sd, p + '.output.dense', i) + a, 1e-12)
+    o = _lin(sd, p + '.output.dense', i)
+    if hid is not None:
+        o = o * hid[1].to(o.dtype)
+    return _ln(sd, p + '.output.LayerNorm', o + a, 1e-12)
 
 
 # --------------------------------------------------------------------------------------------
@@ -221,7 +229,7 @@ def construct_attn_mask(attention_mask, num_img_feats):
 # ViTSplitCLSEmbModel.forward as written   (modeling_bert.py:1408-1516)
 # --------------------------------------------------------------------------------------------
 def joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_type_ids,
-                  tagemb='cls', topk=50, enc=None, attn_keep=None, p_drop=0.0):
+                  tagemb='cls', topk=50, enc=None, attn_keep=None, p_drop=0.0, hid_keep=None, p_hid=0.0):
     """Returns (sequence_output (B,S,768), tag_logit (B,V)).  ``enc`` may carry a precomputed
     (hidden, tag_hidden) pair -- the encoder is a pure function of img_feats."""
     input_ids = input_ids.clone()
@@ -253,10 +261,13 @@ def joint_forward(sd, input_ids, img_feats, attention_mask, position_ids, token_
     am = torch.cat([attention_mask, attention_mask[:, -1].unsqueeze(1)], dim=1)
     am = torch.cat([am, torch.ones(am.shape[0], am.shape[1], 1)], dim=2)
     ext = (1.0 - am.unsqueeze(1)) * -10000.0                                 # :1498-1501
+    if hid_keep is not None:              # BertEmbeddings.dropout on the text rows (:236); the encoder rows are concatenated after it
+        emb = emb * hid_keep['emb'].to(emb.dtype)
     x = torch.cat((emb, enc_out), 1)
     for i in range(4):
         x = bert_layer(sd, 'module.bert.decoder.layer.%d' % i, x, ext,
-                       None if attn_keep is None else attn_keep[i], p_drop)
+                       None if attn_keep is None else attn_keep[i], p_drop,
+                       None if hid_keep is None else (hid_keep['ao'][i], hid_keep['out'][i]), p_hid)
     return x, logit
 
 
@@ -924,7 +935,41 @@ def dropout_keep_joint(layer_seed, B, p_drop, n_text=70, max_len=MAX_LEN, n_vis=
     return torch.from_numpy(keep)
 
 
-def train_losses_as_written(sd, image, batch, tagemb='cls', layer_seeds=None, p_drop=0.0):
+def hidden_keep(seed, B, p, rows=598, D=HID):
+    """Keep decisions (B, rows, 768) bool of vitcap_hidden_dropout (csrc/train.hip) for one site: rows in the device's
+    [578 visual | text] order; stream = vc_drop_stream(seed, b, 0x48), keep iff lowbias32(stream ^ (row << 10) ^ col) >= p * 2^32."""
+    thr = np.uint32(int(float(np.float32(p)) * 4294967296.0))
+    r = (np.arange(rows, dtype=np.uint32)[:, None] << np.uint32(10))
+    d = np.arange(D, dtype=np.uint32)[None, :]
+    out = np.empty((B, rows, D), dtype=bool)
+    for b in range(B):
+        stream = rng_mix(rng_mix(np.uint32(seed & 0xffffffff), np.uint32(b)), np.uint32(0x48))
+        out[b] = _lowbias32(stream ^ r ^ d) >= thr
+    return out
+
+
+def hidden_keep_joint(hseed, B, p, n_text=70, max_len=MAX_LEN, n_vis=578):
+    """All hidden-dropout sites of one training forward, re-indexed to the reference's joint sequence [70 text | tag CLS | 577 visual]
+    (``hseed(layer, site)`` as TrainEngine derives its seeds: site 1 attention.output, 2 output, layer 4 / site 3 the embeddings).
+    Returned as multipliers keep / (1 - p); the 50 tag / padding text slots have no device counterpart and cannot reach the loss: 1."""
+    S = n_text + n_vis
+    dev = np.full(S, -1, dtype=np.int64)
+    dev[:max_len] = n_vis + np.arange(max_len)
+    dev[n_text:] = np.arange(n_vis)
+    idx = np.where(dev >= 0)[0]
+
+    hs = np.float32(1.0) / (np.float32(1.0) - np.float32(p))          # the kernel's fp32 scale
+
+    def site(l, kind):
+        k = hidden_keep(hseed(l, kind), B, p, n_vis + max_len)
+        full = np.ones((B, S, HID), dtype=np.float32)                 # multiplier: keep / (1 - p) where the device has the row, else 1
+        full[:, idx] = k[:, dev[idx]].astype(np.float32) * hs
+        return torch.from_numpy(full)
+    emb = site(4, 3)[:, :n_text]
+    return {'emb': emb, 'ao': [site(l, 1) for l in range(4)], 'out': [site(l, 2) for l in range(4)]}
+
+
+def train_losses_as_written(sd, image, batch, tagemb='cls', layer_seeds=None, p_drop=0.0, hseed=None, p_hid=0.0):
     """ImageCaptioning.forward(train) -> ViTCAP.encode_forward(is_training=True): the full 648-row joint sequence.
     ``layer_seeds`` (4 ints) + ``p_drop`` switch the decoder's attention dropout on with the device's keep decisions;
     None = dropout off.  Returns (masked_loss, tag_loss, class_logits)."""
@@ -933,8 +978,11 @@ def train_losses_as_written(sd, image, batch, tagemb='cls', layer_seeds=None, p_
     keep = None
     if layer_seeds is not None:
         keep = [dropout_keep_joint(sv, image.shape[0], p_drop, n_text=batch['input_ids'].shape[1]) for sv in layer_seeds]
+    hk = None
+    if hseed is not None and p_hid > 0:       # hidden-state dropout with the device's keep decisions (hseed: (layer, site) -> seed)
+        hk = hidden_keep_joint(hseed, image.shape[0], p_hid, n_text=batch['input_ids'].shape[1])
     seq, tag_logit = joint_forward(sd, batch['input_ids'], img_feats, full, None, batch['token_type_ids'], tagemb,
-                                   attn_keep=keep, p_drop=p_drop)
+                                   attn_keep=keep, p_drop=p_drop, hid_keep=hk, p_hid=p_hid)
     T = batch['masked_pos'].shape[-1]
     rows = seq[:, :T][batch['masked_pos'] == 1]
     class_logits = lm_head(sd, 'module.cls', rows)
@@ -976,7 +1024,7 @@ def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
 
 
 def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, clip=1.0, state=None, layer_seeds=None,
-                          p_drop=0.0):
+                          p_drop=0.0, hseed=None, p_hid=0.0):
     """One do_train_dict iteration (trainer.py:95-142) on a dict of leaf tensors: forward, backward, global-norm clip over
     ALL parameters, AdamW over the optimizer's groups, linear LR decay.  Returns dict(loss, tag_loss, grad_norm, grads)."""
     leaves = {}
@@ -985,7 +1033,7 @@ def train_step_as_written(sd, image, batch, step=1, max_iter=10, base_lr=1e-4, c
         if id(t) not in seen:
             seen[id(t)] = t.detach().clone().requires_grad_(True)
         leaves[k] = seen[id(t)]
-    loss, tag_loss, _ = train_losses_as_written(leaves, image, batch, layer_seeds=layer_seeds, p_drop=p_drop)
+    loss, tag_loss, _ = train_losses_as_written(leaves, image, batch, layer_seeds=layer_seeds, p_drop=p_drop, hseed=hseed, p_hid=p_hid)
     loss.backward()
     uniq = {}
     for k, t in leaves.items():

@@ -68,8 +68,9 @@ def test_detokenizer_matches_reference_rules():
 
 def test_unbuilt_model_variants_are_refused():
     """A configuration that names a model variant or training rule this build does not implement is refused, not run as if the key
-    had not been said: another ViT, tag-branch depth, top-k, tied tag head, mask family, optimizer / schedule; training needs
-    `drop_out: 0` as in the shipped YAML (cfg.drop_out is BertConfig.hidden_dropout_prob, ..._bertemb.py:535; default 0.1)."""
+    had not been said: another ViT, tag-branch depth, top-k, tied tag head, mask family, optimizer / schedule.  `drop_out`
+    (BertConfig.hidden_dropout_prob, ..._bertemb.py:535; 0 in the shipped YAML, 0.1 by the pipeline's own default) is built since round 4
+    and accepted as a probability."""
     import pytest
     import yaml
     from vitcap_amd.pipeline import CaptionUniPipeline, check_model_config
@@ -93,11 +94,10 @@ def test_unbuilt_model_variants_are_refused():
                 {'use_img_layernorm': True}, {'ln_no_weight_decay': False}, {'category': 'vinvl'}, {'train_transform': 'inception'}, {'use_amp': True}):
         with pytest.raises(NotImplementedError, match=list(bad)[0]):
             check_model_config(CaptionUniPipeline(**dict(shipped, **bad)).cfg, training=False)
-    with pytest.raises(NotImplementedError, match='drop_out'):
-        check_model_config(CaptionUniPipeline().cfg, training=True)               # the pipeline's own default is 0.1
-    with pytest.raises(NotImplementedError, match='drop_out'):
-        CaptionUniPipeline(drop_out=0.1, init_recipe_seed=0).ensure_train()
+    check_model_config(CaptionUniPipeline().cfg, training=True)                   # the pipeline's own default drop_out = 0.1: hidden-state dropout
     check_model_config(CaptionUniPipeline(drop_out=0.1).cfg, training=False)      # inference: dropout is inactive
+    with pytest.raises(ValueError, match='drop_out'):
+        check_model_config(CaptionUniPipeline(drop_out=1.5).cfg, training=True)
 
 
 def test_text_encoder_config_is_checked(tmp_path):

@@ -109,6 +109,7 @@ _SIGS = {
     'vitcap_layernorm_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_reduce_slabs': (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp]),
     'vitcap_cast_bf16': (C.c_int, [vp, vp, C.c_size_t, vp]),
+    'vitcap_hidden_dropout': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_float, vp]),
     'vitcap_cast_bf16_colsum': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_embed_bwd': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_ls_kl_loss': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, vp]),

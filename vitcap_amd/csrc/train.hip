@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -698,5 +699,42 @@ extern "C" int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bf16, (bf16_t*)wt_bf16, N, K,
                      ldt);
   VC_LAUNCH_CHECK("cast_transpose");
+  return VITCAP_OK;
+}
+
+
+// ---- hidden-state dropout of the BERT parts in training (BertEmbeddings modeling_bert.py:236, BertSelfOutput :355, BertOutput :417;
+// BertConfig.hidden_dropout_prob = the pipeline's `drop_out`, 0 in the shipped YAML, 0.1 by the pipeline's own default):
+//   out[m][d] = x[m][d] * keep(b, r, d) / (1 - p) (+ residual[m][d]),   b = m / rows_per_seq, r = row0 + m % rows_per_seq
+// keep is a pure function of (seed, b, r, d) (csrc/rng.h), so the backward pass recomputes it from the same seed -- no mask is stored
+// -- and the CPU oracle replays it (oracle.hidden_keep).  The same entry point serves the backward pass: dx = dy * keep / (1 - p).
+namespace {
+__global__ __launch_bounds__(256) void hidden_dropout_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                                           int M, int rows_per_seq, int row0, uint32_t seed, uint32_t thr, float scale) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;          // one float4 per thread: 192 per row
+  const int m = gid / 192, c4 = gid - m * 192;
+  if (m >= M) return;
+  const int b = m / rows_per_seq, r = row0 + (m - b * rows_per_seq);
+  const uint32_t stream = vc_drop_stream(seed, (uint32_t)b, 0x48u);
+  const size_t off = (size_t)m * D768 + c4 * 4;
+  f32x4 v = *(const f32x4*)(x + off);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = vc_drop_keep(stream, (uint32_t)r, (uint32_t)(c4 * 4 + e), thr) ? v[e] * scale : 0.f;
+  if (res) v += *(const f32x4*)(res + off);
+  *(f32x4*)(out + off) = v;
+}
+}  // namespace
+
+extern "C" int vitcap_hidden_dropout(const float* x, const float* residual, float* out, int M, int D, int rows_per_seq, int row0,
+                                     uint32_t seed, float p, void* stream) {
+  VC_REQUIRE(x && out && M > 0 && D == D768 && rows_per_seq > 0 && row0 >= 0 && row0 + rows_per_seq <= 1024,
+             "hidden_dropout: bad arguments (D must be 768, rows of a sequence < 1024)");
+  VC_REQUIRE(p >= 0.f && p < 1.f, "hidden_dropout: p must be in [0, 1)");
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p);
+  const long long n4 = (long long)M * 192;
+  hipLaunchKernelGGL(hidden_dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, residual, out, M,
+                     rows_per_seq, row0, seed, thr, scale);
+  VC_LAUNCH_CHECK("hidden_dropout");
   return VITCAP_OK;
 }

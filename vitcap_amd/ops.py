@@ -324,6 +324,17 @@ def cast_bf16(x):
     return y
 
 
+def hidden_dropout(x, residual, rows_per_seq, row0, seed, p, out=None):
+    """out = x * keep / (1 - p) (+ residual): nn.Dropout(hidden_dropout_prob) of the BERT parts, counter-based mask (csrc/train.hip)."""
+    _dev_f32(x)
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vitcap_hidden_dropout(_p(x), _p(residual), _p(out), M, D, int(rows_per_seq), int(row0), int(seed) & 0xffffffff, float(p),
+                                    _stream()), 'hidden_dropout')
+    return out
+
+
 def cast_bf16_colsum(x, colsum):
     """bf16 copy of fp32 x [M][768] and colsum[c] += sum_m bf16(x)[m][c] in one pass (cast_bf16 + colsum_bf16)."""
     _dev_f32(x); _dev_f32(colsum)

@@ -106,18 +106,16 @@ _BUILT_FOR = (
 
 
 def check_model_config(cfg, training):
-    """Refuses configurations that name a model variant or training rule this build does not implement (see _BUILT_FOR).  Training
-    additionally needs `drop_out: 0` as in the shipped YAML: cfg.drop_out becomes BertConfig.hidden_dropout_prob
-    (..._bertemb.py:535; the pipeline's own default is 0.1) and hidden-state dropout is not built -- only the decoder's attention
-    dropout (attention_probs_dropout_prob) is."""
+    """Refuses configurations that name a model variant or training rule this build does not implement (see _BUILT_FOR).
+    `drop_out` (-> BertConfig.hidden_dropout_prob, ..._bertemb.py:535; 0 in the shipped YAML, 0.1 by the pipeline's own default) is
+    built since round 4 (TrainEngine(hidden_dropout=...), csrc/train.hip vitcap_hidden_dropout); it must be a probability."""
     check_text_encoder_config(cfg.text_encoder_type)
     given = cfg.overwrite
     for key, ok, what in _BUILT_FOR:
         if key in given and given[key] not in ok:
             raise NotImplementedError('%s: %r is not built (accepted: %s) -- %s' % (key, given[key], ', '.join(repr(v) for v in ok), what))
-    if training and float(cfg.drop_out or 0) != 0:
-        raise NotImplementedError('drop_out: %r -- hidden-state dropout (BertConfig.hidden_dropout_prob, ..._bertemb.py:535) is not built; '
-                                  'the shipped YAML trains with drop_out: 0 (the pipeline\'s own default is 0.1)' % (cfg.drop_out,))
+    if training and not (0.0 <= float(cfg.drop_out or 0) < 1.0):
+        raise ValueError('drop_out: %r is not a dropout probability' % (cfg.drop_out,))
 
 
 _BERT_CONFIG_BUILT = {   # BertConfig fields of <text_encoder_type>/config.json the kernels are sized for (the shipped VILT-L12-H784 values)
@@ -366,7 +364,7 @@ class CaptionUniPipeline(object):
         eng = TrainEngine(model, dev, base_lr=float(self.cfg.base_lr), weight_decay=float(self.cfg.weight_decay),
                           lr_multiplier=float(self.cfg.lr_multiplier or 1.0), clip=float(self.cfg.gradient_clip),
                           max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist,
-                          attn_dropout=attn_drop, dropout_seed=int(self.cfg.random_seed or 0),
+                          attn_dropout=attn_drop, hidden_dropout=float(self.cfg.drop_out or 0), dropout_seed=int(self.cfg.random_seed or 0),
                           tag_loss='focal' if self.cfg.loss == 'focal' else 'bce')     # modeling_bert.py:713-717
         per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
         ckpt = Checkpointer(model=_EngineState(eng), optimizer=_EngineState(eng, 'optimizer'),

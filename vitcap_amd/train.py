@@ -222,7 +222,7 @@ class _FusedLoss(torch.autograd.Function):
 
 class TrainEngine(object):
     def __init__(self, model, device='cuda', base_lr=1e-4, weight_decay=0.05, lr_multiplier=0.1, clip=1.0, max_iter=1000,
-                 label_smoothing=0.1, dist=None, attn_dropout=0.1, dropout_seed=0, tag_loss='focal'):
+                 label_smoothing=0.1, dist=None, attn_dropout=0.1, dropout_seed=0, tag_loss='focal', hidden_dropout=0.0):
         """tag_loss: 'focal' (the shipped YAML's `loss: focal`: summed focal loss) or 'bce' (any other `loss`: BCEWithLogitsLoss mean,
         modeling_bert.py:713-717) -- the reported `tag_loss`, never back-propagated by this pipeline."""
         if tag_loss not in ('focal', 'bce'):
@@ -235,6 +235,7 @@ class TrainEngine(object):
         self.clip, self.max_iter, self.eps_ls = clip, max_iter, label_smoothing
         self.dist = dist
         self.attn_dropout = float(attn_dropout)
+        self.hidden_dropout = float(hidden_dropout)     # BertConfig.hidden_dropout_prob (the pipeline's drop_out): embeddings, both dense outputs per layer
         # outputs nobody reads are not computed: rows 1..576 of the last tag block, the visual rows of the last decoder layer
         # (forward and backward; same loss and gradients).  VITCAP_TRAIN_FULL_ROWS=1 computes them anyway (A/B measurements).
         self.prune_dead_rows = os.environ.get('VITCAP_TRAIN_FULL_ROWS', '0') != '1'
@@ -628,6 +629,12 @@ class TrainEngine(object):
         check(lib.vitcap_embed_rows(_p(ids20), TT, _p(self.wb('word')), _p(self.wb('pos')), _p(self.wb('type')),
                                     _p(self.vec(e + '.LayerNorm.weight')), _p(self.vec(e + '.LayerNorm.bias')), 1e-12,
                                     _p(pre_emb), _p(xtext), None, B * TT, T if scst else 0, _s()), 'embed_rows')
+        ph = self.hidden_dropout
+
+        def hseed(l, site):            # per step, per layer (4 = embeddings), per site (1 attention.output, 2 output, 3 embeddings)
+            return mix32(mix32(mix32(self.dropout_seed, self.step_no), 16 + l), site)
+        if ph > 0:                     # BertEmbeddings: dropout(LayerNorm(...)) on the text rows (device rows SV .. SV + TT - 1 of a sequence)
+            ops.hidden_dropout(xtext, None, TT, SV, hseed(4, 3), ph, out=xtext)
         dx = torch.empty(B, LR, 768, device=dev)
         dx[:, 0] = xt_cls if KS == 1 else xt_cls.repeat_interleave(KS, 0)
         dx[:, 1:SV] = x.view(Be, NV, 768) if KS == 1 else x.view(Be, NV, 768).repeat_interleave(KS, 0)
@@ -649,13 +656,21 @@ class TrainEngine(object):
                 ctx_t = ctx.view(B, LR, 768)[:, SV:].reshape(B * TT, 768).contiguous()
                 xd_t = xd.view(B, LR, 768)[:, SV:].reshape(B * TT, 768).contiguous()
                 t1 = torch.empty(B * TT, 768, device=dev)
-                ops.gemm_bias_act(ctx_t, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd_t, out=t1)
+                if ph > 0:      # BertSelfOutput: LayerNorm(dropout(dense(ctx)) + x)
+                    ops.gemm_bias_act(ctx_t, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), out=t1)
+                    ops.hidden_dropout(t1, xd_t, TT, SV, hseed(l, 1), ph, out=t1)
+                else:
+                    ops.gemm_bias_act(ctx_t, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd_t, out=t1)
                 ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
                                        self.vec(pre + '.attention.output.LayerNorm.bias'), 1e-12, want_f32=True)
                 z = torch.empty(B * TT, 3072, device=dev, dtype=torch.bfloat16)
                 it = ops.gemm_ex(ab, self.wb(pre + '.i'), bias=self.vec(pre + '.intermediate.dense.bias'), act=L.ACT_GELU_ERF, zout=z)
                 t2 = torch.empty(B * TT, 768, device=dev)
-                ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
+                if ph > 0:      # BertOutput: LayerNorm(dropout(dense(intermediate)) + attention_output)
+                    ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), out=t2)
+                    ops.hidden_dropout(t2, af, TT, SV, hseed(l, 2), ph, out=t2)
+                else:
+                    ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
                 _, text_out = ops.layernorm(t2, self.vec(pre + '.output.LayerNorm.weight'), self.vec(pre + '.output.LayerNorm.bias'),
                                             1e-12, want_bf16=False, want_f32=True)
                 dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2, ctx_t))
@@ -664,13 +679,21 @@ class TrainEngine(object):
             ctx, lse = ops.attn_dense_train(qkv, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
                                             mask_from=SV + T if scst else 0)
             t1 = torch.empty(Md, 768, device=dev)
-            ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
+            if ph > 0:
+                ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), out=t1)
+                ops.hidden_dropout(t1, xd, LR, 0, hseed(l, 1), ph, out=t1)
+            else:
+                ops.gemm_bias_act(ctx, self.wb(pre + '.ao'), self.vec(pre + '.attention.output.dense.bias'), residual=xd, out=t1)
             ab, af = ops.layernorm(t1, self.vec(pre + '.attention.output.LayerNorm.weight'),
                                    self.vec(pre + '.attention.output.LayerNorm.bias'), 1e-12, want_f32=True)
             z = torch.empty(Md, 3072, device=dev, dtype=torch.bfloat16)
             it = ops.gemm_ex(ab, self.wb(pre + '.i'), bias=self.vec(pre + '.intermediate.dense.bias'), act=L.ACT_GELU_ERF, zout=z)
             t2 = torch.empty(Md, 768, device=dev)
-            ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
+            if ph > 0:
+                ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), out=t2)
+                ops.hidden_dropout(t2, af, LR, 0, hseed(l, 2), ph, out=t2)
+            else:
+                ops.gemm_bias_act(it, self.wb(pre + '.o'), self.vec(pre + '.output.dense.bias'), residual=af, out=t2)
             _, yf = ops.layernorm(t2, self.vec(pre + '.output.LayerNorm.weight'), self.vec(pre + '.output.LayerNorm.bias'), 1e-12,
                                   want_bf16=False, want_f32=True)
             dsaved.append((xb, qkv, ctx, lse, t1, ab, af, z, it, t2))
@@ -741,12 +764,16 @@ class TrainEngine(object):
             if l == 3 and prune:
                 xb, qkv, ctx, lse, t1, ab, af, z, it, t2, ctx_t = dsaved[l]
                 dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
+                if ph > 0:      # the dense branch sees the masked gradient, the residual branch (dt2f) the whole one
+                    dt2b = ops.cast_bf16(ops.hidden_dropout(dt2f, None, TT, SV, hseed(l, 2), ph))
                 self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), self.g(pre + '.output.dense.bias').view(-1))
                 dz = ops.gemm_ex(dt2b, self.wt(pre + '.o'), aux=z)
                 self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), self.g(pre + '.intermediate.dense.bias').view(-1))
                 da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
                 dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight',
                                           pre + '.attention.output.LayerNorm.bias', 1e-12)
+                if ph > 0:
+                    dt1b = ops.cast_bf16(ops.hidden_dropout(dt1f, None, TT, SV, hseed(l, 1), ph))
                 self._wgrad_tn(dt1b, ctx_t, self.g(pre + '.attention.output.dense.weight'),
                                self.g(pre + '.attention.output.dense.bias').view(-1))
                 dctx_t = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
@@ -761,14 +788,23 @@ class TrainEngine(object):
                 continue
             xb, qkv, ctx, lse, t1, ab, af, z, it, t2 = dsaved[l]
             # bias gradients = column sums of dt2b / dz / dt1b, added by the kernels that write those operands
-            dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12,
-                                      dxb_colsum=self.g(pre + '.output.dense.bias').view(-1))
+            if ph > 0:      # masked gradient for the dense branch: its bf16 copy + bias column sums from the masked values
+                dt2f, _ = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12)
+                dt2b = ops.cast_bf16_colsum(ops.hidden_dropout(dt2f, None, LR, 0, hseed(l, 2), ph), self.g(pre + '.output.dense.bias').view(-1))
+            else:
+                dt2f, dt2b = self._ln_bwd(t2, dy, pre + '.output.LayerNorm.weight', pre + '.output.LayerNorm.bias', 1e-12,
+                                          dxb_colsum=self.g(pre + '.output.dense.bias').view(-1))
             self._wgrad_tn(dt2b, it, self.g(pre + '.output.dense.weight'), None)
             dz, pend = self._dgrad_gelu(dt2b, self.wt(pre + '.o'), z, self.g(pre + '.intermediate.dense.bias').view(-1))   # [Md,3072] bf16
             self._wgrad_tn(dz, ab, self.g(pre + '.intermediate.dense.weight'), pend)
             da = ops.gemm_ex(dz, self.wt(pre + '.i'), residual=dt2f, out_dtype=torch.float32)
-            dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias',
-                                      1e-12, dxb_colsum=self.g(pre + '.attention.output.dense.bias').view(-1))
+            if ph > 0:
+                dt1f, _ = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias', 1e-12)
+                dt1b = ops.cast_bf16_colsum(ops.hidden_dropout(dt1f, None, LR, 0, hseed(l, 1), ph),
+                                            self.g(pre + '.attention.output.dense.bias').view(-1))
+            else:
+                dt1f, dt1b = self._ln_bwd(t1, da, pre + '.attention.output.LayerNorm.weight', pre + '.attention.output.LayerNorm.bias',
+                                          1e-12, dxb_colsum=self.g(pre + '.attention.output.dense.bias').view(-1))
             self._wgrad_tn(dt1b, ctx, self.g(pre + '.attention.output.dense.weight'), None)
             dctx = ops.gemm_ex(dt1b, self.wt(pre + '.ao'))
             dqkv = ops.attn_dense_bwd(qkv, ctx, dctx, lse, B, LR, p_drop=pd, drop_seed=dseed[l], causal_from=SV,
@@ -779,8 +815,10 @@ class TrainEngine(object):
                 self.reducer.stage_done('dec%d' % (l // 2))
         dyv = dy.view(B, LR, 768)
         # ================= backward: text embeddings
-        demb, _ = self._ln_bwd(pre_emb, dyv[:, SV:].reshape(B * TT, 768).contiguous(), e + '.LayerNorm.weight', e + '.LayerNorm.bias',
-                               1e-12, dres=None)
+        dtext_in = dyv[:, SV:].reshape(B * TT, 768).contiguous()
+        if ph > 0:
+            ops.hidden_dropout(dtext_in, None, TT, SV, hseed(4, 3), ph, out=dtext_in)
+        demb, _ = self._ln_bwd(pre_emb, dtext_in, e + '.LayerNorm.weight', e + '.LayerNorm.bias', 1e-12, dres=None)
         check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), TT, _p(self.g(e + '.word_embeddings.weight')),
                                    _p(self.g(e + '.position_embeddings.weight')), _p(self.g(e + '.token_type_embeddings.weight')),
                                    B * TT, T if scst else 0, _s()), 'embed_bwd')
