@@ -137,3 +137,30 @@ def test_max_iter_in_epochs(tmp_path, monkeypatch):
     assert p.get_checkpoint_file().endswith('output/E/snapshot/model_iter_0000142.pt')
     with pytest.raises(ValueError, match='training set'):
         CaptionUniPipeline(max_iter='30e').parse_iter('30e')
+
+
+def test_ensure_evaluate_writes_a_report(tmp_path, monkeypatch):
+    """ensure_evaluate (uni_pipeline.py:884-911) / evaluate (..._bertemb.py:632-647): the predict TSV scored against
+    data/<test_data>/<split>.caption.tsv into <predict file>.report on rank 0 -- native BLEU / CIDEr-D restatements, marked
+    parity-unpinned in the report (the reference's scorer is the external coco_caption package); skipped when switched off or when
+    there are no reference captions; a fresh report is not recomputed."""
+    import json
+    from vitcap_amd.pipeline import CaptionUniPipeline
+    from vitcap_amd.tsv import tsv_writer
+    monkeypatch.chdir(tmp_path)
+    caps = {'a': ['a man riding a horse', 'a person on a horse'], 'b': ['two dogs play in the grass'], 'c': ['a red bus on a street']}
+    tsv_writer(((k, json.dumps([{'caption': c} for c in v])) for k, v in caps.items()), str(tmp_path / 'data' / 'toy' / 'test.caption.tsv'))
+    pred = tmp_path / 'm.pt.toy.test.predict.tsv'
+    tsv_writer(((k, json.dumps([{'caption': v[0], 'conf': 0.5}])) for k, v in caps.items()), str(pred))
+    pipe = CaptionUniPipeline(test_data='toy', test_split='test', full_expid='E')
+    ef = pipe.ensure_evaluate(str(pred))
+    assert ef == str(pred)[:-4] + '.report'
+    rep = json.load(open(ef))
+    assert rep['images'] == 3 and abs(rep['Bleu_4'] - 1.0) < 1e-6 and rep['CIDEr'] > 0 and 'parity-unpinned' in rep['note']
+    t0 = os.path.getmtime(ef)
+    assert pipe.ensure_evaluate(str(pred)) == ef and os.path.getmtime(ef) == t0          # fresh: not recomputed
+    worse = tmp_path / 'w.pt.toy.test.predict.tsv'
+    tsv_writer(((k, json.dumps([{'caption': 'a cat', 'conf': 0.5}])) for k in caps), str(worse))
+    assert json.load(open(pipe.ensure_evaluate(str(worse))))['Bleu_4'] < 0.1
+    assert CaptionUniPipeline(test_data='toy', ignore_evaluate=True).ensure_evaluate(str(pred)) is None
+    assert CaptionUniPipeline(test_data='synthetic', force_evaluate=True).ensure_evaluate(str(pred)) is None   # no reference captions

@@ -652,10 +652,90 @@ class CaptionUniPipeline(object):
             return predict_result_file
         return self.predict(model_file, predict_result_file)
 
+    def get_evaluate_file(self, predict_file):
+        """uni_pipeline.py:852-882 for a captioning run (evaluate_method 'map', no test_version): <predict_file minus .tsv>.report."""
+        assert predict_file.endswith('.tsv')
+        return op.splitext(predict_file)[0] + '.report'
+
     def ensure_evaluate(self, predict_file=None):
-        logging.info('ensure_evaluate: COCO caption metrics need the external coco_caption/cider packages that the '
-                     'reference does not vendor either (README:24); skipped')
-        return None
+        """uni_pipeline.py:884-911: rank 0 only; skipped when prediction / evaluation is switched off; re-done when the report is
+        older than the prediction or `force_evaluate`."""
+        if self.rank != 0:
+            logging.info('skip because the rank %d != 0', self.rank)
+            return None
+        if self.cfg.ignore_evaluate or self.cfg.ignore_predict:
+            logging.info('ignore evaluate as instructed')
+            return None
+        if not predict_file:
+            predict_file = self.get_predict_file(self.get_checkpoint_file())
+        if not op.isfile(predict_file):
+            logging.info('ignore evaluate: no prediction file %s', predict_file)
+            return None
+        evaluate_file = self.get_evaluate_file(predict_file)
+        fresh = op.isfile(evaluate_file) and op.getmtime(evaluate_file) >= op.getmtime(predict_file)
+        if fresh and not self.cfg.force_evaluate:
+            logging.info('ignore %s', evaluate_file)
+            return evaluate_file
+        return evaluate_file if self.evaluate(predict_file, evaluate_file) is not None else None
+
+    def evaluate(self, predict_file, evaluate_file):
+        """..._bertemb.py:632-647 scores the predict TSV against data/<test_data>/<split>.caption.tsv with the external coco_caption
+        package (pycocoevalcap: PTB tokenizer jar, BLEU / METEOR jar / ROUGE / CIDEr / SPICE jar), which neither the reference
+        vendors (README:24) nor this image has.  Native restatements here of the two metrics that need no Java: corpus BLEU-1..4
+        (Papineni et al., closest reference length) and CIDEr-D (vitcap_amd/scst.py, document frequencies from the references) on
+        lower-cased whitespace tokens.  PARITY-UNPINNED: no coco_caption output exists to check them against; the report says so."""
+        from .scst import CiderD, corpus_bleu
+        from .tsv import TSVFile
+        if not self.cfg.test_data or self.cfg.test_data == 'synthetic':
+            logging.info('evaluate: synthetic test data has no reference captions; skipped')
+            return None
+        cap_file = op.join(self.cfg.data_root or 'data', self.cfg.test_data, '{}.caption.tsv'.format(self.cfg.test_split or 'test'))
+        if not op.isfile(cap_file):
+            logging.info('evaluate: no reference captions (%s); skipped', cap_file)
+            return None
+        gts = {}
+        for row in TSVFile(cap_file):
+            gts[row[0]] = [str(c['caption']).lower().strip() for c in json.loads(row[1])]
+        keys, res = [], []
+        for row in TSVFile(predict_file):
+            if row[0] in gts and gts[row[0]]:
+                keys.append(row[0])
+                res.append(str(json.loads(row[1])[0]['caption']).lower().strip())
+        if not keys:
+            logging.info('evaluate: no predicted key has reference captions; skipped')
+            return None
+        refs = [gts[k] for k in keys]
+        result = {'Bleu_%d' % (n + 1): b for n, b in enumerate(corpus_bleu(refs, res))}
+        result['CIDEr'] = CiderD().compute_score(refs, res)[0] / 10.0
+        result['images'] = len(keys)
+        result['note'] = ('native BLEU / CIDEr-D restatements on lower-cased whitespace tokens; parity-unpinned (the reference\'s scorer '
+                          'is the external coco_caption package: PTB tokenizer, METEOR and SPICE are Java and not reproduced)')
+        with open(evaluate_file, 'w') as fp:
+            json.dump(result, fp)
+        logging.info('evaluation result: %s', {k: v for k, v in result.items() if k != 'note'})
+        logging.info('evaluation result saved to %s', evaluate_file)
+        return result
 
     def monitor_train(self):
-        return None
+        """uni_pipeline.py:1021-1038: predict + evaluate every intermediate snapshot of the run and collect the scores per iteration
+        (the reference plots them to tensorboard, which this image lacks: they go to <output>/monitor_train.json).  Called after
+        training here (run.py has no watcher process), so no snapshot is still being written."""
+        import glob
+        import re
+        self._ensure_initialized()
+        steps = sorted(int(re.search(r'model_iter_(\d+)\.pt$', f).group(1))
+                       for f in glob.glob(op.join(self.get_snapshot_dir(), 'model_iter_*.pt')))
+        iter_to_eval = {}
+        for it in steps:
+            pf = self.ensure_predict(self.get_checkpoint_file(iteration=it))
+            ef = self.ensure_evaluate(pf) if pf else None
+            if ef and op.isfile(ef):
+                with open(ef) as fp:
+                    iter_to_eval[it] = {k: v for k, v in json.load(fp).items() if k != 'note'}
+        if self.rank == 0 and iter_to_eval:
+            with open(op.join(self.output_folder, 'monitor_train.json'), 'w') as fp:
+                json.dump(iter_to_eval, fp, indent=1)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        return iter_to_eval

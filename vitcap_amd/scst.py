@@ -88,6 +88,35 @@ class CiderD(object):
         return (sum(scores) / max(1, len(scores))), scores
 
 
+def corpus_bleu(refs, hyps, n=4):
+    """Corpus-level BLEU-1..n (Papineni et al. 2002): clipped n-gram counts summed over the corpus, brevity penalty from the
+    closest reference length per hypothesis.  refs: per hypothesis a list of reference strings; whitespace tokens.  Used by the
+    pipeline's evaluate() report (parity-unpinned, like CiderD: the reference's scorer is the external coco_caption package)."""
+    match, total = [0] * n, [0] * n
+    hyp_len = ref_len = 0
+    for rs, h in zip(refs, hyps):
+        hw = h.split()
+        rws = [r.split() for r in rs]
+        hyp_len += len(hw)
+        ref_len += min((abs(len(r) - len(hw)), len(r)) for r in rws)[1]
+        for k in range(1, n + 1):
+            hc = Counter(tuple(hw[i:i + k]) for i in range(len(hw) - k + 1))
+            mx = Counter()
+            for r in rws:
+                rc = Counter(tuple(r[i:i + k]) for i in range(len(r) - k + 1))
+                for ng, c in rc.items():
+                    mx[ng] = max(mx[ng], c)
+            match[k - 1] += sum(min(c, mx[ng]) for ng, c in hc.items())
+            total[k - 1] += max(0, len(hw) - k + 1)
+    bp = 1.0 if hyp_len > ref_len else math.exp(1.0 - float(ref_len) / max(1, hyp_len))
+    out, logsum = [], 0.0
+    for k in range(n):
+        p = (match[k] + 1e-15) / (total[k] + 1e-9)
+        logsum += math.log(p)
+        out.append(bp * math.exp(logsum / (k + 1)))
+    return out
+
+
 def _wrap(s):
     """ScstRewardCriterion._wrap_sentence: strip, drop a final period, append ' <eos>'."""
     r = s.strip()
