@@ -48,7 +48,7 @@ const char* vitcap_last_error(void);
  * vitcap_layernorm_bwd's extra pointer, zout / aux carrying gelu').  vitcap_version() returns the library's value: a binding checks
  * the two for equality at load time, and every call that takes one of the two option structs rejects a struct whose first field is
  * not VITCAP_ABI_VERSION (a caller built against an older header passes a shorter struct: its fields would be misread). */
-#define VITCAP_ABI_VERSION 3
+#define VITCAP_ABI_VERSION 4
 int vitcap_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -349,6 +349,46 @@ int vitcap_beam_reorder_cache(const void* src, void* dst, const int32_t* parent,
 int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* out_logprobs, int B, int max_len,
                          int eos, int pad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Constrained beam search, device side (ConstrainedBeamSearch.search with use_hypo = False and
+ * select_best_beam_with_constraints, src/tools/captioning/utils_cbs.py:26-443).  G = S * K sequences per image, slot (s, k) =
+ * beam k of FSM state s, global slot = b * G + s * K + k.
+ *   vitcap_cbs_init        prefixes = [BOS], counters cleared
+ *   vitcap_cbs_start       first step (:127-152): image b reads ROW b of the (B*G)-row logits (`[:batch_size]` of an image-major
+ *                          batch, as written), words that fsm[b][0][i] does not allow score -inf, K best words per state i
+ *   vitcap_cbs_candidates  later steps (:184-247): per slot and target state i the K best words of log_softmax(logits) -- a slot
+ *                          ending in an EOS id continues with an EOS id at cost 0 only -- masked by fsm[b][s][i] (-1e20)
+ *   vitcap_cbs_select      (:245-319) per image and target state the K best of (candidate + the slot's running score) over all
+ *                          slots; prefixes re-ordered by parent and extended, parents for the K/V cache re-ordering.  Ties go to
+ *                          the lower flat index.  Once every slot of the batch ends in EOS the search stops (:177-181):
+ *                          *n_pred = words per sequence so far, later calls pass the state through unchanged
+ *   vitcap_cbs_finalize    (:377-443) per image the best beam of the main state s < 2**num_constraints[b] with at least
+ *                          min(num_constraints[b], min_constraints) bits set that maximises score / (non-EOS words + 1); first
+ *                          maximum on ties.  out_ids [B][max_len]: the n_pred words (no BOS column, like the reference's output),
+ *                          then pad; out_logprobs [B].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t* ids_in;      /* [B*G][max_len] prefixes entering the step (BOS first) */
+  int64_t* ids_out;     /* [B*G][max_len] prefixes leaving it (caller swaps) */
+  float* scores_in;     /* [B*G] running log-probabilities (last_log_probabilities) */
+  float* scores_out;
+  int32_t* parent;      /* [B*G] global slot each slot's prefix was copied from */
+  int32_t* unfinished;  /* [max_len] slots not ending in EOS after step t */
+  int32_t* n_pred;      /* [1] words per sequence when the search stopped (max_len - 1 if it never did) */
+  int32_t* live;        /* [1] 1 while the search runs (the step kernels of a stopped search return at entry) */
+} vitcap_cbs_state;
+int vitcap_cbs_init(const vitcap_cbs_state* s, int B, int S, int K, int max_len, int bos, void* stream);
+int vitcap_cbs_start(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
+                     int B, int S, int K, int max_len, int eos, const int32_t* eos_extra, void* stream);
+int vitcap_cbs_candidates(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
+                          int B, int S, int K, int t, int max_len, int eos, const int32_t* eos_extra, float* cand_val,
+                          int32_t* cand_word, void* stream);
+int vitcap_cbs_select(const float* cand_val, const int32_t* cand_word, const vitcap_cbs_state* s, int B, int S, int K, int t,
+                      int max_len, int eos, const int32_t* eos_extra, void* stream);
+int vitcap_cbs_finalize(const vitcap_cbs_state* s, const int64_t* num_constraints, int min_constraints, int B, int S, int K,
+                        int max_len, int eos, const int32_t* eos_extra, int pad, int64_t* out_ids, float* out_logprobs,
+                        void* stream);
+
 /* Decode-step attention for SEVERAL sequences per image (beam search), one workgroup per (image, head): the 2*K <= 16 query rows
  * of an image are scored against its 578 visual key rows on the matrix pipe (K rows loaded once for all beams), the <= 41 text
  * keys of each sequence on the vector ALU; same softmax as vitcap_attn_decode_step (BertSelfAttention, modeling_bert.py:320-340),
@@ -470,6 +510,16 @@ typedef struct vitcap_gen_opts {
                                  ONE path only, as in the reference: bert.extra_embeddings of the tag rows (tagemb != 'cls',
                                  branch B, modeling_bert.py:1484-1485; every other tag embedding uses the literal 20 of
                                  encode_tag_to_embedding), so it is read when tag_visible > 0 and tagemb_cls == 0             */
+  /* constrained beam search: ViTCAP.generate(use_cbs=True, fsm=..., num_constraints=..., min_constraints_to_satisfy=...)
+     (modeling_bert.py:932-933, 949-953, 1035-1057 -> src/tools/captioning/utils_cbs.py:26-443).  Every image then decodes
+     cbs_states * num_beams sequences (num_beams per state of its finite-state machine) */
+  int32_t use_cbs;            /* 1: constrained beam search; needs fsm, num_constraints, no sampling / penalty / n-best        */
+  int32_t cbs_states;         /* S = fsm.shape[1] (2**max_given_constraints main states + the sub-states in use), 1..32        */
+  int32_t min_constraints_to_satisfy;   /* the pipeline passes 2 (..._bertemb.py:175-179)                                    */
+  int32_t cbs_reserved;
+  const uint8_t* fsm;         /* device, uint8 [B][S][S][30522]: fsm[b][s1][s2][w] != 0 iff word w moves image b's machine from
+                                 state s1 to s2 (FiniteStateMachineBuilder.build, utils_cbs.py:733-871)                        */
+  const int64_t* num_constraints;       /* device, int64 [B]: constraints given per image (2**n main states can be valid)      */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */

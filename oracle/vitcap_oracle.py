@@ -790,11 +790,10 @@ def beam_bookkeeping(step_logits_fn, B, num_beams, max_length=MAX_LEN, length_pe
     return decoded, logprobs
 
 
-def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
-                    repetition_penalty=1.0, eos=EOS, sample=None):
-    """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
+def _as_written_stepper(sd, image, K, tagemb='cls', max_length=MAX_LEN):
+    """``step(input_ids (B*K, cur_len), beam_idx)`` -> next-token logits (B*K, V) with the model re-run on the full prefix
+    (past=None: ``_do_output_past`` is False for this model, modeling_bert.py:1072), K sequences per image."""
     B = image.shape[0]
-    K = num_beams
     img_feats = patch_embed(sd, image)
     enc1 = split_encoder(sd, img_feats)
     input_ids0, am = test_text_inputs(B, max_length)
@@ -814,17 +813,24 @@ def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, leng
         tt = torch.zeros(B * K, curr + OD_LEN, dtype=torch.long)
         logits = encode_forward_infer(sd, ids, img_feats_k, mask, pp, tt, tagemb, enc=enc_k)
         return logits[:, cur, :]
-    return beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos, sample=sample)
+    return step
 
 
-def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
-                     num_keep_best=1, repetition_penalty=1.0, eos=EOS, return_margins=False, sample=None):
-    """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
-    image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
+def beam_as_written(sd, image, num_beams, tagemb='cls', max_length=MAX_LEN, length_penalty=1.0, num_keep_best=1,
+                    repetition_penalty=1.0, eos=EOS, sample=None):
+    """Reference beam search with the model re-run on the full prefix at every step (past=None)."""
+    step = _as_written_stepper(sd, image, num_beams, tagemb, max_length)
+    return beam_bookkeeping(step, image.shape[0], num_beams, max_length, length_penalty, num_keep_best, repetition_penalty,
+                            eos=eos, sample=sample)
+
+
+def _incremental_stepper(sd, image, K, emulate_bf16=False, max_length=MAX_LEN, trace=None):
+    """``step(input_ids (B*K, cur_len), beam_idx)`` on the incremental formulation (what the HIP path computes): encoder and
+    visual prefill once per image, per-sequence text K/V caches re-ordered by ``beam_idx`` (the parents chosen since the
+    previous call), K sequences per image."""
     r = _R(emulate_bf16)
     sdw = _rw(sd, r)
     B = image.shape[0]
-    K = num_beams
     hidden, tag_hidden = encoder_incremental(sdw, image, r)
     vis = torch.cat([tag_hidden[:, :1], hidden], dim=1)
     S = vis.shape[1]
@@ -843,7 +849,6 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
     N = B * K
     tk = [torch.zeros(N, max_length, HID) for _ in range(4)]
     tv = [torch.zeros(N, max_length, HID) for _ in range(4)]
-    trace = []
 
     def step(input_ids, beam_idx):
         t = input_ids.shape[1]
@@ -873,12 +878,207 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
         c = 'module.cls.predictions'
         h = _ln(sdw, c + '.transform.LayerNorm', gelu_erf(_lin(sdw, c + '.transform.dense', r(x[:, 1]))), 1e-12)
         logits = F.linear(r(h), sdw[c + '.decoder.weight']) + sdw[c + '.bias']
-        if return_trace:
+        if trace is not None:
             trace.append(logits.clone())
         return logits
-    out = beam_bookkeeping(step, B, K, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos,
+    return step
+
+
+def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LEN, return_trace=False, length_penalty=1.0,
+                     num_keep_best=1, repetition_penalty=1.0, eos=EOS, return_margins=False, sample=None):
+    """Beam search on the incremental formulation (what the HIP path computes): encoder and visual prefill once per
+    image, per-sequence text K/V caches re-ordered by the chosen parent beams."""
+    trace = [] if return_trace else None
+    step = _incremental_stepper(sd, image, num_beams, emulate_bf16, max_length, trace)
+    out = beam_bookkeeping(step, image.shape[0], num_beams, max_length, length_penalty, num_keep_best, repetition_penalty, eos=eos,
                            return_margins=return_margins, sample=sample)
     return out + (trace,) if return_trace else out
+
+
+# --------------------------------------------------------------------------------------------
+# f4  constrained beam search   (src/tools/captioning/utils_cbs.py:26-374 search, 377-443 selection, 646-871 FSM builder;
+#     hooks in ViTCAP.generate modeling_bert.py:949-953, 994, 1035-1057; step = _decode_step modeling_utils.py:747-766)
+# --------------------------------------------------------------------------------------------
+CBS_MASKED = -1e20          # utils_cbs.py:240: a transition the FSM does not allow scores -1e20 (NOT -inf)
+
+
+def cbs_search(step_logits_fn, fsm, num_beams, max_length=MAX_LEN, eos=EOS, return_margins=False):
+    """``ConstrainedBeamSearch.search`` as ViTCAP.generate drives it (use_hypo=False, no decoding_constraint_flag, no
+    bad_ending_ids, per_node_beam_size = beam_size, state = None because the model returns no past).
+
+    fsm (B, S, S, V) uint8: fsm[b, s1, s2, w] = 1 iff word w moves image b's machine from state s1 to s2.  Every image carries
+    S * K sequences, slot (s, k) = beam k of state s; ``step_logits_fn(curr_ids (B*S*K, cur_len), parents)`` returns the
+    next-token logits, ``parents`` = the global slot each slot's prefix was copied from since the previous call (None first).
+
+    * first step (:127-152): log-softmax of the FIRST B ROWS of the expanded batch -- ``[:batch_size]`` on an image-major
+      (B*S*K, V) tensor, i.e. row b belongs to image b // (S*K): for B > 1 every image starts from image 0's distribution
+      (restated as written); words not allowed out of state 0 into state i are -inf; K best words per state.
+    * every later step (:169-319): a slot whose last word is an EOS id may only continue with an EOS id at cost 0; for target
+      state i the candidates of slot (s, k) are its words masked by fsm[b, s, i] (-1e20 where not allowed), K best per slot,
+      plus the slot's running score, K best overall -> slot (i, 0..K-1), parent = the candidate's slot.  The loop stops early
+      once every slot of the batch ends in EOS.
+    Ties (e.g. among the -1e20 fillers of a state fewer than K allowed candidates reach) fall as torch.topk leaves them; the
+    device breaks them by lowest flat index, tests use constraints whose valid states never depend on that.
+
+    Returns (beams (B, S, K, T) without the BOS column, T <= max_length - 1, scores (B, S, K)).  ``return_margins``: also
+    (B, S) the smallest gap, over the steps, between neighbours among the K+1 best FINITE candidates of a state (inf if
+    fewer than two)."""
+    B, S, _, Vn = fsm.shape
+    K = num_beams
+    G = S * K
+    eos_ids = _eos_list(eos)
+    allowed = fsm.to(torch.bool)
+    NEG = float('-inf')
+    margins = torch.full((B, S), float('inf'))
+
+    curr = torch.full((B * G, 1), BOS, dtype=torch.long)
+    lp0 = F.log_softmax(step_logits_fn(curr, None), dim=-1)[:B]
+    start = lp0[:, None, :].expand(B, S, Vn).masked_fill(~allowed[:, 0], NEG)
+    last, words = start.topk(K)                                        # (B, S, K): running scores, first words
+    if return_margins:
+        margins = _finite_gap(start.topk(K + 1).values, K)
+    preds, backs = [words.reshape(B, G)], []
+    after_end = torch.full((Vn,), NEG)
+    after_end[eos_ids] = 0.0
+    base = (torch.arange(B) * G)[:, None]
+    for _ in range(max_length - 2):
+        lastw = preds[-1].reshape(-1)
+        fin = torch.zeros_like(lastw, dtype=torch.bool)
+        for e in eos_ids:
+            fin |= lastw == e
+        if bool(fin.all()):
+            break
+        curr = torch.cat([curr, lastw[:, None]], dim=1)
+        parents = (backs[-1] + base).reshape(-1) if backs else None
+        lp = F.log_softmax(step_logits_fn(curr, parents), dim=-1)
+        lp = torch.where(fin[:, None], after_end[None], lp).view(B, S, K, Vn)
+        nw = torch.empty(B, S, K, dtype=torch.long)
+        nb = torch.empty(B, S, K, dtype=torch.long)
+        ns = torch.empty(B, S, K)
+        for i in range(S):
+            m = lp.masked_fill(~allowed[:, :, i, None, :], CBS_MASKED)  # (B, S, K, V): into state i
+            top, cls = m.topk(K)                                        # K best words of every slot
+            summed = (top + last[..., None]).reshape(B, G * K)
+            sc, idx = summed.topk(K)
+            nw[:, i], nb[:, i], ns[:, i] = cls.reshape(B, G * K).gather(1, idx), idx // K, sc
+            if return_margins:
+                margins[:, i] = torch.minimum(margins[:, i], _finite_gap(summed.topk(min(K + 1, G * K)).values, K))
+        preds.append(nw.reshape(B, G))
+        backs.append(nb.reshape(B, G))
+        last = ns
+        curr = curr.view(B, G, -1).gather(1, backs[-1][..., None].expand(B, G, curr.shape[1])).reshape(B * G, -1)
+    # walk the back-pointers (:321-350; the reference asserts that this equals its re-ordered curr_ids)
+    seqs = [preds[-1]]
+    bp = backs[-1] if backs else None
+    for t in range(len(preds) - 2, -1, -1):
+        seqs.append(preds[t].gather(1, bp))
+        if t > 0:
+            bp = backs[t - 1].gather(1, bp)
+    beams = torch.stack(list(reversed(seqs)), dim=2).view(B, S, K, -1)
+    full = torch.cat([curr, preds[-1].reshape(-1, 1)], dim=1)[:, 1:].view(B, S, K, -1)
+    assert bool((beams == full).all())
+    if return_margins:
+        return beams, last, margins
+    return beams, last
+
+
+def _finite_gap(sorted_vals, K):
+    v = sorted_vals[..., :K + 1]
+    if v.shape[-1] < 2:
+        return torch.full(v.shape[:-1], float('inf'))
+    gap = v[..., :-1] - v[..., 1:]
+    ok = (v[..., :-1] > -1e19) & (v[..., 1:] > -1e19)
+    return torch.where(ok, gap, torch.full_like(gap, float('inf'))).min(-1).values
+
+
+def cbs_select_best(beams, scores, num_constraints, min_constraints_to_satisfy, eos=EOS, return_margins=False):
+    """``select_best_beam_with_constraints`` (utils_cbs.py:377-443): per image, among the MAIN states s < 2**given whose bit
+    count is >= min(given, min_constraints_to_satisfy), the best beam (index 0) of the state with the largest
+    score / (number of non-EOS tokens + 1); torch.argmax = first maximum.  Returns (ids (B, T), logprobs (B,))."""
+    B = beams.shape[0]
+    eos_ids = _eos_list(eos)
+    out_ids, out_lp, gaps = [], [], []
+    for b in range(B):
+        given = int(num_constraints[b])
+        need = min(given, int(min_constraints_to_satisfy))
+        valid = [s for s in range(2 ** given) if bin(s).count('1') >= need]
+        vb = beams[b, valid, 0, :]
+        keep = torch.ones_like(vb)
+        for e in eos_ids:
+            keep = keep * vb.ne(e).long()
+        norm = scores[b, valid, 0] / (keep.sum(1) + 1)
+        j = int(torch.argmax(norm))
+        out_ids.append(vb[j])
+        out_lp.append(norm[j])
+        srt = torch.sort(norm, descending=True).values
+        gaps.append(float(srt[0] - srt[1]) if len(valid) > 1 else float('inf'))
+    if return_margins:
+        return torch.stack(out_ids).long(), torch.stack(out_lp), torch.tensor(gaps)
+    return torch.stack(out_ids).long(), torch.stack(out_lp)
+
+
+def cbs_as_written(sd, image, fsm, num_constraints, num_beams, min_constraints_to_satisfy=2, tagemb='cls', max_length=MAX_LEN,
+                   eos=EOS):
+    """ViTCAP.generate(use_cbs=True) (modeling_bert.py:1035-1057) with the model re-run on the full prefix at every step."""
+    S = fsm.shape[1]
+    step = _as_written_stepper(sd, image, S * num_beams, tagemb, max_length)
+    beams, scores = cbs_search(lambda ids, parents: step(ids, parents), fsm, num_beams, max_length, eos)
+    return cbs_select_best(beams, scores, num_constraints, min_constraints_to_satisfy, eos)
+
+
+def cbs_incremental(sd, image, fsm, num_constraints, num_beams, min_constraints_to_satisfy=2, emulate_bf16=False,
+                    max_length=MAX_LEN, eos=EOS, return_margins=False):
+    """The same on the incremental formulation: the S*K slots of an image share its visual K/V, text K/V caches follow the
+    back-pointers."""
+    S = fsm.shape[1]
+    step = _incremental_stepper(sd, image, S * num_beams, emulate_bf16, max_length)
+    res = cbs_search(step, fsm, num_beams, max_length, eos, return_margins=return_margins)
+    sel = cbs_select_best(res[0], res[1], num_constraints, min_constraints_to_satisfy, eos, return_margins=return_margins)
+    if return_margins:
+        return sel[0], sel[1], res[2], sel[2], res[0], res[1]
+    return sel
+
+
+def fsm_build(constraints, vocab_size, max_given_constraints=3, max_words_per_constraint=4):
+    """``FiniteStateMachineBuilder.build`` (utils_cbs.py:733-871) on TOKEN IDS: ``constraints`` = list (<= max_given) of
+    constraints, each a list of words, each word a list of word-form token ids.  Main states 0 .. 2**max_given - 1 (bit n-1
+    set = constraint n satisfied) loop on every word; constraint n links every main state without bit n-1 to the one with it
+    through a chain of sub-states, one per word but the last; a sub-state falls back to the chain's main state on any word
+    but the expected forms.  Returns (fsm (T, T, V) uint8 with T = 2**max_given * max_words, next unused sub-state)."""
+    nmain = 2 ** max_given_constraints
+    T = nmain * max_words_per_constraint
+    fsm = torch.zeros(T, T, vocab_size, dtype=torch.uint8)
+    for s in range(nmain):
+        fsm[s, s, :] = 1
+    sub = nmain
+
+    def connect(frm, to, forms, reset):
+        for wid in forms:
+            fsm[frm, to, wid] = 1
+            fsm[frm, frm, wid] = 0
+        if reset is not None:
+            fsm[frm, frm, :] = 0
+            fsm[frm, reset, :] = 1
+            for wid in forms:
+                fsm[frm, reset, wid] = 0
+
+    for n, words in enumerate(constraints, start=1):
+        words = words[:max_words_per_constraint]
+        stride = 2 ** (n - 1)
+        frm = 0
+        while frm < nmain:
+            for _ in range(stride):
+                cur = frm
+                for i, forms in enumerate(words):
+                    if i != len(words) - 1:
+                        connect(cur, sub, forms, frm)
+                        cur = sub
+                        sub += 1
+                    else:
+                        connect(cur, frm + stride, forms, frm)
+                frm += 1
+            frm += stride
+    return fsm, sub
 
 
 # --------------------------------------------------------------------------------------------

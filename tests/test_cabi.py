@@ -95,8 +95,14 @@ def test_engine_lifecycle_and_workspace(L):
     assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(o)) == w64
     assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(num_beams=5))) > w64
     assert L.lib.vitcap_engine_workspace_bytes(64, C.byref(L.gen_opts(max_length=40))) > w64
+    # constrained beam search: cbs_states * num_beams sequences per image size the workspace (the pointers are not followed here)
+    ocbs = L.gen_opts(use_cbs=1, cbs_states=8, num_beams=2, fsm=4096, num_constraints=4096)
+    assert L.lib.vitcap_gen_opts_check(C.byref(ocbs)) == 0
+    assert L.lib.vitcap_engine_workspace_bytes(4, C.byref(ocbs)) > L.lib.vitcap_engine_workspace_bytes(4, C.byref(L.gen_opts(num_beams=8)))
     for bad in (dict(num_beams=9), dict(max_length=41), dict(max_length=1), dict(num_beams=1, num_keep_best=2),
-                dict(num_beams=2, seqs_per_image=2), dict(repetition_penalty=0.0), dict(eos_token_id=30522), dict(gemm_mode=7), dict(tag_pos0=19), dict(tag_pos0=463)):
+                dict(num_beams=2, seqs_per_image=2), dict(repetition_penalty=0.0), dict(eos_token_id=30522), dict(gemm_mode=7), dict(tag_pos0=19), dict(tag_pos0=463),
+                dict(use_cbs=1), dict(use_cbs=1, cbs_states=8, fsm=4096, num_constraints=4096, num_keep_best=2, num_beams=2),
+                dict(use_cbs=1, cbs_states=33, fsm=4096, num_constraints=4096), dict(use_cbs=1, cbs_states=8, fsm=4096)):
         ob = L.gen_opts(**bad)
         assert L.lib.vitcap_gen_opts_check(C.byref(ob)) == -1 and L.lib.vitcap_last_error(), bad
         assert L.lib.vitcap_engine_workspace_bytes(4, C.byref(ob)) == 0
@@ -115,7 +121,9 @@ def test_struct_sizes_match_header(L):
     assert C.sizeof(L.VitBlockW) == 12 * 8 and C.sizeof(L.BertLayerW) == 12 * 8 and C.sizeof(L.LmHeadW) == 6 * 8
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
     assert C.sizeof(L.GemmDesc) == 16 * 4 + 24          # abi + 15 ints, three pointers (live, rowstat, colsum)
-    assert C.sizeof(L.GenOpts) == 4 + 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4
+    # ... + the constrained-beam-search block: 4 ints, (4 bytes of alignment), 2 pointers
+    assert C.sizeof(L.GenOpts) == 4 + 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4 + 4 * 4 + 4 + 2 * 8
+    assert L.GenOpts.fsm.offset % 8 == 0 and C.sizeof(L.CbsState) == 8 * 8
 
 
 def test_model_surface(L, sd_np):
@@ -135,13 +143,19 @@ def test_model_surface(L, sd_np):
     with pytest.raises(RuntimeError, match='TrainEngine'):         # training forward needs the HIP engine attached
         m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
     m.eval()
-    for bad in ({'eos_token_ids': [102, 1012, 5, 6, 7]}, {'eos_token_ids': [102, 1012], 'num_beams': 2}, {'use_cbs': True}, {'max_length': 41}, {'add_od_labels': False},
+    for bad in ({'eos_token_ids': [102, 1012, 5, 6, 7]}, {'eos_token_ids': [102, 1012], 'num_beams': 2}, {'max_length': 41}, {'add_od_labels': False},
                 {'num_return_sequences': 2}):
         keep = dict(m.test_extra_input)
         m.test_extra_input.update(bad)
         with pytest.raises(NotImplementedError):                    # unsupported generate() options are refused, not ignored
             m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
         m.test_extra_input = keep
+    # use_cbs without the machines: the reference dies on `fsm.shape` (modeling_bert.py:952); here the missing tensors are named
+    keep = dict(m.test_extra_input)
+    m.test_extra_input['use_cbs'] = True
+    with pytest.raises(ValueError, match='fsm'):
+        m({'image': torch.zeros(1, 3, 384, 384), 'key': [0]})
+    m.test_extra_input = keep
     # the tag slots' start position follows generate(): max(od_labels_start_posid, max_length) (modeling_bert.py:958-959)
     assert m.gen_options().tag_pos0 == 20 and m.gen_options(od_labels_start_posid=40).tag_pos0 == 40
     assert m.gen_options(od_labels_start_posid=8, max_length=33).tag_pos0 == 33

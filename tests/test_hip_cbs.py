@@ -1,0 +1,221 @@
+"""Constrained beam search on the device (ViTCAP.generate(use_cbs=True), modeling_bert.py:1035-1057 ->
+src/tools/captioning/utils_cbs.py:26-443).
+
+* the bookkeeping kernels (csrc/cbs.hip) against the oracle's restatement of ConstrainedBeamSearch.search +
+  select_best_beam_with_constraints on synthetic table models -- both sides see identical fp32 logits, so every valid state's best
+  beam, its score and the selected caption must agree exactly;
+* the whole path (vitcap_gen_opts.use_cbs through the engine) against the captions the REFERENCE produced
+  (tests/golden/reference_cbs.npz: the reference's own generate() with its own FiniteStateMachineBuilder) and against the oracle's
+  bf16 emulation."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitcap_oracle as O
+from vitcap_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_cbs.npz')
+
+
+def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None):
+    """search + selection by the C-ABI kernels on a table model: logits of a slot = table[(last token * 5 + length * 11) % R]."""
+    from vitcap_amd import _lib as L
+    from vitcap_amd._lib import lib, check
+    dev = 'cuda'
+    B, S, _, V = fsm.shape
+    G = S * K
+    NS = B * G
+    bufs = {
+        'ids_in': torch.zeros(NS, max_len, dtype=torch.int64, device=dev), 'ids_out': torch.zeros(NS, max_len, dtype=torch.int64, device=dev),
+        'scores_in': torch.zeros(NS, dtype=torch.float32, device=dev), 'scores_out': torch.zeros(NS, dtype=torch.float32, device=dev),
+        'parent': torch.zeros(NS, dtype=torch.int32, device=dev), 'unfinished': torch.zeros(max_len, dtype=torch.int32, device=dev),
+        'n_pred': torch.zeros(1, dtype=torch.int32, device=dev), 'live': torch.zeros(1, dtype=torch.int32, device=dev),
+    }
+    st = L.CbsState()
+    for k, v in bufs.items():
+        setattr(st, k, v.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ex = (C.c_int32 * 3)(*(list(extra or []) + [-1] * 3)[:3])
+    fsm_d, nc_d = fsm.to(dev).contiguous(), ncons.to(dev).to(torch.int64)
+    check(lib.vitcap_cbs_init(C.byref(st), B, S, K, max_len, O.BOS, s), 'init')
+    cv = torch.empty(NS, S, K, dtype=torch.float32, device=dev)
+    cw = torch.empty(NS, S, K, dtype=torch.int32, device=dev)
+    tv, ti = torch.empty(NS, dtype=torch.float32, device=dev), torch.empty(NS, dtype=torch.int32, device=dev)
+    lse = torch.empty(NS, dtype=torch.float32, device=dev)
+    R = table.shape[0]
+    parents = []
+    for t in range(1, max_len):
+        cur = bufs['ids_in'] if st.ids_in == bufs['ids_in'].data_ptr() else bufs['ids_out']
+        logits = table[(cur[:, t - 1] * 5 + t * 11) % R].contiguous()
+        check(lib.vitcap_row_topk_lse(p(logits), V, V, 1, p(tv), p(ti), p(lse), NS, s), 'lse')
+        if t == 1:
+            check(lib.vitcap_cbs_start(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, max_len, eos, ex, s), 'start')
+        else:
+            check(lib.vitcap_cbs_candidates(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, t, max_len, eos, ex, p(cv), p(cw), s),
+                  'candidates')
+            check(lib.vitcap_cbs_select(p(cv), p(cw), C.byref(st), B, S, K, t, max_len, eos, ex, s), 'select')
+        parents.append(bufs['parent'].clone())
+        st.ids_in, st.ids_out = st.ids_out, st.ids_in
+        st.scores_in, st.scores_out = st.scores_out, st.scores_in
+    ids = torch.empty(B, max_len, dtype=torch.int64, device=dev)
+    lp = torch.empty(B, dtype=torch.float32, device=dev)
+    check(lib.vitcap_cbs_finalize(C.byref(st), p(nc_d), min_c, B, S, K, max_len, eos, ex, 0, p(ids), p(lp), s), 'finalize')
+    torch.cuda.synchronize()
+    n_pred = int(bufs['n_pred'][0])
+    final = bufs['ids_in'] if st.ids_in == bufs['ids_in'].data_ptr() else bufs['ids_out']
+    sc = bufs['scores_in'] if st.scores_in == bufs['scores_in'].data_ptr() else bufs['scores_out']
+    return (ids[:, :n_pred].cpu(), lp.cpu(), final[:, 1:n_pred + 1].view(B, S, K, n_pred).cpu(), sc.view(B, S, K).cpu(), n_pred)
+
+
+@pytest.mark.parametrize('B,K,max_given,cons,eos_boost,max_len', [
+    (3, 2, 2, [[[7, 8]], [[9], [10]]], 0.0, 12),                 # one word with two forms; a two-word constraint -> sub-states
+    (2, 3, 3, [[[11]], [[12, 13]], [[14], [15], [16]]], 0.0, 20),  # three constraints, one of three words: 8 main + 8 sub-states
+    (4, 1, 2, [[[7]], [[9]]], 5.0, 10),                          # EOS likely: finished slots pad with EOS, the search stops early
+    (2, 8, 1, [[[21, 22, 23]]], 1.0, 20),                        # widest beam
+    (3, 4, 2, [[[7]]], 2.0, 16),                                  # fewer constraints given than slots
+])
+def test_cbs_bookkeeping_matches_oracle(B, K, max_given, cons, eos_boost, max_len):
+    Vn, R, eos = 500, 64, 2
+    g = torch.Generator().manual_seed(17 * B + K)
+    table = torch.randn(R, Vn, generator=g) * 2.0
+    table[:, eos] += eos_boost
+    fsm1, used = O.fsm_build(cons, Vn, max_given_constraints=max_given, max_words_per_constraint=4)
+    fsm = torch.stack([fsm1[:used, :used]] * B)
+    ncons = torch.full((B,), len(cons), dtype=torch.int64)
+
+    def step(ids, parents):
+        return table[(ids[:, -1] * 5 + ids.shape[1] * 11) % R]
+
+    beams, scores = O.cbs_search(step, fsm, K, max_length=max_len, eos=eos)
+    want_ids, want_lp = O.cbs_select_best(beams, scores, ncons, 2, eos=eos)
+    got_ids, got_lp, got_beams, got_scores, n_pred = _run_device(table.cuda(), fsm, ncons, K, 2, max_len, eos)
+    assert n_pred == beams.shape[3]                        # the same early stop (utils_cbs.py:177-181)
+    np.testing.assert_array_equal(got_ids.numpy(), want_ids.numpy())
+    np.testing.assert_allclose(got_lp.numpy(), want_lp.numpy(), rtol=1e-5, atol=1e-5)
+    # every slot with a finite score: same beam, same score (slots that only -1e20 fillers reach are ties torch leaves open)
+    fin = scores > -1e19
+    assert bool(((got_scores > -1e19) == fin).all())
+    np.testing.assert_allclose(got_scores[fin].numpy(), scores[fin].numpy(), rtol=1e-5, atol=1e-5)
+    # a swap among slots whose scores tie within fp32 rounding is legitimate; otherwise the beams are identical
+    diff = (got_beams != beams).any(-1) & fin
+    for b, s, k in diff.nonzero().tolist():
+        near = (scores[b, s] - scores[b, s, k]).abs() < 1e-5
+        assert int(near.sum()) > 1, (b, s, k)
+
+
+def test_cbs_several_eos_ids_and_min_constraints():
+    """`eos_token_ids` with two ids (utils_cbs.py:177-179, 157, 432-433) and min_constraints_to_satisfy = 1: the selection may then
+    take a state with one bit set."""
+    Vn, R, B, K = 300, 64, 3, 2
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(R, Vn, generator=g) * 2.0
+    table[:, 2] += 2.0
+    table[:, 5] += 2.0
+    fsm1, used = O.fsm_build([[[7]], [[9]]], Vn, max_given_constraints=2)
+    fsm = torch.stack([fsm1[:used, :used]] * B)
+    ncons = torch.tensor([2, 1, 2])
+
+    def step(ids, parents):
+        return table[(ids[:, -1] * 5 + ids.shape[1] * 11) % R]
+    for min_c in (1, 2):
+        beams, scores = O.cbs_search(step, fsm, K, max_length=14, eos=[2, 5])
+        want_ids, want_lp = O.cbs_select_best(beams, scores, ncons, min_c, eos=[2, 5])
+        got_ids, got_lp, _, _, n_pred = _run_device(table.cuda(), fsm, ncons, K, min_c, 14, 2, extra=[5])
+        assert n_pred == beams.shape[3]
+        np.testing.assert_array_equal(got_ids.numpy(), want_ids.numpy())
+        np.testing.assert_allclose(got_lp.numpy(), want_lp.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- the whole path
+def _case(vec, n):
+    B, K, max_given, S = [int(x) for x in vec['case%d_cfg' % n]]
+    tab = vec['case%d_constraint_ids' % n]
+    fsms = []
+    for b in range(B):
+        per = []
+        for c in range(tab.shape[1]):
+            words = [[int(f) for f in tab[b, c, w] if f >= 0] for w in range(tab.shape[2]) if (tab[b, c, w] >= 0).any()]
+            if words:
+                per.append(words)
+        fsms.append(O.fsm_build(per, int(vec['vocab_size']), max_given, 4)[0][:S, :S])
+    return B, K, S, torch.stack(fsms), torch.from_numpy(vec['case%d_num_constraints' % n])
+
+
+@pytest.fixture(scope='module')
+def model():
+    from vitcap_amd.model import ImageCaptioning
+    m = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+    m.pack('cuda')
+    return m
+
+
+CBS_SCORE_TOL = 1e-2          # as for beam search: accumulated bf16 logit noise on a 19-step score
+
+
+@pytest.mark.parametrize('n', [0, 1, 2])
+def test_cbs_captions_vs_reference(model, n):
+    """Device captions under constraints against the reference's own generate(use_cbs=True) output.  The constrained words must be
+    in the caption; ids equal the reference's, or -- a decision inside the noise floor resolved the other way -- the selected
+    caption's length-normalised score is within CBS_SCORE_TOL of the reference's."""
+    vec = np.load(GOLD)
+    B, K, S, fsm, ncons = _case(vec, n)
+    im = torch.from_numpy(W.gen_image_batch(B, int(vec['image_seed']))).cuda()
+    ids, lp = model.generate_cbs(im, fsm.cuda(), ncons.cuda(), num_beams=K, min_constraints_to_satisfy=2)
+    want_ids, want_lp = vec['case%d_ids' % n], vec['case%d_logprobs' % n]
+    assert tuple(ids.shape) == (B, 1, want_ids.shape[1]) and tuple(lp.shape) == (B, 1)
+    tab = vec['case%d_constraint_ids' % n]
+    for b in range(B):
+        seq = ids[b, 0].tolist()
+        for c in range(int(ncons[b])):                    # every given constraint (<= 2 here) is satisfied: its words in order
+            words = [set(int(f) for f in tab[b, c, w] if f >= 0) for w in range(tab.shape[2]) if (tab[b, c, w] >= 0).any()]
+            assert any(all(seq[i + j] in words[j] for j in range(len(words))) for i in range(len(seq) - len(words) + 1)), (b, c, seq)
+        if seq != want_ids[b].tolist():
+            assert abs(float(lp[b, 0]) - float(want_lp[b])) < CBS_SCORE_TOL, (b, seq, want_ids[b].tolist(), float(lp[b, 0]), float(want_lp[b]))
+    exact = sum(ids[b, 0].tolist() == want_ids[b].tolist() for b in range(B))
+    print('case %d: %d / %d captions exactly equal to the reference' % (n, exact, B))
+    np.testing.assert_allclose(lp[:, 0].cpu().numpy(), want_lp, rtol=0, atol=5e-2)
+
+
+def test_cbs_vs_oracle_emulation_and_replay(model, sd_t):
+    """Against the oracle's bf16 emulation of the incremental path (same tolerance rule), plus: deterministic, and the hipGraph
+    replay of the decode loop returns the same captions."""
+    vec = np.load(GOLD)
+    B, K, S, fsm, ncons = _case(vec, 0)
+    im_c = torch.from_numpy(W.gen_image_batch(B, int(vec['image_seed'])))
+    with torch.no_grad():
+        o_ids, o_lp = O.cbs_incremental(sd_t, im_c, fsm, ncons, K, 2, emulate_bf16=True)
+    im = im_c.cuda()
+    fd, nd = fsm.cuda(), ncons.cuda()
+    ids, lp = model.generate_cbs(im, fd, nd, num_beams=K)
+    for b in range(B):
+        if ids[b, 0].tolist() != o_ids[b].tolist():
+            assert abs(float(lp[b, 0]) - float(o_lp[b])) < CBS_SCORE_TOL
+    ids2, lp2 = model.generate_cbs(im, fd, nd, num_beams=K)
+    assert torch.equal(ids, ids2) and torch.equal(lp, lp2)
+    ids3, lp3 = model.generate_cbs(im, fd, nd, num_beams=K, use_graph=True)
+    ids4, lp4 = model.generate_cbs(im, fd, nd, num_beams=K, use_graph=True)      # replayed
+    assert torch.equal(ids, ids3) and torch.equal(lp, lp3) and torch.equal(ids, ids4) and torch.equal(lp, lp4)
+
+
+def test_cbs_forward_contract(model):
+    """The wrapper's test branch with `use_cbs` in test_extra_input (..._bertemb.py:175-181): fsm / num_constraints travel in the
+    batch; without them the call fails naming them (the reference dies on fsm.shape)."""
+    vec = np.load(GOLD)
+    B, K, S, fsm, ncons = _case(vec, 0)
+    im = torch.from_numpy(W.gen_image_batch(B, int(vec['image_seed']))).cuda()
+    keep = dict(model.test_extra_input)
+    try:
+        model.test_extra_input.update({'use_cbs': True, 'num_beams': K})
+        with pytest.raises(ValueError, match='fsm'):
+            model({'image': im})
+        ids, lp = model({'image': im, 'fsm': fsm.cuda(), 'num_constraints': ncons.cuda()})
+        want, _ = model.generate_cbs(im, fsm.cuda(), ncons.cuda(), num_beams=K)
+        assert torch.equal(ids, want)
+    finally:
+        model.test_extra_input = keep

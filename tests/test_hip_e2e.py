@@ -694,6 +694,26 @@ def test_batch64_properties(model):
     assert torch.isfinite(lp1).all()
 
 
+def test_batch64_vs_oracle(model, sd_t):
+    """BASELINE configs[1]'s batch (64 images) compared with the ORACLE, not only with itself: the oracle's
+    incremental fp32 model (token-exact with the reference on every golden, tests/test_oracle_golden.py) captions the same 64 images on
+    the host; every device caption equals the oracle's up to its first decision below the bf16 noise floor, whole captions wherever
+    every decision clears it, log-probs of the equal captions within 1e-2."""
+    from oracle import vitcap_oracle as O
+    B = 64
+    img = _images(B, seed=6400)
+    with torch.no_grad():
+        ids_o, lp_o, tr = O.greedy_incremental(sd_t, img, emulate_bf16=False, return_trace=True)
+    margins = torch.stack([st['margin'] for st in tr['steps']], 1).numpy()
+    ids, lp = model.generate(img.cuda().to(torch.bfloat16))
+    got, want = ids.cpu().numpy(), ids_o.view(B, 1, -1).numpy()
+    rep = assert_tokens_match_reference(got, want, margins, GREEDY_MARGIN_FLOOR, min_full=8, what='B = 64 vs oracle')
+    equal = [r[0] for r in rep if r[4]]
+    print('B = 64: %d / %d captions equal the oracle\'s, %d whole-caption comparable' % (len(equal), B, sum(1 for r in rep if r[2])))
+    np.testing.assert_allclose(lp.cpu().numpy()[equal, 0], lp_o.view(B, -1).numpy()[equal, 0], rtol=0, atol=1e-2)
+    assert len(equal) >= int(0.8 * B)
+
+
 def test_early_exit_and_finished_rows(model, golden):
     """`if cur_unfinished.max() == 0: break` (modeling_utils.py:866) on the device: with a frequent token as EOS and a batch in
     which every caption ends early, the live counter reaches 0, the remaining steps' kernels return at entry, and ids / scores

@@ -23,7 +23,7 @@ OUT_BF16, OUT_F32 = 0, 1
 vp = C.c_void_p
 
 
-ABI_VERSION = 3          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
+ABI_VERSION = 4          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
 
 
 class GemmDesc(C.Structure):
@@ -58,7 +58,15 @@ class GenOpts(C.Structure):
                 ('pad_token_id', C.c_int32), ('mask_token_id', C.c_int32), ('length_penalty', C.c_float),
                 ('repetition_penalty', C.c_float), ('sampling', SampleParams), ('gemm_mode', C.c_int32),
                 ('early_exit', C.c_int32), ('use_graph', C.c_int32), ('tag_visible', C.c_int32), ('tagemb_cls', C.c_int32),
-                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3), ('tag_pos0', C.c_int32)]
+                ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3), ('tag_pos0', C.c_int32),
+                # constrained beam search (ViTCAP.generate use_cbs / fsm / num_constraints / min_constraints_to_satisfy)
+                ('use_cbs', C.c_int32), ('cbs_states', C.c_int32), ('min_constraints_to_satisfy', C.c_int32),
+                ('cbs_reserved', C.c_int32), ('fsm', C.c_void_p), ('num_constraints', C.c_void_p)]
+
+
+class CbsState(C.Structure):
+    """vitcap_cbs_state: device arrays of the constrained beam search bookkeeping (csrc/cbs.hip)."""
+    _fields_ = [(n, C.c_void_p) for n in ('ids_in', 'ids_out', 'scores_in', 'scores_out', 'parent', 'unfinished', 'n_pred', 'live')]
 
 
 class Image(C.Structure):
@@ -175,6 +183,12 @@ _SIGS = {
                                            C.c_float, vp]),
     'vitcap_beam_reorder_cache': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_beam_finalize': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_cbs_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_cbs_start': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'vitcap_cbs_candidates': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                        vp, vp, vp]),
+    'vitcap_cbs_select': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'vitcap_cbs_finalize': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
     'vitcap_assemble_visual': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_gather_rows_bf16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     'vitcap_engine_create': (C.c_int, [C.POINTER(vp)]),

@@ -107,6 +107,8 @@ vitcap_gen_opts default_opts() {
   o.encode_parts = 0;
   o.eos_extra[0] = o.eos_extra[1] = o.eos_extra[2] = -1;
   o.tag_pos0 = VITCAP_MAXLEN;
+  o.use_cbs = 0; o.cbs_states = 0; o.min_constraints_to_satisfy = 2; o.cbs_reserved = 0;
+  o.fsm = nullptr; o.num_constraints = nullptr;
   return o;
 }
 
@@ -136,6 +138,21 @@ int check_opts(const vitcap_gen_opts& o) {
     // be EOS words and `assert len(next_sent_beam) == num_beams` fires (modeling_utils.py:1037)
     OPT_REQ(o.eos_extra[i] < 0 || o.num_beams == 1, "gen_opts: several eos_token_ids need num_beams == 1 (the reference's beam search asserts with them)");
   }
+  if (o.use_cbs) {
+    // ViTCAP.generate(use_cbs=True): utils_cbs.py keeps num_keep_best = 1 and a plain log-softmax (modeling_bert.py:1038-1042)
+    OPT_REQ(o.use_cbs == 1, "gen_opts: use_cbs must be 0 or 1 (got %d)", o.use_cbs);
+    OPT_REQ(o.fsm && o.num_constraints, "gen_opts: use_cbs needs fsm [B][S][S][%d] uint8 and num_constraints [B] int64 on the device "
+            "(the reference reads fsm.shape, modeling_bert.py:952)", VITCAP_VOCAB);
+    OPT_REQ(o.cbs_states >= 1 && o.cbs_states <= 32, "gen_opts: cbs_states must be 1..32 (got %d)", o.cbs_states);
+    OPT_REQ(o.cbs_states * o.num_beams <= 256, "gen_opts: cbs_states * num_beams must be <= 256 sequences per image (got %d)",
+            o.cbs_states * o.num_beams);
+    OPT_REQ(o.min_constraints_to_satisfy >= 0, "gen_opts: min_constraints_to_satisfy must be >= 0 (got %d)", o.min_constraints_to_satisfy);
+    OPT_REQ(o.num_keep_best == 1, "gen_opts: not supported n_best > 1 for CBS (modeling_bert.py:1038)");
+    OPT_REQ(o.seqs_per_image == 1 && !o.sampling.do_sample && o.repetition_penalty == 1.0f,
+            "gen_opts: use_cbs runs neither sampling, num_return_sequences > 1 nor the repetition penalty (utils_cbs.py:184-185)");
+    OPT_REQ(o.tag_visible == 0, "gen_opts: use_cbs with tag tokens visible to the caption is not built");
+    OPT_REQ(o.max_length >= 3, "gen_opts: use_cbs needs max_length >= 3 (got %d)", o.max_length);
+  }
 #undef OPT_REQ
   return VITCAP_OK;
 }
@@ -163,6 +180,8 @@ struct Layout {
   int NT;
   int L, NS, K;
   bool beam;
+  bool cbs;          // constrained beam search: K = cbs_states * num_beams sequences per image
+  size_t cbs_val, cbs_word, cbs_sc, cbs_sc2, cbs_unf, cbs_npred;
   // the same layout seen from image i0 on: every image-major buffer of the encoder / prefill advanced by i0 images
   Layout from_image(int i0) const {
     Layout v = *this;
@@ -181,10 +200,11 @@ struct Layout {
   }
   Layout(int B, const vitcap_gen_opts& o) {
     L = o.max_length;
-    beam = o.num_beams > 1;
-    K = beam ? o.num_beams : o.seqs_per_image;
+    cbs = o.use_cbs != 0;
+    beam = !cbs && o.num_beams > 1;
+    K = cbs ? o.cbs_states * o.num_beams : (beam ? o.num_beams : o.seqs_per_image);
     NS = B * K;
-    const bool two = K > 1;                       // layouts with several sequences per image carry the second cache / id buffer
+    const bool two = K > 1 || cbs;                // layouts with several sequences per image carry the second cache / id buffer
     const size_t b = (size_t)B, n = (size_t)NS, l = (size_t)L;
     patches = take(b * 576 * D * 2);
     x = take(b * NV * D * 4);
@@ -259,6 +279,22 @@ struct Layout {
     for (int i = 0; i < 4; ++i) vt[i] = 0;
     if (beam && NT == 0)
       for (int i = 0; i < 4; ++i) vt[i] = take(b * VT_BYTES);
+    cbs_val = cbs_word = cbs_sc = cbs_sc2 = cbs_unf = cbs_npred = 0;
+    if (cbs) {
+      const size_t per = (size_t)o.cbs_states * o.num_beams;        // candidates per slot: K words for each of the S target states
+      cbs_val = take(n * per * 4);
+      cbs_word = take(n * per * 4);
+      cbs_sc = take(n * 4);
+      cbs_sc2 = take(n * 4);
+      cbs_unf = take(l * 4);
+      cbs_npred = take(256);
+      lse = take(n * 4);
+      cand_val = take(n * 4);              // row maxima next to the log-sum-exp (vitcap_row_topk_lse with k = 1)
+      cand_idx = take(n * 4);
+      parent = take(n * 4);
+      fin_ids = take(b * l * 8);
+      fin_lp = take(b * 4);
+    }
     if (beam) {
       cand_val = take(n * 16 * 4);
       cand_idx = take(n * 16 * 4);
@@ -299,7 +335,12 @@ struct CallScope {
 
 int gemm_desc(const void* A, const void* W, const float* bias, const float* res, void* C, vitcap_gemm_desc d, void* s) {
   vitcap_engine* e = g_cur;
-  const bool eligible = e && e->timing && d.M > 256;
+  // the big-tile launches of the encoder / prefill (the decode-step GEMMs of large batches are a different, latency-bound population)
+  bool eligible = e && e->timing && d.M >= 2048;
+  if (eligible) {      // a launch that is being captured into a hipGraph cannot carry events that are queried afterwards
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) eligible = false;
+  }
   const bool timed = eligible && (e->timing_seen++ % e->timing_stride) == 0 && e->used < e->pool.size();
   GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
   // one tile per workgroup for the large GEMMs when the caller overlaps a second stream (vitcap_gen_opts.gemm_mode)
@@ -1087,8 +1128,55 @@ static int beam_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen
   return VITCAP_OK;
 }
 
+// Constrained beam search loop (ViTCAP.generate with use_cbs, modeling_bert.py:1035-1057): B * S * num_beams
+// sequences through the same decode step as beam search, bookkeeping of utils_cbs.py:26-443 on the device (csrc/cbs.hip).  The
+// reference re-runs the whole model on every prefix (`state` stays None); here the text K/V caches follow the back-pointers.
+static int cbs_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
+  const vitcap_weights& w = e->w;
+  const int NS = lo.NS, L = lo.L, S = o.cbs_states, K = o.num_beams;
+  vitcap_cbs_state st;
+  st.ids_in = (int64_t*)(ws + lo.ids);
+  st.ids_out = (int64_t*)(ws + lo.ids2);
+  st.scores_in = (float*)(ws + lo.cbs_sc);
+  st.scores_out = (float*)(ws + lo.cbs_sc2);
+  st.parent = (int32_t*)(ws + lo.parent);
+  st.unfinished = (int32_t*)(ws + lo.cbs_unf);
+  st.n_pred = (int32_t*)(ws + lo.cbs_npred);
+  st.live = (int32_t*)(ws + lo.live);
+  CK(vitcap_cbs_init(&st, B, S, K, L, o.bos_token_id, s));
+  char* tc_cur = ws + lo.tcache;
+  char* tc_alt = ws + lo.tcache2;
+  const float* logits = (const float*)(ws + lo.logits);
+  float* lse = (float*)(ws + lo.lse);
+  auto swap_state = [&] {
+    int64_t* ti = st.ids_in; st.ids_in = st.ids_out; st.ids_out = ti;
+    float* tf = st.scores_in; st.scores_in = st.scores_out; st.scores_out = tf;
+  };
+  for (int t = 1; t < L; ++t) {
+    CK(step_forward(w, lo, o, ws, t, st.ids_in, tc_cur, true, false, Part{0, NS, 0}, s));
+    CK(vitcap_row_topk_lse(logits, VP, VITCAP_VOCAB, 1, (float*)(ws + lo.cand_val), (int32_t*)(ws + lo.cand_idx), lse, NS, s));
+    if (t == 1) {
+      CK(vitcap_cbs_start(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, L, o.eos_token_id, o.eos_extra, s));
+    } else {
+      CK(vitcap_cbs_candidates(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, t, L, o.eos_token_id, o.eos_extra,
+                               (float*)(ws + lo.cbs_val), (int32_t*)(ws + lo.cbs_word), s));
+      CK(vitcap_cbs_select((const float*)(ws + lo.cbs_val), (const int32_t*)(ws + lo.cbs_word), &st, B, S, K, t, L, o.eos_token_id,
+                           o.eos_extra, s));
+    }
+    if (t + 1 < L) {   // the text K/V history (positions 0..t-1) follows the back-pointers
+      CK(vitcap_beam_reorder_cache(tc_cur, tc_alt, st.parent, 4, NS, L, t, s));
+      char* tmp = tc_cur; tc_cur = tc_alt; tc_alt = tmp;
+    }
+    swap_state();
+  }
+  CK(vitcap_cbs_finalize(&st, o.num_constraints, o.min_constraints_to_satisfy, B, S, K, L, o.eos_token_id, o.eos_extra, o.pad_token_id,
+                         (int64_t*)(ws + lo.fin_ids), (float*)(ws + lo.fin_lp), s));
+  return VITCAP_OK;
+}
+
 static int decode_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_opts& o, char* ws, void* s) {
   CallScope scope(e, o.gemm_mode, o.early_exit ? (const int32_t*)(ws + lo.live) : nullptr, &o);
+  if (lo.cbs) return cbs_loop(e, B, lo, o, ws, s);
   return lo.beam ? beam_loop(e, B, lo, o, ws, s) : greedy_loop(e, lo, o, ws, s);
 }
 
@@ -1122,7 +1210,10 @@ static int decode_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, cons
     HIPCK(hipGraphLaunch(hit->exec, st), "decode: graph launch");
   }
   const size_t L = (size_t)lo.L;
-  if (lo.beam) {
+  if (lo.cbs) {       // [B][1][max_length]: the n_pred words of the selected beam (no BOS column), then pad; tap "cbs_npred" = n_pred
+    HIPCK(hipMemcpyAsync(out_ids, ws + lo.fin_ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, st), "decode: output copy");
+    HIPCK(hipMemcpyAsync(out_logprobs, ws + lo.fin_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, st), "decode: output copy");
+  } else if (lo.beam) {
     const size_t n = (size_t)B * o.num_keep_best;
     HIPCK(hipMemcpyAsync(out_ids, ws + lo.fin_ids, n * L * 8, hipMemcpyDeviceToDevice, st), "decode: output copy");
     HIPCK(hipMemcpyAsync(out_logprobs, ws + lo.fin_lp, n * 4, hipMemcpyDeviceToDevice, st), "decode: output copy");
@@ -1193,5 +1284,6 @@ extern "C" const void* vitcap_engine_tap(vitcap_engine* e, const char* name, voi
   if (!strcmp(name, "tag_len")) return ws + lo.tag_len;
   if (!strcmp(name, "ids")) return ws + lo.ids;
   if (!strcmp(name, "live")) return ws + lo.live;
+  if (!strcmp(name, "cbs_npred")) return lo.cbs ? ws + lo.cbs_npred : nullptr;
   return nullptr;
 }

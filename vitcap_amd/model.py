@@ -257,8 +257,22 @@ class ImageCaptioning(nn.Module):
         does not implement instead of silently ignoring them; used by forward() AND by the pipeline's predict loop."""
         te = dict(self.test_extra_input)
         te.update(over)
+        cbs = None
         if te.get('use_cbs', False):
-            raise NotImplementedError('constrained beam search (use_cbs, src/tools/captioning/utils_cbs.py) is not built')
+            # ViTCAP.generate(use_cbs=True, fsm=, num_constraints=, min_constraints_to_satisfy=) (modeling_bert.py:932-933, 949-953,
+            # 1035-1057).  The reference's pipeline sets use_cbs / min_constraints_to_satisfy (..._bertemb.py:175-179) but nothing in
+            # it ever supplies `fsm`: there generate() dies on `fsm.shape`; here the missing tensors are named.
+            fsm, ncons = te.get('fsm'), te.get('num_constraints')
+            if fsm is None or ncons is None:
+                raise ValueError('use_cbs needs `fsm` (B, S, S, %d) uint8 and `num_constraints` (B,) next to it (vitcap_amd.cbs.batch_fsm); '
+                                 'the reference reads fsm.shape at modeling_bert.py:952' % L.VOCAB)
+            if fsm.dim() != 4 or fsm.shape[1] != fsm.shape[2] or fsm.shape[3] != L.VOCAB:
+                raise AssertionError('fsm must be (B, S, S, %d), got %s (modeling_bert.py:953)' % (L.VOCAB, tuple(fsm.shape)))
+            if not (fsm.is_cuda and ncons.is_cuda and fsm.is_contiguous() and fsm.dtype in (torch.uint8, torch.bool)):
+                raise ValueError('fsm / num_constraints must be contiguous device tensors (uint8 / int64)')
+            ncons = ncons.to(torch.int64).contiguous()
+            cbs = (fsm, ncons)
+            self._cbs_keep = cbs                       # the option struct holds raw pointers into these
         if not te.get('add_od_labels', True):
             # without the 50 od slots ViTSplitCLSEmbModel.forward has no rows to write its tag embeddings over
             # (`embedding_output[:, -pred_topk.shape[1]:] = tag_embedding`, modeling_bert.py:1467 / 1489) and the reference fails
@@ -295,6 +309,10 @@ class ImageCaptioning(nn.Module):
                        tag_visible=int(te.get('tag_visible', 0) or 0), tagemb_cls=int(self.tagemb == 'cls'),
                        decode_streams=int(te.get('decode_streams', 0) or 0), encode_parts=int(te.get('encode_parts', 0) or 0),
                        eos_extra=eos[1:], tag_pos0=max(int(te.get('od_labels_start_posid', 20) or 0), ml, 20))
+        if cbs is not None:
+            o.use_cbs, o.cbs_states = 1, int(cbs[0].shape[1])
+            o.min_constraints_to_satisfy = int(te.get('min_constraints_to_satisfy', 2))
+            o.fsm, o.num_constraints = cbs[0].data_ptr(), cbs[1].data_ptr()
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
@@ -377,7 +395,9 @@ class ImageCaptioning(nn.Module):
         return self._packed[2]
 
     def _out_buffers(self, B, o, dev):
-        if o.num_beams > 1:
+        if o.use_cbs:
+            shape = (B, 1)
+        elif o.num_beams > 1:
             shape = (B, o.num_keep_best)
         else:
             shape = (B * o.seqs_per_image, 1)
@@ -431,6 +451,22 @@ class ImageCaptioning(nn.Module):
         o = self.gen_options(num_beams=int(num_beams), length_penalty=float(length_penalty), num_keep_best=int(num_keep_best),
                              num_return_sequences=1, **over)
         return self.run(image, o, slot=slot)
+
+    def generate_cbs(self, image, fsm, num_constraints, num_beams=1, min_constraints_to_satisfy=2, slot=0, **over):
+        """Constrained beam search: ViTCAP.generate(use_cbs=True, fsm=fsm, num_constraints=..., min_constraints_to_satisfy=...)
+        (modeling_bert.py:1035-1057 -> utils_cbs.py:26-443) -> (ids (B, 1, T), logprobs (B, 1)).  Like the reference's output the
+        ids carry NO BOS column and T <= max_length - 1 is the number of words decoded before every one of the batch's
+        B * S * num_beams sequences had ended (one host synchronisation reads it).  fsm / num_constraints: vitcap_amd.cbs.batch_fsm."""
+        if fsm is None or num_constraints is None:
+            self.gen_options(use_cbs=True, fsm=fsm, num_constraints=num_constraints)       # raises, naming what is missing
+        if fsm.shape[0] != image.shape[0] or num_constraints.shape[0] != image.shape[0]:
+            raise AssertionError('fsm / num_constraints are for %d images, the batch has %d (modeling_bert.py:953)'
+                                 % (fsm.shape[0], image.shape[0]))
+        o = self.gen_options(use_cbs=True, fsm=fsm, num_constraints=num_constraints, num_beams=int(num_beams), num_keep_best=1,
+                             min_constraints_to_satisfy=int(min_constraints_to_satisfy), do_sample=False, num_return_sequences=1, **over)
+        ids, lp = self.run(image, o, slot=slot)
+        n_pred = int(self.tap('cbs_npred', image.shape[0], (1,), dtype=torch.int32, slot=slot, opts=o)[0])
+        return ids[:, :, :n_pred].contiguous(), lp
 
     def generate_async(self, image, num_beams=1, length_penalty=1.0, lane=0, opts=None):
         """Captions through a two-slot software pipeline: the ViT encoder + decoder prefill of THIS batch run on one
@@ -531,6 +567,15 @@ class ImageCaptioning(nn.Module):
             # beyond the engine's sequences-per-image limit: expand the inputs like the reference does (modeling_bert.py:976-994)
             image = image.repeat_interleave(nret, 0).contiguous()
             over['num_return_sequences'] = 1
+        if te.get('use_cbs', False):
+            # the batch carries the machines (modeling_bert.py:932: generate's own kwargs)
+            n_tag = self.check_text_inputs(data, int(te.get('max_length', L.MAXLEN)))
+            if n_tag:
+                raise NotImplementedError('use_cbs with tag tokens visible to the caption is not built')
+            return self.generate_cbs(image, data.get('fsm', te.get('fsm')), data.get('num_constraints', te.get('num_constraints')),
+                                     num_beams=int(te.get('num_beams', 1) or 1),
+                                     min_constraints_to_satisfy=int(data.get('min_constraints_to_satisfy',
+                                                                             te.get('min_constraints_to_satisfy', 2))))
         opts = self.gen_options(**over)
         n_tag = self.check_text_inputs(data, opts.max_length)
         if n_tag != opts.tag_visible:
