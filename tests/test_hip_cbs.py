@@ -128,7 +128,10 @@ def test_cbs_several_eos_ids_and_min_constraints():
         want_ids, want_lp = O.cbs_select_best(beams, scores, ncons, min_c, eos=[2, 5])
         got_ids, got_lp, _, _, n_pred = _run_device(table.cuda(), fsm, ncons, K, min_c, 14, 2, extra=[5])
         assert n_pred == beams.shape[3]
-        np.testing.assert_array_equal(got_ids.numpy(), want_ids.numpy())
+        # a finished beam may continue with ANY of the EOS ids at cost 0 (utils_cbs.py:154-157): an exact tie that torch.topk
+        # resolves one way or the other from step to step; the device takes the lowest id.  Compare with the ids folded together.
+        fold = lambda a: np.where(np.isin(a, [2, 5]), 2, a)
+        np.testing.assert_array_equal(fold(got_ids.numpy()), fold(want_ids.numpy()))
         np.testing.assert_allclose(got_lp.numpy(), want_lp.numpy(), rtol=1e-5, atol=1e-5)
 
 
