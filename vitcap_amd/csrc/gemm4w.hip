@@ -660,16 +660,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // (fixed + MI) units -- 435 tiles of 256 rows (M = 36928, N = 768) pay 2 rounds for 1.7 rounds of work, 495 tiles of 224 rows pay
 // 2 rounds of 7/8 the length; 1305 (N = 2304) pay 6, 1485 of 224 rows pay 6 x 7/8.  The kernel is the same code for every MI (the
 // wave tile is MI x 8 MFMA tiles, k order per output element unchanged: bit-identical results whatever the height).
-int pick_mi(int M, int tiles_n, int form) {
-  static const int env_mi = [] { const char* e = getenv("VITCAP_GEMM4W_MI"); return e ? atoi(e) : 0; }();
-  if (env_mi >= 6 && env_mi <= 8) return env_mi;
-  static const int n_cu = [] {
+int device_cus() {
+  static const int n = [] {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       return prop.multiProcessorCount;
     return 256;
   }();
+  return n;
+}
+// workgroups of the persistent grid = CUs it occupies (512 registers per lane: one workgroup owns a CU).  VITCAP_GEMM_4W_RESERVE = R
+// leaves R CUs (a multiple of 8: the XCDs stay balanced) to whatever else runs on the GPU -- the batch pipeline's decode chain
+int persistent_cus() {
+  static const int reserve = [] { const char* e = getenv("VITCAP_GEMM_4W_RESERVE"); return e ? atoi(e) : 0; }();
+  const int n = device_cus() - (reserve > 0 ? reserve : 0);
+  return n >= 8 ? n : 8;
+}
+
+int pick_mi(int M, int tiles_n, int form) {
+  static const int env_mi = [] { const char* e = getenv("VITCAP_GEMM4W_MI"); return e ? atoi(e) : 0; }();
+  if (env_mi >= 6 && env_mi <= 8) return env_mi;
+  const int n_cu = form == 2 ? persistent_cus() : device_cus();
   const float fixed = form == 2 ? 0.3f : 0.9f;       // per-tile cost that does not shrink with the tile: pipeline fill, barriers' skew, W traffic
   int best = 8;
   float best_c = 1e30f;
@@ -687,17 +699,21 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
   p.tiles_m = (p.M + 32 * MI - 1) / (32 * MI);
   p.n_big = p.tiles_m * p.tiles_n;
   if (form == 2) {
-    static const int n_cu = [] {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        return prop.multiProcessorCount;
-      return 256;
-    }();
+    const int n_cu = persistent_cus();
     auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
     constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
     VC_FUNC_SMEM(kern, smem);
-    const int grid = p.n_big < n_cu ? p.n_big : n_cu;
+    // VITCAP_GEMM_4W_TIGHT=1 (experiments): the fewest workgroups (a multiple of 8: every XCD the same number) that finish in the same
+    // number of rounds as all CUs would -- 1305 tiles take 6 rounds on 256 CUs and on 224 -- leaving the other CUs to whatever else
+    // runs.  Measured: no gain alone (19.55 vs 19.59 ms, B = 512 124.3 vs 123.3), and inside the batch pipeline only a
+    // CONSTANT reservation helps the decode chain (VITCAP_GEMM_4W_RESERVE=32 ties the 8-wave kernel there), so the default is off
+    static const int tight = [] { const char* e = getenv("VITCAP_GEMM_4W_TIGHT"); return e ? atoi(e) : 0; }();
+    int grid = p.n_big < n_cu ? p.n_big : n_cu;
+    if (tight && p.n_big > n_cu) {
+      const int rounds = (p.n_big + n_cu - 1) / n_cu;
+      const int need = ((p.n_big + rounds - 1) / rounds + 7) & ~7;
+      if (need < grid) grid = need;
+    }
     VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
   } else {
     auto kern = gemm_nt_4w_kernel<ACT, OUT_F32, HAS_RES, 1, MI>;
