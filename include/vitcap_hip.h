@@ -43,12 +43,13 @@ extern "C" {
 #define VITCAP_OUT_F32 1
 
 const char* vitcap_last_error(void);
-/* ABI version of this header: bumped whenever a struct layout or a function signature changes (3: `abi` heads vitcap_gemm_desc and
+/* ABI version of this header: bumped whenever a struct layout or a function signature changes (5: vitcap_gemm_desc.ln_*; 4:
+ * vitcap_gen_opts' constrained-beam-search block + the vitcap_cbs_* entry points; 3: `abi` heads vitcap_gemm_desc and
  * vitcap_gen_opts; 2 -> 3 also covers round 3's additions: gemm_desc.colsum, gen_opts.eos_extra / tag_pos0, vitcap_tag_embed's pos0,
  * vitcap_layernorm_bwd's extra pointer, zout / aux carrying gelu').  vitcap_version() returns the library's value: a binding checks
  * the two for equality at load time, and every call that takes one of the two option structs rejects a struct whose first field is
  * not VITCAP_ABI_VERSION (a caller built against an older header passes a shorter struct: its fields would be misread). */
-#define VITCAP_ABI_VERSION 4
+#define VITCAP_ABI_VERSION 5
 int vitcap_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -98,6 +99,20 @@ typedef struct {
                           accumulation, as vitcap_colsum_bf16 of C would add them) -- the bias gradient of the layer whose output
                           gradient this GEMM produces, without another pass over C.  Needs bf16 output, no residual / row remap /
                           split-K, M >= 2048, N and ldc multiples of 8 (the 256x256 kernel's 16-byte-store epilogue). */
+  /* optional LayerNorm of the finished rows (what vitcap_layernorm_fwd over C would write, bit for bit; timm Block.norm1 / norm2
+   * behind the residual adds, vision_transformer.py:246-247, BertSelfOutput / BertOutput.LayerNorm, modeling_bert.py:356, 418):
+   * ln_out_bf16 [M][768] and / or ln_out_f32 [M][768] = LayerNorm(C[row]; ln_gamma, ln_beta, ln_eps).  Needs N == 768, ldc == 768, fp32
+   * output, plain rows, no activation.  Where the launch form supports it the pass runs INSIDE the GEMM: the last of a 256-row
+   * block's three column tiles to finish normalises the block (write-through output stores, one counter per row block in
+   * ln_counters -- int32 [ceil(M / 128) + 8], zero before the first launch, left zero by every launch); otherwise a LayerNorm launch
+   * follows the GEMM on the same stream.  The outputs may alias A (a row block's A rows are read by its own tiles only). */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int ln_reserved;
+  void* ln_out_bf16;
+  float* ln_out_f32;
+  int32_t* ln_counters;
 } vitcap_gemm_desc;
 
 int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const float* residual,

@@ -585,3 +585,45 @@ def test_attn_decode_beams_vs_single_sequences(ops, K, t, L):
     s[:, :, 0, -1] = float('-inf')
     ref = O.softmax_pv_rounded(s, V.view(B, -1, 12, 64).transpose(1, 2), r).transpose(1, 2).reshape(B, 2, 768)
     _close(got.view(B, 2, 768), ref, 2 ** -7, 2e-3, 'beam attention vs reference K=%d t=%d' % (K, t))
+
+
+@pytest.mark.parametrize('variant', ['proj', 'fc2', 'no_res', 'ragged', 'post_ln_f32'])
+def test_gemm_with_fused_layernorm_bit_identical(ops, variant):
+    """vitcap_gemm_desc.ln_*: the residual GEMM that normalises its own finished rows (the last of a row block's three column tiles
+    to arrive does it: write-through stores, one ticket counter per row block, sc1 loads) against the same GEMM followed by
+    vitcap_layernorm_fwd -- fp32 rows and LayerNorm outputs bit for bit, counters left at zero, repeated launches included (every
+    launch deals the row blocks' last arrivers differently).  In place on the residual and with the LayerNorm output aliasing A,
+    as the engine's proj launch does."""
+    M, K = {'proj': (36928, 768), 'fc2': (9232, 3072), 'no_res': (4099, 768), 'ragged': (2049, 768), 'post_ln_f32': (5780, 768)}[variant]
+    N = 768
+    a = _bf(_rand((M, K), 91)).cuda()
+    w = _bf(_rand((N, K), 92, 0.05)).cuda()
+    bias = _rand((N,), 93, 0.1).cuda()
+    g = (1.0 + _rand((N,), 94, 0.2)).cuda()
+    b = _rand((N,), 95, 0.2).cuda()
+    x0 = _rand((M, N), 96).cuda() if variant != 'no_res' else None
+    eps = 1e-12 if variant == 'post_ln_f32' else 1e-6
+    want_f32 = variant == 'post_ln_f32'
+    # reference: plain GEMM (same kernel family, tile_hint 5) + the LayerNorm kernel
+    x_ref = ops.gemm_bias_act(a, w, bias, residual=x0, out=x0.clone() if x0 is not None else None, out_dtype=torch.float32, tile_hint=5)
+    hb_ref, hf_ref = ops.layernorm(x_ref, g, b, eps, want_bf16=True, want_f32=want_f32)
+    cnt = torch.zeros(M // 128 + 8, dtype=torch.int32, device='cuda')
+    for rep in range(3):
+        xin = x0.clone() if x0 is not None else None
+        if variant == 'proj':                       # LayerNorm output written over A's buffer (a row block's A rows are its own tiles')
+            a_buf = a.clone()
+            x, hb, hf = ops.gemm_layernorm(a_buf, w, bias, xin, g, b, eps, out=xin, ln_out=a_buf, counters=cnt, tile_hint=5)
+        else:
+            x, hb, hf = ops.gemm_layernorm(a, w, bias, xin, g, b, eps, out=xin, want_f32=want_f32, counters=cnt, tile_hint=5)
+        torch.cuda.synchronize()
+        assert torch.equal(x, x_ref), 'fp32 rows differ (%s, launch %d): max |d| %g' % (variant, rep, float((x - x_ref).abs().max()))
+        assert torch.equal(hb, hb_ref), 'LayerNorm rows differ (%s, launch %d): %d rows' % (
+            variant, rep, int((hb != hb_ref).any(1).sum()))
+        if want_f32:
+            assert torch.equal(hf, hf_ref)
+        assert int(cnt.abs().sum()) == 0, 'ticket counters not back at zero'
+    # without counters (or under a launch form without the pass) the LayerNorm launch follows: same bits
+    x2, hb2, _ = ops.gemm_layernorm(a, w, bias, x0.clone() if x0 is not None else None, g, b, eps, tile_hint=5)
+    x3, hb3, _ = ops.gemm_layernorm(a, w, bias, x0.clone() if x0 is not None else None, g, b, eps, counters=cnt, tile_hint=0)
+    torch.cuda.synchronize()
+    assert torch.equal(hb2, hb_ref) and torch.equal(x2, x_ref) and torch.equal(hb3, hb_ref)

@@ -23,13 +23,16 @@ OUT_BF16, OUT_F32 = 0, 1
 vp = C.c_void_p
 
 
-ABI_VERSION = 4          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
+ABI_VERSION = 5          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
 
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('abi', 'M', 'N', 'K', 'lda', 'ldw', 'ldc', 'ldr', 'act', 'out_dtype',
                                        'row_group', 'out_group_rows', 'out_row_off', 'res_periodic', 'tile_hint', 'split_k')] \
-        + [('live', C.c_void_p), ('rowstat', C.c_void_p), ('colsum', C.c_void_p)]
+        + [('live', C.c_void_p), ('rowstat', C.c_void_p), ('colsum', C.c_void_p),
+           # fused LayerNorm of the finished rows (vitcap_gemm_desc.ln_*)
+           ('ln_gamma', C.c_void_p), ('ln_beta', C.c_void_p), ('ln_eps', C.c_float), ('ln_reserved', C.c_int),
+           ('ln_out_bf16', C.c_void_p), ('ln_out_f32', C.c_void_p), ('ln_counters', C.c_void_p)]
 
     def __init__(self, *a, **kw):
         kw.setdefault('abi', ABI_VERSION)

@@ -207,6 +207,52 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm of one 768-wide row held by one wave (lane l: columns i*256 + 4l .. +3, i = 0..2): two-pass statistics, the arithmetic of
+// nn.LayerNorm in fp32.  Shared by the LayerNorm kernels (norm.hip) and the GEMM epilogues that normalise their own finished rows
+// (gemm.hip / gemm4w.hip), so that a row's result does not depend on which of them produced it.
+constexpr int D768 = 768;
+__device__ __forceinline__ void ln_row(const f32x4 (&v)[3], const float* gamma, const float* beta, float eps,
+                                       int lane, bf16_t* yb, float* yf) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) * (1.0f / D768);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q += d * d;
+    }
+  const float var = wave_sum(q) * (1.0f / D768);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 g = *(const f32x4*)(gamma + c);
+    const f32x4 b = *(const f32x4*)(beta + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+    if (yf) *(f32x4*)(yf + c) = y;
+    if (yb) {
+      uint2 o;
+      o.x = pack2bf(y[0], y[1]);
+      o.y = pack2bf(y[2], y[3]);
+      *(uint2*)(yb + c) = o;
+    }
+  }
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned vc_u32x4;
+// raw buffer descriptor over `bytes` bytes from `base` (clipped to the 4 GiB a descriptor can span); out-of-range lanes read 0 / are dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vc_rsrc(const void* base, long long bytes) {
+  const unsigned rec = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec, 0x00020000);
+}
+
+
 // Visibility of key row k to query row q in the decoder's joint sequence under teacher forcing, rows laid out as
 // [0, cf) visual | [cf, mf) caption tokens | [mf, S) [MASK] probes (mf = 0: no probe rows):
 //   visual rows see visual rows only; token row i sees visual + tokens <= i (seq2seq mask, dataset.py:377-390);

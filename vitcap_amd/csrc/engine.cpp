@@ -174,6 +174,7 @@ struct Layout {
   size_t hd_f, hd_b, logits, rowstat;
   size_t ids, ids2, unf, sum_lp, cnt, margins, logprob, last_tok, live;
   size_t cand_val, cand_idx, lse, beam_scores, parent, done, has_hyp, hyp_score, hyp_len, hyp_tok, fin_ids, fin_lp;
+  size_t ln_cnt, ln_cnt_tag;   // row-block ticket counters of the GEMMs that normalise their own rows (main chain / tag branch); (4 B + 16) ints each
   size_t vt[4];      // beam search: per decoder layer the visual V rows transposed per (image, head) for vitcap_attn_decode_beams (0: unused)
   // tag rows visible to the caption (vitcap_gen_opts.tag_visible = n > 0): per embedding branch v in {A, B}
   size_t tagx_f[2], tagx_b[2], tqkv_c[2][4], jqkv, jout, jlse, tg_ctx, tg_sa_f, tg_sa_b, tg_mlp, tg_tmp;
@@ -196,6 +197,7 @@ struct Layout {
     for (int l = 0; l < 4; ++l) if (v.vt[l]) v.vt[l] += i * VT_BYTES;
     v.pool_in += i * D * 2; v.pooled += i * D * 2; v.tg_f += i * D * 4; v.tg_b += i * D * 2;
     v.tag_logits += i * VP * 4; v.tag_ids += i * TOPK * 8; v.tag_prob += i * TOPK * 4; v.tag_len += i * 8;
+    v.ln_cnt += i * 4 * 4; v.ln_cnt_tag += i * 4 * 4;      // a part of n images owns <= 3.01 n + 1 row blocks of 192+ rows
     return v;
   }
   Layout(int B, const vitcap_gen_opts& o) {
@@ -230,6 +232,8 @@ struct Layout {
     tag_ids = take(b * TOPK * 8);
     tag_prob = take(b * TOPK * 4);
     tag_len = take(b * 8);
+    ln_cnt = take((b * 4 + 16) * 4);
+    ln_cnt_tag = take((b * 4 + 16) * 4);
     xs_f = take(n * 2 * D * 4);
     xs_b = take(n * 2 * D * 2);
     sqkv = take(n * 2 * 3 * D * 2);
@@ -371,6 +375,24 @@ int gemm(const void* A, int lda, const void* W, const float* bias, const float* 
   d.M = M; d.N = N; d.K = K;
   d.lda = lda; d.ldw = K; d.ldc = ldc; d.ldr = ldr;
   d.act = act; d.out_dtype = out;
+  return gemm_desc(A, W, bias, res, C, d, s);
+}
+
+// residual GEMM (N = 768, fp32 out) + LayerNorm of its finished rows -> ln_b (bf16) / ln_f (fp32, optional): one launch where the
+// kernel normalises its own rows (vitcap_gemm_desc.ln_*), GEMM + LayerNorm launches otherwise; same bits either way
+int gemm_ln(const void* A, int lda, const void* W, const float* bias, const float* res, void* C, int M, int K, const float* g,
+            const float* beta, float eps, void* ln_b, float* ln_f, int32_t* cnt, void* s) {
+  vitcap_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.abi = VITCAP_ABI_VERSION;
+  d.M = M; d.N = D; d.K = K;
+  d.lda = lda; d.ldw = K; d.ldc = D; d.ldr = D;
+  d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
+  d.ln_gamma = g; d.ln_beta = beta; d.ln_eps = eps;
+  // the in-kernel LayerNorm (last arriver of a row block) is built, bit-identical and SLOWER than the separate launch:
+  // the counters are handed over only under VITCAP_GEMM_LN_FUSE=1, otherwise vitcap_gemm_ex launches the LayerNorm kernel behind the GEMM
+  static const int fuse = [] { const char* e = getenv("VITCAP_GEMM_LN_FUSE"); return e ? atoi(e) : 0; }();
+  d.ln_out_bf16 = ln_b; d.ln_out_f32 = ln_f; d.ln_counters = fuse ? cnt : nullptr;
   return gemm_desc(A, W, bias, res, C, d, s);
 }
 
@@ -616,15 +638,20 @@ static int check(vitcap_engine* e, int B, const vitcap_gen_opts& o, void* ws, si
 // x_in: the block's input (read by LN1 and as the residual of proj); x: its output buffer, updated in place from proj on.
 // x_in != x only at the fork (block 8 and tag block 0 both read the output of block 7 and write their own stream), which
 // replaces a 113 MB device-to-device copy of the fork state per batch.
-static int vit_block(const vitcap_vit_block_w& w, const float* x_in, float* x, void* h, void* qkv, void* mlp, int B, void* s) {
+// have_ln1: `h` already holds norm1(x_in) (written by the previous block's fc2, below).  next: the block that consumes this one's
+// output on the same chain, or null -- its norm1 then rides in this block's fc2 (-> h); norm2 always rides in proj.  Each fused
+// LayerNorm is the separate vitcap_layernorm_fwd launch's arithmetic on the same fp32 rows (vitcap_gemm_desc.ln_*).
+static int vit_block(const vitcap_vit_block_w& w, const float* x_in, float* x, void* h, void* qkv, void* mlp, int B, void* s,
+                     int32_t* cnt = nullptr, bool have_ln1 = false, const vitcap_vit_block_w* next = nullptr) {
   const int M = B * NV;
-  CK(vitcap_layernorm_fwd(x_in, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  if (!have_ln1) CK(vitcap_layernorm_fwd(x_in, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
   CK(gemm(h, D, w.qkv_w, w.qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
   CK(vitcap_attn_dense_fwd(qkv, h, B, NV, 0.125f, s));
-  CK(gemm(h, D, w.proj_w, w.proj_b, x_in, D, x, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
-  CK(vitcap_layernorm_fwd(x, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, M, D, s));
+  // proj reads h (the attention output) as A and its norm2 writes h: a row block's A rows are read by its own three tiles only
+  CK(gemm_ln(h, D, w.proj_w, w.proj_b, x_in, x, M, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, cnt, s));
   CK(gemm(h, D, w.fc1_w, w.fc1_b, nullptr, 0, mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
-  CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  if (next) CK(gemm_ln(mlp, 4 * D, w.fc2_w, w.fc2_b, x, x, M, 4 * D, next->n1_g, next->n1_b, 1e-6f, h, nullptr, cnt, s));
+  else CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
   return VITCAP_OK;
 }
 
@@ -632,10 +659,11 @@ static int vit_block(const vitcap_vit_block_w& w, const float* x_in, float* x, v
 // (modeling_bert.py:1424) and the joint sequence takes tag_hidden[:, 0] as its first visual token (1493).  So: LN1 and the
 // K/V projections on all 577 rows (the CLS query attends every key), Q / attention / proj / LN2 / MLP for the CLS rows only
 // (strided views of the same buffers: row b*577).  Rows 1..576 of `x` keep the previous block's output.
-static int vit_block_cls_only(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, void* mlp, void* cls_h, int B, void* s) {
+static int vit_block_cls_only(const vitcap_vit_block_w& w, float* x, void* h, void* qkv, void* mlp, void* cls_h, int B, void* s,
+                              bool have_ln1 = false) {
   const int M = B * NV;
   const int RS = NV * D;                      // row stride between CLS rows
-  CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  if (!have_ln1) CK(vitcap_layernorm_fwd(x, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
   CK(gemm(h, D, (const char*)w.qkv_w + (size_t)D * D * 2, w.qkv_b + D, nullptr, 0, (char*)qkv + (size_t)D * 2, 3 * D, M, 2 * D, D,
           VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));                                         // K | V of every row
   CK(gemm(h, RS, w.qkv_w, w.qkv_b, nullptr, 0, qkv, NV * 3 * D, B, D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));   // Q of the CLS rows
@@ -671,6 +699,11 @@ static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, i
   // matter: B=64 pipelined +2.3 %; with persistent GEMMs or at B=512 it costs 1-2 % (measured), so it stays serial there.
   const bool fork = allow_fork && e->fork_tag_branch && o.gemm_mode == VITCAP_GEMM_TILES && B <= 128;
   float* x2 = (float*)(ws + lo.x2);
+  // ticket counters of the GEMMs that normalise their own rows: zero before the first of them (the workspace is the caller's)
+  int32_t* cnt = (int32_t*)(ws + lo.ln_cnt);
+  // (exactly this part's 4 B counters: a batch part on another stream owns the ints behind them)
+  HIPCK(hipMemsetAsync(cnt, 0, (size_t)B * 4 * 4, (hipStream_t)s), "encode: counters");
+  HIPCK(hipMemsetAsync(ws + lo.ln_cnt_tag, 0, (size_t)B * 4 * 4, (hipStream_t)s), "encode: counters");
   for (int i = 0; i < 12; ++i) {
     if (i == 8 && fork) {
       // fork: the tag branch depends only on x (the output of block 7), which nobody writes from here on
@@ -687,8 +720,10 @@ static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, i
       CK(tag_branch(e, lo, ws, B, e->side));
       HIPCK(hipEventRecord(e->ev_join, e->side), "encode: join record");
     }
-    if (i < 8) CK(vit_block(w.blocks[i], x, x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
-    else CK(vit_block(w.blocks[i], i == 8 ? x : x2, x2, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s));
+    // norm1 of block i+1 rides in block i's fc2 (block 7 feeds block 8 that way; the tag branch normalises the fork state itself)
+    const vitcap_vit_block_w* next = i + 1 < 12 ? &w.blocks[i + 1] : nullptr;
+    if (i < 8) CK(vit_block(w.blocks[i], x, x, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s, cnt, i > 0, next));
+    else CK(vit_block(w.blocks[i], i == 8 ? x : x2, x2, ws + lo.h, ws + lo.qkv, ws + lo.mlp, B, s, cnt, true, next));
   }
   if (fork) {
     HIPCK(hipStreamWaitEvent((hipStream_t)s, e->ev_join, 0), "encode: join wait");
@@ -779,11 +814,13 @@ static int tag_branch(vitcap_engine* e, const Layout& lo, char* ws, int B, void*
   const vitcap_weights& w = e->w;
   float* xt = (float*)(ws + lo.xt);
   const float* xf = (const float*)(ws + lo.x);       // fork state (output of block 7)
-  for (int i = 0; i < 3; ++i) CK(vit_block(w.tag_blocks[i], i == 0 ? xf : xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+  int32_t* cnt = (int32_t*)(ws + lo.ln_cnt_tag);      // its own counters: the branch may run next to caption blocks 8-11
+  for (int i = 0; i < 3; ++i)
+    CK(vit_block(w.tag_blocks[i], i == 0 ? xf : xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s, cnt, i > 0, &w.tag_blocks[i + 1]));
   if (e->full_last_tag_block)
-    CK(vit_block(w.tag_blocks[3], xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s));
+    CK(vit_block(w.tag_blocks[3], xt, xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, B, s, cnt, true, nullptr));
   else
-    CK(vit_block_cls_only(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, ws + lo.pool_in, B, s));
+    CK(vit_block_cls_only(w.tag_blocks[3], xt, ws + lo.th, ws + lo.tqkv, ws + lo.tmlp, ws + lo.pool_in, B, s, true));
   CK(vitcap_gather_rows_bf16(xt, NV, ws + lo.pool_in, B, D, s));
   CK(gemm(ws + lo.pool_in, D, w.pooler_w, w.pooler_b, nullptr, 0, ws + lo.pooled, D, B, D, D, VITCAP_ACT_TANH,
           VITCAP_OUT_BF16, s));
@@ -868,14 +905,14 @@ static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
     CK(gemm(vis_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, dq, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
     if (lo.vt[l]) CK(vitcap_attn_beam_vt(dq, ws + lo.vt[l], B, SV, s));
     CK(vitcap_attn_dense_fwd(dq, ws + lo.h, B, SV, 0.125f, s));
-    CK(gemm(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, D, ws + lo.dtmp, D, M, D, D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
-    CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,
-                            (float*)(ws + lo.da_f), M, D, s));
+    // BertSelfOutput / BertOutput: dense + residual, then LayerNorm (post-LN) -- the LayerNorm rides in the GEMM
+    int32_t* cnt = (int32_t*)(ws + lo.ln_cnt);
+    CK(gemm_ln(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, ws + lo.dtmp, M, D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,
+               (float*)(ws + lo.da_f), cnt, s));
     CK(gemm(ws + lo.da_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF,
             VITCAP_OUT_BF16, s));
-    CK(gemm(ws + lo.mlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.da_f), D, ws + lo.dtmp, D, M, D, 4 * D,
-            VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
-    CK(vitcap_layernorm_fwd((const float*)(ws + lo.dtmp), D, lw.o_g, lw.o_beta, 1e-12f, vis_b, vis_f, M, D, s));
+    CK(gemm_ln(ws + lo.mlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.da_f), ws + lo.dtmp, M, 4 * D, lw.o_g, lw.o_beta, 1e-12f,
+               vis_b, vis_f, cnt, s));
   }
   if (lo.NT > 0) CK(prefill_tags(e, B, o, lo, ws, s));
   return VITCAP_OK;

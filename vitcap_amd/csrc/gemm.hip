@@ -548,7 +548,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[NI][4], const GemmA
 // launch uses for the rows behind the last full round of 256-row tiles (launch_256).  Same k order per output element and the
 // same epilogue arithmetic whatever MT, so the results do not depend on the tile height.
 template <int ACT, int OUT_F32, bool HAS_RES, int PH, int MT>
-__device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, const int m0, const int n0) {
+__device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, const int m0, const int n0, const int cidx = 0) {
   constexpr int BK = 64;
   constexpr int A_BYTES = 256 * BK * 2, BUF_BYTES = 2 * A_BYTES;   // the W tile sits behind a full-height A slot whatever MT
   constexpr int WR = 32 * MT;                                      // rows of one wave's block (2 waves along M, 4 along N)
@@ -556,7 +556,11 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
   constexpr int NP = MT + 4;                                       // LDS-DMA pieces (8 rows x 128 B per lane group) per wave and k-tile
   constexpr bool EXTRAS = (PH & 8) != 0;   // training extras (pre-activation copy `zout`, gelu' factor `aux`) compiled in: the
                                            // inference instantiations do not carry their 32 prefetch registers (222 instead of 226 VGPRs)
-  constexpr int ABL = PH >> 4;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
+  constexpr int ABL = (PH >> 4) & 31;   // timing ablations (tools/gemm_bench.py only; results are wrong when != 0)
+#ifndef LN_LOAD_AUX
+#define LN_LOAD_AUX 0
+#endif
+  constexpr bool LN = (PH & 512) != 0;  // LayerNorm of the finished rows by the last of the row block's column tiles (GemmArgs.ln_*)
   constexpr bool NO_DMA = ABL & 1, NO_LDS = ABL & 2, NO_MFMA = ABL & 4, NO_STORE = ABL & 8, NO_EPI = ABL & 16;
 
   const int tid = threadIdx.x;
@@ -838,6 +842,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
       return;
     }
   }
+  // fused LayerNorm launches address C through a buffer descriptor from the tile's first row (plain rows only)
+  const __amdgpu_buffer_rsrc_t ln_rc = vc_rsrc(LN ? (const char*)p.C + (size_t)m0 * p.ldc * 4 : nullptr, LN ? (long long)(p.M - m0) * p.ldc * 4 : 0);
   ISSUE_RES(0);
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
@@ -880,7 +886,12 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
         if (HAS_RES) v += rres[c & 1][it];
         if (ok) {
           if (OUT_F32) {
-            *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+            if constexpr (LN) {
+              // write-through (sc1): the row block's last-arriving workgroup reads these rows back, wherever on the chip it runs
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vc_u32x4, v), ln_rc, (unsigned)((orow - m0) * p.ldc + ncol) * 4u, 0, 16);
+            } else {
+              *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + ncol) = v;
+            }
           } else {
             uint2 o;
             o.x = pack2bf(v[0], v[1]);
@@ -893,6 +904,46 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& p, char* smem, cons
   }
 #undef ISSUE_RES
 #undef ROWS_OF
+  if constexpr (LN) {
+    // ---- LayerNorm of the row block by the LAST of its column tiles to get here (any placement of the tiles over XCDs / CUs):
+    // every wave's write-through stores acknowledged -> barrier -> one relaxed agent-scope ticket; the workgroup that draws the last
+    // ticket reads the block's rows back with sc1 loads (they bypass this CU's L1 and the XCD's L2 lines other XCDs wrote behind)
+    // and normalises them with the LayerNorm kernel's own row function.  The ticket counter goes back to zero for the next launch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_flag = (int*)smem;
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(p.ln_cnt + cidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == p.tiles_n - 1;
+      if (last) __hip_atomic_store(p.ln_cnt + cidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_flag = last;
+    }
+    __syncthreads();
+    if (*s_flag == 0) return;
+    if (!p.ln_out && !p.ln_out_f) return;      // (timing experiments: publish only)
+    // the other tiles' rows sit in memory (write-through); one agent-scope acquire drops whatever this CU's L1 holds of them, then
+    // plain loads fetch them through the L2 at the ordinary rate (sc1 loads measured 5x slower here: 85 row blocks finish together
+    // and the uncached path serves them one after the other)
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const int rows = p.M - m0 < 64 * MT ? p.M - m0 : 64 * MT;
+    constexpr int RB = 8;                      // rows in flight per wave: 8 waves x 8 rows x 3 KB = 196 KB of requests per pass
+    for (int r0 = w * RB; r0 < rows; r0 += 8 * RB) {
+      f32x4 v[RB][3];
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)           // rows past the block's end: the descriptor's range check returns zeros for the last block only
+          v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ln_rc, (unsigned)((r0 + j) * p.ldc + i * 256 + lane * 4) * 4u, 0, LN_LOAD_AUX));
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int row = m0 + r0 + j;
+        if (r0 + j < rows)
+          ln_row(v[j], p.ln_g, p.ln_b, p.ln_eps, lane, p.ln_out ? p.ln_out + (size_t)row * D768 : nullptr,
+                 p.ln_out_f ? p.ln_out_f + (size_t)row * D768 : nullptr);
+      }
+    }
+  }
 }
 
 // The launch: n_big workgroups own 256-row tiles of rows [0, 256 * tiles_m); with MTS != 0 the workgroups behind them own
@@ -925,9 +976,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(VC_GEMM256_VGPR
   const int gw = gleft < p.group_n ? gleft : p.group_n;
   const int tm = rem / gw, tn = gi * p.group_n + rem - tm * gw;
   if (!small) {
-    gemm256_tile<ACT, OUT_F32, HAS_RES, PH, 4>(p, smem, tm * 256, tn * 256);
+    gemm256_tile<ACT, OUT_F32, HAS_RES, PH, 4>(p, smem, tm * 256, tn * 256, tm);
   } else {
-    if constexpr (MTS != 0) gemm256_tile<ACT, OUT_F32, HAS_RES, PH, MTS>(p, smem, p.tiles_m * 256 + tm * (64 * MTS), tn * 256);
+    if constexpr (MTS != 0) gemm256_tile<ACT, OUT_F32, HAS_RES, PH, MTS>(p, smem, p.tiles_m * 256 + tm * (64 * MTS), tn * 256, p.tiles_m + tm);
   }
 }
 
@@ -1007,11 +1058,12 @@ int launch_256_t(const GemmArgs& p, int nwg, hipStream_t s) {
 // mix: -1 = plan_tiles decides, 0 = 256-row tiles only, 3 / 2 = every tile 192 / 128 rows (tile-cost measurements)
 template <int ACT, int OUT_F32, bool HAS_RES, int PH>
 int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
+  if constexpr ((PH & 512) != 0) mix = 0;          // fused-LayerNorm launches: 256-row tiles only
   GemmArgs p = a;
   p.tiles_n = (a.N + 255) / 256;
   p.group_n = tile_group_n(p.tiles_n);
   TilePlan pl{(a.M + 255) / 256, 0, 0};
-  if constexpr ((PH >> 4) == 0) {
+  if constexpr (((PH >> 4) & 31) == 0) {
     if (a.aux || a.zout || a.colsum) mix = 0;
     if (mix < 0) pl = plan_tiles(a.M, p.tiles_n, a.K);
     else if (mix > 0) pl = TilePlan{0, mix, (a.M + 64 * mix - 1) / (64 * mix)};
@@ -1020,7 +1072,7 @@ int launch_256(const GemmArgs& a, hipStream_t s, int mix = 0) {
   p.tiles_m_small = pl.tm_small;
   p.n_big = pl.tm_big * p.tiles_n;
   const int nwg = p.n_big + pl.tm_small * p.tiles_n;
-  if constexpr ((PH >> 4) == 0) {
+  if constexpr (((PH >> 4) & 31) == 0 && (PH & 512) == 0) {
     if (a.aux || a.zout || a.colsum) return launch_256_t<ACT, OUT_F32, HAS_RES, PH | 8, 0>(p, nwg, s);   // training extras: 256-row tiles only
     if (pl.mts == 3) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 3>(p, nwg, s);
     if (pl.mts == 2) return launch_256_t<ACT, OUT_F32, HAS_RES, PH, 2>(p, nwg, s);
@@ -1663,6 +1715,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
   a.live = d->live;
   a.rowstat = (float*)d->rowstat;
+  a.ln_g = a.ln_b = nullptr; a.ln_eps = 0.f; a.ln_out = nullptr; a.ln_out_f = nullptr; a.ln_cnt = nullptr;
   {
     static const int direct = [] { const char* e = getenv("VITCAP_GEMM_DIRECT_EPILOGUE"); return e ? atoi(e) : 1; }();
     a.direct_epilogue = direct;
@@ -1677,6 +1730,30 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   const int hint = d->tile_hint;
   const int split_k = d->split_k > 1 ? d->split_k : 1;
   const bool plain_rows = d->row_group == 0;
+  if (d->ln_out_bf16 || d->ln_out_f32) {
+    // LayerNorm of the finished rows: inside the kernel where the launch form has the last-arriver pass, a LayerNorm launch behind
+    // the GEMM otherwise -- the same row function either way, so the outputs do not depend on which
+    VC_REQUIRE(d->ln_gamma && d->ln_beta, "gemm(ln): ln_gamma / ln_beta missing");
+    VC_REQUIRE(d->N == 768 && d->ldc == 768 && d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && plain_rows && split_k == 1 &&
+                   !aux_bf16 && !zout_bf16 && !d->rowstat && !d->colsum,
+               "gemm(ln): needs N == ldc == 768, fp32 output, no activation / row remap / split-K / training extras");
+    // in-kernel only on request (ln_counters given) and under the 8-wave one-tile-per-workgroup form.  MEASURED A LOSS (DESIGN.md
+    // 4.3: a row block's last arriver pulls its 786 KB back at ~20 GB/s, 40 us per block on one CU, against 31 us for the LayerNorm
+    // kernel over ALL rows on the whole chip): the engine does not ask for it unless VITCAP_GEMM_LN_FUSE=1
+    const bool fused = d->ln_counters && d->M >= 2048 && hint == 5 && large_gemm_form(d->M, d->N, hint) < 0;
+    if (fused) {
+      a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.ln_eps = d->ln_eps;
+      a.ln_out = (bf16_t*)d->ln_out_bf16; a.ln_out_f = d->ln_out_f32; a.ln_cnt = d->ln_counters;
+      static const int dbg = [] { const char* e = getenv("VITCAP_GEMM_LN_DEBUG"); return e ? atoi(e) : 0; }();   // 1: no LayerNorm pass (timing; wrong results)
+      if (dbg == 1) { a.ln_out = nullptr; a.ln_out_f = nullptr; }
+      return residual ? launch_256<VITCAP_ACT_NONE, 1, true, 4 | 512>(a, s, 0) : launch_256<VITCAP_ACT_NONE, 1, false, 4 | 512>(a, s, 0);
+    }
+    vitcap_gemm_desc d2 = *d;
+    d2.ln_out_bf16 = nullptr; d2.ln_out_f32 = nullptr;
+    const int rc = vitcap_gemm_ex(A, W, bias, residual, C, &d2, aux_bf16, ldaux, zout_bf16, ldz, stream);
+    if (rc != VITCAP_OK) return rc;
+    return vitcap_layernorm_fwd((const float*)C, d->ldc, d->ln_gamma, d->ln_beta, d->ln_eps, d->ln_out_bf16, d->ln_out_f32, d->M, 768, stream);
+  }
   if (d->rowstat) {
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && !residual && plain_rows && split_k == 1 && !aux_bf16 && !zout_bf16,
                "gemm(rowstat): fp32 output, no activation / residual / split-K");

@@ -28,6 +28,14 @@ struct GemmArgs {
   int group_n;                 // persistent kernel: width of a column group in tiles (tile walk order)
   const int32_t* live;         // decode loop: return at entry once *live == 0 (vitcap_gemm_desc.live)
   float* rowstat;              // ROWSTAT kernels: per (row, 32-column piece) {max, argmax column, sum exp(x - max), 0}
+  // fused LayerNorm of the finished rows (N == 768, fp32 output; vitcap_gemm_desc.ln_*): the last of a row block's column tiles to
+  // finish normalises the block
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  bf16_t* ln_out;              // [M][768] bf16 or null
+  float* ln_out_f;             // [M][768] fp32 or null
+  int32_t* ln_cnt;             // one counter per row block, zero on entry, zero again on exit
 };
 
 // launch of a large-tile GEMM: with kernel-bound timing events when the engine's timing run asked for them (common.h)

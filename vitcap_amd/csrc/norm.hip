@@ -7,41 +7,6 @@
 
 namespace {
 
-constexpr int D768 = 768;
-
-__device__ __forceinline__ void ln_row(const f32x4 (&v)[3], const float* gamma, const float* beta, float eps,
-                                       int lane, bf16_t* yb, float* yf) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-  const float mean = wave_sum(s) * (1.0f / D768);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float d = v[i][e] - mean;
-      q += d * d;
-    }
-  const float var = wave_sum(q) * (1.0f / D768);
-  const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int c = i * 256 + lane * 4;
-    const f32x4 g = *(const f32x4*)(gamma + c);
-    const f32x4 b = *(const f32x4*)(beta + c);
-    f32x4 y;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-    if (yf) *(f32x4*)(yf + c) = y;
-    if (yb) {
-      uint2 o;
-      o.x = pack2bf(y[0], y[1]);
-      o.y = pack2bf(y[2], y[3]);
-      *(uint2*)(yb + c) = o;
-    }
-  }
-}
 
 __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ gamma,

@@ -8,7 +8,6 @@
 
 namespace {
 
-constexpr int D768 = 768;
 
 // ---------------------------------------------------------------------------------------------------------------
 // XT[c][r] = X[r][c] (bf16), rows padded with zeros to Rp (multiple of 64); optional column sums (bias gradients).

@@ -69,6 +69,28 @@ def gemm_bias_act(a, w, bias=None, residual=None, act=L.ACT_NONE, out_dtype=torc
     return out
 
 
+def gemm_layernorm(a, w, bias, residual, gamma, beta, eps, out=None, ln_out=None, want_f32=False, counters=None, tile_hint=0):
+    """x = A @ W.T + bias (+ residual) in fp32 [M, 768], and LayerNorm(x) -> bf16 [M, 768] (and fp32 with want_f32): the residual
+    GEMMs of a ViT / BERT block with the LayerNorm behind them (vitcap_gemm_desc.ln_*).  `counters`: int32 [>= M // 128 + 8], zero --
+    with them (and a launch form that supports it: tile_hint 5 at M >= 2048) the kernel normalises its own rows; without, a
+    LayerNorm launch follows.  `out` may be `residual` (in place); `ln_out` may alias `a`.  Returns (x, ln_bf16, ln_f32 or None)."""
+    _dev_bf16(a)
+    _dev_bf16(w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    if ln_out is None:
+        ln_out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    ln_f = torch.empty((M, N), device=a.device, dtype=torch.float32) if want_f32 else None
+    d = L.GemmDesc(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+                   ldr=residual.stride(0) if residual is not None else 0, act=L.ACT_NONE, out_dtype=L.OUT_F32, tile_hint=tile_hint,
+                   ln_gamma=_p(gamma).value, ln_beta=_p(beta).value, ln_eps=float(eps), ln_out_bf16=ln_out.data_ptr(),
+                   ln_out_f32=ln_f.data_ptr() if want_f32 else None, ln_counters=counters.data_ptr() if counters is not None else None)
+    check(lib.vitcap_gemm_bias_act(_p(a), _p(w), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), 'gemm_layernorm')
+    return out, ln_out, ln_f
+
+
 def gemm_tile_plan(M, N, K):
     """(256-row m-tiles, height class of the tiles behind them: 0 none / 3 = 192 rows / 2 = 128 rows, their count) of the
     256-column GEMM kernel for this problem on the current device (host-side query)."""
