@@ -222,3 +222,30 @@ def test_cbs_forward_contract(model):
         assert torch.equal(ids, want)
     finally:
         model.test_extra_input = keep
+
+
+def test_cbs_wide_groups_vs_oracle(model, sd_t):
+    """40 sequences per image (8 states x 5 beams -- the shipped pipeline's num_beams would be 1; 5 is BASELINE configs[2]'s) on three
+    images with different machines, against the oracle's bf16 emulation: same captions, or scores within the noise tolerance; the
+    constrained words are in every caption."""
+    B, K, max_given = 3, 5, 3
+    cons = [[[[3899, 6077]]], [[[4937]], [[3392, 3628]]], [[[2543], [100]], [[3899]]]]      # dog|dogs; cat + tree|trees; "fire [UNK]" + dog
+    fsms = [O.fsm_build(c, O.V, max_given, 4) for c in cons]
+    S = max(u for _, u in fsms)
+    fsm = torch.stack([f[:S, :S] for f, _ in fsms])
+    ncons = torch.tensor([len(c) for c in cons])
+    im_c = torch.from_numpy(W.gen_image_batch(B, 77))
+    with torch.no_grad():
+        o_ids, o_lp = O.cbs_incremental(sd_t, im_c, fsm, ncons, K, 2, emulate_bf16=True)
+    ids, lp = model.generate_cbs(im_c.cuda(), fsm.cuda(), ncons.cuda(), num_beams=K)
+    assert ids.shape[0] == B and ids.shape[2] == o_ids.shape[1]
+    exact = 0
+    for b in range(B):
+        seq = ids[b, 0].tolist()
+        for words in cons[b][:2]:
+            assert any(all(seq[i + j] in words[j] for j in range(len(words))) for i in range(len(seq) - len(words) + 1)), (b, words, seq)
+        if seq == o_ids[b].tolist():
+            exact += 1
+        else:
+            assert abs(float(lp[b, 0]) - float(o_lp[b])) < CBS_SCORE_TOL, (b, seq, o_ids[b].tolist(), float(lp[b, 0]), float(o_lp[b]))
+    print('wide groups: %d / %d captions equal the oracle emulation' % (exact, B))
