@@ -31,7 +31,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r03_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r04_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 # What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
 # visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row
@@ -41,6 +41,11 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROAR
 # kernel names in the PMC file: <activation, fp32 output, residual, schedule, short-tile height class (0 = 256-row tiles only)>
 PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4, 0>', 0: 'void gemm_nt_256_kernel<0, 0, false, 4, 0>',
               4: 'void gemm_nt_256_kernel<1, 0, false, 4, 0>'}
+# the 4-wave persistent kernels of the same variants (one-stream runs, and the pipeline from 8 rounds of tiles on): <activation, fp32
+# output, residual, m-tiles of 16 rows per wave> -- the B = 64 file holds the 224-row forms, the B = 512 file the 256-row ones
+PMC_KERNEL_4W = {3: ['void gemm_nt_4wp_kernel<0, 1, true, 7>', 'void gemm_nt_4wp_kernel<0, 1, true, 8>'],
+                 0: ['void gemm_nt_4wp_kernel<0, 0, false, 7>', 'void gemm_nt_4wp_kernel<0, 0, false, 8>'],
+                 4: ['void gemm_nt_4wp_kernel<1, 0, false, 8>']}
 VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
                  2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
                  4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}
@@ -485,8 +490,14 @@ def main():
     traffic = None
     try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh);
         # FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), KiB -> bytes
-        with open(TRAFFIC_FILE) as f:
-            traffic = json.load(f)[PMC_KERNEL[dom]]['hbm_bytes_per_launch_corrected']
+        four_wave = kernel_form(lib, B * 577, dom, piped or args.gemm_tiles).startswith('4-wave')
+        tfile = TRAFFIC_FILE if B < 256 else TRAFFIC_FILE.replace('.json', '_b512.json')
+        with open(tfile) as f:
+            tab = json.load(f)
+        names = PMC_KERNEL_4W[dom] if four_wave else [PMC_KERNEL[dom]]
+        traffic = max((tab[n] for n in names if n in tab), key=lambda e: e['launches'])['hbm_bytes_per_launch_corrected']
+        if B not in (64, 512):
+            traffic = None          # the committed passes are B = 64 and B = 512 runs
     except Exception:
         traffic = None
     out = {
@@ -518,7 +529,7 @@ def main():
             'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'traffic_note': ('HBM bytes per launch from a COMMITTED rocprofv3 PMC pass, not measured in this run: (2*FETCH_SIZE+WRITE_SIZE)*1024 '
-                             'in %s (tools/pmc_traffic.sh regenerates it)' % os.path.relpath(TRAFFIC_FILE, REPO)) if traffic else None,
+                             'in %s (tools/pmc_traffic.sh regenerates it)' % os.path.relpath(tfile, REPO)) if traffic else None,
             'launches': int(ln[dom]), 'avg_launch_ms': round(kms[dom] / max(1, ln[dom]), 4),
             'avg_launch_gflop': round(fl[dom] / max(1, ln[dom]) / 1e9, 3),
             'timing': 'HIP events bound to each kernel dispatch (hipExtLaunchKernelGGL start / stop events on the launch stream: kernel '
