@@ -43,13 +43,14 @@ extern "C" {
 #define VITCAP_OUT_F32 1
 
 const char* vitcap_last_error(void);
-/* ABI version of this header: bumped whenever a struct layout or a function signature changes (5: vitcap_gemm_desc.ln_*; 4:
+/* ABI version of this header: bumped whenever a struct layout or a function signature changes (6: vitcap_gen_opts.cbs_no_repeat / cbs_bad_ending, vitcap_cbs_candidates' two
+ * arguments; 5: vitcap_gemm_desc.ln_*; 4:
  * vitcap_gen_opts' constrained-beam-search block + the vitcap_cbs_* entry points; 3: `abi` heads vitcap_gemm_desc and
  * vitcap_gen_opts; 2 -> 3 also covers round 3's additions: gemm_desc.colsum, gen_opts.eos_extra / tag_pos0, vitcap_tag_embed's pos0,
  * vitcap_layernorm_bwd's extra pointer, zout / aux carrying gelu').  vitcap_version() returns the library's value: a binding checks
  * the two for equality at load time, and every call that takes one of the two option structs rejects a struct whose first field is
  * not VITCAP_ABI_VERSION (a caller built against an older header passes a shorter struct: its fields would be misread). */
-#define VITCAP_ABI_VERSION 5
+#define VITCAP_ABI_VERSION 6
 int vitcap_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -371,8 +372,9 @@ int vitcap_beam_finalize(const vitcap_beam_state* s, int64_t* out_ids, float* ou
  *   vitcap_cbs_init        prefixes = [BOS], counters cleared
  *   vitcap_cbs_start       first step (:127-152): image b reads ROW b of the (B*G)-row logits (`[:batch_size]` of an image-major
  *                          batch, as written), words that fsm[b][0][i] does not allow score -inf, K best words per state i
- *   vitcap_cbs_candidates  later steps (:184-247): per slot and target state i the K best words of log_softmax(logits) -- a slot
- *                          ending in an EOS id continues with an EOS id at cost 0 only -- masked by fsm[b][s][i] (-1e20)
+ *   vitcap_cbs_candidates  later steps (:184-247): per slot and target state i the K best words of log_softmax(logits) -- minus the
+ *                          slot's last word (no_repeat) and the EOS ids behind a bad-ending word; a slot ending in an EOS id
+ *                          continues with an EOS id at cost 0 only -- masked by fsm[b][s][i] (-1e20)
  *   vitcap_cbs_select      (:245-319) per image and target state the K best of (candidate + the slot's running score) over all
  *                          slots; prefixes re-ordered by parent and extended, parents for the K/V cache re-ordering.  Ties go to
  *                          the lower flat index.  Once every slot of the batch ends in EOS the search stops (:177-181):
@@ -395,9 +397,10 @@ typedef struct {
 int vitcap_cbs_init(const vitcap_cbs_state* s, int B, int S, int K, int max_len, int bos, void* stream);
 int vitcap_cbs_start(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
                      int B, int S, int K, int max_len, int eos, const int32_t* eos_extra, void* stream);
+/* no_repeat / bad_ending (host, 16 ids, -1 = unused, or NULL): vitcap_gen_opts.cbs_no_repeat / cbs_bad_ending */
 int vitcap_cbs_candidates(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
-                          int B, int S, int K, int t, int max_len, int eos, const int32_t* eos_extra, float* cand_val,
-                          int32_t* cand_word, void* stream);
+                          int B, int S, int K, int t, int max_len, int eos, const int32_t* eos_extra, int no_repeat,
+                          const int32_t* bad_ending, float* cand_val, int32_t* cand_word, void* stream);
 int vitcap_cbs_select(const float* cand_val, const int32_t* cand_word, const vitcap_cbs_state* s, int B, int S, int K, int t,
                       int max_len, int eos, const int32_t* eos_extra, void* stream);
 int vitcap_cbs_finalize(const vitcap_cbs_state* s, const int64_t* num_constraints, int min_constraints, int B, int S, int K,
@@ -531,10 +534,12 @@ typedef struct vitcap_gen_opts {
   int32_t use_cbs;            /* 1: constrained beam search; needs fsm, num_constraints, no sampling / penalty / n-best        */
   int32_t cbs_states;         /* S = fsm.shape[1] (2**max_given_constraints main states + the sub-states in use), 1..32        */
   int32_t min_constraints_to_satisfy;   /* the pipeline passes 2 (..._bertemb.py:175-179)                                    */
-  int32_t cbs_reserved;
+  int32_t cbs_no_repeat;      /* generate's decoding_constraint_flag: a live sequence may not repeat its last word (utils_cbs.py:187-190) */
   const uint8_t* fsm;         /* device, uint8 [B][S][S][30522]: fsm[b][s1][s2][w] != 0 iff word w moves image b's machine from
                                  state s1 to s2 (FiniteStateMachineBuilder.build, utils_cbs.py:733-871)                        */
   const int64_t* num_constraints;       /* device, int64 [B]: constraints given per image (2**n main states can be valid)      */
+  int32_t cbs_bad_ending[16]; /* generate's bad_ending_ids, -1 = unused: a live sequence whose last word is one of them may not end --
+                                 every EOS id scores -inf (utils_cbs.py:192-198)                                               */
 } vitcap_gen_opts;
 void vitcap_gen_opts_init(vitcap_gen_opts* o);
 /* VITCAP_OK or VITCAP_EINVAL with the offending field in vitcap_last_error() */

@@ -902,7 +902,8 @@ def beam_incremental(sd, image, num_beams, emulate_bf16=False, max_length=MAX_LE
 CBS_MASKED = -1e20          # utils_cbs.py:240: a transition the FSM does not allow scores -1e20 (NOT -inf)
 
 
-def cbs_search(step_logits_fn, fsm, num_beams, max_length=MAX_LEN, eos=EOS, return_margins=False):
+def cbs_search(step_logits_fn, fsm, num_beams, max_length=MAX_LEN, eos=EOS, return_margins=False, no_repeat=False,
+               bad_ending_ids=None):
     """``ConstrainedBeamSearch.search`` as ViTCAP.generate drives it (use_hypo=False, no decoding_constraint_flag, no
     bad_ending_ids, per_node_beam_size = beam_size, state = None because the model returns no past).
 
@@ -917,6 +918,9 @@ def cbs_search(step_logits_fn, fsm, num_beams, max_length=MAX_LEN, eos=EOS, retu
       state i the candidates of slot (s, k) are its words masked by fsm[b, s, i] (-1e20 where not allowed), K best per slot,
       plus the slot's running score, K best overall -> slot (i, 0..K-1), parent = the candidate's slot.  The loop stops early
       once every slot of the batch ends in EOS.
+    * ``no_repeat`` = generate's ``decoding_constraint_flag`` (:187-190): a live slot may not repeat its last word (-inf);
+      ``bad_ending_ids`` (:192-198): a live slot whose last word is in the list may not end (every EOS id -inf).  Both act on the
+      log-probabilities before the finished-slot override and not on the first step.
     Ties (e.g. among the -1e20 fillers of a state fewer than K allowed candidates reach) fall as torch.topk leaves them; the
     device breaks them by lowest flat index, tests use constraints whose valid states never depend on that.
 
@@ -951,6 +955,14 @@ def cbs_search(step_logits_fn, fsm, num_beams, max_length=MAX_LEN, eos=EOS, retu
         curr = torch.cat([curr, lastw[:, None]], dim=1)
         parents = (backs[-1] + base).reshape(-1) if backs else None
         lp = F.log_softmax(step_logits_fn(curr, parents), dim=-1)
+        if no_repeat:
+            lp = lp.scatter(1, lastw[:, None], NEG)
+        if bad_ending_ids:
+            prev_bad = torch.zeros_like(fin)
+            for w in bad_ending_ids:
+                prev_bad |= lastw == int(w)
+            for e in eos_ids:
+                lp[prev_bad, e] = NEG
         lp = torch.where(fin[:, None], after_end[None], lp).view(B, S, K, Vn)
         nw = torch.empty(B, S, K, dtype=torch.long)
         nb = torch.empty(B, S, K, dtype=torch.long)
@@ -1018,21 +1030,23 @@ def cbs_select_best(beams, scores, num_constraints, min_constraints_to_satisfy, 
 
 
 def cbs_as_written(sd, image, fsm, num_constraints, num_beams, min_constraints_to_satisfy=2, tagemb='cls', max_length=MAX_LEN,
-                   eos=EOS):
+                   eos=EOS, no_repeat=False, bad_ending_ids=None):
     """ViTCAP.generate(use_cbs=True) (modeling_bert.py:1035-1057) with the model re-run on the full prefix at every step."""
     S = fsm.shape[1]
     step = _as_written_stepper(sd, image, S * num_beams, tagemb, max_length)
-    beams, scores = cbs_search(lambda ids, parents: step(ids, parents), fsm, num_beams, max_length, eos)
+    beams, scores = cbs_search(lambda ids, parents: step(ids, parents), fsm, num_beams, max_length, eos, no_repeat=no_repeat,
+                               bad_ending_ids=bad_ending_ids)
     return cbs_select_best(beams, scores, num_constraints, min_constraints_to_satisfy, eos)
 
 
 def cbs_incremental(sd, image, fsm, num_constraints, num_beams, min_constraints_to_satisfy=2, emulate_bf16=False,
-                    max_length=MAX_LEN, eos=EOS, return_margins=False):
+                    max_length=MAX_LEN, eos=EOS, return_margins=False, no_repeat=False, bad_ending_ids=None):
     """The same on the incremental formulation: the S*K slots of an image share its visual K/V, text K/V caches follow the
     back-pointers."""
     S = fsm.shape[1]
     step = _incremental_stepper(sd, image, S * num_beams, emulate_bf16, max_length)
-    res = cbs_search(step, fsm, num_beams, max_length, eos, return_margins=return_margins)
+    res = cbs_search(step, fsm, num_beams, max_length, eos, return_margins=return_margins, no_repeat=no_repeat,
+                     bad_ending_ids=bad_ending_ids)
     sel = cbs_select_best(res[0], res[1], num_constraints, min_constraints_to_satisfy, eos, return_margins=return_margins)
     if return_margins:
         return sel[0], sel[1], res[2], sel[2], res[0], res[1]

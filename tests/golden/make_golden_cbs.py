@@ -31,6 +31,8 @@ CASES = [
     (1, 2, 2, [['dog']]),
     (1, 3, 2, [['cat', 'fire hydrant']]),
     (2, 1, 3, [['dog'], ['cat', 'tree']]),
+    # generate()'s decoding_constraint_flag (no word twice in a row) and bad_ending_ids (no EOS right behind these words)
+    (1, 2, 2, [['dog']], {'decoding_constraint_flag': True, 'bad_ending_ids': [9138, 27024, 3899]}),
 ]
 # constraint word -> tokens (constraint2tokens TSV), token -> word forms (tokenforms TSV); all single WordPiece tokens
 C2T = {'dog': ['dog'], 'cat': ['cat'], 'fire': ['fire'], 'hydrant': ['hydrant'], 'tree': ['tree']}
@@ -91,7 +93,14 @@ def main():
         out = dict(np.load(os.path.join(HERE, 'reference_cbs.npz')))
     out['c2t'] = np.array(['%s=%s' % (k, ','.join(v)) for k, v in C2T.items()])
     out['forms'] = np.array(['%s=%s' % (k, ','.join(v)) for k, v in FORMS.items()])
-    for n, (B, K, max_given, per_image) in enumerate(CASES):
+    only = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--only=')]      # recompute these cases, keep the others from disk
+    if only:
+        out = dict(np.load(os.path.join(HERE, 'reference_cbs.npz')))
+    for n, case in enumerate(CASES):
+        if only and n not in only:
+            continue
+        B, K, max_given, per_image = case[:4]
+        extra = case[4] if len(case) > 4 else {}
         builder = cbs.FiniteStateMachineBuilder(tok, os.path.join(tmp, 'c2t.tsv'), os.path.join(tmp, 'forms.tsv'), max_given)
         fsms, used, cons_ids = [], [], []
         for cons in per_image:
@@ -124,9 +133,10 @@ def main():
                               eos_token_ids=[102], mask_token_id=103, add_od_labels=True, od_labels_start_posid=20,
                               max_length=20, num_beams=K, temperature=1, top_k=0, top_p=1, repetition_penalty=1,
                               length_penalty=1, num_return_sequences=1, num_keep_best=1,
-                              use_cbs=True, fsm=fsm, num_constraints=num_constraints, min_constraints_to_satisfy=2)
-            o_ids, o_lp, m_search, m_sel, o_beams, o_scores = O.cbs_incremental(sd, img, fsm, num_constraints, K, 2,
-                                                                                return_margins=True)
+                              use_cbs=True, fsm=fsm, num_constraints=num_constraints, min_constraints_to_satisfy=2, **extra)
+            o_ids, o_lp, m_search, m_sel, o_beams, o_scores = O.cbs_incremental(
+                sd, img, fsm, num_constraints, K, 2, return_margins=True, no_repeat=bool(extra.get('decoding_constraint_flag')),
+                bad_ending_ids=extra.get('bad_ending_ids'))
         ids, logp = ids[:, 0], logp[:, 0]
         print('case', n, 'S', S, 'ids', ids.tolist(), 'lp', logp.tolist())
         print('  oracle', o_ids.tolist(), o_lp.tolist(), 'margins', m_search.min(1).values.tolist(), m_sel.tolist())
@@ -139,6 +149,8 @@ def main():
                 if bin(s).count('1') >= min(given, 2):
                     assert bool((captured['beams'][b, s, 0] == o_beams[b, s, 0]).all()), (b, s)
         out['case%d_cfg' % n] = np.array([B, K, max_given, S], dtype=np.int64)
+        out['case%d_no_repeat' % n] = np.array(int(bool(extra.get('decoding_constraint_flag'))))
+        out['case%d_bad_ending_ids' % n] = np.array(extra.get('bad_ending_ids') or [], dtype=np.int64)
         out['case%d_num_constraints' % n] = num_constraints.numpy().copy()
         # constraints as a padded id table: [image, constraint, word, form] (-1 = unused)
         tab = -np.ones((B, 3, 4, 4), dtype=np.int64)

@@ -122,8 +122,8 @@ def test_struct_sizes_match_header(L):
     assert C.sizeof(L.Weights) == (4 + 16 * 12 + 2 + 6 + 5 + 4 * 12 + 6 + 5) * 8
     # abi + 15 ints, three pointers (live, rowstat, colsum), the fused-LayerNorm block: 2 pointers, float + int, 3 pointers
     assert C.sizeof(L.GemmDesc) == 16 * 4 + 24 + 2 * 8 + 8 + 3 * 8
-    # ... + the constrained-beam-search block: 4 ints, (4 bytes of alignment), 2 pointers
-    assert C.sizeof(L.GenOpts) == 4 + 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4 + 4 * 4 + 4 + 2 * 8
+    # ... + the constrained-beam-search block: 4 ints, (4 bytes of alignment), 2 pointers, 16 bad-ending ids
+    assert C.sizeof(L.GenOpts) == 4 + 10 * 4 + 5 * 4 + 7 * 4 + 3 * 4 + 4 + 4 * 4 + 4 + 2 * 8 + 16 * 4
     assert L.GenOpts.fsm.offset % 8 == 0 and C.sizeof(L.CbsState) == 8 * 8
 
 

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_cbs.npz')
 
 
-def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None):
+def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None, no_repeat=False, bad_ending=None):
     """search + selection by the C-ABI kernels on a table model: logits of a slot = table[(last token * 5 + length * 11) % R]."""
     from vitcap_amd import _lib as L
     from vitcap_amd._lib import lib, check
@@ -57,8 +57,9 @@ def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None):
         if t == 1:
             check(lib.vitcap_cbs_start(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, max_len, eos, ex, s), 'start')
         else:
-            check(lib.vitcap_cbs_candidates(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, t, max_len, eos, ex, p(cv), p(cw), s),
-                  'candidates')
+            bad = (C.c_int32 * 16)(*(list(bad_ending or []) + [-1] * 16)[:16])
+            check(lib.vitcap_cbs_candidates(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, t, max_len, eos, ex, int(no_repeat), bad,
+                                            p(cv), p(cw), s), 'candidates')
             check(lib.vitcap_cbs_select(p(cv), p(cw), C.byref(st), B, S, K, t, max_len, eos, ex, s), 'select')
         parents.append(bufs['parent'].clone())
         st.ids_in, st.ids_out = st.ids_out, st.ids_in
@@ -135,6 +136,38 @@ def test_cbs_several_eos_ids_and_min_constraints():
         np.testing.assert_allclose(got_lp.numpy(), want_lp.numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_cbs_no_repeat_and_bad_endings():
+    """generate's decoding_constraint_flag (a live sequence never repeats its last word) and bad_ending_ids (no EOS right behind the
+    listed words), utils_cbs.py:187-198, against the oracle on a table model that likes to repeat and to end."""
+    Vn, R, B, K, eos = 120, 64, 3, 3, 2
+    g = torch.Generator().manual_seed(11)
+    table = torch.randn(R, Vn, generator=g) * 1.5
+    table[:, eos] += 2.5
+    for r in range(R):
+        table[r, (r * 7) % Vn] += 3.0
+    fsm1, used = O.fsm_build([[[7, 8]], [[9]]], Vn, max_given_constraints=2)
+    fsm = torch.stack([fsm1[:used, :used]] * B)
+    ncons = torch.tensor([2, 2, 1])
+    bad = [7, 9, 30, 31, 32, 33]
+
+    def step(ids, parents):
+        return table[(ids[:, -1] * 5 + ids.shape[1] * 11) % R]
+    for no_repeat, be in ((True, None), (False, bad), (True, bad)):
+        beams, scores = O.cbs_search(step, fsm, K, max_length=14, eos=eos, no_repeat=no_repeat, bad_ending_ids=be)
+        want_ids, want_lp = O.cbs_select_best(beams, scores, ncons, 2, eos=eos)
+        got_ids, got_lp, got_beams, got_scores, n_pred = _run_device(table.cuda(), fsm, ncons, K, 2, 14, eos, no_repeat=no_repeat, bad_ending=be)
+        assert n_pred == beams.shape[3]
+        np.testing.assert_array_equal(got_ids.numpy(), want_ids.numpy())
+        np.testing.assert_allclose(got_lp.numpy(), want_lp.numpy(), rtol=1e-5, atol=1e-5)
+        for b in range(B):                      # the rules hold in what comes out
+            seq = got_ids[b].tolist()
+            live = seq[:seq.index(eos)] if eos in seq else seq
+            if no_repeat:
+                assert all(a != c for a, c in zip(live, live[1:])), seq
+            if be and eos in seq and live:
+                assert live[-1] not in be, seq
+
+
 # ---------------------------------------------------------------------------------------------- the whole path
 def _case(vec, n):
     B, K, max_given, S = [int(x) for x in vec['case%d_cfg' % n]]
@@ -161,7 +194,7 @@ def model():
 CBS_SCORE_TOL = 1e-2          # as for beam search: accumulated bf16 logit noise on a 19-step score
 
 
-@pytest.mark.parametrize('n', [0, 1, 2])
+@pytest.mark.parametrize('n', [0, 1, 2, 3])
 def test_cbs_captions_vs_reference(model, n):
     """Device captions under constraints against the reference's own generate(use_cbs=True) output.  The constrained words must be
     in the caption; ids equal the reference's, or -- a decision inside the noise floor resolved the other way -- the selected
@@ -169,7 +202,10 @@ def test_cbs_captions_vs_reference(model, n):
     vec = np.load(GOLD)
     B, K, S, fsm, ncons = _case(vec, n)
     im = torch.from_numpy(W.gen_image_batch(B, int(vec['image_seed']))).cuda()
-    ids, lp = model.generate_cbs(im, fsm.cuda(), ncons.cuda(), num_beams=K, min_constraints_to_satisfy=2)
+    over = {}
+    if 'case%d_no_repeat' % n in vec:             # generate's decoding_constraint_flag / bad_ending_ids (case 3)
+        over = {'decoding_constraint_flag': bool(vec['case%d_no_repeat' % n]), 'bad_ending_ids': vec['case%d_bad_ending_ids' % n].tolist()}
+    ids, lp = model.generate_cbs(im, fsm.cuda(), ncons.cuda(), num_beams=K, min_constraints_to_satisfy=2, **over)
     want_ids, want_lp = vec['case%d_ids' % n], vec['case%d_logprobs' % n]
     assert tuple(ids.shape) == (B, 1, want_ids.shape[1]) and tuple(lp.shape) == (B, 1)
     tab = vec['case%d_constraint_ids' % n]

@@ -424,21 +424,24 @@ def test_cbs_fsm_builders_equal_the_reference_machines():
         np.testing.assert_array_equal(fsm.long().sum(-1).numpy(), vec['case%d_fsm_count' % n])
         np.testing.assert_array_equal((fsm.long() * wts).sum(-1).numpy(), vec['case%d_fsm_check' % n])
         n += 1
-    assert n == 3
+    assert n == 4
 
 
 def test_cbs_incremental_matches_reference(sd_t):
     """ViTCAP.generate(use_cbs=True) of the reference (search + select_best_beam_with_constraints) against the oracle's restatement
-    on the incremental fp32 formulation: returned ids and log-probabilities of three cases (1 and 2 images, 1..3 beams per state,
-    single- and two-word constraints; with 2 images the first step reads image 0's distribution for both, as written), and every
-    valid state's best beam as `search` returned it."""
+    on the incremental fp32 formulation: returned ids and log-probabilities of four cases (1 and 2 images, 1..3 beams per state,
+    single- and two-word constraints; with 2 images the first step reads image 0's distribution for both, as written; one case with
+    decoding_constraint_flag and bad_ending_ids), and every valid state's best beam as `search` returned it."""
     vec = _cbs_vec()
     n = 0
     while 'case%d_cfg' % n in vec:
         B, K, max_given, S, cons, fsm, ncons = _cbs_case(vec, n)
         im = torch.from_numpy(W.gen_image_batch(B, int(vec['image_seed'])))
+        rules = {}
+        if 'case%d_no_repeat' % n in vec:     # generate's decoding_constraint_flag / bad_ending_ids (utils_cbs.py:187-198)
+            rules = {'no_repeat': bool(vec['case%d_no_repeat' % n]), 'bad_ending_ids': vec['case%d_bad_ending_ids' % n].tolist()}
         with torch.no_grad():
-            ids, lp, m_search, m_sel, beams, scores = O.cbs_incremental(sd_t, im, fsm, ncons, K, 2, return_margins=True)
+            ids, lp, m_search, m_sel, beams, scores = O.cbs_incremental(sd_t, im, fsm, ncons, K, 2, return_margins=True, **rules)
         np.testing.assert_array_equal(ids.numpy(), vec['case%d_ids' % n])
         np.testing.assert_allclose(lp.numpy(), vec['case%d_logprobs' % n], rtol=0, atol=2e-4)
         want_b, want_s = vec['case%d_beams' % n], vec['case%d_scores' % n]
@@ -450,7 +453,7 @@ def test_cbs_incremental_matches_reference(sd_t):
                     np.testing.assert_allclose(float(scores[b, s, 0]), want_s[b, s, 0], rtol=0, atol=2e-3)
         np.testing.assert_allclose(m_search.numpy(), vec['case%d_margin_search' % n], rtol=0, atol=1e-4)
         n += 1
-    assert n == 3
+    assert n == 4
 
 
 @pytest.mark.slow

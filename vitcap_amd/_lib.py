@@ -23,7 +23,7 @@ OUT_BF16, OUT_F32 = 0, 1
 vp = C.c_void_p
 
 
-ABI_VERSION = 5          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
+ABI_VERSION = 6          # include/vitcap_hip.h VITCAP_ABI_VERSION: checked against vitcap_version() when the library is loaded
 
 
 class GemmDesc(C.Structure):
@@ -64,7 +64,7 @@ class GenOpts(C.Structure):
                 ('decode_streams', C.c_int32), ('encode_parts', C.c_int32), ('eos_extra', C.c_int32 * 3), ('tag_pos0', C.c_int32),
                 # constrained beam search (ViTCAP.generate use_cbs / fsm / num_constraints / min_constraints_to_satisfy)
                 ('use_cbs', C.c_int32), ('cbs_states', C.c_int32), ('min_constraints_to_satisfy', C.c_int32),
-                ('cbs_reserved', C.c_int32), ('fsm', C.c_void_p), ('num_constraints', C.c_void_p)]
+                ('cbs_no_repeat', C.c_int32), ('fsm', C.c_void_p), ('num_constraints', C.c_void_p), ('cbs_bad_ending', C.c_int32 * 16)]
 
 
 class CbsState(C.Structure):
@@ -189,7 +189,7 @@ _SIGS = {
     'vitcap_cbs_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_cbs_start': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_cbs_candidates': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
-                                        vp, vp, vp]),
+                                        C.c_int, vp, vp, vp, vp]),
     'vitcap_cbs_select': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_cbs_finalize': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
     'vitcap_assemble_visual': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
@@ -254,6 +254,9 @@ def gen_opts(**kw):
         elif k == 'eos_extra':
             ids = list(v) + [-1] * (3 - len(v))
             o.eos_extra = (C.c_int32 * 3)(*[int(x) for x in ids[:3]])
+        elif k == 'cbs_bad_ending':
+            ids = list(v) + [-1] * 16
+            o.cbs_bad_ending = (C.c_int32 * 16)(*[int(x) for x in ids[:16]])
         else:
             if not hasattr(o, k):
                 raise AttributeError('vitcap_gen_opts has no field %r' % k)

@@ -37,6 +37,8 @@ __device__ __forceinline__ unsigned long long ck_wave_max(unsigned long long a) 
   return a;
 }
 
+struct BadEnding { int32_t id[16]; };
+
 // a thread's K best keys, descending; 0 = empty (below every real key: real keys have a non-zero high word)
 struct TopK {
   unsigned long long k[CBS_MAXK];
@@ -120,20 +122,31 @@ __global__ __launch_bounds__(256) void cbs_start_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void cbs_candidates_kernel(const float* __restrict__ logits, int ldl, int V,
                                                              const float* __restrict__ lse, const uint8_t* __restrict__ fsm,
                                                              const int64_t* __restrict__ ids_in, int S, int K, int t, int max_len,
-                                                             int eos, VcEosExtra ex, float* __restrict__ cand_val,
-                                                             int32_t* __restrict__ cand_word, const int32_t* __restrict__ live) {
+                                                             int eos, VcEosExtra ex, int no_repeat, BadEnding bad,
+                                                             float* __restrict__ cand_val, int32_t* __restrict__ cand_word,
+                                                             const int32_t* __restrict__ live) {
   VC_LIVE_EXIT(live);
   __shared__ unsigned long long s_w[4], s_out[CBS_MAXK];
   const int i = blockIdx.x, slot = blockIdx.y, G = S * K;
   const int b = slot / G, s = (slot - b * G) / K;
   const float* row = logits + (size_t)slot * ldl;
   const float l = lse[slot];
-  const bool fin = vc_is_eos((int)ids_in[(size_t)slot * max_len + t - 1], eos, ex);
+  const int lastw = (int)ids_in[(size_t)slot * max_len + t - 1];
+  const bool fin = vc_is_eos(lastw, eos, ex);
+  bool prev_bad = false;                      // bad_ending_ids: no EOS right behind these words (utils_cbs.py:192-198)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) prev_bad |= bad.id[q] >= 0 && bad.id[q] == lastw;
   const uint8_t* m = fsm + ((size_t)(b * S + s) * S + i) * V;
   TopK top;
   top.clear();
   for (int v = threadIdx.x; v < V; v += 256) {
-    float x = fin ? (vc_is_eos(v, eos, ex) ? 0.f : -INFINITY) : row[v] - l;
+    float x;
+    if (fin) {
+      x = vc_is_eos(v, eos, ex) ? 0.f : -INFINITY;
+    } else {
+      x = row[v] - l;
+      if ((no_repeat && v == lastw) || (prev_bad && vc_is_eos(v, eos, ex))) x = -INFINITY;      // :187-198, before the finished override
+    }
     if (!m[v]) x = CBS_MASKED;
     top.push(ck_key(x, v));
   }
@@ -223,6 +236,12 @@ __global__ __launch_bounds__(64) void cbs_finalize_kernel(const int64_t* __restr
   if (lane == 0) out_lp[b] = ck_val(best);
 }
 
+BadEnding make_bad(const int32_t* e) {
+  BadEnding x;
+  for (int i = 0; i < 16; ++i) x.id[i] = e ? e[i] : -1;
+  return x;
+}
+
 VcEosExtra make_extra(const int32_t* e) {
   VcEosExtra x{{-1, -1, -1}};
   if (e)
@@ -261,12 +280,13 @@ extern "C" int vitcap_cbs_start(const float* logits, int ldl, int V, const float
 
 extern "C" int vitcap_cbs_candidates(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm,
                                      const vitcap_cbs_state* s, int B, int S, int K, int t, int max_len, int eos,
-                                     const int32_t* eos_extra, float* cand_val, int32_t* cand_word, void* stream) {
+                                     const int32_t* eos_extra, int no_repeat, const int32_t* bad_ending, float* cand_val,
+                                     int32_t* cand_word, void* stream) {
   VC_REQUIRE(logits && lse && fsm && s && cand_val && cand_word && shape_ok(B, S, K, max_len) && V >= K && ldl >= V,
              "cbs_candidates: bad arguments");
   VC_REQUIRE(t >= 2 && t < max_len, "cbs_candidates: t=%d out of 2..%d", t, max_len - 1);
   hipLaunchKernelGGL(cbs_candidates_kernel, dim3(S, B * S * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, lse, fsm,
-                     s->ids_in, S, K, t, max_len, eos, make_extra(eos_extra), cand_val, cand_word, s->live);
+                     s->ids_in, S, K, t, max_len, eos, make_extra(eos_extra), no_repeat, make_bad(bad_ending), cand_val, cand_word, s->live);
   VC_LAUNCH_CHECK("cbs_candidates");
   return VITCAP_OK;
 }

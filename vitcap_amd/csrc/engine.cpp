@@ -107,7 +107,8 @@ vitcap_gen_opts default_opts() {
   o.encode_parts = 0;
   o.eos_extra[0] = o.eos_extra[1] = o.eos_extra[2] = -1;
   o.tag_pos0 = VITCAP_MAXLEN;
-  o.use_cbs = 0; o.cbs_states = 0; o.min_constraints_to_satisfy = 2; o.cbs_reserved = 0;
+  o.use_cbs = 0; o.cbs_states = 0; o.min_constraints_to_satisfy = 2; o.cbs_no_repeat = 0;
+  for (int i = 0; i < 16; ++i) o.cbs_bad_ending[i] = -1;
   o.fsm = nullptr; o.num_constraints = nullptr;
   return o;
 }
@@ -152,6 +153,9 @@ int check_opts(const vitcap_gen_opts& o) {
             "gen_opts: use_cbs runs neither sampling, num_return_sequences > 1 nor the repetition penalty (utils_cbs.py:184-185)");
     OPT_REQ(o.tag_visible == 0, "gen_opts: use_cbs with tag tokens visible to the caption is not built");
     OPT_REQ(o.max_length >= 3, "gen_opts: use_cbs needs max_length >= 3 (got %d)", o.max_length);
+    OPT_REQ(o.cbs_no_repeat == 0 || o.cbs_no_repeat == 1, "gen_opts: cbs_no_repeat must be 0 or 1 (got %d)", o.cbs_no_repeat);
+    for (int i = 0; i < 16; ++i)
+      OPT_REQ(o.cbs_bad_ending[i] >= -1 && o.cbs_bad_ending[i] < VITCAP_VOCAB, "gen_opts: cbs_bad_ending[%d] = %d is neither -1 nor a token id", i, o.cbs_bad_ending[i]);
   }
 #undef OPT_REQ
   return VITCAP_OK;
@@ -1195,8 +1199,8 @@ static int cbs_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_
     if (t == 1) {
       CK(vitcap_cbs_start(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, L, o.eos_token_id, o.eos_extra, s));
     } else {
-      CK(vitcap_cbs_candidates(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, t, L, o.eos_token_id, o.eos_extra,
-                               (float*)(ws + lo.cbs_val), (int32_t*)(ws + lo.cbs_word), s));
+      CK(vitcap_cbs_candidates(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, t, L, o.eos_token_id, o.eos_extra, o.cbs_no_repeat,
+                               o.cbs_bad_ending, (float*)(ws + lo.cbs_val), (int32_t*)(ws + lo.cbs_word), s));
       CK(vitcap_cbs_select((const float*)(ws + lo.cbs_val), (const int32_t*)(ws + lo.cbs_word), &st, B, S, K, t, L, o.eos_token_id,
                            o.eos_extra, s));
     }

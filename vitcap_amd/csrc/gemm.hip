@@ -1650,6 +1650,10 @@ static int large_gemm_form(int M, int N, int hint) {
   static const int env_auto = [] { const char* e = getenv("VITCAP_GEMM_4W"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : (e ? atoi(e) : -1); }();
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
   if (M < 2048) return -1;
+  // VITCAP_GEMM_4W_TILES_N=<N>[,<form>] (experiments): under tile_hint 5 the 4-wave kernel (form 1 unless given) for outputs N wide only
+  static const int only_n = [] { const char* e = getenv("VITCAP_GEMM_4W_TILES_N"); return e ? atoi(e) : 0; }();
+  static const int only_form = [] { const char* e = getenv("VITCAP_GEMM_4W_TILES_N"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 1; }();
+  if (hint == 5 && only_n > 0 && tiles256 < 8 * 256) return N == only_n ? only_form : -1;
   if (hint == 5) return env_set ? env_tiles : (tiles256 >= 8 * 256 ? 2 : -1);
   if (hint == 0) return env_set ? env_auto : 2;
   return -1;

@@ -313,6 +313,15 @@ class ImageCaptioning(nn.Module):
             o.use_cbs, o.cbs_states = 1, int(cbs[0].shape[1])
             o.min_constraints_to_satisfy = int(te.get('min_constraints_to_satisfy', 2))
             o.fsm, o.num_constraints = cbs[0].data_ptr(), cbs[1].data_ptr()
+            # the search's optional rules (generate kwargs, modeling_bert.py:933, 1039-1042)
+            if te.get('use_hypo', False):
+                # upstream cannot run it either: utils_cbs.py:273 indexes a tensor with `beam_id / per_node_beam_size`, a float
+                raise NotImplementedError('use_hypo: the reference\'s own hypothesis branch fails on a float tensor index (utils_cbs.py:273)')
+            o.cbs_no_repeat = int(bool(te.get('decoding_constraint_flag', False)))
+            bad = [int(x) for x in (te.get('bad_ending_ids') or [])]
+            if len(bad) > 16:
+                raise NotImplementedError('bad_ending_ids: at most 16 ids in this build (got %d)' % len(bad))
+            o.cbs_bad_ending = (C.c_int32 * 16)(*(bad + [-1] * (16 - len(bad))))
         check(lib.vitcap_gen_opts_check(C.byref(o)), 'gen_opts')
         return o
 
