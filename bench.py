@@ -527,7 +527,8 @@ def main():
             'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),
             'kernel_form': kernel_form(lib, B * 577, dom, piped or args.gemm_tiles),
             'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4) if ln[dom] else None, 'traffic': traffic,
+            'note': None if ln[dom] else 'no large-GEMM launch (M >= 2048 rows) in this configuration: the per-launch events cover those only',
             'traffic_note': ('HBM bytes per launch from a COMMITTED rocprofv3 PMC pass, not measured in this run: (2*FETCH_SIZE+WRITE_SIZE)*1024 '
                              'in %s (tools/pmc_traffic.sh regenerates it)' % os.path.relpath(tfile, REPO)) if traffic else None,
             'launches': int(ln[dom]), 'avg_launch_ms': round(kms[dom] / max(1, ln[dom]), 4),
