@@ -5,7 +5,6 @@ Tolerances (stated per test): kernels take bf16 operands and accumulate in fp32;
 computed in fp32 on the SAME bf16-rounded operands, so the only differences are fp32 summation order
 (~1e-6 relative) plus one bf16 rounding of the output where the kernel stores bf16 (2^-9 relative).
 """
-import math
 
 import numpy as np
 import pytest

@@ -1,7 +1,6 @@
 """Parity of the training-step kernels (backward GEMM forms, LayerNorm backward, joint causal decoder attention, losses,
 AdamW) against fp32 torch (autograd) on the same bf16-rounded inputs.  GPU only."""
 import ctypes as C
-import math
 
 import numpy as np
 import pytest

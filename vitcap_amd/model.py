@@ -11,7 +11,6 @@ All arithmetic runs in the hand-written HIP kernels of libvitcap_hip.so through 
 per batch; PyTorch only owns the memory.  There is no CPU/eager fallback.
 """
 import ctypes as C
-from collections import OrderedDict
 
 import numpy as np
 import torch

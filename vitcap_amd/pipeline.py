@@ -18,7 +18,6 @@ get_raw_model 566-618, predict_output_to_tsv_row 620-630) for what the hot path 
 import copy
 import json
 import logging
-import os
 import os.path as op
 
 import torch
@@ -421,7 +420,7 @@ class CaptionUniPipeline(object):
         if tsv is not None:
             # (key, base64 JPEG) rows; rank r takes rows r, r+world, ... like DistributedSampler(shuffle=False)
             # (uni_pipeline.py:782-850); decode on the host, transform on the GPU (csrc/preproc.hip)
-            from .imageio import ImagePreprocessor, decode_image
+            from .imageio import ImagePreprocessor
             from .tsv import TSVFile
             rows = TSVFile(tsv)
             pre = ImagePreprocessor(torch.device('cuda', self.local_rank), int(self.cfg.test_crop_size),
