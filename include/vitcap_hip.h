@@ -415,6 +415,12 @@ int vitcap_cbs_finalize(const vitcap_cbs_state* s, const int64_t* num_constraint
 int vitcap_attn_beam_vt(const void* vis_qkv, void* vis_vt, int n_images, int S_vis, void* stream);
 int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out, int n_images,
                              int seq_per_image, int S_vis, int t, int max_len, float scale, void* stream);
+/* the same for images that own SEVERAL groups of <= 8 sequences (constrained beam search: states x beams sequences per image, cut
+ * into groups_per_image groups of seq_per_group): group g = sequences [g * seq_per_group, (g + 1) * seq_per_group) of the batch,
+ * image g / groups_per_image */
+int vitcap_attn_decode_beam_groups(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out,
+                                   int n_images, int seq_per_group, int groups_per_image, int S_vis, int t, int max_len, float scale,
+                                   void* stream);
 
 /* small data movers used by the engine and exposed for tests */
 int vitcap_assemble_visual(const float* hidden, const float* tag_hidden, float* vis_f32, void* vis_bf16,

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void attn_decode_beam_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ vis_vt,
                                                                bf16_t* __restrict__ text_kv, bf16_t* __restrict__ out,
                                                                int S_vis, int t, int max_len, int K, float c_log2,
-                                                               const int32_t* __restrict__ live) {
+                                                               const int32_t* __restrict__ live, int groups_per_image) {
   VC_LIVE_EXIT(live);
   // dynamic LDS sized by the image's 2*K query rows (5 beams: 47 KB -> three workgroups per CU): scores [NQ][BEAM_SC_LD], the
   // four waves' partial contexts [4][NQ][64], the text part [NQ][64]
@@ -601,10 +601,12 @@ __global__ __launch_bounds__(256) void attn_decode_beam_kernel(const bf16_t* __r
   __shared__ float s_lt[16];
   __shared__ __attribute__((aligned(16))) bf16_t s_q[16][HD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int h = blockIdx.x, img = blockIdx.y;
+  // blockIdx.y = a group of K <= 8 sequences that share one image's visual rows; an image may own several groups (constrained beam
+  // search decodes states x beams sequences per image)
+  const int h = blockIdx.x, img = blockIdx.y / groups_per_image;
   const int frow = lane & 15, fk = lane >> 4;
-  const int NQ = 2 * K;                       // query rows of this image: row n = sequence n / 2, step row n % 2
-  const int b0 = img * K;
+  const int NQ = 2 * K;                       // query rows of this group: row n = sequence n / 2, step row n % 2
+  const int b0 = blockIdx.y * K;
   const int ntext = t + 1;                    // text keys per sequence: cache rows 0..t-2, this step's row 0, the [MASK] row
 
   // publish this step's real-token K/V (row 0) of every sequence into its cache at position t-1
@@ -846,10 +848,25 @@ extern "C" int vitcap_attn_beam_vt(const void* vis_qkv, void* vis_vt, int n_imag
   return VITCAP_OK;
 }
 
+static int attn_decode_groups(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out, int n_images,
+                              int seq_per_image, int groups_per_image, int S_vis, int t, int max_len, float scale, void* stream);
+
 extern "C" int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out,
                                         int n_images, int seq_per_image, int S_vis, int t, int max_len, float scale, void* stream) {
-  VC_REQUIRE(qkv_step && vis_qkv && vis_vt && text_kv && out && n_images > 0, "attn_decode_beams: bad arguments");
-  VC_REQUIRE(seq_per_image >= 1 && seq_per_image <= 8, "attn_decode_beams: 1..8 sequences per image (got %d)", seq_per_image);
+  return attn_decode_groups(qkv_step, vis_qkv, vis_vt, text_kv, out, n_images, seq_per_image, 1, S_vis, t, max_len, scale, stream);
+}
+
+extern "C" int vitcap_attn_decode_beam_groups(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out,
+                                              int n_images, int seq_per_group, int groups_per_image, int S_vis, int t, int max_len,
+                                              float scale, void* stream) {
+  return attn_decode_groups(qkv_step, vis_qkv, vis_vt, text_kv, out, n_images, seq_per_group, groups_per_image, S_vis, t, max_len, scale,
+                            stream);
+}
+
+static int attn_decode_groups(const void* qkv_step, const void* vis_qkv, const void* vis_vt, void* text_kv, void* out, int n_images,
+                              int seq_per_image, int groups_per_image, int S_vis, int t, int max_len, float scale, void* stream) {
+  VC_REQUIRE(qkv_step && vis_qkv && vis_vt && text_kv && out && n_images > 0 && groups_per_image >= 1, "attn_decode_beams: bad arguments");
+  VC_REQUIRE(seq_per_image >= 1 && seq_per_image <= 8, "attn_decode_beams: 1..8 sequences per group (got %d)", seq_per_image);
   VC_REQUIRE(t >= 1 && t < max_len && max_len <= 41 && S_vis > 16 && S_vis <= VT_KP && (S_vis + 15) / 16 <= 40,
              "attn_decode_beams: t=%d max_len=%d S_vis=%d out of range", t, max_len, S_vis);
   const float c = scale * 1.4426950408889634f;
@@ -858,13 +875,13 @@ extern "C" int vitcap_attn_decode_beams(const void* qkv_step, const void* vis_qk
   VC_FUNC_SMEM((attn_decode_beam_kernel<4, 3>), 64 * 1024);
   VC_FUNC_SMEM((attn_decode_beam_kernel<11, 6>), 64 * 1024);
   if (seq_per_image * (t + 1) <= 32 * 4 && t + 1 <= 8 * 3)
-    hipLaunchKernelGGL((attn_decode_beam_kernel<4, 3>), dim3(NH, n_images), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
+    hipLaunchKernelGGL((attn_decode_beam_kernel<4, 3>), dim3(NH, n_images * groups_per_image), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
                        (const bf16_t*)vis_qkv, (const bf16_t*)vis_vt, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len,
-                       seq_per_image, c, vc_tls_live);
+                       seq_per_image, c, vc_tls_live, groups_per_image);
   else
-    hipLaunchKernelGGL((attn_decode_beam_kernel<11, 6>), dim3(NH, n_images), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
+    hipLaunchKernelGGL((attn_decode_beam_kernel<11, 6>), dim3(NH, n_images * groups_per_image), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)qkv_step,
                        (const bf16_t*)vis_qkv, (const bf16_t*)vis_vt, (bf16_t*)text_kv, (bf16_t*)out, S_vis, t, max_len,
-                       seq_per_image, c, vc_tls_live);
+                       seq_per_image, c, vc_tls_live, groups_per_image);
   VC_LAUNCH_CHECK("attn_decode_beams");
   return VITCAP_OK;
 }

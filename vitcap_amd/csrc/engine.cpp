@@ -184,6 +184,7 @@ struct Layout {
   size_t tagx_f[2], tagx_b[2], tqkv_c[2][4], jqkv, jout, jlse, tg_ctx, tg_sa_f, tg_sa_b, tg_mlp, tg_tmp;
   int NT;
   int L, NS, K;
+  int group_k;       // K > 8: the largest divisor of K that is <= 8 (sequences per attention workgroup), 1 if K is a prime above 8
   bool beam;
   bool cbs;          // constrained beam search: K = cbs_states * num_beams sequences per image
   size_t cbs_val, cbs_word, cbs_sc, cbs_sc2, cbs_unf, cbs_npred;
@@ -210,6 +211,9 @@ struct Layout {
     beam = !cbs && o.num_beams > 1;
     K = cbs ? o.cbs_states * o.num_beams : (beam ? o.num_beams : o.seqs_per_image);
     NS = B * K;
+    group_k = 1;
+    for (int g = 8; g >= 2; --g)
+      if (K % g == 0) { group_k = g; break; }
     const bool two = K > 1 || cbs;                // layouts with several sequences per image carry the second cache / id buffer
     const size_t b = (size_t)B, n = (size_t)NS, l = (size_t)L;
     patches = take(b * 576 * D * 2);
@@ -285,7 +289,7 @@ struct Layout {
     }
     cand_val = cand_idx = lse = beam_scores = parent = done = has_hyp = hyp_score = hyp_len = hyp_tok = fin_ids = fin_lp = 0;
     for (int i = 0; i < 4; ++i) vt[i] = 0;
-    if (beam && NT == 0)
+    if ((beam || cbs) && NT == 0)
       for (int i = 0; i < 4; ++i) vt[i] = take(b * VT_BYTES);
     cbs_val = cbs_word = cbs_sc = cbs_sc2 = cbs_unf = cbs_npred = 0;
     if (cbs) {
@@ -979,9 +983,13 @@ static int step_forward(const vitcap_weights& w, const Layout& lo, const vitcap_
       CK(vitcap_attn_decode_step_tags(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f,
                                       ws + lo.tqkv_c[0][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2, ws + lo.tqkv_c[1][l] + (size_t)pt.i0 * lo.NT * 3 * D * 2,
                                       lo.NT, (const int64_t*)(ws + lo.tag_len), s));
-    else if (lo.vt[l] && K >= 2 && !no_beam_attn)
+    else if (lo.vt[l] && K >= 2 && K <= 8 && !no_beam_attn)
       // several sequences per image (beam search): all of an image's query rows against its visual rows on the matrix pipe
       CK(vitcap_attn_decode_beams(sqkv, vis, ws + lo.vt[l] + (size_t)pt.i0 * VT_BYTES, tc, sctx, ns / K, K, SV, t, L, 0.125f, s));
+    else if (lo.vt[l] && K > 8 && lo.group_k > 1 && !no_beam_attn)
+      // more than 8 sequences per image (constrained beam search: states x beams): groups of group_k sequences, K / group_k per image
+      CK(vitcap_attn_decode_beam_groups(sqkv, vis, ws + lo.vt[l] + (size_t)pt.i0 * VT_BYTES, tc, sctx, ns / K, lo.group_k, K / lo.group_k, SV, t,
+                                        L, 0.125f, s));
     else
       CK(vitcap_attn_decode_step(sqkv, vis, tc, sctx, ns, SV, t, L, K, 0.125f, s));
     // attention.output.dense and output.dense: fp32 partial slabs (one per 768-long k range; split-K 6 / 12 for beam batches),
