@@ -213,7 +213,8 @@ __global__ __launch_bounds__(64) void cbs_finalize_kernel(const int64_t* __restr
                                                           int min_c, int S, int K, int max_len, int eos, VcEosExtra ex, int pad,
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_lp) {
   const int b = blockIdx.x, lane = threadIdx.x, G = S * K, T = *n_pred;
-  const int given = (int)ncons[b];
+  int given = (int)ncons[b];
+  given = given < 0 ? 0 : (given > 5 ? 5 : given);          // 2**given main states, at most CBS_MAXS = 32 of them
   const int need = given < min_c ? given : min_c;
   const int nmain = 1 << given;
   // lane s < 2**given: the state's best beam (index 0) if the state satisfies enough constraints
