@@ -397,10 +397,13 @@ typedef struct {
 int vitcap_cbs_init(const vitcap_cbs_state* s, int B, int S, int K, int max_len, int bos, void* stream);
 int vitcap_cbs_start(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
                      int B, int S, int K, int max_len, int eos, const int32_t* eos_extra, void* stream);
+/* flags [B][S][S] uint8 (device): 1 iff any word moves image b's machine from s1 to s2 -- computed once per call; handed to
+ * vitcap_cbs_candidates (or NULL) it lets the pairs without a transition skip the scan of the vocabulary (same output) */
+int vitcap_cbs_pair_flags(const uint8_t* fsm, int B, int S, int V, uint8_t* flags, void* stream);
 /* no_repeat / bad_ending (host, 16 ids, -1 = unused, or NULL): vitcap_gen_opts.cbs_no_repeat / cbs_bad_ending */
 int vitcap_cbs_candidates(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm, const vitcap_cbs_state* s,
                           int B, int S, int K, int t, int max_len, int eos, const int32_t* eos_extra, int no_repeat,
-                          const int32_t* bad_ending, float* cand_val, int32_t* cand_word, void* stream);
+                          const int32_t* bad_ending, const uint8_t* pair_flags, float* cand_val, int32_t* cand_word, void* stream);
 int vitcap_cbs_select(const float* cand_val, const int32_t* cand_word, const vitcap_cbs_state* s, int B, int S, int K, int t,
                       int max_len, int eos, const int32_t* eos_extra, void* stream);
 int vitcap_cbs_finalize(const vitcap_cbs_state* s, const int64_t* num_constraints, int min_constraints, int B, int S, int K,

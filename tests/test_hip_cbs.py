@@ -49,6 +49,8 @@ def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None, no_repeat
     tv, ti = torch.empty(NS, dtype=torch.float32, device=dev), torch.empty(NS, dtype=torch.int32, device=dev)
     lse = torch.empty(NS, dtype=torch.float32, device=dev)
     R = table.shape[0]
+    flags = torch.empty(B * S * S, dtype=torch.uint8, device=dev)
+    check(lib.vitcap_cbs_pair_flags(p(fsm_d), B, S, V, p(flags), s), 'pair_flags')
     parents = []
     for t in range(1, max_len):
         cur = bufs['ids_in'] if st.ids_in == bufs['ids_in'].data_ptr() else bufs['ids_out']
@@ -58,8 +60,9 @@ def _run_device(table, fsm, ncons, K, min_c, max_len, eos, extra=None, no_repeat
             check(lib.vitcap_cbs_start(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, max_len, eos, ex, s), 'start')
         else:
             bad = (C.c_int32 * 16)(*(list(bad_ending or []) + [-1] * 16)[:16])
+            # every other step with the per-pair transition flags (pairs without a transition skip the scan): same output
             check(lib.vitcap_cbs_candidates(p(logits), V, V, p(lse), p(fsm_d), C.byref(st), B, S, K, t, max_len, eos, ex, int(no_repeat), bad,
-                                            p(cv), p(cw), s), 'candidates')
+                                            p(flags) if t % 2 else None, p(cv), p(cw), s), 'candidates')
             check(lib.vitcap_cbs_select(p(cv), p(cw), C.byref(st), B, S, K, t, max_len, eos, ex, s), 'select')
         parents.append(bufs['parent'].clone())
         st.ids_in, st.ids_out = st.ids_out, st.ids_in

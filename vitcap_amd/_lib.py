@@ -189,8 +189,9 @@ _SIGS = {
     'vitcap_beam_finalize': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_cbs_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_cbs_start': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'vitcap_cbs_pair_flags': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_cbs_candidates': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
-                                        C.c_int, vp, vp, vp, vp]),
+                                        C.c_int, vp, vp, vp, vp, vp]),
     'vitcap_cbs_select': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_cbs_finalize': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
     'vitcap_assemble_visual': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),

@@ -118,17 +118,42 @@ __global__ __launch_bounds__(256) void cbs_start_kernel(const float* __restrict_
   }
 }
 
+// once per call: flags[b][s][i] = does ANY word move image b's machine from state s to state i.  Most (s, i) pairs of a machine have
+// no transition at all (8 main states: 8 loops + 12 steps out of 64 pairs); their candidates are K fillers of -1e20 whatever the
+// logits say, and the slot stage need not scan 30522 words to find that out.
+__global__ __launch_bounds__(256) void cbs_pair_flags_kernel(const uint8_t* __restrict__ fsm, int V, uint8_t* __restrict__ flags) {
+  __shared__ int s_any;
+  const uint8_t* m = fsm + (size_t)blockIdx.x * V;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  int any = 0;
+  for (int v = threadIdx.x; v < V; v += 256) any |= m[v];
+  if (any) s_any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) flags[blockIdx.x] = (uint8_t)s_any;
+}
+
 // later steps, slot stage: grid (S targets, B*G slots)
 __global__ __launch_bounds__(256) void cbs_candidates_kernel(const float* __restrict__ logits, int ldl, int V,
                                                              const float* __restrict__ lse, const uint8_t* __restrict__ fsm,
                                                              const int64_t* __restrict__ ids_in, int S, int K, int t, int max_len,
                                                              int eos, VcEosExtra ex, int no_repeat, BadEnding bad,
                                                              float* __restrict__ cand_val, int32_t* __restrict__ cand_word,
-                                                             const int32_t* __restrict__ live) {
+                                                             const int32_t* __restrict__ live, const uint8_t* __restrict__ pair_flags) {
   VC_LIVE_EXIT(live);
   __shared__ unsigned long long s_w[4], s_out[CBS_MAXK];
   const int i = blockIdx.x, slot = blockIdx.y, G = S * K;
   const int b = slot / G, s = (slot - b * G) / K;
+  if (pair_flags && !pair_flags[(b * S + s) * S + i]) {
+    // no word leads from s to i: every candidate is the -1e20 filler, the K lowest word ids under the tie rule -- what the scan below
+    // would return
+    if (threadIdx.x < K) {
+      const size_t o = ((size_t)slot * S + i) * K + threadIdx.x;
+      cand_val[o] = CBS_MASKED;
+      cand_word[o] = threadIdx.x;
+    }
+    return;
+  }
   const float* row = logits + (size_t)slot * ldl;
   const float l = lse[slot];
   const int lastw = (int)ids_in[(size_t)slot * max_len + t - 1];
@@ -281,14 +306,21 @@ extern "C" int vitcap_cbs_start(const float* logits, int ldl, int V, const float
 
 extern "C" int vitcap_cbs_candidates(const float* logits, int ldl, int V, const float* lse, const uint8_t* fsm,
                                      const vitcap_cbs_state* s, int B, int S, int K, int t, int max_len, int eos,
-                                     const int32_t* eos_extra, int no_repeat, const int32_t* bad_ending, float* cand_val,
-                                     int32_t* cand_word, void* stream) {
+                                     const int32_t* eos_extra, int no_repeat, const int32_t* bad_ending, const uint8_t* pair_flags,
+                                     float* cand_val, int32_t* cand_word, void* stream) {
   VC_REQUIRE(logits && lse && fsm && s && cand_val && cand_word && shape_ok(B, S, K, max_len) && V >= K && ldl >= V,
              "cbs_candidates: bad arguments");
   VC_REQUIRE(t >= 2 && t < max_len, "cbs_candidates: t=%d out of 2..%d", t, max_len - 1);
   hipLaunchKernelGGL(cbs_candidates_kernel, dim3(S, B * S * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, lse, fsm,
-                     s->ids_in, S, K, t, max_len, eos, make_extra(eos_extra), no_repeat, make_bad(bad_ending), cand_val, cand_word, s->live);
+                     s->ids_in, S, K, t, max_len, eos, make_extra(eos_extra), no_repeat, make_bad(bad_ending), cand_val, cand_word, s->live, pair_flags);
   VC_LAUNCH_CHECK("cbs_candidates");
+  return VITCAP_OK;
+}
+
+extern "C" int vitcap_cbs_pair_flags(const uint8_t* fsm, int B, int S, int V, uint8_t* flags, void* stream) {
+  VC_REQUIRE(fsm && flags && B > 0 && S >= 1 && S <= CBS_MAXS && V > 0, "cbs_pair_flags: bad arguments");
+  hipLaunchKernelGGL(cbs_pair_flags_kernel, dim3(B * S * S), dim3(256), 0, (hipStream_t)stream, fsm, V, flags);
+  VC_LAUNCH_CHECK("cbs_pair_flags");
   return VITCAP_OK;
 }
 

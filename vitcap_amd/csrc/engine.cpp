@@ -187,7 +187,7 @@ struct Layout {
   int group_k;       // K > 8: the largest divisor of K that is <= 8 (sequences per attention workgroup), 1 if K is a prime above 8
   bool beam;
   bool cbs;          // constrained beam search: K = cbs_states * num_beams sequences per image
-  size_t cbs_val, cbs_word, cbs_sc, cbs_sc2, cbs_unf, cbs_npred;
+  size_t cbs_val, cbs_word, cbs_sc, cbs_sc2, cbs_unf, cbs_npred, cbs_flags;
   // the same layout seen from image i0 on: every image-major buffer of the encoder / prefill advanced by i0 images
   Layout from_image(int i0) const {
     Layout v = *this;
@@ -291,7 +291,7 @@ struct Layout {
     for (int i = 0; i < 4; ++i) vt[i] = 0;
     if ((beam || cbs) && NT == 0)
       for (int i = 0; i < 4; ++i) vt[i] = take(b * VT_BYTES);
-    cbs_val = cbs_word = cbs_sc = cbs_sc2 = cbs_unf = cbs_npred = 0;
+    cbs_val = cbs_word = cbs_sc = cbs_sc2 = cbs_unf = cbs_npred = cbs_flags = 0;
     if (cbs) {
       const size_t per = (size_t)o.cbs_states * o.num_beams;        // candidates per slot: K words for each of the S target states
       cbs_val = take(n * per * 4);
@@ -300,6 +300,7 @@ struct Layout {
       cbs_sc2 = take(n * 4);
       cbs_unf = take(l * 4);
       cbs_npred = take(256);
+      cbs_flags = take(b * (size_t)o.cbs_states * o.cbs_states);
       lse = take(n * 4);
       cand_val = take(n * 4);              // row maxima next to the log-sum-exp (vitcap_row_topk_lse with k = 1)
       cand_idx = take(n * 4);
@@ -1193,6 +1194,7 @@ static int cbs_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_
   st.n_pred = (int32_t*)(ws + lo.cbs_npred);
   st.live = (int32_t*)(ws + lo.live);
   CK(vitcap_cbs_init(&st, B, S, K, L, o.bos_token_id, s));
+  CK(vitcap_cbs_pair_flags(o.fsm, B, S, VITCAP_VOCAB, (uint8_t*)(ws + lo.cbs_flags), s));
   char* tc_cur = ws + lo.tcache;
   char* tc_alt = ws + lo.tcache2;
   const float* logits = (const float*)(ws + lo.logits);
@@ -1208,7 +1210,8 @@ static int cbs_loop(vitcap_engine* e, int B, const Layout& lo, const vitcap_gen_
       CK(vitcap_cbs_start(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, L, o.eos_token_id, o.eos_extra, s));
     } else {
       CK(vitcap_cbs_candidates(logits, VP, VITCAP_VOCAB, lse, o.fsm, &st, B, S, K, t, L, o.eos_token_id, o.eos_extra, o.cbs_no_repeat,
-                               o.cbs_bad_ending, (float*)(ws + lo.cbs_val), (int32_t*)(ws + lo.cbs_word), s));
+                               o.cbs_bad_ending, (const uint8_t*)(ws + lo.cbs_flags), (float*)(ws + lo.cbs_val),
+                               (int32_t*)(ws + lo.cbs_word), s));
       CK(vitcap_cbs_select((const float*)(ws + lo.cbs_val), (const int32_t*)(ws + lo.cbs_word), &st, B, S, K, t, L, o.eos_token_id,
                            o.eos_extra, s));
     }
