@@ -683,9 +683,9 @@ int vitcap_embed_rows(const int64_t* ids, int rows_per_seq, const void* word_emb
  * stream around every GEMM launch with M > 256.  begin() sizes the event pool (outside the timed region);
  * end() synchronises and returns sums per epilogue variant (index = act*4 + out_f32*2 + has_residual). */
 int vitcap_engine_timing_begin(vitcap_engine* e, int max_launches);
-/* time only every stride-th eligible launch from the next timing_begin on (default 1 = all): four event records per timed launch cost
- * 2.6 % of a pipelined B = 64 step when every launch is timed (bench.py `unarmed_ms_per_step`); a stride co-prime with the number of
- * GEMM variants samples all of them evenly */
+/* time the large-GEMM launches of every stride-th STEP (vitcap_engine_encode call + the prefill behind it) from the next timing_begin
+ * on (default 1 = every step): four event records per timed launch cost 2.6 % of a pipelined B = 64 step when every launch is timed
+ * (bench.py `unarmed_ms_per_step`).  Whole steps, so that the busy-interval union of the sampled launches stays meaningful */
 int vitcap_engine_timing_sample(vitcap_engine* e, int stride);
 int vitcap_engine_timing_end(vitcap_engine* e, double* ms12, double* flops12, int* launches12);
 /* the same plus busy_ms12: per variant the length of the union of its launches' [start, stop] intervals (launches of one kernel

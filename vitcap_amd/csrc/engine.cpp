@@ -56,8 +56,9 @@ struct vitcap_engine {
   vitcap_weights w;
   bool bound = false;
   bool timing = false;
-  int timing_stride = 1;      // every timing_stride-th eligible launch is timed (vitcap_engine_timing_sample)
-  long long timing_seen = 0;  // eligible launches since timing_begin
+  int timing_stride = 1;      // the large-GEMM launches of every timing_stride-th STEP (encode call) are timed (vitcap_engine_timing_sample)
+  long long timing_seen = 0;  // steps since timing_begin
+  bool timing_this_step = true;
   // one enqueue at a time per engine: the side stream / fork-join events and the graph cache are shared by all callers
   std::mutex mu;
   // the tag branch of the encoder (4 tag blocks + tag head) runs on this side stream next to caption blocks 8-11
@@ -354,7 +355,7 @@ int gemm_desc(const void* A, const void* W, const float* bias, const float* res,
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) eligible = false;
   }
-  const bool timed = eligible && (e->timing_seen++ % e->timing_stride) == 0 && e->used < e->pool.size();
+  const bool timed = eligible && e->timing_this_step && e->used < e->pool.size();
   GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
   // one tile per workgroup for the large GEMMs when the caller overlaps a second stream (vitcap_gen_opts.gemm_mode)
   if (d.tile_hint == 0 && g_gemm_mode == VITCAP_GEMM_TILES && d.M >= 2048 && d.act != VITCAP_ACT_TANH && d.split_k <= 1) d.tile_hint = 5;
@@ -776,6 +777,9 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
                          char* ws, void* s) {
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
   CallScope scope(e, o.gemm_mode, nullptr);
+  // timing runs: a step is sampled WHOLE (its encoder and prefill launches), so that the union of the sampled launches' intervals
+  // still sees which of them ran next to each other (tag branch beside caption blocks 8-11, batch parts)
+  if (e->timing) e->timing_this_step = (e->timing_seen++ % e->timing_stride) == 0;
   const int np = encode_parts(o, B, lo);
   if (np >= 2) {
     if (!e->ev_pfork) HIPCK(hipEventCreateWithFlags(&e->ev_pfork, hipEventDisableTiming), "encode: event");
