@@ -416,14 +416,20 @@ def main():
         elapsed, (ids, lp) = region(True)
         regions = [elapsed]
         unarmed = None
-        if elapsed < 2.0 and not args.single_region:
+        events_region = 0
+        # every rank must take the same branch (each region holds barriers): the decision uses the MAX over ranks of the first region
+        first = D.max_over_ranks(elapsed, dist, device='cuda')
+        if first < 2.0 and not args.single_region:
             ms_keep = None
             for _ in range(2):
                 check(lib.vitcap_engine_timing_end_kernel(model._engine, (C.c_double * 12)(), (C.c_double * 12)(), (C.c_int * 12)(), None,
                                                           (C.c_double * 12)(), None), 'timing_end')
                 e2, (ids, lp) = region(True)
                 regions.append(e2)
-            elapsed = sorted(regions)[1]
+            events_region = len(regions) - 1
+            # median by the max-over-ranks times, so that every rank reports the SAME region
+            rmax = [D.max_over_ranks(r, dist, device='cuda') for r in regions]
+            elapsed = regions[sorted(range(len(regions)), key=lambda i: rmax[i])[1]]
             # the events of the LAST armed region stay in the engine for the roofline below; one unarmed region first would lose
             # them, so the unarmed one runs after they have been read (see below)
             unarmed = 'pending'
@@ -556,6 +562,7 @@ def main():
             # the sampled steps are 0, STRIDE, 2 STRIDE, ... of the region
             'large_gemm_share_of_step_time': round(tot_ms / len(range(0, args.steps, TIMING_STRIDE)) / (elapsed / args.steps * 1e3), 4),
             'timing_sample': 'the large-GEMM launches of every %dth step of the timed region carry the events (launches / ms are the sampled ones); on every step they would cost 2.6 %% of it' % TIMING_STRIDE,
+            'events_region': 'the per-launch events are those of timed region #%d of %d (the last armed one); value / ms_per_step are the median region\'s' % (events_region + 1, len(regions)),
             'per_variant': {VARIANT_NAMES.get(i, str(i)): {'launches': int(ln[i]), 'ms': round(kms[i], 3),
                                                             'tflops': round(fl[i] / (kms[i] * 1e-3) / 1e12, 2)}
                             for i in range(12) if ln[i] > 0},

@@ -126,6 +126,13 @@ int vitcap_gemm_tile_plan(int M, int N, int K, int* plan3);
  * -1 = the 8-wave 256x256 kernel (gemm.hip); otherwise form + 10 * MI of the 4-wave kernel (gemm4w.hip): form 1 = one tile per
  * workgroup, 2 = persistent pipeline; MI = 8 / 7 / 6 -> 256- / 224- / 192-row tiles.  Results do not depend on the choice. */
 int vitcap_gemm_large_form(int M, int N, int K, int tile_hint);
+/* CUs the persistent large-GEMM grids (one 512-register workgroup per CU) leave free from now on, for launches of this process
+ * (0 = none; rounded up to a multiple of 8 so that every XCD keeps the same number of workgroups; at most the device's CUs - 8).
+ * Returns the previous value.  Why it exists: a collective's kernel (RCCL over xGMI, the data-parallel gradient exchange of
+ * reference trainer.py:119-126 / uni_pipeline.py:497-505) cannot start while persistent workgroups own every CU -- stream priority
+ * orders dispatch, it does not evict a resident workgroup -- so the training engine reserves a few CUs between the first
+ * bucket's launch and the exchange's end (vitcap_amd/dist_util.py).  Host-side state (an atomic), no launch, no synchronisation. */
+int vitcap_gemm_reserve_cus(int cus);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (768): y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 statistics.

@@ -88,7 +88,7 @@ def test_grad_buckets_cover_exactly_the_tensors_that_get_gradients():
         assert max(sizes) < 128 and sum(s > 32 for s in sizes) >= 10      # MB: few large messages
 
 
-def _reduce_worker(rank, world, port, out, algo='all_reduce'):
+def _reduce_worker(rank, world, port, out, algo='all_reduce', wire='f32'):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     from vitcap_amd import dist_util as D
@@ -98,7 +98,7 @@ def _reduce_worker(rank, world, port, out, algo='all_reduce'):
     flat = torch.randn(n, generator=g)
     mine = flat.clone()
     buckets = {'last': [(3000, 4000)], 'mid': [(1024, 2048), (2100, 2901)], 'first': [(0, 1000)]}    # 801: odd, exercises the tail
-    red = D.BucketedAllReduce(flat, buckets, ['last', 'mid', 'first'], dist, algo=algo)
+    red = D.BucketedAllReduce(flat, buckets, ['last', 'mid', 'first'], dist, algo=algo, wire=wire)
     red.begin()
     err = None
     try:
@@ -149,6 +149,60 @@ def test_bucketed_all_reduce_two_ranks_gloo(algo):
     assert torch.allclose(f0[inside], mean[inside]) and torch.equal(f0[inside], f1[inside])
     assert torch.equal(f0[~inside], m0[~inside]) and torch.equal(f1[~inside], m1[~inside])   # untouched outside buckets
     assert nb == int(inside.sum()) * 4
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_bucketed_exchange_bf16_wire_vs_fp32(world):
+    """wire='bf16' (bf16 on the links, fp32 accumulate: all-to-all of slices, local fp32 sum in rank order, all-gather of the rounded
+    means) against the exact mean: within bf16 rounding of the contributions and of the result, IDENTICAL bits on every rank (the
+    replicas must not drift apart), untouched outside the buckets, odd range tails exact."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q, 'rs_ag', 'bf16')) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    mine = [torch.from_numpy(r[1]) for r in res]
+    flat = [torch.from_numpy(r[2]) for r in res]
+    mean = sum(mine) / world
+    inside = torch.zeros(4096, dtype=torch.bool)
+    for a, b in ((3000, 4000), (1024, 2048), (2100, 2901), (0, 1000)):
+        inside[a:b] = True
+    for f in flat[1:]:
+        assert torch.equal(f, flat[0]) or torch.equal(f[inside], flat[0][inside])
+    # two steps ran: step 1 leaves bf16(mean of bf16 contributions), step 2 averages equal copies of a bf16 value (exact)
+    bound = (sum(m.abs() for m in mine) / world + mean.abs()) * 2.0 ** -8 + 1e-12
+    assert bool(((flat[0] - mean).abs()[inside] <= bound[inside]).all())
+    body = inside.clone()
+    body[2100 + (801 // world) * world:2901] = False         # the tail of the odd range travels as fp32: exact mean
+    tail = inside & ~body
+    if bool(tail.any()):
+        assert torch.allclose(flat[0][tail], mean[tail], rtol=1e-6, atol=1e-7)
+    for m, f in zip(mine, flat):
+        assert torch.equal(f[~inside], m[~inside])
+
+
+def test_bench_self_launches_eight_ranks():
+    """The driver's widest launch: `python bench.py --gpus 8` starts eight ranks (child torch.distributed.run), every rank takes
+    part in the barriers and the max-over-ranks, rank 0 prints the ONE line (CPU stand-in workload, gloo)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--stub',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert abs(rec['value'] - 8 * 3 / (rec['ms_per_step'] * 3e-3)) < 1e-2 * rec['value'] + 1.0
 
 
 def test_bench_self_launches_n_ranks():

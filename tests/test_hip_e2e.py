@@ -1021,6 +1021,15 @@ def test_pipeline_predict_honours_the_batches_masks(tmp_path, monkeypatch, golde
         for i in range(2):
             cap, conf = rows['%s%d' % (k, i)]
             assert cap == want[i][0] and abs(conf - want[i][1]) <= 1e-7 * want[i][1], (k, i, conf, want[i][1])
+    # consecutive device-resident batches that CHANGE the count: one batch is always in flight, so the second of two
+    # batches with a new count was submitted against the old one as well -- it must be decoded again with its own options, not
+    # reported as an unsupported mask; and a third change back is handled the same way
+    rows = run([batch(50, 'cuda', ['f0', 'f1']), batch(0, 'cuda', ['g0', 'g1']), batch(0, 'cuda', ['h0', 'h1']), batch(0, 'cuda', ['i0', 'i1']),
+                batch(50, 'cuda', ['j0', 'j1']), batch(50, 'cuda', ['k0', 'k1'])], 'changing')
+    for k, want in (('f', want50), ('g', want0), ('h', want0), ('i', want0), ('j', want50), ('k', want50)):
+        for i in range(2):
+            cap, conf = rows['%s%d' % (k, i)]
+            assert cap == want[i][0] and abs(conf - want[i][1]) <= 1e-7 * want[i][1], (k, i, conf, want[i][1])
     bad = batch(50, 'cuda', ['e0', 'e1'])
     bad['attention_mask'][1, 3, 9] = 1
     with pytest.raises(NotImplementedError, match='mask structure'):

@@ -749,13 +749,16 @@ static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
 // streams (part 0 on the caller's), so that the tile-quantisation tail of one part's GEMM (qkv: 5.1 rounds of 256 CUs cost 6 at
 // B = 64) is filled by the other part's kernels; every row's arithmetic is unchanged (bit-identical results).  Measured,
 // 2-slot pipeline, images/s without / with 2 parts: B = 16 2039 / 2034, 32 2825 / 2854, 64 3560 / 3635, 128 3724 / 3808,
-// 512 3975 / 3990; 3 and 4 parts lose (B = 64: 3318 / 3460).  auto = 1 part: the gain is 1-2 %, and with two GEMM chains in
-// flight every launch of the dominant kernel shares the chip with the other chain (its per-launch rate, the bench's roofline
-// figure, drops from 0.24 to 0.17 of peak although throughput rises).  VITCAP_ENCODE_SPLIT overrides for experiments.
+// 512 3975 / 3990; 3 and 4 parts lose (B = 64: 3318 / 3460).  With two GEMM chains in flight every launch of the dominant kernel
+// shares the chip with the other chain: its per-launch rate (the bench's roofline.frac) drops from 0.24 to 0.17 of peak although
+// throughput rises -- roofline.frac_busy (flops / union of the launches' intervals) is the figure that stays comparable.
+// VITCAP_ENCODE_SPLIT overrides for experiments.
 static int encode_parts(const vitcap_gen_opts& o, int B, const Layout& lo) {
   static const int env = [] { const char* e = getenv("VITCAP_ENCODE_SPLIT"); return e ? atoi(e) : -1; }();
   int p = env >= 0 ? env : o.encode_parts;
-  if (p == 0) p = 1;
+  // auto (round 5): two parts inside the batch pipeline from 32 images on -- images/s is the metric (+2.1 % at B = 64, +2.3 % at 128,
+  // +0.4 % at 512, measured above); the bench reports the dominant kernel's busy-interval rate (frac_busy) beside the per-launch one
+  if (p == 0) p = (o.gemm_mode == VITCAP_GEMM_TILES && B >= 32) ? 2 : 1;
   if (p > 4) p = 4;
   if (B < 8 || lo.NT > 0) p = 1;
   return p;
@@ -906,6 +909,9 @@ static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
   float* vis_f = (float*)(ws + lo.vis_f);
   void* vis_b = ws + lo.vis_b;
   CK(vitcap_assemble_visual((const float*)(ws + lo.x2), (const float*)(ws + lo.xt), vis_f, vis_b, B, NV, s));
+  // the ticket counters of the GEMMs that normalise their own rows are zero on exit of every completed launch; zero them here as well,
+  // so that a launch that was aborted (or a caller that runs prefill without encode) cannot poison the next one
+  HIPCK(hipMemsetAsync(ws + lo.ln_cnt, 0, (size_t)B * 4 * 4, (hipStream_t)s), "prefill: counters");
   for (int l = 0; l < 4; ++l) {
     const vitcap_bert_layer_w& lw = w.dec[l];
     void* dq = ws + lo.dqkv[l];

@@ -1660,9 +1660,13 @@ static int large_gemm_form(int M, int N, int hint) {
 }
 
 extern "C" int vitcap_gemm_large_form(int M, int N, int K, int tile_hint) {
-  (void)K;
-  const int form = large_gemm_form(M, N, tile_hint);
+  int form = large_gemm_form(M, N, tile_hint);
   if (form < 0 || form > 2) return -1;
+  if (K < 128) return -1;                                   // vc_4w_supports
+  // launch_4w's downgrade rules for plain rows (what the engine's large GEMMs use): the persistent pipeline needs three k-tiles and
+  // whole 256-column tiles, the register epilogue 16-byte bf16 stores
+  if (form == 2 && (K < 192 || (N & 255) != 0)) form = 1;
+  if (form != 0 && (N & 7) != 0) form = 0;
   return form + 10 * vc_4w_pick_mi(M, (N + 255) / 256, form);
 }
 

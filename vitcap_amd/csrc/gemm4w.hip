@@ -20,6 +20,7 @@
 #include "common.h"
 #include "gemm_args.h"
 
+#include <atomic>
 #include <utility>
 
 namespace {
@@ -104,6 +105,10 @@ __device__ __forceinline__ Loop make_loop(const GemmArgs& p, uint32_t smem_base,
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
   L.voff_a = (uint32_t)(srow * p.lda * 2 + schunk * 16);
   L.voff_w = (uint32_t)(srow * p.ldw * 2 + schunk * 16);
+#ifdef VC_4W_DMA64
+  L.voff_a = (uint32_t)((lane >> 2) * p.lda * 2 + (lane & 3) * 16);
+  L.voff_w = (uint32_t)((lane >> 2) * p.ldw * 2 + (lane & 3) * 16);
+#endif
   const int a_row0 = w * (8 * MI), w_row0 = w * 64;
   L.soff_a = (uint32_t)(a_row0 * p.lda * 2);
   L.soff_w = (uint32_t)(w_row0 * p.ldw * 2);
@@ -123,6 +128,11 @@ __device__ __forceinline__ Loop make_loop(const GemmArgs& p, uint32_t smem_base,
 template <int MI, int Q>
 __device__ __forceinline__ void dma_piece(const Loop& L, const Src& src, uint32_t bufoff, uint32_t kb) {
   // piece Q of a k-tile: Q < MI -> 8 rows of A, else 8 rows of W
+#ifdef VC_4W_DMA64     // probe (wrong results): every piece as 16 rows x 64 B (half lines) instead of 8 rows x 128 B -- same pieces, same bytes
+  if constexpr (Q < MI) dma16(L.lds_a + bufoff + Q * 1024, L.voff_a, src.ra, L.soff_a + (Q / 2) * 2 * L.pstep_a + (Q & 1) * 64 + kb);
+  else dma16(L.lds_w + bufoff + (Q - MI) * 1024, L.voff_w, src.rw, L.soff_w + ((Q - MI) / 2) * 2 * L.pstep_w + (Q & 1) * 64 + kb);
+  return;
+#endif
   if constexpr (Q < MI) dma16(L.lds_a + bufoff + Q * 1024, L.voff_a, src.ra, L.soff_a + Q * L.pstep_a + kb);
   else dma16(L.lds_w + bufoff + (Q - MI) * 1024, L.voff_w, src.rw, L.soff_w + (Q - MI) * L.pstep_w + kb);
 }
@@ -176,10 +186,61 @@ __device__ __forceinline__ void half_steps(f32x4 (&acc)[MI][8], Frags& f, const 
   (half_step<MI, MODE, FIRST, S>(acc, f, L, src, rd_a, rd_w, bufoff, kb), ...);
 }
 
+// ---- schedule E ("early release", round 5).  With ONE rendezvous per k-tile the buffer of tile t is released at the tile's middle and
+// tile t+2's pieces, requested behind k-half 1's MFMAs, must have landed one k-tile later: a lead of 1.25-2 k-halves (1.3-2.0k cycles),
+// enough for operands that sit in the L2 / Infinity Cache (M = 36 928: the loop runs at 25.4k cycles per 12 k-tiles, the MFMA floor is
+// 24.6k), NOT for an A panel that streams from HBM under load (M = 295 424: 35.9k, profiles/r04_g4w_probe.txt).  Here the k-half-1
+// fragments of tile t are read behind the FIRST half of k-half 0's MFMAs, a first rendezvous (X) releases the buffer there, and the
+// pieces of tile t+2 follow behind the second half of k-half 0: requested half a k-tile earlier, still awaited at the mid-tile
+// rendezvous (Y) of tile t+1 with a COUNTED wait (the pieces requested in this tile stay in flight across it): lead 2.0-2.5 k-halves.
+// Same MFMA order, same operands: bit-identical results.
+constexpr int slot_of(int S, int N, int Q) {       // index r in [0, N) whose position (r * Q) / N is step S (Q >= N), else -1
+  const int r = (S * N + Q - 1) / Q;
+  return (S >= 0 && r < N && (r * Q) / N == S) ? r : -1;
+}
+//   H0: k-half 0 of tile t: reads of the tile's k-half-1 fragments in steps [0, QA), rendezvous X after step QA - 1 (DMA only), pieces
+//       of tile t+2 in steps [QA, STEPS)
+template <int MI, bool DMA, bool FIRST, int S>
+__device__ __forceinline__ void half0_step_e(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t rd_a, uint32_t rd_w,
+                                             uint32_t bufoff, uint32_t kb) {
+  constexpr int STEPS = MI * 8, NOPS = MI + 8, QA = STEPS / 2, QB = STEPS - QA;
+  if constexpr (FIRST) mfma_zero(acc[S / 8][S % 8], f.w[0][S % 8], f.a[0][S / 8]);
+  else mfma_acc(acc[S / 8][S % 8], f.w[0][S % 8], f.a[0][S / 8]);
+  if constexpr (S < QA) {
+    constexpr int R = slot_of(S, NOPS, QA);
+    if constexpr (R >= 0) read_frag<MI, 1, R>(f, rd_a, rd_w);
+    if constexpr (S == QA - 1 && DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else if constexpr (DMA) {
+    constexpr int Q = slot_of(S - QA, NOPS, QB);
+    if constexpr (Q >= 0) dma_piece<MI, Q>(L, src, bufoff, kb);
+  }
+}
+template <int MI, bool DMA, bool FIRST, int... S>
+__device__ __forceinline__ void half0_steps_e(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t rd_a, uint32_t rd_w,
+                                              uint32_t bufoff, uint32_t kb, std::integer_sequence<int, S...>) {
+  (half0_step_e<MI, DMA, FIRST, S>(acc, f, L, src, rd_a, rd_w, bufoff, kb), ...);
+}
+// MODE1 as in k_tile: 1 = pieces + next tile's k-half-0 fragments, 2 = fragments only, 3 = neither, 4 = pieces only
+template <int MI, int MODE1, bool FIRST>
+__device__ __forceinline__ void k_tile_e(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2) {
+  const uint32_t nxt = BUF_BYTES - cur;
+  constexpr bool DMA = MODE1 == 1 || MODE1 == 4;
+  half0_steps_e<MI, DMA, FIRST>(acc, f, L, src, L.a_rd[1] + cur, L.w_rd[1] + cur, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
+  // Y: tile t+1 has landed (this wave's pieces: everything older than the MI + 8 pieces just requested), then every wave's
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  half_steps<MI, MODE1 == 3 || MODE1 == 4 ? 3 : 2, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
+  if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // One k-tile t (cur = its buffer's byte offset): k-half 0, the mid-tile rendezvous, k-half 1 (whose DMA, MODE1 == 1, requests the
 // k-tile at byte offset kb2 of the panels `src` -- two k-tiles ahead in the stream, possibly the NEXT output tile's -- into `cur`).
 template <int MI, int MODE1, bool FIRST>
 __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2) {
+#ifdef VC_4W_EARLY
+  k_tile_e<MI, MODE1, FIRST>(acc, f, L, src, cur, kb2);
+  return;
+#endif
   const uint32_t nxt = BUF_BYTES - cur;
   half_steps<MI, 0, FIRST>(acc, f, L, src, L.a_rd[1] + cur, L.w_rd[1] + cur, 0, 0, std::make_integer_sequence<int, MI * 8>{});
   // every wave has read the whole of buffer `cur` (lgkmcnt) and its own pieces of tile t+1 have landed (vmcnt): after the barrier
@@ -672,8 +733,11 @@ int device_cus() {
 }
 // workgroups of the persistent grid = CUs it occupies (512 registers per lane: one workgroup owns a CU).  VITCAP_GEMM_4W_RESERVE = R
 // leaves R CUs (a multiple of 8: the XCDs stay balanced) to whatever else runs on the GPU -- the batch pipeline's decode chain
+std::atomic<int> g_reserve_cus{0};       // vitcap_gemm_reserve_cus: set by the caller while a collective is in flight
 int persistent_cus() {
-  static const int reserve = [] { const char* e = getenv("VITCAP_GEMM_4W_RESERVE"); return e ? atoi(e) : 0; }();
+  static const int env_reserve = [] { const char* e = getenv("VITCAP_GEMM_4W_RESERVE"); return e ? atoi(e) : 0; }();
+  const int run = g_reserve_cus.load(std::memory_order_relaxed);
+  const int reserve = run > env_reserve ? run : env_reserve;
   const int n = device_cus() - (reserve > 0 ? reserve : 0);
   return n >= 8 ? n : 8;
 }
@@ -754,13 +818,21 @@ int launch_4w(const GemmArgs& a, hipStream_t s, int form) {
 
 }  // namespace
 
+extern "C" int vitcap_gemm_reserve_cus(int cus) {
+  if (cus < 0) cus = 0;
+  cus = (cus + 7) & ~7;
+  return g_reserve_cus.exchange(cus, std::memory_order_relaxed);
+}
+
 int vc_4w_pick_mi(int M, int tiles_n, int form) { return form == 0 ? 8 : pick_mi(M, tiles_n, form); }
 
 bool vc_4w_supports(const GemmArgs& a, int act) {
 #ifdef VC_4W_STAMP
   if (a.rowstat) return true;
 #endif
-  return !a.aux && !a.zout && !a.colsum && !a.rowstat && a.split_k <= 1 && a.K >= 128 && (act == VITCAP_ACT_NONE || act == VITCAP_ACT_GELU_ERF);
+  // a.live (decode loops: early exit once every sequence has finished) is honoured by the 8-wave kernels only: such launches stay there
+  return !a.aux && !a.zout && !a.colsum && !a.rowstat && !a.live && a.split_k <= 1 && a.K >= 128 &&
+         (act == VITCAP_ACT_NONE || act == VITCAP_ACT_GELU_ERF);
 }
 
 int vc_dispatch_4w(const GemmArgs& a, int act, int out_f32, hipStream_t s, int form) {

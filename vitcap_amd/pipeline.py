@@ -18,12 +18,26 @@ get_raw_model 566-618, predict_output_to_tsv_row 620-630) for what the hot path 
 import copy
 import json
 import logging
+import os
 import os.path as op
 
 import torch
 
 from . import dist_util as D
 
+
+
+def _release_slab(shm):
+    """close() raises BufferError while a numpy view of the segment is still exported; the name must be unlinked all the same, or the
+    segment outlives the process until the resource tracker reaps it."""
+    try:
+        shm.close()
+    except Exception:
+        pass
+    try:
+        shm.unlink()
+    except Exception:
+        pass
 
 
 def _prefetched(gen, device, depth=2):
@@ -35,6 +49,16 @@ def _prefetched(gen, device, depth=2):
     import threading
     q = queue.Queue(maxsize=max(1, depth))
     END = object()
+    stop = threading.Event()            # set when the consumer goes away (exception, generator closed): the producer must not block in put
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
@@ -43,20 +67,32 @@ def _prefetched(gen, device, depth=2):
             for b in gen:
                 if device.type == 'cuda':
                     torch.cuda.current_stream(device).synchronize()
-                q.put(b)
-            q.put(END)
+                if not put(b):
+                    break
+            else:
+                put(END)
         except BaseException as e:          # surfaces in the consumer
-            q.put(e)
+            put(e)
+        finally:
+            close = getattr(gen, 'close', None)     # runs the generator's own `finally` (worker pool, shared-memory slabs) in this thread
+            if close is not None:
+                try:
+                    close()
+                except Exception:
+                    pass
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        b = q.get()
-        if b is END:
-            break
-        if isinstance(b, BaseException):
-            raise b
-        yield b
-    t.join()
+    try:
+        while True:
+            b = q.get()
+            if b is END:
+                break
+            if isinstance(b, BaseException):
+                raise b
+            yield b
+    finally:
+        stop.set()
+        t.join(timeout=30)
 
 
 LAST_PREDICT_STATS = {}     # filled by CaptionUniPipeline.predict: rows, steady-state images/sec of this rank (tools/input_side_bench.py)
@@ -451,7 +487,26 @@ class CaptionUniPipeline(object):
                 # decoded pixels come back through shared memory (vitcap_amd/jpegdec.py); a slab holds one task's images and is reused
                 # two batches after the batch that read it went to the GPU
                 slab_bytes = int(self.cfg.loader_slab_mb or 24) << 20
-                slabs = [shared_memory.SharedMemory(create=True, size=slab_bytes) for _ in range((ahead + 3) * per_batch)]
+                n_slabs = (ahead + 3) * per_batch
+                # a /dev/shm too small for the slabs (container default: 64 MB) would kill the workers with SIGBUS on first touch:
+                # check the free space first and fall back to returning the pixels through the pool's pipe (decode_many)
+                try:
+                    st = os.statvfs('/dev/shm')
+                    room = st.f_bavail * st.f_frsize
+                except OSError:
+                    room = 0
+                if room >= (n_slabs * slab_bytes * 5) // 4:
+                    try:
+                        for _ in range(n_slabs):
+                            slabs.append(shared_memory.SharedMemory(create=True, size=slab_bytes))
+                    except OSError as e:
+                        logging.warning('shared-memory slabs unavailable (%s): decoded images return through the worker pipe', e)
+                        for shm in slabs:
+                            _release_slab(shm)
+                        slabs = []
+                else:
+                    logging.warning('/dev/shm has %.0f MB free, the loader wants %.0f MB of slabs: decoded images return through the worker '
+                                    'pipe (lower num_workers / loader_slab_mb, or enlarge /dev/shm)', room / 2**20, n_slabs * slab_bytes / 2**20)
                 free = list(range(len(slabs)))
             retired = []                                               # slab ids of the last batches handed to the GPU
             try:
@@ -496,11 +551,7 @@ class CaptionUniPipeline(object):
                         yield batch
             finally:
                 for shm in slabs:
-                    try:
-                        shm.close()
-                        shm.unlink()
-                    except Exception:
-                        pass
+                    _release_slab(shm)
             return
         from . import weights as W
         n = int(self.cfg.synthetic_num_images or 8)
@@ -558,17 +609,19 @@ class CaptionUniPipeline(object):
         seen = {'n': None}                        # visible tag slots of the last batch whose text tensors live on the device
 
         def collect(entry):
-            b, out, flag = entry
+            b, out, flag, expect_n = entry
             out = out.result() if overlap else out          # synchronises with the batch's decode stream
             if flag is not None and not bool(flag):
                 # the device-side comparison against the count of the earlier batches failed: either this batch's (valid) mask shows
                 # another number of visible tag slots -- then it is decoded again with the options of ITS count, as a host-resident
                 # batch would have been from the start -- or the mask is not one the engine implements
                 n_tag = model.check_text_inputs(b, base.max_length)         # raises NotImplementedError for an unsupported mask
-                if n_tag == seen['n']:
+                # compared with the count THIS batch was submitted against (one batch is always in flight: by now `seen` may already
+                # hold the count an earlier re-decode found -- ADVICE r4)
+                if n_tag == expect_n:
                     raise NotImplementedError('a batch\'s attention_mask / token_type_ids on the device do not describe the mask structure '
                                               'the HIP engine implements (ImageCaptioning.check_text_inputs)')
-                logging.info('visible tag slots changed from %s to %d: batch decoded again with its own options', seen['n'], n_tag)
+                logging.info('visible tag slots changed from %s to %d: batch decoded again with its own options', expect_n, n_tag)
                 seen['n'] = n_tag
                 out = model.generate_async(b['image'], opts=opts_for(n_tag)).result()
             return self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu()))
@@ -580,6 +633,7 @@ class CaptionUniPipeline(object):
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
                     flag = None
+                    expect_n = None
                     if overlap:
                         # host tensors (what the loader yields) are checked on the host; tensors already on the device cost ONE host
                         # synchronisation (the first batch, to read the number of visible tag slots), afterwards they are compared on
@@ -587,7 +641,8 @@ class CaptionUniPipeline(object):
                         # 2-slot pipeline
                         am = batch.get('attention_mask')
                         if am is not None and am.is_cuda and seen['n'] is not None:
-                            n_tag, flag = model.check_text_inputs(batch, base.max_length, expect_n_tag=seen['n'])
+                            expect_n = seen['n']
+                            n_tag, flag = model.check_text_inputs(batch, base.max_length, expect_n_tag=expect_n)
                         else:
                             n_tag = model.check_text_inputs(batch, base.max_length)
                             if am is not None and am.is_cuda:
@@ -595,7 +650,7 @@ class CaptionUniPipeline(object):
                         out = model.generate_async(batch['image'], opts=opts_for(n_tag))
                     else:
                         out = model(batch)
-                    pending.append((batch, out, flag))
+                    pending.append((batch, out, flag, expect_n))
                     while len(pending) > (1 if overlap else 0):
                         for key, js in collect(pending.pop(0)):
                             yield key, js
@@ -705,7 +760,7 @@ class CaptionUniPipeline(object):
             return None
         refs = [gts[k] for k in keys]
         result = {'Bleu_%d' % (n + 1): b for n, b in enumerate(corpus_bleu(refs, res))}
-        result['CIDEr'] = CiderD().compute_score(refs, res)[0] / 10.0
+        result['CIDEr'] = CiderD().compute_score(refs, res)[0]      # CiderD's own x10: the scale coco_caption reports under this key
         result['images'] = len(keys)
         result['note'] = ('native BLEU / CIDEr-D restatements on lower-cased whitespace tokens; parity-unpinned (the reference\'s scorer '
                           'is the external coco_caption package: PTB tokenizer, METEOR and SPICE are Java and not reproduced)')
