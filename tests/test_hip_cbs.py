@@ -194,7 +194,9 @@ def model():
     return m
 
 
-CBS_SCORE_TOL = 1e-2          # as for beam search: accumulated bf16 logit noise on a 19-step score
+CBS_SCORE_TOL = 1e-2          # as for beam search: accumulated bf16 logit noise on a 19-step score (a near tie resolved the other way)
+CBS_LP_TOL = 2e-3             # score of an IDENTICAL caption: measured on MI355X 7.7e-4 / 4.2e-5 / 7.7e-4 / 3.4e-4 on the four reference cases
+CBS_MARGIN_FLOOR = 0.012      # a caption may differ from the reference only where a recorded decision margin is below the logit noise floor
 
 
 @pytest.mark.parametrize('n', [0, 1, 2, 3])
@@ -218,10 +220,17 @@ def test_cbs_captions_vs_reference(model, n):
             words = [set(int(f) for f in tab[b, c, w] if f >= 0) for w in range(tab.shape[2]) if (tab[b, c, w] >= 0).any()]
             assert any(all(seq[i + j] in words[j] for j in range(len(words))) for i in range(len(seq) - len(words) + 1)), (b, c, seq)
         if seq != want_ids[b].tolist():
+            # only a decision the reference itself took inside the noise floor may be resolved the other way (the fixture stores the
+            # smallest search / selection margins of the reference run); measured: all four cases reproduce token for token
+            ms = np.concatenate([np.ravel(vec['case%d_margin_search' % n][b]), np.ravel(vec['case%d_margin_select' % n][b])])
+            assert float(ms[np.isfinite(ms)].min()) < CBS_MARGIN_FLOOR, 'caption differs although every recorded margin clears the floor'
             assert abs(float(lp[b, 0]) - float(want_lp[b])) < CBS_SCORE_TOL, (b, seq, want_ids[b].tolist(), float(lp[b, 0]), float(want_lp[b]))
+        else:
+            assert abs(float(lp[b, 0]) - float(want_lp[b])) < CBS_LP_TOL, (b, float(lp[b, 0]), float(want_lp[b]))
     exact = sum(ids[b, 0].tolist() == want_ids[b].tolist() for b in range(B))
-    print('case %d: %d / %d captions exactly equal to the reference' % (n, exact, B))
-    np.testing.assert_allclose(lp[:, 0].cpu().numpy(), want_lp, rtol=0, atol=5e-2)
+    print('case %d: %d / %d captions exactly equal to the reference; max |logprob - reference| = %.3g' % (
+        n, exact, B, float(np.abs(lp[:, 0].cpu().numpy() - want_lp).max())))
+    np.testing.assert_allclose(lp[:, 0].cpu().numpy(), want_lp, rtol=0, atol=CBS_SCORE_TOL)
 
 
 def test_cbs_vs_oracle_emulation_and_replay(model, sd_t):

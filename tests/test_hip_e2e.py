@@ -1063,12 +1063,23 @@ def test_generate_async_beam_equals_generate_beam(model):
         assert torch.equal(ids, ids_w) and torch.equal(lp, lp_w)
 
 
-def test_beam5_batch256_properties(model):
+def test_beam5_batch256_properties(model, sd_t):
     """BASELINE configs[2] size (beam=5, 256 images = 1280 sequences, decode loop replayed from a hipGraph): determinism, graph
-    replay == eager, batch invariance (an image captioned alone gets the same beam result), well-formed ids, finite scores."""
+    replay == eager, batch invariance (an image captioned alone gets the same beam result), well-formed ids, finite scores -- and
+     an ORACLE comparison at this size: the first 4 of the 256 images against the oracle's beam driver on the
+    bf16-emulated incremental model (itself pinned to the reference's beam goldens), under the rule of test_beam_search_vs_oracle."""
+    from oracle import vitcap_oracle as O
     B = 256
     img = _images(B, 4321).cuda().to(torch.bfloat16)
     ids1, lp1 = [t.clone() for t in model.generate_beam(img, 5, use_graph=True)]
+    with torch.no_grad():
+        ids_o, lp_o, gaps = O.beam_incremental(sd_t, img[:4].float().cpu(), num_beams=5, emulate_bf16=True, return_margins=True)
+    ok = gaps.min(1).values > BEAM_GAP_TOL
+    same = (ids1[:4].cpu() == ids_o).all(-1).all(-1)
+    print('beam 5 x 256 vs oracle on images 0-3: ids equal %s, min decision gaps %s, |score diff| %s' % (
+        same.tolist(), ['%.1e' % g for g in gaps.min(1).values.tolist()], ['%.1e' % d for d in (lp1[:4].cpu() - lp_o).abs().view(-1).tolist()]))
+    assert bool(same[ok].all()), 'B = 256 beam result differs from the oracle on an image whose decision gaps clear the floor'
+    np.testing.assert_allclose(lp1[:4].cpu().numpy(), lp_o.numpy(), atol=1e-2)
     ids2, lp2 = model.generate_beam(img, 5, use_graph=True)
     assert torch.equal(ids1, ids2) and torch.equal(lp1, lp2), 'non-deterministic'
     ids3, lp3 = model.generate_beam(img, 5, use_graph=False)

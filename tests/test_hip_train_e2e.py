@@ -67,9 +67,11 @@ def test_loss_trajectory_five_steps(sd_t):
     (O.train_step_as_written carrying its AdamW state: trainer.py:95-142, solver AdamW, WarmupLinearSchedule) started from the same
     weights.  Adam's first steps are sign-like (lr * g / (|g| + eps)): every coordinate whose tiny gradient has another sign in bf16
     than in fp32 moves the other way by lr, so the two parameter trajectories drift apart by O(lr) per step and the losses with them
-    (measured on MI355X: 1e-3, 8e-3, 1.7e-2, 5.6e-2, 9e-3 over the five steps, on losses of 9.3 .. 10.4).  Asserted: step 1 within
-    2e-3 (the one-step test's tolerance), every later step within 8e-2, and the loss CHANGES from step to step -- -0.15, +0.06, +0.98,
-    -1.13 in the oracle -- reproduced within 35 % + 0.03: the updates move the model the way the reference's optimizer does."""
+    (measured on MI355X, rounds 4 and 5 alike: 1.0e-3, 7.6e-3, 1.8e-2, 5.6e-2, 9.7e-3 over the five steps, on losses of 9.3 .. 10.4).
+    Asserted (the measured spread x 1.25, no wider): per-step bounds 2e-3 (the one-step test's tolerance), 9.5e-3, 2.3e-2,
+    7e-2, 1.25e-2, and the loss CHANGES from step to step -- -0.151, +0.057, +0.977, -1.133 in the oracle, reproduced by the device to
+    0.007, 0.026, 0.038, 0.046 -- within 6 % of the oracle's change + 0.03: a wrong sign or a missing tensor in the update moves a
+    step's loss by more than that (the +0.98 / -1.13 swings are the learning-rate-sized moves of the whole model)."""
     from oracle import vitcap_oracle as O
     from vitcap_amd import weights as W
     from vitcap_amd.model import ImageCaptioning
@@ -97,11 +99,12 @@ def test_loss_trajectory_five_steps(sd_t):
         dev_losses.append(float(eng.train_step(db)['masked_loss']))
     torch.cuda.synchronize()
     print('loss trajectory  oracle:', ['%.4f' % x for x in ref_losses], ' device:', ['%.4f' % x for x in dev_losses])
+    bounds = (2e-3, 9.5e-3, 2.3e-2, 7e-2, 1.25e-2)
     for it, (a, b) in enumerate(zip(dev_losses, ref_losses)):
-        assert abs(a - b) < (2e-3 if it == 0 else 8e-2), (it, a, b)
+        assert abs(a - b) < bounds[it], (it, a, b)
     for it in range(1, steps):
         d_ref, d_dev = ref_losses[it] - ref_losses[it - 1], dev_losses[it] - dev_losses[it - 1]
-        assert abs(d_dev - d_ref) < 0.35 * abs(d_ref) + 0.03, (it, d_dev, d_ref)
+        assert abs(d_dev - d_ref) < 0.06 * abs(d_ref) + 0.03, (it, d_dev, d_ref)
 
 
 def test_parameter_update(run):
@@ -607,7 +610,7 @@ def _toy_tokenizer():
     return CaptionDetokenizer(tokens=toks)
 
 
-def test_scst_step_at_config_size():
+def test_scst_step_at_config_size(sd_t):
     """BASELINE configs[4] per-GPU size: scst_num_return = 5, 16 images (80 sampled sequences + 16 greedy baselines per step).
     Size-independent properties of the step: (a) the 5 samples of an image share ONE encoder pass yet equal the sequences the
     generator draws on the 5-times repeated batch (same per-sequence random streams); (b) loss and gradients of the
@@ -648,6 +651,19 @@ def test_scst_step_at_config_size():
     rel = float((g0 - g1).norm() / g0.norm())
     print('scst (16 x 5) loss expanded %.6f shared %.6f, gradient rel diff %.2e' % (l0, l1, rel))
     assert abs(l0 - l1) < 2e-5 * max(1.0, abs(l0)) and rel < 2e-3
+    # Oracle comparison at this size: with the weights of every other image zeroed the (16 x 5) loss is
+    # -sum_s w_s * logprob_s over image 0's five samples; the oracle evaluates those five sequences the way the generator produced
+    # them (sequence_logprob_as_written: 19 full forwards, modeling_utils.py:850-877).  Dropout off on both sides.
+    from oracle import vitcap_oracle as O
+    w0 = torch.zeros(B * K)
+    w0[:K] = torch.tensor([0.31, -0.22, 0.17, 0.4, -0.35])
+    eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    l_dev = float(eng.forward_backward({'sample_ids': fed, 'sample_weight': w0.cuda(), 'image': img, 'seq_per_image': K})[0])
+    with torch.no_grad():
+        lp_o = O.sequence_logprob_as_written(sd_t, img[:1].float().cpu().repeat(K, 1, 1, 1), fed[:K].cpu())
+    l_o = float(-(lp_o * w0[:K]).sum())
+    print('scst (16 x 5), image 0 weighted: device %.6f oracle %.6f' % (l_dev, l_o))
+    assert abs(l_dev - l_o) < 3e-3
     del res, g0, g1
     torch.cuda.empty_cache()
     tok = _toy_tokenizer()
@@ -761,10 +777,14 @@ def test_inference_engine_bound_to_training_buffers():
     assert not torch.equal(ids2, ids) or True   # (captions may or may not change; equality with `fresh` above is the check)
 
 
-def test_train_step_batch64_properties():
+def test_train_step_batch64_properties(sd_t):
     """BASELINE configs[3] per-GPU size (64 samples): size-independent properties of the training step -- finite loss and
     gradient norm, the loss on a fixed batch goes down over a few steps, the step is reproducible up to the float atomics of
-    its reductions, and the mean of two half-batch gradients equals the full-batch gradient (what DDP averaging relies on)."""
+    its reductions, and the mean of two half-batch gradients equals the full-batch gradient (what DDP averaging relies on).
+    Oracle-compared at this size through the same invariant: the B = 64 loss is the mean of its sixteen
+    4-sample slices' losses (every sample carries 3 masked tokens), and the first slice's loss equals the oracle's
+    train_losses_as_written (the reference's encode_forward + BertCaptioningLoss restated) on those 4 samples."""
+    from oracle import vitcap_oracle as O
     from vitcap_amd import weights as W
     from vitcap_amd.model import ImageCaptioning
     from vitcap_amd.synthetic import synthetic_train_inputs
@@ -786,6 +806,14 @@ def test_train_step_batch64_properties():
     rel = float(((halves[0][1] + halves[1][1]) / 2 - g_full).norm() / g_full.norm())
     print('B=64 loss %.4f, half-batch gradient mean vs full: rel %.2e' % (l_full, rel))
     assert rel < 2e-2
+    slices = [float(eng.forward_backward({k: v[i:i + 4].contiguous() for k, v in b.items()})[0]) for i in range(0, B, 4)]
+    assert abs(sum(slices) / len(slices) - l_full) < 2e-4, (sum(slices) / len(slices), l_full)
+    with torch.no_grad():
+        cb = {k: v[:4].cpu() for k, v in b.items() if k != 'image'}
+        o = O.train_losses_as_written(sd_t, b['image'][:4].float().cpu(), cb)
+    o_loss = float(o['masked_loss'] if isinstance(o, dict) else o[0])
+    print('B=64 slice 0 loss: device %.5f oracle %.5f' % (slices[0], o_loss))
+    assert abs(slices[0] - o_loss) < 2e-3
     losses = [float(eng.train_step(b)['masked_loss']) for _ in range(4)]
     print('losses over 4 steps on one batch:', ['%.4f' % v for v in losses], 'grad norm %.3f' % eng.grad_norm())
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0] - 0.05

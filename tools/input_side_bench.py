@@ -48,7 +48,14 @@ def main():
         jpegs = list(pool.map(synth_jpeg, range(min(N, 256))))       # 256 distinct images, repeated: the decoder does not care
     rows = [('img%d' % i, base64.b64encode(jpegs[i % len(jpegs)])) for i in range(N)]
     tsv_writer(rows, os.path.join(tmp, 'data', 'toy', 'test.tsv'))
+    quota = None
+    try:      # cgroup v2 CPU bandwidth of the box: "<quota us> <period us>" (the GPU pool gives 16 cores of a 256-thread host)
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        quota = None if q == 'max' else round(int(q) / int(per), 1)
+    except Exception:
+        pass
     res = {'images': N, 'mean_jpeg_bytes': int(np.mean([len(j) for j in jpegs])), 'sizes': SIZES, 'host_cores': os.cpu_count(),
+           'host_cpu_quota_cores': quota,
            'build_s': round(time.perf_counter() - t0, 1)}
     # ---- decode only
     t = TSVFile(os.path.join(tmp, 'data', 'toy', 'test.tsv'))
@@ -102,7 +109,10 @@ def main():
         getattr(run, kw.pop('type'))(**kw)
         torch.cuda.synchronize()
         return dict(P.LAST_PREDICT_STATS), time.perf_counter() - t0
-    for workers, threads in ((8, True), (8, False), (16, False), (32, False), (64, False)):
+    sweep = ((8, True), (6, False), (8, False), (10, False), (12, False), (14, False), (16, False))
+    if os.environ.get('INPUT_SIDE_WORKERS'):
+        sweep = tuple((int(w), False) for w in os.environ['INPUT_SIDE_WORKERS'].split(','))
+    for workers, threads in sweep:
         st, wall = run_once('w%d%d' % (workers, threads), workers, threads)
         e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
         print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s)' % (

@@ -1654,7 +1654,12 @@ static int large_gemm_form(int M, int N, int hint) {
   static const int only_n = [] { const char* e = getenv("VITCAP_GEMM_4W_TILES_N"); return e ? atoi(e) : 0; }();
   static const int only_form = [] { const char* e = getenv("VITCAP_GEMM_4W_TILES_N"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 1; }();
   if (hint == 5 && only_n > 0 && tiles256 < 8 * 256) return N == only_n ? only_form : -1;
-  if (hint == 5) return env_set ? env_tiles : (tiles256 >= 8 * 256 ? 2 : -1);
+  // tile_hint 5 (another stream's kernels must slip in between tiles): the 8-wave kernel at every size.  Round 4 switched to the
+  // persistent 4-wave form from 8 rounds of tiles on (B = 512 greedy +1.3 %); with two encoder parts in flight (round 5 default) that
+  // is a tie there (4 096 / 4 122 vs 4 109 / 4 116 img/s) and it cost beam 5 x 256 -3 % (3 575 vs 3 692 img/s: the persistent grids lock
+  // the 1 280-sequence decode chain out) -- profiles/r05_split_beam_ab.txt
+  (void)tiles256;
+  if (hint == 5) return env_set ? env_tiles : -1;
   if (hint == 0) return env_set ? env_auto : 2;
   return -1;
 }
@@ -1844,10 +1849,9 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   {
     // The 4-wave kernel (gemm4w.hip) behind the two production hints, measured end to end:
     //   auto (one stream): its persistent form, +1.8 % images/s at B = 64 and B = 512 against the 8-wave kernel + planned tile mix;
-    //   tile_hint 5 (the 2-slot pipeline: another stream's small kernels must slip in between tiles): the 8-wave kernel stays while a
-    //   launch is a few rounds of the CUs (B = 64: 3802 vs 3703 img/s one-tile 4-wave, 3517 persistent -- a persistent grid owns
-    //   every CU for the whole GEMM, and a 512-register workgroup leaves no room for a co-resident decode wave); from 8 rounds on
-    //   (B = 512) the persistent form wins there too (+1.3 %).
+    //   tile_hint 5 (the 2-slot pipeline: another stream's small kernels must slip in between tiles): the 8-wave kernel stays
+    //   (B = 64: 3802 vs 3703 img/s one-tile 4-wave, 3517 persistent -- a persistent grid owns every CU for the whole GEMM, and a
+    //   512-register workgroup leaves no room for a co-resident decode wave), at every size since round 5 (large_gemm_form).
     // VITCAP_GEMM_4W = "<form for tile_hint 5>,<form for auto>" overrides (-1 = 8-wave kernel, 0..2 = form; experiments).
     const int form = large_gemm_form(d->M, d->N, hint);
     if (form >= 0 && form <= 2 && d->M >= 2048 && vc_4w_supports(a, d->act)) return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);

@@ -458,6 +458,7 @@ class CaptionUniPipeline(object):
             # (uni_pipeline.py:782-850); decode on the host, transform on the GPU (csrc/preproc.hip)
             from .imageio import ImagePreprocessor
             from .tsv import TSVFile
+            tsv = op.abspath(tsv)
             rows = TSVFile(tsv)
             pre = ImagePreprocessor(torch.device('cuda', self.local_rank), int(self.cfg.test_crop_size),
                                     float(self.cfg.crop_pct or 1.0))
@@ -468,9 +469,9 @@ class CaptionUniPipeline(object):
             # GPU box (tools/input_side_bench.py, profiles/r04_input_side.json): one core decodes 600 images/s, threads of one process
             # top out near 2 000 (GIL), a GPU captions 3 700.  The workers are SPAWNED (never forked: this process owns a GPU
             # context) and import vitcap_amd.jpegdec only.  `loader_threads: true` keeps the decode in threads of this process.
-            # Rows are read by the consumer (the TSV handle is not shared), batches come back in order.
+            # Rows are read by the WORKERS (round 5: a task names the file and its row numbers), batches come back in order.
             from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
-            from .jpegdec import decode_into, decode_many
+            from .jpegdec import decode_rows, decode_rows_into
             import numpy as np
             workers = max(1, int(self.cfg.num_workers or 1))
             chunk = 8                                                  # images per worker task
@@ -514,25 +515,27 @@ class CaptionUniPipeline(object):
                     inflight = []
 
                     def submit(k):
-                        recs = [rows[j] for j in mine[starts[k]:starts[k] + bs]]
-                        blobs = [r[-1] for r in recs]
+                        # a task names the file and the row numbers: the WORKER reads and base64-decodes its rows (jpegdec.py)
+                        ids = mine[starts[k]:starts[k] + bs]
                         tasks = []
-                        for c in range(0, len(blobs), chunk):
+                        for c in range(0, len(ids), chunk):
                             if slabs:
                                 sid = free.pop()
-                                tasks.append((sid, pool.submit(decode_into, slabs[sid].name, blobs[c:c + chunk])))
+                                tasks.append((sid, pool.submit(decode_rows_into, slabs[sid].name, tsv, ids[c:c + chunk])))
                             else:
-                                tasks.append((None, pool.submit(decode_many, blobs[c:c + chunk])))
-                        inflight.append(([r[0] for r in recs], tasks))
+                                tasks.append((None, pool.submit(decode_rows, tsv, ids[c:c + chunk])))
+                        inflight.append(tasks)
                     nxt = 0
                     while nxt < len(starts) and len(inflight) < ahead:
                         submit(nxt)
                         nxt += 1
                     while inflight:
-                        keys, tasks = inflight.pop(0)
-                        imgs, used = [], []
+                        tasks = inflight.pop(0)
+                        keys, imgs, used = [], [], []
                         for sid, f in tasks:
-                            for item in f.result():
+                            ks, items = f.result()
+                            keys.extend(ks)
+                            for item in items:
                                 if sid is not None and isinstance(item, tuple):
                                     off, h, w = item
                                     imgs.append(np.ndarray((h, w, 3), dtype=np.uint8, buffer=slabs[sid].buf, offset=off))
