@@ -54,7 +54,8 @@ VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256
 def kernel_form(lib, M, variant, tiles_mode):
     """Which kernel family ran the dominant large-GEMM variant (vitcap_gemm_large_form: the dispatch rule of vitcap_gemm_ex)."""
     N, K = {0: (2304, 768), 4: (3072, 768), 3: (768, 768)}.get(variant, (768, 768))
-    code = lib.vitcap_gemm_large_form(M, N, K, 5 if tiles_mode else 0)
+    # variants 0 / 4 (bias -> bf16, bias + GELU -> bf16) have neither fp32 output nor residual: flag 0x100 of the query
+    code = lib.vitcap_gemm_large_form(M, N, K, (5 if tiles_mode else 0) | (0x100 if variant in (0, 4) else 0))
     if code < 0:
         return '8-wave 256x256x64 tiles, two waves per SIMD, one tile per workgroup (csrc/gemm.hip)'
     return '4-wave %dx256x64 tiles, one wave per SIMD / 512 registers, %s (csrc/gemm4w.hip)' % (
@@ -496,7 +497,7 @@ def main():
     traffic = None
     try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh);
         # FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), KiB -> bytes
-        four_wave = kernel_form(lib, B * 577, dom, piped or args.gemm_tiles).startswith('4-wave')
+        four_wave = kernel_form(lib, B * 577 // (2 if (piped and B >= 32) else 1), dom, piped or args.gemm_tiles).startswith('4-wave')
         tfile = TRAFFIC_FILE if B < 256 else TRAFFIC_FILE.replace('.json', '_b512.json')
         with open(tfile) as f:
             tab = json.load(f)
@@ -531,7 +532,8 @@ def main():
         'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),
         'roofline': {
             'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, 'gemm_nt variant %d' % dom),
-            'kernel_form': kernel_form(lib, B * 577, dom, piped or args.gemm_tiles),
+            'kernel_form': kernel_form(lib, B * 577 // (2 if (piped and B >= 32) else 1), dom, piped or args.gemm_tiles),
+            'encode_parts': int(os.environ['VITCAP_ENCODE_SPLIT']) if os.environ.get('VITCAP_ENCODE_SPLIT') else (2 if (piped and B >= 32) else 1),
             'achieved': round(dom_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(dom_tf / PEAK_BF16_TFLOPS, 4) if ln[dom] else None, 'traffic': traffic,
             'note': None if ln[dom] else 'no large-GEMM launch (M >= 2048 rows) in this configuration: the per-launch events cover those only',

@@ -124,7 +124,9 @@ int vitcap_gemm_bias_act(const void* A, const void* W, const float* bias, const 
 int vitcap_gemm_tile_plan(int M, int N, int K, int* plan3);
 /* Which kernel family runs an M x N x K GEMM with M >= 2048 under `tile_hint` (0 = auto, 5) on the current device (host-side query):
  * -1 = the 8-wave 256x256 kernel (gemm.hip); otherwise form + 10 * MI of the 4-wave kernel (gemm4w.hip): form 1 = one tile per
- * workgroup, 2 = persistent pipeline; MI = 8 / 7 / 6 -> 256- / 224- / 192-row tiles.  Results do not depend on the choice. */
+ * workgroup, 2 = persistent pipeline; MI = 8 / 7 / 6 -> 256- / 224- / 192-row tiles.  Results do not depend on the choice.
+ * tile_hint | 0x100 asks about a bf16-output GEMM without residual (qkv, fc1): under tile_hint 5 those run the 4-wave one-tile form,
+ * the fp32 + residual GEMMs the 8-wave kernel. */
 int vitcap_gemm_large_form(int M, int N, int K, int tile_hint);
 /* CUs the persistent large-GEMM grids (one 512-register workgroup per CU) leave free from now on, for launches of this process
  * (0 = none; rounded up to a multiple of 8 so that every XCD keeps the same number of workgroups; at most the device's CUs - 8).

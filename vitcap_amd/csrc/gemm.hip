@@ -1644,7 +1644,7 @@ int dispatch(const GemmArgs& a, int act, int out_f32, hipStream_t s) {
 
 // which kernel family runs a large GEMM under tile_hint `hint` (0 = auto, 5 = one tile per workgroup): -1 = the 8-wave kernel of this
 // file, 0..2 = a form of the 4-wave kernel (gemm4w.hip); see the measurements at the call site in vitcap_gemm_ex
-static int large_gemm_form(int M, int N, int hint) {
+static int large_gemm_form(int M, int N, int hint, bool f32_or_res = true) {
   static const int env_set = getenv("VITCAP_GEMM_4W") != nullptr;
   static const int env_tiles = [] { const char* e = getenv("VITCAP_GEMM_4W"); return e ? atoi(e) : -1; }();
   static const int env_auto = [] { const char* e = getenv("VITCAP_GEMM_4W"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : (e ? atoi(e) : -1); }();
@@ -1658,14 +1658,21 @@ static int large_gemm_form(int M, int N, int hint) {
   // persistent 4-wave form from 8 rounds of tiles on (B = 512 greedy +1.3 %); with two encoder parts in flight (round 5 default) that
   // is a tie there (4 096 / 4 122 vs 4 109 / 4 116 img/s) and it cost beam 5 x 256 -3 % (3 575 vs 3 692 img/s: the persistent grids lock
   // the 1 280-sequence decode chain out) -- profiles/r05_split_beam_ab.txt
+  // What DOES pay inside the pipeline (round 5, 2 encoder parts, same box, interleaved; profiles/r05_pipeline_gemm_forms.txt): the 4-wave
+  // kernel in its one-tile-per-workgroup form for the bf16-output GEMMs only -- qkv alone 3 900, fc1 alone 3 907 against 3 856 / 3 866
+  // img/s all 8-wave -- while the fp32 + residual GEMMs (proj / fc2: 3 748) and the LDS-epilogue form (3 580 / 3 599) lose.
   (void)tiles256;
-  if (hint == 5) return env_set ? env_tiles : -1;
+  static const int env_mix = [] { const char* e = getenv("VITCAP_GEMM_4W_MIX"); return e ? atoi(e) : 1; }();
+  if (hint == 5) return env_set ? env_tiles : ((env_mix && !f32_or_res) ? 1 : -1);
   if (hint == 0) return env_set ? env_auto : 2;
   return -1;
 }
 
 extern "C" int vitcap_gemm_large_form(int M, int N, int K, int tile_hint) {
-  int form = large_gemm_form(M, N, tile_hint);
+  // tile_hint | 0x100: the query is about a bf16-output GEMM without residual (under tile_hint 5 those run the 4-wave one-tile form)
+  const bool plain_bf16 = (tile_hint & 0x100) != 0;
+  tile_hint &= 0xff;
+  int form = large_gemm_form(M, N, tile_hint, !plain_bf16);
   if (form < 0 || form > 2) return -1;
   if (K < 128) return -1;                                   // vc_4w_supports
   // launch_4w's downgrade rules for plain rows (what the engine's large GEMMs use): the persistent pipeline needs three k-tiles and
@@ -1853,7 +1860,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     //   (B = 64: 3802 vs 3703 img/s one-tile 4-wave, 3517 persistent -- a persistent grid owns every CU for the whole GEMM, and a
     //   512-register workgroup leaves no room for a co-resident decode wave), at every size since round 5 (large_gemm_form).
     // VITCAP_GEMM_4W = "<form for tile_hint 5>,<form for auto>" overrides (-1 = 8-wave kernel, 0..2 = form; experiments).
-    const int form = large_gemm_form(d->M, d->N, hint);
+    const int form = large_gemm_form(d->M, d->N, hint, d->out_dtype == VITCAP_OUT_F32 || residual != nullptr);
     if (form >= 0 && form <= 2 && d->M >= 2048 && vc_4w_supports(a, d->act)) return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);
   }
   if (hint >= 40 && hint <= 42) return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent

@@ -57,6 +57,15 @@ __device__ __forceinline__ void dma16(uint32_t lds, uint32_t voff, const i32x4& 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// VC_4W_PREFETCH probe: one dword per lane into an LDS scratch line -- pulls the 128-byte lines of 64 rows of a LATER k-tile's A slice
+// into this XCD's L2 (no VGPR destination: nothing for the compiler to reuse while the load is in flight)
+__device__ __forceinline__ void pf64(uint32_t lds, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+#ifndef VC_4W_PF_AHEAD
+#define VC_4W_PF_AHEAD 2        // k-tiles between the slice a DMA requests and the slice prefetched next to it
+#endif
+
 // probe builds only (tools/probes/g4w_probe.hip defines VC_4W_STAMP): wave 0 of every workgroup records the shader clock at four
 // points into p.rowstat (reused as a uint64 buffer): start, main loop entry, main loop exit, end
 #ifdef VC_4W_STAMP
@@ -81,6 +90,7 @@ struct Loop {
   uint32_t voff_a, voff_w;        // per-lane global byte offset inside a piece
   uint32_t soff_a, soff_w;        // wave's first piece (scalar byte offset)
   uint32_t pstep_a, pstep_w;      // 8 rows
+  uint32_t voff_pf, lds_pf;       // VC_4W_PREFETCH probe: this lane's row of the A tile (or out of range), 256 B of LDS scratch
 };
 // buffer descriptors of one output tile's operand panels (base = the tile's first row, range-checked to the matrix end: rows past
 // M / N read as out-of-range -- no fault, and their outputs are never stored)
@@ -88,6 +98,12 @@ struct Src {
   i32x4 ra, rw;
 };
 __device__ __forceinline__ Src make_src(const GemmArgs& p, int m0, int n0) {
+#ifdef VC_4W_A_RESIDENT      // probe (wrong results): every tile reads one of 8 A panels (3 MB: L2 / Infinity-Cache resident) -- same stream, no HBM
+  m0 = (m0 >> 8 & 7) << 8;
+#endif
+#ifdef VC_4W_W_RESIDENT      // probe (wrong results): every tile reads one of 2 W panels
+  n0 = (n0 >> 8 & 1) << 8;
+#endif
   const bf16_t* abase = p.A + (size_t)m0 * p.lda;
   const bf16_t* wbase = p.W + (size_t)n0 * p.ldw;
   const long long arem = ((long long)(p.M - m0 - 1) * p.lda + p.K) * 2, wrem = ((long long)(p.N - n0 - 1) * p.ldw + p.K) * 2;
@@ -118,6 +134,8 @@ __device__ __forceinline__ Loop make_loop(const GemmArgs& p, uint32_t smem_base,
   L.lds_w = smem_base + A_BYTES + w_row0 * 128;
   const int wm = w >> 1, wn = w & 1, frow = lane & 15, fk = lane >> 4;
   const uint32_t arow = smem_base + (wm * 16 * MI + frow) * 128, wrow = smem_base + A_BYTES + (wn * 128 + frow) * 128;
+  L.voff_pf = 0xfffffff0u;
+  L.lds_pf = 0;
   L.a_rd[0] = arow + ((0 * 4 + fk) ^ (frow & 7)) * 16;
   L.a_rd[1] = arow + ((1 * 4 + fk) ^ (frow & 7)) * 16;
   L.w_rd[0] = wrow + ((0 * 4 + fk) ^ (frow & 7)) * 16;
@@ -247,10 +265,15 @@ __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop
   // `cur` may be overwritten and buffer `nxt` may be read
 #if defined(VC_LOOP_ABL) && (VC_LOOP_ABL & 4)     // probe ablation: no mid-tile barrier (wrong results)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(VC_4W_PREFETCH)                       // the prefetch issued behind the awaited pieces stays in flight
+  asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
   half_steps<MI, MODE1, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
+#ifdef VC_4W_PREFETCH
+  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, kb2 + VC_4W_PF_AHEAD * 128);      // every k-tile issues exactly one (keeps the counted wait exact)
+#endif
   if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -652,10 +675,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // probe: start the XCDs a fraction of a tile period apart (p.direct_epilogue = units of 64 cycles per XCD step)
   for (int i = 0; i < ((int)blockIdx.x >> 3) * p.direct_epilogue; ++i) __builtin_amdgcn_s_sleep(1);
 #endif
-  const Loop L = make_loop<MI>(p, lds_addr(smem), lane, w);
+  Loop L = make_loop<MI>(p, lds_addr(smem), lane, w);
   int tm, tn;
   tile_of(p, pos, tm, tn);
   Src src = make_src(p, tm * (32 * MI), tn * 256);
+#ifdef VC_4W_PREFETCH
+  // the tiles of a column group that share an A panel split its rows: sibling c of gw takes the rows r with r % gw == c
+  // (probe: the fp32 / residual forms own all 160 KiB of LDS already -- no scratch line, no prefetch, their timing is not the question)
+  L.lds_pf = (OUT_F32 || HAS_RES) ? 0u : lds_addr(smem) + 2 * BUF_BYTES + w * 256;
+  {
+    const int gw_ = p.group_n < p.tiles_n ? p.group_n : p.tiles_n, row_ = w * 64 + lane;
+#ifdef VC_4W_PF_ALL
+    L.voff_pf = row_ < 32 * MI ? (uint32_t)(row_ * p.lda * 2) : 0xfffffff0u;
+#else
+    L.voff_pf = (row_ < 32 * MI && row_ % gw_ == tn % gw_) ? (uint32_t)(row_ * p.lda * 2) : 0xfffffff0u;
+#endif
+  }
+#endif
   f32x4 acc[MI][8];
   Frags f;
   const int nk = p.K / 64;      // >= 2 (launcher)
@@ -663,7 +699,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the only prologue: k-tiles 0 and 1 of the first tile
   dma_tile<MI>(L, src, 0, 0, PIECES);
   dma_tile<MI>(L, src, BUF_BYTES, 128, PIECES);
+#ifdef VC_4W_PREFETCH
+  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, 2 * 128);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8 + 1) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
+#endif
   read_frags<MI, 0>(f, L.a_rd[0], L.w_rd[0], PIECES);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   uint32_t cur = 0;
@@ -765,7 +806,11 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
   if (form == 2) {
     const int n_cu = persistent_cus();
     auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
+#ifdef VC_4W_PREFETCH
+    constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES + 1024;
+#else
     constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
+#endif
     VC_FUNC_SMEM(kern, smem);
     // VITCAP_GEMM_4W_TIGHT=1 (experiments): the fewest workgroups (a multiple of 8: every XCD the same number) that finish in the same
     // number of rounds as all CUs would -- 1305 tiles take 6 rounds on 256 CUs and on 224 -- leaving the other CUs to whatever else

@@ -40,6 +40,36 @@ def _release_slab(shm):
         pass
 
 
+def _pin_slabs(slabs):
+    """hipHostRegister on every shared-memory slab -> list of registered base addresses (empty when the runtime refuses: the copies
+    then take the pageable path, slower but correct).  VITCAP_LOADER_PIN=0 disables."""
+    import ctypes
+    if os.environ.get('VITCAP_LOADER_PIN', '1') == '0':
+        return []
+    done = []
+    try:
+        rt = torch.cuda.cudart()
+        for shm in slabs:
+            addr = ctypes.addressof(ctypes.c_char.from_buffer(shm.buf))
+            err = rt.cudaHostRegister(addr, shm.size, 0)
+            if int(getattr(err, 'value', err)) != 0:
+                logging.warning('hipHostRegister refused a loader slab (error %s): host -> device copies stay pageable', err)
+                break
+            done.append(addr)
+    except Exception as e:          # noqa
+        logging.warning('loader slabs not page-locked (%s)', e)
+    return done
+
+
+def _unpin_slabs(addrs):
+    try:
+        rt = torch.cuda.cudart()
+        for a in addrs:
+            rt.cudaHostUnregister(a)
+    except Exception:
+        pass
+
+
 def _prefetched(gen, device, depth=2):
     """Runs the batch generator in a background thread, `depth` batches ahead: reading the TSV rows, handing them to the decode workers,
     the host -> device copies and the launch of the transform kernel no longer sit between two caption launches of the consumer
@@ -509,6 +539,9 @@ class CaptionUniPipeline(object):
                     logging.warning('/dev/shm has %.0f MB free, the loader wants %.0f MB of slabs: decoded images return through the worker '
                                     'pipe (lower num_workers / loader_slab_mb, or enlarge /dev/shm)', room / 2**20, n_slabs * slab_bytes / 2**20)
                 free = list(range(len(slabs)))
+                # page-lock the slabs: a pageable source makes every host -> device copy go through the runtime's staging buffer (a
+                # single-threaded memcpy of ~1 MB per image in THIS process, then the DMA); registered, the DMA reads the slab itself
+                pinned = _pin_slabs(slabs)
             retired = []                                               # slab ids of the last batches handed to the GPU
             try:
                 with pool:
@@ -553,6 +586,12 @@ class CaptionUniPipeline(object):
                             nxt += 1
                         yield batch
             finally:
+                if slabs:
+                    try:
+                        torch.cuda.current_stream(torch.device('cuda', self.local_rank)).synchronize()     # no copy still reads a slab
+                    except Exception:
+                        pass
+                    _unpin_slabs(pinned)
                 for shm in slabs:
                     _release_slab(shm)
             return
