@@ -76,7 +76,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                         int causal_from, int mask_from, int q_lo, int q_rows) {
+                                                         int causal_from, int mask_from, int q_lo, int q_rows, int rev) {
   __shared__ __attribute__((aligned(1024))) char smem[NSTG * STG_B];   // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
     wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
   }
+  if (rev) wid = nwork - 1 - wid;      // images last-to-first (common.h: vc_tls_walk_rev)
   const int qb = (q_lo >> 7) + wid % nqb;
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
@@ -888,7 +889,7 @@ static int attn_decode_groups(const void* qkv_step, const void* vis_qkv, const v
 
 
 #define VC_LAUNCH_DENSE(DROP_, grid_, stream_, ...) \
-  hipLaunchKernelGGL(attn_dense_kernel<DROP_>, grid_, dim3(256), 0, (hipStream_t)(stream_), __VA_ARGS__)
+  hipLaunchKernelGGL(attn_dense_kernel<DROP_>, grid_, dim3(256), 0, (hipStream_t)(stream_), __VA_ARGS__, vc_tls_walk_rev ? 1 : 0)
 
 extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream) {
   VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");

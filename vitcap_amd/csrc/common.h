@@ -26,6 +26,14 @@ extern thread_local const int32_t* vc_tls_live;
 // Engine-internal: further EOS token ids of the call being enqueued (vitcap_gen_opts.eos_extra; -1 = unused).  The reference's
 // greedy / sampling loop stops a sequence at ANY id of `eos_token_ids` (modeling_utils.py:862-865) and forces eos_token_ids[0]
 // at the last position (:870-871); the step launchers read this next to their `eos` argument, which stays the first id.
+// Engine-internal: walk direction of the streaming kernels of the call being enqueued (round 5).  Every kernel of the encoder /
+// prefill chain is one pass over the batch's rows; a consumer that walks them in the SAME order as its producer finds, in the 256 MB
+// Infinity Cache, the END of what the producer wrote while it asks for the BEGINNING (fc2's A operand at B = 64 is 227 MB: the probe
+// with that operand cache-resident runs the kernel 21 % faster, profiles/r05_g4w_probe.txt).  With the flag set a kernel visits its
+// row blocks last-to-first, so that what was written last is read first; the engine flips it after every streaming launch.
+// Results do not depend on it (the order in which independent tiles run).  False outside the engine.
+extern thread_local bool vc_tls_walk_rev;
+extern thread_local bool vc_tls_zigzag;        // the engine call being enqueued alternates directions (GEMM + LayerNorm pairs flip in between)
 struct VcEosExtra { int32_t id[3]; };
 extern thread_local VcEosExtra vc_tls_eos_extra;
 __device__ __forceinline__ bool vc_is_eos(int tok, int eos, const VcEosExtra& x) {

@@ -30,6 +30,8 @@ struct VcEosExtra { int32_t id[3]; };              // csrc/common.h: eos_token_i
 extern thread_local VcEosExtra vc_tls_eos_extra;
 extern thread_local hipEvent_t vc_tls_kev_start, vc_tls_kev_stop;   // csrc/common.h: kernel-bound timing events (timing runs only)
 extern thread_local bool vc_tls_kev_used;
+extern thread_local bool vc_tls_walk_rev;       // csrc/common.h: walk direction of the streaming kernels
+extern thread_local bool vc_tls_zigzag;
 
 #include <vector>
 
@@ -331,6 +333,21 @@ thread_local int g_gemm_mode = VITCAP_GEMM_AUTO; // vitcap_gen_opts.gemm_mode of
 thread_local const int32_t* g_live = nullptr;    // live counter handed to the decode-step GEMMs (vitcap_gemm_desc.live)
 
 // sets the per-call context (timing hook, GEMM launch form, early-exit counter) for the duration of one engine call
+// Zig-zag walk of the encoder / prefill chain (common.h: vc_tls_walk_rev): `zz()` after every streaming launch flips the direction
+// for the next one, so that each kernel starts on the rows its producer wrote last (still in the Infinity Cache).
+// VITCAP_ZIGZAG=0 keeps every kernel first-to-last (A/B measurements).
+static bool zigzag_on() {
+  static const bool on = [] { const char* e = getenv("VITCAP_ZIGZAG"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
+static inline void zz() {
+  if (zigzag_on()) vc_tls_walk_rev = !vc_tls_walk_rev;
+}
+struct WalkScope {        // the direction never leaks out of an engine call
+  WalkScope() { vc_tls_walk_rev = false; vc_tls_zigzag = zigzag_on(); }
+  ~WalkScope() { vc_tls_walk_rev = false; vc_tls_zigzag = false; }
+};
+
 struct CallScope {
   CallScope(vitcap_engine* e, int gemm_mode, const int32_t* live, const vitcap_gen_opts* o = nullptr) {
     g_cur = e;
@@ -654,14 +671,23 @@ static int check(vitcap_engine* e, int B, const vitcap_gen_opts& o, void* ws, si
 static int vit_block(const vitcap_vit_block_w& w, const float* x_in, float* x, void* h, void* qkv, void* mlp, int B, void* s,
                      int32_t* cnt = nullptr, bool have_ln1 = false, const vitcap_vit_block_w* next = nullptr) {
   const int M = B * NV;
-  if (!have_ln1) CK(vitcap_layernorm_fwd(x_in, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s));
+  // zz(): each streaming kernel walks the rows the other way round than the one before it (common.h: vc_tls_walk_rev); gemm_ln is two
+  // launches (GEMM, then the LayerNorm of its rows) and flips between them itself
+  if (!have_ln1) { CK(vitcap_layernorm_fwd(x_in, D, w.n1_g, w.n1_b, 1e-6f, h, nullptr, M, D, s)); zz(); }
   CK(gemm(h, D, w.qkv_w, w.qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+  zz();
   CK(vitcap_attn_dense_fwd(qkv, h, B, NV, 0.125f, s));
+  zz();
   // proj reads h (the attention output) as A and its norm2 writes h: a row block's A rows are read by its own three tiles only
-  CK(gemm_ln(h, D, w.proj_w, w.proj_b, x_in, x, M, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, cnt, s));
+  CK(gemm_ln(h, D, w.proj_w, w.proj_b, x_in, x, M, D, w.n2_g, w.n2_b, 1e-6f, h, nullptr, cnt, s));      // GEMM, LayerNorm: two flips = none
   CK(gemm(h, D, w.fc1_w, w.fc1_b, nullptr, 0, mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF, VITCAP_OUT_BF16, s));
-  if (next) CK(gemm_ln(mlp, 4 * D, w.fc2_w, w.fc2_b, x, x, M, 4 * D, next->n1_g, next->n1_b, 1e-6f, h, nullptr, cnt, s));
-  else CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+  zz();
+  if (next) {
+    CK(gemm_ln(mlp, 4 * D, w.fc2_w, w.fc2_b, x, x, M, 4 * D, next->n1_g, next->n1_b, 1e-6f, h, nullptr, cnt, s));
+  } else {
+    CK(gemm(mlp, 4 * D, w.fc2_w, w.fc2_b, x, D, x, D, M, D, 4 * D, VITCAP_ACT_NONE, VITCAP_OUT_F32, s));
+    zz();
+  }
   return VITCAP_OK;
 }
 
@@ -702,6 +728,7 @@ static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, i
     d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
     d.row_group = 576; d.out_group_rows = NV; d.out_row_off = 1; d.res_periodic = 1;
     CK(gemm_desc(ws + lo.patches, w.patch_w, w.patch_b, w.pos_embed + D, x, d, s));
+    zz();
   }
   CK(vitcap_cls_rows(w.cls_token, w.pos_embed, x, B, NV, s));
   // a5: 12 blocks, fork before block 8, 4 tag blocks on the fork.  Run the fork on a side stream when the large GEMMs are
@@ -780,6 +807,7 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
                          char* ws, void* s) {
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
   CallScope scope(e, o.gemm_mode, nullptr);
+  WalkScope walk;
   // timing runs: a step is sampled WHOLE (its encoder and prefill launches), so that the union of the sampled launches' intervals
   // still sees which of them ran next to each other (tag branch beside caption blocks 8-11, batch parts)
   if (e->timing) e->timing_this_step = (e->timing_seen++ % e->timing_stride) == 0;
@@ -899,6 +927,7 @@ static int prefill_tags(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
 
 static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
   CallScope scope(e, o.gemm_mode, nullptr);
+  WalkScope walk;
   if (encode_parts(o, B, lo) >= 2) return VITCAP_OK;       // done by encode_locked, per part
   return prefill_part(e, B, o, lo, ws, s);
 }
@@ -922,14 +951,17 @@ static int prefill_part(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
       break;
     }
     CK(gemm(vis_b, D, lw.qkv_w, lw.qkv_b, nullptr, 0, dq, 3 * D, M, 3 * D, D, VITCAP_ACT_NONE, VITCAP_OUT_BF16, s));
+    zz();
     if (lo.vt[l]) CK(vitcap_attn_beam_vt(dq, ws + lo.vt[l], B, SV, s));
     CK(vitcap_attn_dense_fwd(dq, ws + lo.h, B, SV, 0.125f, s));
+    zz();
     // BertSelfOutput / BertOutput: dense + residual, then LayerNorm (post-LN) -- the LayerNorm rides in the GEMM
     int32_t* cnt = (int32_t*)(ws + lo.ln_cnt);
     CK(gemm_ln(ws + lo.h, D, lw.ao_w, lw.ao_b, vis_f, ws + lo.dtmp, M, D, lw.ao_g, lw.ao_beta, 1e-12f, ws + lo.da_b,
                (float*)(ws + lo.da_f), cnt, s));
     CK(gemm(ws + lo.da_b, D, lw.i_w, lw.i_b, nullptr, 0, ws + lo.mlp, 4 * D, M, 4 * D, D, VITCAP_ACT_GELU_ERF,
             VITCAP_OUT_BF16, s));
+    zz();
     CK(gemm_ln(ws + lo.mlp, 4 * D, lw.o_w, lw.o_b, (const float*)(ws + lo.da_f), ws + lo.dtmp, M, 4 * D, lw.o_g, lw.o_beta, 1e-12f,
                vis_b, vis_f, cnt, s));
   }

@@ -11,6 +11,8 @@ thread_local const int32_t* vc_tls_live = nullptr;   // see common.h
 thread_local VcEosExtra vc_tls_eos_extra = {{-1, -1, -1}};
 thread_local hipEvent_t vc_tls_kev_start = nullptr, vc_tls_kev_stop = nullptr;
 thread_local bool vc_tls_kev_used = false;
+thread_local bool vc_tls_walk_rev = false;         // see common.h
+thread_local bool vc_tls_zigzag = false;
 
 void vitcap_set_error(const char* fmt, ...) {
   va_list ap;

@@ -974,7 +974,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(VC_GEMM256_VGPR
   const int gi = bid / per_g, rem = bid - gi * per_g;
   const int gleft = p.tiles_n - gi * p.group_n;
   const int gw = gleft < p.group_n ? gleft : p.group_n;
-  const int tm = rem / gw, tn = gi * p.group_n + rem - tm * gw;
+  int tm = rem / gw;
+  const int tn = gi * p.group_n + rem - tm * gw;
+  // walk direction (common.h: vc_tls_walk_rev): row tiles last-to-first, and every other column group the other way round (a
+  // group's pass over A ends where the next one starts)
+  if ((p.rev != 0) != ((gi & 1) != 0)) tm = tiles_m - 1 - tm;
   if (!small) {
     gemm256_tile<ACT, OUT_F32, HAS_RES, PH, 4>(p, smem, tm * 256, tn * 256, tm);
   } else {
@@ -1663,7 +1667,8 @@ static int large_gemm_form(int M, int N, int hint, bool f32_or_res = true) {
   // img/s all 8-wave -- while the fp32 + residual GEMMs (proj / fc2: 3 748) and the LDS-epilogue form (3 580 / 3 599) lose.
   (void)tiles256;
   static const int env_mix = [] { const char* e = getenv("VITCAP_GEMM_4W_MIX"); return e ? atoi(e) : 1; }();
-  if (hint == 5) return env_set ? env_tiles : ((env_mix && !f32_or_res) ? 1 : -1);
+  // (from 64 k rows per launch on -- B = 512, beam 5 x 256 -- the mix is a tie or slightly behind: 8-wave there)
+  if (hint == 5) return env_set ? env_tiles : ((env_mix && !f32_or_res && M < 65536) ? 1 : -1);
   if (hint == 0) return env_set ? env_auto : 2;
   return -1;
 }
@@ -1734,6 +1739,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   a.zout = (bf16_t*)zout_bf16; a.ldz = ldz;
   a.split_k = 1; a.kt_per_split = 0; a.slab = 0;
   a.live = d->live;
+  a.rev = vc_tls_walk_rev ? 1 : 0;
   a.rowstat = (float*)d->rowstat;
   a.ln_g = a.ln_b = nullptr; a.ln_eps = 0.f; a.ln_out = nullptr; a.ln_out_f = nullptr; a.ln_cnt = nullptr;
   {
@@ -1772,7 +1778,13 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     d2.ln_out_bf16 = nullptr; d2.ln_out_f32 = nullptr;
     const int rc = vitcap_gemm_ex(A, W, bias, residual, C, &d2, aux_bf16, ldaux, zout_bf16, ldz, stream);
     if (rc != VITCAP_OK) return rc;
-    return vitcap_layernorm_fwd((const float*)C, d->ldc, d->ln_gamma, d->ln_beta, d->ln_eps, d->ln_out_bf16, d->ln_out_f32, d->M, 768, stream);
+    // the LayerNorm reads the rows the GEMM has just written: it walks them the other way round (common.h: vc_tls_walk_rev; only the
+    // engine ever sets the flag, and only there does this flip have an effect worth having)
+    const bool dir = vc_tls_walk_rev;
+    if (vc_tls_zigzag && d->M >= 2048) vc_tls_walk_rev = !dir;
+    const int rc2 = vitcap_layernorm_fwd((const float*)C, d->ldc, d->ln_gamma, d->ln_beta, d->ln_eps, d->ln_out_bf16, d->ln_out_f32, d->M, 768, stream);
+    vc_tls_walk_rev = dir;
+    return rc2;
   }
   if (d->rowstat) {
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && !residual && plain_rows && split_k == 1 && !aux_bf16 && !zout_bf16,

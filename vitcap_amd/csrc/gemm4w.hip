@@ -593,6 +593,7 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int pos, int& tm, int
   const int gw = gleft < p.group_n ? gleft : p.group_n;
   tm = rem / gw;
   tn = gi * p.group_n + rem - tm * gw;
+  if ((p.rev != 0) != ((gi & 1) != 0)) tm = p.tiles_m - 1 - tm;      // walk direction, see gemm.hip / common.h
 }
 
 // ---- one tile per workgroup (EPI: 0 = LDS epilogue, 1 = register epilogue)

@@ -36,6 +36,7 @@ struct GemmArgs {
   bf16_t* ln_out;              // [M][768] bf16 or null
   float* ln_out_f;             // [M][768] fp32 or null
   int32_t* ln_cnt;             // one counter per row block, zero on entry, zero again on exit
+  int rev;                     // 256-row-tile kernels: walk the tile list last-to-first (vc_tls_walk_rev / tile_hint flag 0x1000)
 };
 
 // launch of a large-tile GEMM: with kernel-bound timing events when the engine's timing run asked for them (common.h)

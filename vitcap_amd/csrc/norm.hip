@@ -11,9 +11,10 @@ namespace {
 __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
-                                                           bf16_t* __restrict__ yb, float* __restrict__ yf, int M) {
+                                                           bf16_t* __restrict__ yb, float* __restrict__ yf, int M, int rev) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // rev: workgroups are dispatched in blockIdx order -- the rows are then visited last-to-first (common.h: vc_tls_walk_rev)
+  const int row = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (size_t)row * ldx;
   f32x4 v[3];
@@ -344,7 +345,7 @@ extern "C" int vitcap_layernorm_fwd(const float* x, int ldx, const float* gamma,
   VC_REQUIRE(D == D768, "layernorm: only D=768 is built (got %d)", D);
   VC_REQUIRE(M > 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "layernorm: bad M/ldx/alignment");
   hipLaunchKernelGGL(layernorm768_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
-                     eps, (bf16_t*)y_bf16, y_f32, M);
+                     eps, (bf16_t*)y_bf16, y_f32, M, vc_tls_walk_rev ? 1 : 0);
   VC_LAUNCH_CHECK("layernorm");
   return VITCAP_OK;
 }
