@@ -149,6 +149,7 @@ def bench_train(args, rank, world, local, dist, D):
     B = args.batch
     model = ImageCaptioning().load_recipe(0)
     eng = TrainEngine(model, 'cuda:%d' % local, max_iter=10 ** 6, dist=dist)
+    eng.use_graphs = bool(args.train_graph)          # the step as ~11 host calls (captured segments) instead of ~750
     batch = synthetic_train_inputs(B, seed=D.shard_seed(4321, rank))
     batch = {k: v.cuda() for k, v in batch.items()}
     batch['image'] = torch.from_numpy(W.gen_image_batch(B, D.shard_seed(1234, rank))).cuda().to(torch.bfloat16).contiguous()
@@ -162,13 +163,16 @@ def bench_train(args, rank, world, local, dist, D):
     for _ in range(max(args.warmup, 1)):
         out = eng.train_step(batch)
     barrier()
-    ops.TIMING = []                      # events on the launch stream around every large GEMM of the timed region
+    ops.TIMING = None if eng.use_graphs else []      # events on the launch stream around every large GEMM of the timed region (eager only)
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         out = eng.train_step(batch)
+        host_s += time.perf_counter() - h0          # time the HOST spends issuing a step (enqueue only: no synchronisation inside)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dist, device='cuda')
-    timing, ops.TIMING = ops.TIMING, None
+    timing, ops.TIMING = (ops.TIMING or []), None
     kinds = {}
     for kind, fl, e0, e1 in timing:
         k = kinds.setdefault(kind, [0.0, 0.0, 0])
@@ -200,6 +204,9 @@ def bench_train(args, rank, world, local, dist, D):
             'end_to_end_tflops_executed': round(value / world * TRAIN_FLOP_EXECUTED_PER_SAMPLE / 1e12, 2),
             'end_to_end_frac_of_bf16_peak': round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_TFLOPS, 4),
             'roofline': roof,
+            'launch': ('hipGraph segments replayed (TrainEngine.train_step_graph): copies + salt + %d replay(s) + optimizer' % len(next(iter(eng._graphs.values()))['segs'])
+                       if eng.use_graphs else 'eager: every kernel launched from Python (ctypes)'),
+            'host_issue_ms_per_step': round(host_s / args.steps * 1e3, 3),
             'masked_loss': float(out['masked_loss']), 'tag_loss': float(out['tag_loss'])})
     if dist is not None:
         dist.barrier()
@@ -324,6 +331,8 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1: two-slot batch pipeline (encode+prefill of step i+1 overlaps the decode of step i on a second '
                          'stream; same results); 0: one stream, steps strictly back to back')
+    ap.add_argument('--train-graph', type=int, default=1,
+                    help='--mode train: 1 = the step replays hipGraph segments captured once per batch shape, 0 = eager launches from Python')
     ap.add_argument('--stub', action='store_true',
                     help='CPU stand-in for the workload (tests of the launch / barrier / max-over-ranks / JSON plumbing only: gloo, no '
                          'GPU, no kernels; never a measurement)')

@@ -632,6 +632,12 @@ int vitcap_cast_bf16(const float* x, void* y, size_t n, void* stream);
  * x, residual (or NULL), out: fp32 [M][768]; out may alias x. */
 int vitcap_hidden_dropout(const float* x, const float* residual, float* out, int M, int D, int rows_per_seq, int row0,
                           uint32_t seed, float p, void* stream);
+/* Dropout salt: a device-resident uint32 that the training kernels XOR into every dropout seed they are launched with (attention
+ * dropout of vitcap_attn_dense_fwd_train* / vitcap_attn_dense_bwd*, vitcap_hidden_dropout; modeling_bert.py:236, 330-333, 356, 418).
+ * Seeds are launch arguments and therefore frozen inside a captured hipGraph; a captured training step draws new keep decisions on
+ * every replay by rewriting this word before the replay.  Per calling thread; NULL (the default) = no salt.  Returns 0. */
+int vitcap_set_dropout_salt(const void* device_u32);
+
 /* the same over [M][768] rows, with colsum[c] += sum over rows of the ROUNDED values (cast + vitcap_colsum_bf16 in one pass) */
 int vitcap_cast_bf16_colsum(const float* x, void* y, float* colsum, int M, int D, void* stream);
 /* BertEmbeddings backward: scatter-add into word / position / token-type gradient tables (modeling_bert.py:230-234) */

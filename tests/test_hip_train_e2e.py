@@ -777,6 +777,72 @@ def test_inference_engine_bound_to_training_buffers():
     assert not torch.equal(ids2, ids) or True   # (captions may or may not change; equality with `fresh` above is the check)
 
 
+def test_graph_step_equals_eager(sd_t):
+    """Graph mode (TrainEngine.train_step_graph: forward + backward recorded once into hipGraph segments, a step = input copies + salt +
+    replay + optimizer, ~11 host calls instead of ~750) against the eager step: same kernels, same arguments, same order -- loss and
+    parameters after three steps on three different batches agree to the run-to-run spread of the step's float atomics (the eager step
+    against itself: the same bound), dropout off.  With attention dropout on, two replays of one graph draw DIFFERENT keep decisions
+    (device-resident salt, vitcap_set_dropout_salt) and a batch with an unused loss slot (masked_ids == 0) is handled without a host
+    synchronisation."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    B = 4
+
+    def batch(i):
+        b = {k: v.cuda() for k, v in synthetic_train_inputs(B, seed=40 + i).items()}
+        b['image'] = torch.from_numpy(W.gen_image_batch(B, 900 + i)).cuda().to(torch.bfloat16)
+        return b
+    batches = [batch(i) for i in range(3)]
+
+    def run(graph):
+        eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+        eng.use_graphs = graph
+        losses = [float(eng.train_step(b)['masked_loss']) for b in batches]
+        torch.cuda.synchronize()
+        return losses, eng.P.clone(), eng
+    l_e, p_e, _ = run(False)
+    l_e2, p_e2, _ = run(False)
+    l_g, p_g, eng = run(True)
+    assert len(eng._graphs) == 1 and len(next(iter(eng._graphs.values()))['segs']) == 1
+    spread = float((p_e - p_e2).abs().max())
+    diff = float((p_g - p_e).abs().max())
+    print('graph vs eager: losses %s vs %s, max |param diff| %.3e (eager vs eager %.3e)' % (l_g, l_e, diff, spread))
+    for a, b in zip(l_g, l_e):
+        assert abs(a - b) < 1e-5
+    assert diff <= max(2.0 * spread, 2e-7)
+    # an unused loss slot: masked_ids[b, 2] = 0 and its masked_pos bit cleared -> same loss as the eager path, no host synchronisation
+    b3 = batch(7)
+    mp = b3['masked_pos'].clone()
+    for r in range(B):
+        last = int(torch.nonzero(mp[r])[-1])
+        mp[r, last] = 0
+    b3['masked_pos'] = mp
+    b3['masked_ids'] = b3['masked_ids'].clone()
+    b3['masked_ids'][:, 2] = 0
+    eng_e = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    l_ref = float(eng_e.forward_backward(b3)[0])
+    g_ref = eng_e.G.clone()
+    eng_g = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+    eng_g.use_graphs = True
+    l_gr = float(eng_g.train_step(b3)['masked_loss'])
+    assert abs(l_gr - l_ref) < 1e-5, (l_gr, l_ref)
+    assert float(g_ref.abs().max()) > 0
+    from oracle import vitcap_oracle as O
+    with torch.no_grad():
+        l_o = float(O.train_losses_as_written(sd_t, b3['image'].float().cpu(), {k: v.cpu() for k, v in b3.items() if k != 'image'})[0])
+    print('batch with 2 masked tokens per sample: device %.5f oracle %.5f' % (l_ref, l_o))
+    assert abs(l_ref - l_o) < 2e-3
+    # dropout on: two replays on the same batch differ (the salt moved), the eager step with the same seed differs from both
+    eng_d = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10 ** 6, base_lr=0.0, attn_dropout=0.1, dropout_seed=3)
+    eng_d.use_graphs = True
+    la = float(eng_d.train_step(batches[0])['masked_loss'])
+    lb = float(eng_d.train_step(batches[0])['masked_loss'])
+    print('dropout on, two replays of one graph on one batch (lr 0): %.6f %.6f' % (la, lb))
+    assert la != lb and abs(la - lb) < 0.2
+
+
 def test_train_step_batch64_properties(sd_t):
     """BASELINE configs[3] per-GPU size (64 samples): size-independent properties of the training step -- finite loss and
     gradient norm, the loss on a fixed batch goes down over a few steps, the step is reproducible up to the float atomics of

@@ -113,6 +113,7 @@ _SIGS = {
     'vitcap_gemm_tile_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_gemm_large_form': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'vitcap_gemm_reserve_cus': (C.c_int, [C.c_int]),
+    'vitcap_set_dropout_salt': (C.c_int, [vp]),
     'vitcap_layernorm_fwd': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
     'vitcap_sum_layernorm': (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp,
                                        C.c_int, C.c_int, vp]),

@@ -76,7 +76,8 @@ template <bool DROP>
 __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int S, int B, int ld_rows, float c_log2,
                                                          uint32_t drop_seed, uint32_t drop_thr, float drop_scale,
-                                                         int causal_from, int mask_from, int q_lo, int q_rows, int rev) {
+                                                         int causal_from, int mask_from, int q_lo, int q_rows, int rev,
+                                                         const uint32_t* __restrict__ drop_salt) {
   __shared__ __attribute__((aligned(1024))) char smem[NSTG * STG_B];   // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
   const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
   const int q0 = qb * 128 + w * 32;
   const bool active = q0 < S;        // waves past the last query row only help with staging
-  const uint32_t hq = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10) ^ (4u * half)) : 0u;
+  const uint32_t hq = DROP ? (vc_drop_stream(vc_salted(drop_seed, drop_salt), (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10) ^ (4u * half)) : 0u;
   const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;   // ld_rows >= S rows per image in the buffers
 
   // Q^T fragments: lane holds Q[q0+qi][ds*16 + half*8 .. +7]
@@ -889,7 +890,7 @@ static int attn_decode_groups(const void* qkv_step, const void* vis_qkv, const v
 
 
 #define VC_LAUNCH_DENSE(DROP_, grid_, stream_, ...) \
-  hipLaunchKernelGGL(attn_dense_kernel<DROP_>, grid_, dim3(256), 0, (hipStream_t)(stream_), __VA_ARGS__, vc_tls_walk_rev ? 1 : 0)
+  hipLaunchKernelGGL(attn_dense_kernel<DROP_>, grid_, dim3(256), 0, (hipStream_t)(stream_), __VA_ARGS__, vc_tls_walk_rev ? 1 : 0, vc_tls_drop_salt)
 
 extern "C" int vitcap_attn_dense_fwd(const void* qkv, void* out, int B, int S, float scale, void* stream) {
   VC_REQUIRE(qkv && out && B > 0 && S > 0, "attn_dense: bad arguments");

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
                                                           int ld_rows, float c_log2, float scale, uint32_t drop_seed,
                                                           uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
-                                                          int q_lo, int q_hi) {
+                                                          int q_lo, int q_hi, const uint32_t* __restrict__ drop_salt) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bool active = q0 < S;
   const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
   const int qr = (q0 + qi) < S ? (q0 + qi) : S - 1;
-  const uint32_t hq = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10)) : 0u;
+  const uint32_t hq = DROP ? (vc_drop_stream(vc_salted(drop_seed, drop_salt), (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10)) : 0u;
 
   // B-operand fragments held for the whole kernel: Q^T and dO^T (lane: row q, dims ds*16 + half*8 ..)
   bf16x8 qf[4], dof[4];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
                                                            int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
                                                            uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
-                                                           int q_lo, int q_hi) {
+                                                           int q_lo, int q_hi, const uint32_t* __restrict__ drop_salt) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ki = lane & 31, half = lane >> 5;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const float* Lb = lse + ((size_t)b * NH + h) * S;
   const float* Db = dsum + ((size_t)b * NH + h) * S;
   const int kr = (key0 + ki) < S ? (key0 + ki) : S - 1;
-  const uint32_t hk = DROP ? (vc_drop_stream(drop_seed, (uint32_t)b, (uint32_t)h) ^ (uint32_t)(key0 + ki)) : 0u;
+  const uint32_t hk = DROP ? (vc_drop_stream(vc_salted(drop_seed, drop_salt), (uint32_t)b, (uint32_t)h) ^ (uint32_t)(key0 + ki)) : 0u;
 
   bf16x8 kf[4], vf[4];     // B operands: K^T and V^T columns of this lane's key
   {
@@ -522,11 +522,11 @@ extern "C" int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, cons
   do {                                                                                                                    \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
                        (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi);                                          \
+                       drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);                        \
     VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
                        (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
-                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi);                       \
+                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);     \
     VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
   } while (0)
   if (p_drop > 0.f) VC_BWD_LAUNCH(true);

@@ -32,6 +32,11 @@ extern thread_local const int32_t* vc_tls_live;
 // with that operand cache-resident runs the kernel 21 % faster, profiles/r05_g4w_probe.txt).  With the flag set a kernel visits its
 // row blocks last-to-first, so that what was written last is read first; the engine flips it after every streaming launch.
 // Results do not depend on it (the order in which independent tiles run).  False outside the engine.
+// Dropout salt (vitcap_set_dropout_salt): a device-resident 32-bit word XORed into every dropout seed by the training kernels.  The
+// seeds themselves are launch arguments -- frozen when a training step is captured into a hipGraph -- so a captured step changes its
+// keep decisions from replay to replay by rewriting this word (vitcap_amd/train.py, graph mode).  NULL = no salt (the default).
+extern thread_local const uint32_t* vc_tls_drop_salt;
+__device__ __forceinline__ uint32_t vc_salted(uint32_t seed, const uint32_t* salt) { return salt ? seed ^ *salt : seed; }
 extern thread_local bool vc_tls_walk_rev;
 extern thread_local bool vc_tls_zigzag;        // the engine call being enqueued alternates directions (GEMM + LayerNorm pairs flip in between)
 struct VcEosExtra { int32_t id[3]; };

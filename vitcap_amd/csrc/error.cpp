@@ -13,6 +13,11 @@ thread_local hipEvent_t vc_tls_kev_start = nullptr, vc_tls_kev_stop = nullptr;
 thread_local bool vc_tls_kev_used = false;
 thread_local bool vc_tls_walk_rev = false;         // see common.h
 thread_local bool vc_tls_zigzag = false;
+thread_local const uint32_t* vc_tls_drop_salt = nullptr;
+extern "C" int vitcap_set_dropout_salt(const void* device_u32) {
+  vc_tls_drop_salt = (const uint32_t*)device_u32;
+  return 0;
+}
 
 void vitcap_set_error(const char* fmt, ...) {
   va_list ap;

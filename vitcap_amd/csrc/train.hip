@@ -709,12 +709,13 @@ extern "C" int vitcap_cast_transpose(const float* w, void* w_bf16, void* wt_bf16
 // -- and the CPU oracle replays it (oracle.hidden_keep).  The same entry point serves the backward pass: dx = dy * keep / (1 - p).
 namespace {
 __global__ __launch_bounds__(256) void hidden_dropout_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
-                                                           int M, int rows_per_seq, int row0, uint32_t seed, uint32_t thr, float scale) {
+                                                           int M, int rows_per_seq, int row0, uint32_t seed, uint32_t thr, float scale,
+                                                           const uint32_t* __restrict__ drop_salt) {
   const int gid = blockIdx.x * 256 + threadIdx.x;          // one float4 per thread: 192 per row
   const int m = gid / 192, c4 = gid - m * 192;
   if (m >= M) return;
   const int b = m / rows_per_seq, r = row0 + (m - b * rows_per_seq);
-  const uint32_t stream = vc_drop_stream(seed, (uint32_t)b, 0x48u);
+  const uint32_t stream = vc_drop_stream(vc_salted(seed, drop_salt), (uint32_t)b, 0x48u);
   const size_t off = (size_t)m * D768 + c4 * 4;
   f32x4 v = *(const f32x4*)(x + off);
 #pragma unroll
@@ -733,7 +734,7 @@ extern "C" int vitcap_hidden_dropout(const float* x, const float* residual, floa
   const float scale = 1.0f / (1.0f - p);
   const long long n4 = (long long)M * 192;
   hipLaunchKernelGGL(hidden_dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, residual, out, M,
-                     rows_per_seq, row0, seed, thr, scale);
+                     rows_per_seq, row0, seed, thr, scale, vc_tls_drop_salt);
   VC_LAUNCH_CHECK("hidden_dropout");
   return VITCAP_OK;
 }

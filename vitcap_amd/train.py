@@ -264,6 +264,8 @@ class TrainEngine(object):
         self.reducer = BucketedAllReduce(self.G, grad_buckets(order, self.off, self.shape), GRAD_STAGES, dist)
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self._pending = False
+        self.use_graphs = os.environ.get('VITCAP_TRAIN_GRAPH', '0') == '1'      # train_step() replays captured segments (graph mode below)
+        self._graphs = {}
         model.__dict__['train_engine'] = self          # ImageCaptioning.forward (training mode) routes here
 
     def loss_dict(self, batch):
@@ -520,7 +522,24 @@ class TrainEngine(object):
 
     # ------------------------------------------------------------------ forward + backward
     def forward_backward(self, batch):
-        """batch: image (B,3,384,384) fp32/bf16 cuda; input_ids (B,70) int64; masked_pos (B,70) int; masked_ids (B,3) int64;
+        """One fused forward + backward (see _fb_gen): drives the stage generator and starts a bucket's gradient exchange after each
+        backward stage."""
+        self.reducer.begin()
+        gen = self._fb_gen(batch)
+        while True:
+            try:
+                stage = next(gen)
+            except StopIteration as done:
+                return done.value
+            self.reducer.stage_done(stage)
+
+    def _fb_gen(self, batch, capture=False):
+        """Generator: yields the name of every backward stage right after that stage's last kernel was enqueued (the driver starts the
+        stage's gradient exchange there, or -- graph mode -- ends a captured segment), returns (masked_loss, tag_loss).
+        capture=True: the body is being recorded into hipGraph segments (train_step_graph): no host synchronisation, dropout seeds
+        of step 0 (the per-step variation comes from the device-resident salt, vitcap_set_dropout_salt).
+
+        batch: image (B,3,384,384) fp32/bf16 cuda; input_ids (B,70) int64; masked_pos (B,70) int; masked_ids (B,3) int64;
         label (B,30522) fp32 -- the dict the reference's collate feeds ImageCaptioning.forward in training.
         Accumulates gradients into self.G (zeroed here) and returns (masked_loss, tag_loss) device scalars.
 
@@ -530,7 +549,15 @@ class TrainEngine(object):
         forwards the reference differentiates through (one full re-encode per generated token) collapse into ONE pass:
         the decoder runs on [578 visual | 20 token rows | 19 [MASK] probe rows], probe j sees tokens 0..j."""
         dev = self.dev
-        self.check_text_inputs(batch)
+        if capture:       # the device-side comparison only (read by flush_text_check every 50 steps, outside the graph)
+            ok = train_text_inputs_ok(batch)
+            if ok is not None:
+                if getattr(self, '_text_bad', None) is None:
+                    self._text_bad = torch.zeros((), dtype=torch.int32, device=ok.device)
+                self._text_bad += (~ok).to(torch.int32)
+        else:
+            self.check_text_inputs(batch)
+        seed_step = 0 if capture else self.step_no
         img = batch['image']
         Be = img.shape[0]                       # images the encoder runs on
         KS = int(batch.get('seq_per_image', 1))   # decoder sequences per image (self-critical step: the samples of an image
@@ -541,7 +568,6 @@ class TrainEngine(object):
         LR = SV + TT                         # decoder rows per image (shadows the module constant on purpose)
         M, Md = Be * NV, B * LR
         self.G.zero_()
-        self.reducer.begin()
         self.loss_buf.zero_()
         ie = 'image_encoder.module.'
         # ================= forward: patch embed
@@ -632,7 +658,7 @@ class TrainEngine(object):
         ph = self.hidden_dropout
 
         def hseed(l, site):            # per step, per layer (4 = embeddings), per site (1 attention.output, 2 output, 3 embeddings)
-            return mix32(mix32(mix32(self.dropout_seed, self.step_no), 16 + l), site)
+            return mix32(mix32(mix32(self.dropout_seed, seed_step), 16 + l), site)
         if ph > 0:                     # BertEmbeddings: dropout(LayerNorm(...)) on the text rows (device rows SV .. SV + TT - 1 of a sequence)
             ops.hidden_dropout(xtext, None, TT, SV, hseed(4, 3), ph, out=xtext)
         dx = torch.empty(B, LR, 768, device=dev)
@@ -642,7 +668,7 @@ class TrainEngine(object):
         xd = dx.view(Md, 768)
         dsaved = []
         pd = self.attn_dropout
-        dseed = [mix32(mix32(self.dropout_seed, self.step_no), l) for l in range(4)]      # per step, per layer
+        dseed = [mix32(mix32(self.dropout_seed, seed_step), l) for l in range(4)]      # per step, per layer
         QLO = (SV // 128) * 128                       # first 128-row query block that holds text rows
         for l in range(4):
             pre = 'module.bert.decoder.layer.%d' % l
@@ -714,14 +740,36 @@ class TrainEngine(object):
             wrow = (batch['sample_weight'].to(dev).to(torch.float32) / cnt)[:, None].expand(B, TP)
             row_w = wrow[unf].contiguous()
             tgt = tok[unf].contiguous()
+            sel = mp.view(-1).nonzero().view(-1)                              # rows of the (B*TT) text grid
+            n = int(sel.numel())
+            assert int(tgt.numel()) == n, 'sample_ids / unfinished mask disagree'
+            sel_bwd = sel
         else:
-            mp = torch.zeros(B, TT, dtype=torch.bool, device=dev)
-            mp[:, :T] = batch['masked_pos'][:, :T].to(dev).bool()
-            tgt = batch['masked_ids'].to(dev)
-            tgt = tgt[tgt != 0].contiguous()
-        sel = mp.view(-1).nonzero().view(-1)                                  # rows of the (B*TT) text grid
-        n = int(sel.numel())
-        assert int(tgt.numel()) == n, 'masked_pos / masked_ids disagree'
+            # Static form (no host synchronisation, same shapes every step: graph-capturable).  Slot (b, j) = the j-th masked position of
+            # sample b; masked_ids[b, j] == 0 marks an unused slot (a caption with fewer than 3 masked tokens).  The used slots are moved
+            # to the front in their original order (stable sort), so with every slot used -- the synthetic batches -- rows, targets and
+            # weights are exactly what `nonzero()` / boolean indexing produced; an unused slot becomes a row with weight 0 (zero loss,
+            # zero gradient rows: exact zeros in every sum) whose gradient lands in a dummy row behind the text grid.
+            mpos = batch['masked_pos'][:, :T].to(dev) != 0                       # (B, T)
+            mids = batch['masked_ids'].to(dev)                                   # (B, J)
+            J = mids.shape[1]
+            cum = mpos.to(torch.int32).cumsum(1)                                 # 1-based rank of every masked position
+            want = torch.arange(1, J + 1, device=dev, dtype=torch.int32).view(1, J, 1)
+            tpos = ((cum.unsqueeze(1) == want) & mpos.unsqueeze(1)).to(torch.int32).argmax(2)      # (B, J): position of the j-th masked token
+            rows_all = (torch.arange(B, device=dev).view(B, 1) * TT + tpos).view(-1)
+            used = (mids != 0).view(-1)
+            # a batch whose masked_pos and masked_ids disagree is reported like a bad mask (device counter, TrainEngine.flush_text_check)
+            bad = (mpos.sum(1) != (mids != 0).sum(1)).any()
+            if getattr(self, '_text_bad', None) is None:
+                self._text_bad = torch.zeros((), dtype=torch.int32, device=dev)
+            self._text_bad += bad.to(torch.int32)
+            order = torch.argsort((~used).to(torch.int8), stable=True)
+            used_s = used[order]
+            sel = rows_all[order].contiguous()                                   # forward: any valid row index (weight 0 where unused)
+            sel_bwd = torch.where(used_s, sel, torch.full_like(sel, B * TT))     # backward: unused slots -> the dummy row
+            tgt = mids.view(-1)[order].contiguous()
+            n = B * J
+            row_w = (used_s.to(torch.float32) / used.sum().clamp(min=1).to(torch.float32)).contiguous()     # 1 / #masked tokens: the mean
         hrows = ops.cast_bf16(text_out.index_select(0, sel).contiguous())
         c = 'module.cls.predictions'
         zt = torch.empty(n, 768, device=dev, dtype=torch.bfloat16)
@@ -749,9 +797,10 @@ class TrainEngine(object):
         check(lib.vitcap_gelu_bwd(_p(dgt), _p(zt), _p(dzt), n * 768, _s()), 'gelu_bwd')
         self._wgrad_tn(dzt, hrows, self.g(c + '.transform.dense.weight'), self.g(c + '.transform.dense.bias').view(-1))
         dh = ops.gemm_ex(dzt, self.wt('cls.t'), out_dtype=torch.float32)      # [n,768] fp32
-        self.reducer.stage_done('cls')
-        dtext = torch.zeros(B * TT, 768, device=dev)
-        dtext.index_copy_(0, sel, dh)
+        yield 'cls'
+        dtext = torch.zeros(B * TT + 1, 768, device=dev)            # + the dummy row unused loss slots write to
+        dtext.index_copy_(0, sel_bwd, dh)
+        dtext = dtext[:B * TT]
         if prune:
             dy = dtext                               # the last layer's backward runs on the text rows (see the forward)
         else:
@@ -812,7 +861,7 @@ class TrainEngine(object):
             self._wgrad_tn(dqkv, xb, self.qkv_w_grad(pre), self.qkv_bias_grad(pre))
             dy = ops.gemm_ex(dqkv, self.wt(pre + '.qkv'), residual=dt1f, out_dtype=torch.float32)
             if l % 2 == 0:
-                self.reducer.stage_done('dec%d' % (l // 2))
+                yield 'dec%d' % (l // 2)
         dyv = dy.view(B, LR, 768)
         # ================= backward: text embeddings
         dtext_in = dyv[:, SV:].reshape(B * TT, 768).contiguous()
@@ -822,7 +871,7 @@ class TrainEngine(object):
         check(lib.vitcap_embed_bwd(_p(demb), _p(ids20.view(-1)), TT, _p(self.g(e + '.word_embeddings.weight')),
                                    _p(self.g(e + '.position_embeddings.weight')), _p(self.g(e + '.token_type_embeddings.weight')),
                                    B * TT, T if scst else 0, _s()), 'embed_bwd')
-        self.reducer.stage_done('emb')
+        yield 'emb'
         # ================= backward: encoder
         if KS > 1:      # the KS sequences of an image saw the same visual rows: their gradients add up
             dyv_vis = dyv[:, :SV].reshape(Be, KS, SV, 768).sum(1)
@@ -885,23 +934,23 @@ class TrainEngine(object):
             else:
                 dtag = block_bwd('module.bert.encoder.tag_blocks.%d' % i, dtag)
             if i % 2 == 0:
-                self.reducer.stage_done('tag%d' % (i // 2))
+                yield 'tag%d' % (i // 2)
         for i in (11, 10, 9, 8):
             dhid = block_bwd('module.bert.encoder.blocks.%d' % i, dhid)
             if i % 2 == 0:
-                self.reducer.stage_done('blk%d' % (i // 2))
+                yield 'blk%d' % (i // 2)
         dxe = dhid
         ops.reduce_slabs(dtag.view(1, M * 768), dxe.view(-1), accumulate=True)      # fork point: the two branches' gradients meet
         for i in range(7, -1, -1):
             dxe = block_bwd('module.bert.encoder.blocks.%d' % i, dxe)
             if i % 2 == 0:
-                self.reducer.stage_done('blk%d' % (i // 2))
+                yield 'blk%d' % (i // 2)
         # ================= backward: patch embed, cls token, position embedding
         check(lib.vitcap_sum_over_batch(_p(dxe), NV * 768, Be, _p(self.g(ie + 'pos_embed')), NV * 768, _s()), 'sum_over_batch')
         self.g(ie + 'cls_token').view(-1).copy_(self.g(ie + 'pos_embed').view(NV, 768)[0])
         dpatch = ops.cast_bf16(dxe.view(Be, NV, 768)[:, 1:].reshape(Be * 576, 768).contiguous())
         self._wgrad_tn(dpatch, patches, self.g(ie + 'patch_embed.proj.weight').view(768, 768), self.g(ie + 'patch_embed.proj.bias').view(-1))
-        self.reducer.stage_done('patch')
+        yield 'patch'
         return self.loss_buf[0], self.loss_buf[1]
 
     # ------------------------------------------------------------------ optimizer
@@ -920,10 +969,81 @@ class TrainEngine(object):
         self.refresh_weights()
 
     def train_step(self, batch):
+        if self.use_graphs and self._graphable(batch):
+            return self.train_step_graph(batch)
         loss, tag_loss = self.forward_backward(batch)
         self.all_reduce_grads()
         self.optimizer_step()
         return {'masked_loss': loss, 'tag_loss': tag_loss}
+
+    # ------------------------------------------------------------------ graph mode: the step as a few host calls
+    # The eager step issues ~600 ctypes launches + ~150 torch calls from Python (with 8 ranks x (loader processes +
+    # launcher) on one host that is the fragile part).  Here the whole forward + backward is recorded ONCE per batch shape into hipGraph
+    # segments (torch.cuda.graph: the stream capture also records torch's own small kernels and keeps the step's activations in a
+    # private pool) and a step becomes: copy the batch into the static input buffers (5 calls), rewrite the dropout salt (1), replay
+    # the segments (1 without a gradient exchange; 4 with one, the buckets of a segment's stages start behind it), clip + AdamW +
+    # weight refresh (4).  Same kernels, same arguments, same order as the eager step: bit-identical parameters with dropout off
+    # (tests/test_hip_train_e2e.py::test_graph_step_equals_eager); with dropout on the keep decisions of step t are those of
+    # seed(step 0) ^ salt(t) -- another stream than the eager step's, equally distributed.
+    GRAPH_SEGMENT_ENDS = ('dec0', 'tag0', 'blk3', 'patch')       # with a gradient exchange: 4 segments (cls+dec | emb+tag | blk5-3 | blk2-0+patch)
+    _GRAPH_KEYS = ('image', 'input_ids', 'attention_mask', 'masked_pos', 'masked_ids', 'label')
+
+    def _graphable(self, batch):
+        return ('sample_ids' not in batch and int(batch.get('seq_per_image', 1)) == 1 and 'masked_pos' in batch and 'masked_ids' in batch
+                and all(torch.is_tensor(batch[k]) for k in self._GRAPH_KEYS if k in batch))
+
+    def _graph_build(self, key, batch):
+        dev = self.dev
+        static = {k: batch[k].to(dev).clone().contiguous() for k in self._GRAPH_KEYS if k in batch}
+        salt = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one eager pass on the static buffers first: every kernel's launch attributes exist, the caching allocator is warm, and (multi-
+        # rank) every rank runs the same collectives -- it changes gradients and the loss buffer only
+        self.forward_backward(static)
+        self.all_reduce_grads()
+        torch.cuda.synchronize(dev)
+        segs = []
+        pool = torch.cuda.graph_pool_handle()
+        gen = self._fb_gen(static, capture=True)
+        done = False
+        check(lib.vitcap_set_dropout_salt(C.c_void_p(salt.data_ptr())), 'set_dropout_salt')
+        try:
+            while not done:
+                g = torch.cuda.CUDAGraph()
+                stages = []
+                with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):     # a loader thread may copy meanwhile
+                    while True:
+                        try:
+                            st = next(gen)
+                        except StopIteration:
+                            done = True
+                            break
+                        stages.append(st)
+                        if self.reducer.exchange and st in self.GRAPH_SEGMENT_ENDS:
+                            break
+                segs.append((g, stages))
+        finally:
+            check(lib.vitcap_set_dropout_salt(None), 'set_dropout_salt')
+        entry = {'static': static, 'salt': salt, 'segs': segs}
+        self._graphs[key] = entry
+        return entry
+
+    def train_step_graph(self, batch):
+        key = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self._GRAPH_KEYS if k in batch)
+        entry = self._graphs.get(key) or self._graph_build(key, batch)
+        for k, t in entry['static'].items():
+            t.copy_(batch[k], non_blocking=True)
+        if self.attn_dropout > 0 or self.hidden_dropout > 0:
+            entry['salt'].fill_(mix32(0x85ebca6b, self.step_no) & 0x7fffffff)
+        self.reducer.begin()
+        for g, stages in entry['segs']:
+            g.replay()
+            for st in stages:
+                self.reducer.stage_done(st)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        if self.step_no % 50 == 0:
+            self.flush_text_check()
+        return {'masked_loss': self.loss_buf[0], 'tag_loss': self.loss_buf[1]}
 
     def grad_norm(self):
         return float(self.gsumsq.sqrt())
