@@ -31,7 +31,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r04_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r05_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 # What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
 # visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row

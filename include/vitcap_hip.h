@@ -611,7 +611,7 @@ const void* vitcap_engine_tap(vitcap_engine* e, const char* name, void* workspac
 /* GEMM with training extras.  Forward, act == gelu_erf: `zout` (bf16 [M][ldz]) receives gelu'(pre-activation) = Phi(z) + z phi(z),
  * evaluated in fp32 from the same erfc as the activation itself.  Backward (nn.GELU / `_gelu_python`): `aux` (bf16 [M][ldaux]) =
  * that stored factor multiplies the result -- the input-gradient GEMM's epilogue is one multiply per element instead of a gelu'
- * evaluation from a stored z (measured: DESIGN.md 7).  With
+ * evaluation from a stored z (measured: docs/LAB_r01_r04.md 7).  With
  * d->split_k > 1 and M > 256 (weight gradients) K is split raggedly and C is fp32 [split_k][M][ldc]. */
 int vitcap_gemm_ex(const void* A, const void* W, const float* bias, const float* residual, void* C,
                    const vitcap_gemm_desc* d, const void* aux_bf16, int ldaux, void* zout_bf16, int ldz, void* stream);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of BASELINE configs[1..4], rocprof summaries, PMC traffic.
 # Usage: bash scripts_gpu_round.sh [tag] [notests]
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
@@ -9,6 +9,11 @@ python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/tests_$TAG.log
 python -m pytest tests/test_hip_e2e.py -m gpu -q -s -k population 2>&1 | grep "population" > gpurun_out/population_$TAG.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 fi
+# HBM traffic of the kernels (PMC passes) FIRST: bench.py reads the dominant kernel's bytes per launch from profiles/<tag>_hbm_traffic_pmc*.json
+bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
+bash tools/pmc_traffic.sh ${TAG}_b512 "--batch 512" > gpurun_out/traffic_${TAG}_b512.log 2>&1
+cp gpurun_out/traffic_$TAG.json profiles/${TAG}_hbm_traffic_pmc.json
+cp gpurun_out/traffic_${TAG}_b512.json profiles/${TAG}_hbm_traffic_pmc_b512.json
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --no-cpu-baseline > gpurun_out/bench_long_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 50 --warmup 3 --pipeline 0 --no-cpu-baseline > gpurun_out/bench_seq_$TAG.json 2>> gpurun_out/bench_$TAG.err
@@ -20,11 +25,9 @@ python bench.py --steps 30 --warmup 3 --mode scst > gpurun_out/bench_scst_$TAG.j
 python bench.py --steps 10 --warmup 2 --batch 512 --no-cpu-baseline > gpurun_out/bench_b512_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu-baseline > gpurun_out/bench_b1_$TAG.json 2>> gpurun_out/bench_$TAG.err
 (python tools/library_yardstick.py; python tools/library_yardstick.py 295424) 2>&1 | grep -v amdgpu.ids > gpurun_out/library_yardstick_$TAG.txt
-(for f in 1 2; do for m in 36928 295424; do tools/probes/_bin/g4w_probe $m $f; done; done) 2>&1 | cut -c1-260 > gpurun_out/g4w_probe_$TAG.txt
+python bench.py --steps 30 --warmup 3 --mode train --train-graph 0 > gpurun_out/bench_train_eager_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python tools/exact_rate.py 2>&1 | grep EXACT > gpurun_out/exact_rate_$TAG.txt
-python tools/input_side_bench.py 8192 gpurun_out/input_side_$TAG.json > gpurun_out/input_side_$TAG.log 2>&1
-bash tools/pmc_traffic.sh $TAG > gpurun_out/traffic_$TAG.log 2>&1
-bash tools/pmc_traffic.sh ${TAG}_b512 "--batch 512" > gpurun_out/traffic_${TAG}_b512.log 2>&1
+INPUT_SIDE_WORKERS=6,8 OMP_NUM_THREADS=4 python tools/input_side_bench.py 6144 gpurun_out/input_side_$TAG.json > gpurun_out/input_side_$TAG.log 2>&1
 bash tools/pmc_hot.sh $TAG > gpurun_out/pmc_hot_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline --single-region > $R/gpurun_out/prof_$TAG.log 2>&1

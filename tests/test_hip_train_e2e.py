@@ -796,22 +796,35 @@ def test_graph_step_equals_eager(sd_t):
         return b
     batches = [batch(i) for i in range(3)]
 
-    def run(graph):
+    def run(graph, n):
         eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
         eng.use_graphs = graph
-        losses = [float(eng.train_step(b)['masked_loss']) for b in batches]
+        losses = [float(eng.train_step(b)['masked_loss']) for b in batches[:n]]
         torch.cuda.synchronize()
         return losses, eng.P.clone(), eng
-    l_e, p_e, _ = run(False)
-    l_e2, p_e2, _ = run(False)
-    l_g, p_g, eng = run(True)
+    # ONE step from the same state: the replay runs the eager step's kernels with the eager step's arguments, so loss and parameters
+    # differ by no more than two eager runs differ from each other (the float atomics of the reductions)
+    l_e, p_e, _ = run(False, 1)
+    l_e2, p_e2, _ = run(False, 1)
+    l_g, p_g, eng = run(True, 1)
     assert len(eng._graphs) == 1 and len(next(iter(eng._graphs.values()))['segs']) == 1
     spread = float((p_e - p_e2).abs().max())
     diff = float((p_g - p_e).abs().max())
-    print('graph vs eager: losses %s vs %s, max |param diff| %.3e (eager vs eager %.3e)' % (l_g, l_e, diff, spread))
+    print('graph vs eager, one step: loss %.7f vs %.7f, max |param diff| %.3e (eager vs eager %.3e)' % (l_g[0], l_e[0], diff, spread))
+    assert abs(l_g[0] - l_e[0]) < 1e-5
+    assert diff <= 2.0 * spread + 1e-7
+    # three steps on three batches: Adam's sign-like first updates amplify the atomics' last-bit differences from step to step
+    # (measured on MI355X: eager vs eager 1e-4 on the parameters after 3 steps, losses to 1e-3) -- the graph run stays inside that band
+    l_e, p_e, _ = run(False, 3)
+    l_e2, p_e2, _ = run(False, 3)
+    l_g, p_g, eng = run(True, 3)
+    spread = float((p_e - p_e2).abs().max())
+    diff = float((p_g - p_e).abs().max())
+    lsp = max(abs(a - b) for a, b in zip(l_e, l_e2))
+    print('graph vs eager, three steps: losses %s vs %s, max |param diff| %.3e (eager vs eager %.3e, losses %.1e)' % (l_g, l_e, diff, spread, lsp))
     for a, b in zip(l_g, l_e):
-        assert abs(a - b) < 1e-5
-    assert diff <= max(2.0 * spread, 2e-7)
+        assert abs(a - b) < max(4.0 * lsp, 3e-3)
+    assert diff <= 4.0 * spread + 1e-6
     # an unused loss slot: masked_ids[b, 2] = 0 and its masked_pos bit cleared -> same loss as the eager path, no host synchronisation
     b3 = batch(7)
     mp = b3['masked_pos'].clone()

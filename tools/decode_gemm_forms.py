@@ -1,5 +1,5 @@
 """Decode-step GEMM shapes at M = 2 rows per sequence: the resident whole-K form (tile_hint 20 / 21 / 22) the engine uses against the
-4-stage ring forms (hints 1 / 13 / 14 / 15) now that their counted LDS-DMA waits work (DESIGN.md 4.2 i).  GPU box.
+4-stage ring forms (hints 1 / 13 / 14 / 15) now that their counted LDS-DMA waits work (docs/LAB_r01_r04.md 4.2 i).  GPU box.
     python tools/decode_gemm_forms.py [M ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

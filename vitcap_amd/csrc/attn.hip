@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
   }
   // Every VGPR load so far (Q fragments, left-over rows) must be provably complete on ALL paths into the loop: otherwise the
   // compiler's waitcnt pass keeps those registers "possibly pending" across the loop and puts vmcnt(0) in front of the first
-  // MFMAs of every iteration, i.e. it waits for the tile it has just requested (DESIGN.md "waitcnt false dependency")
+  // MFMAs of every iteration, i.e. it waits for the tile it has just requested (docs/LAB_r01_r04.md "waitcnt false dependency")
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   // One key-tile step; MASKED_ is a literal so the left-over masking exists only in the peeled tail instance
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
     f32x16 st[2];                                                                                               \
     if (VC_ATTN_ABL & 1) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { st[0][r] = (float)(r + qi) * 1e-3f; st[1][r] = (float)(r - qi) * 1e-3f; } } else { \
     /* all eight K fragments are requested before the first MFMA (left to itself hipcc reads them two at a time, each pair     \
-       behind its own lgkmcnt(0): four exposed LDS round trips per tile; measured anatomy in DESIGN.md 4.2 iii) */          \
+       behind its own lgkmcnt(0): four exposed LDS round trips per tile; measured anatomy in docs/LAB_r01_r04.md 4.2 iii) */          \
     bf16x8 kfr[2][4];                                                                                           \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
       _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) kfr[kt][ds] = *(const bf16x8*)(kl + kt * 4096 + koff[ds]); \

@@ -416,7 +416,7 @@ int gemm_ln(const void* A, int lda, const void* W, const float* bias, const floa
   d.lda = lda; d.ldw = K; d.ldc = D; d.ldr = D;
   d.act = VITCAP_ACT_NONE; d.out_dtype = VITCAP_OUT_F32;
   d.ln_gamma = g; d.ln_beta = beta; d.ln_eps = eps;
-  // the in-kernel LayerNorm (last arriver of a row block) is built, bit-identical and SLOWER than the separate launch:
+  // the in-kernel LayerNorm (last arriver of a row block) is built, bit-identical and SLOWER than the separate launch (docs/LAB_r01_r04.md 4.3):
   // the counters are handed over only under VITCAP_GEMM_LN_FUSE=1, otherwise vitcap_gemm_ex launches the LayerNorm kernel behind the GEMM
   static const int fuse = [] { const char* e = getenv("VITCAP_GEMM_LN_FUSE"); return e ? atoi(e) : 0; }();
   d.ln_out_bf16 = ln_b; d.ln_out_f32 = ln_f; d.ln_counters = fuse ? cnt : nullptr;
@@ -446,7 +446,7 @@ int gemm_small(const void* A, int lda, const void* W, const float* bias, void* C
   d.act = act; d.out_dtype = out;
   d.tile_hint = hint;
   // K = 768: the 4-stage LDS-DMA ring on 64x32 (32x32 for a handful of rows) tiles.  Round 2 used the resident whole-K form here
-  // too -- a workaround for the ring's counted waits having silently become vmcnt(0) (DESIGN.md 4.2 i); with the waits real the
+  // too -- a workaround for the ring's counted waits having silently become vmcnt(0) (docs/LAB_r01_r04.md 4.2 i); with the waits real the
   // ring wins at every batch size: decode phase 5.54 -> 5.28 ms at 64 images, 3.84 -> 3.59 at one, 8.65 -> 7.78 at 128.
   if (K == 768 && hint >= 20 && hint <= 22) d.tile_hint = M <= 32 ? 14 : 13;
   // K = 3072 (`output.dense`): the same ring with one raw fp32 slab per 768-long k range (hints 23 / 24 = the resident form's

@@ -1622,7 +1622,7 @@ int launch_rowstat_t(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_rowstat(const GemmArgs& a, hipStream_t s) {
-  // re-measured with the ring's counted waits working (DESIGN.md 4.2 x): 3 / 6 / 8 stages and 64x128 tiles are all slower than
+  // re-measured with the ring's counted waits working (docs/LAB_r01_r04.md 4.2 x): 3 / 6 / 8 stages and 64x128 tiles are all slower than
   // 64x64 x 4 stages in the decode loop (decode phase 5.10-5.18 ms against 5.17-5.26)
   return a.M <= 256 ? launch_rowstat_t<2, 2, 4>(a, s) : launch_rowstat_t<4, 4, 2>(a, s);
 }
@@ -1763,7 +1763,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     VC_REQUIRE(d->N == 768 && d->ldc == 768 && d->out_dtype == VITCAP_OUT_F32 && d->act == VITCAP_ACT_NONE && plain_rows && split_k == 1 &&
                    !aux_bf16 && !zout_bf16 && !d->rowstat && !d->colsum,
                "gemm(ln): needs N == ldc == 768, fp32 output, no activation / row remap / split-K / training extras");
-    // in-kernel only on request (ln_counters given) and under the 8-wave one-tile-per-workgroup form.  MEASURED A LOSS (DESIGN.md
+    // in-kernel only on request (ln_counters given) and under the 8-wave one-tile-per-workgroup form.  MEASURED A LOSS (docs/LAB_r01_r04.md
     // 4.3: a row block's last arriver pulls its 786 KB back at ~20 GB/s, 40 us per block on one CU, against 31 us for the LayerNorm
     // kernel over ALL rows on the whole chip): the engine does not ask for it unless VITCAP_GEMM_LN_FUSE=1
     const bool fused = d->ln_counters && d->M >= 2048 && hint == 5 && large_gemm_form(d->M, d->N, hint) < 0;
@@ -1866,7 +1866,7 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
   const bool wide_ok = d->out_dtype == VITCAP_OUT_F32 || residual || (d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)C & 15) == 0);
   if (hint == 12 && wide_ok) return dispatch_256p(a, d->act, d->out_dtype, s);
   {
-    // The 4-wave kernel (gemm4w.hip) behind the two production hints, measured end to end:
+    // The 4-wave kernel (gemm4w.hip) behind the two production hints, measured end to end (docs/LAB_r01_r04.md section 4.3):
     //   auto (one stream): its persistent form, +1.8 % images/s at B = 64 and B = 512 against the 8-wave kernel + planned tile mix;
     //   tile_hint 5 (the 2-slot pipeline: another stream's small kernels must slip in between tiles): the 8-wave kernel stays
     //   (B = 64: 3802 vs 3703 img/s one-tile 4-wave, 3517 persistent -- a persistent grid owns every CU for the whole GEMM, and a

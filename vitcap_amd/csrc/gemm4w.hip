@@ -1,7 +1,7 @@
 // bf16 NT GEMM, 256 x 256 x 64 tiles, FOUR waves of 128 x 128 each (one wave per SIMD, 512 registers per lane):
 //   C = act(A . W^T + bias) (+ residual),  A[M][K], W[N][K] both K-contiguous.
 //
-// Why this form (round 4): the 8-wave kernel of gemm.hip (two waves per SIMD, 128 x 64 per wave) issues
+// Why this form (round 4; docs/LAB_r01_r04.md section 4.3): the 8-wave kernel of gemm.hip (two waves per SIMD, 128 x 64 per wave) issues
 // 24 ds_read_b128 per 64 MFMAs and pays two s_barriers per 16 MFMAs to alternate its wave pairs; its instruction stream is 29 %
 // MFMA.  With ONE wave per SIMD the 128 x 128 wave tile keeps its 256 accumulator registers in the AGPR half of the unified
 // 512-entry file and both k-halves' fragments (2 x 16 x 4 VGPRs) in the VGPR half:
@@ -254,7 +254,15 @@ __device__ __forceinline__ void k_tile_e(f32x4 (&acc)[MI][8], Frags& f, const Lo
 // One k-tile t (cur = its buffer's byte offset): k-half 0, the mid-tile rendezvous, k-half 1 (whose DMA, MODE1 == 1, requests the
 // k-tile at byte offset kb2 of the panels `src` -- two k-tiles ahead in the stream, possibly the NEXT output tile's -- into `cur`).
 template <int MI, int MODE1, bool FIRST>
+__device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2,
+                                       const Src& pf, uint32_t pf_soff);
+template <int MI, int MODE1, bool FIRST>
 __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2) {
+  k_tile<MI, MODE1, FIRST>(acc, f, L, src, cur, kb2, src, 0xfffffff0u);
+}
+template <int MI, int MODE1, bool FIRST>
+__device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2,
+                                       const Src& pf, uint32_t pf_soff) {
 #ifdef VC_4W_EARLY
   k_tile_e<MI, MODE1, FIRST>(acc, f, L, src, cur, kb2);
   return;
@@ -272,7 +280,9 @@ __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop
 #endif
   half_steps<MI, MODE1, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
 #ifdef VC_4W_PREFETCH
-  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, kb2 + VC_4W_PF_AHEAD * 128);      // every k-tile issues exactly one (keeps the counted wait exact)
+  // whole rows of the NEXT output tile's A panel (this workgroup's share of them), a few rows per k-tile: every k-tile issues exactly
+  // one instruction (keeps the counted wait exact); lanes without a line and the one-tile kernel's calls are out of range (no fetch)
+  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, pf.ra, pf_soff);
 #endif
   if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -681,17 +691,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   tile_of(p, pos, tm, tn);
   Src src = make_src(p, tm * (32 * MI), tn * 256);
 #ifdef VC_4W_PREFETCH
-  // the tiles of a column group that share an A panel split its rows: sibling c of gw takes the rows r with r % gw == c
   // (probe: the fp32 / residual forms own all 160 KiB of LDS already -- no scratch line, no prefetch, their timing is not the question)
   L.lds_pf = (OUT_F32 || HAS_RES) ? 0u : lds_addr(smem) + 2 * BUF_BYTES + w * 256;
-  {
-    const int gw_ = p.group_n < p.tiles_n ? p.group_n : p.tiles_n, row_ = w * 64 + lane;
-#ifdef VC_4W_PF_ALL
-    L.voff_pf = row_ < 32 * MI ? (uint32_t)(row_ * p.lda * 2) : 0xfffffff0u;
-#else
-    L.voff_pf = (row_ < 32 * MI && row_ % gw_ == tn % gw_) ? (uint32_t)(row_ * p.lda * 2) : 0xfffffff0u;
-#endif
-  }
+  uint32_t pf_step = 0;      // byte offset between the row chunks of consecutive k-tiles
 #endif
   f32x4 acc[MI][8];
   Frags f;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   dma_tile<MI>(L, src, 0, 0, PIECES);
   dma_tile<MI>(L, src, BUF_BYTES, 128, PIECES);
 #ifdef VC_4W_PREFETCH
-  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, 2 * 128);
+  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, 0);      // out of range: no fetch, one instruction for the counted wait
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8 + 1) : "memory");
 #else
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
@@ -723,18 +725,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       nsrc.ra[2] = 0;
       nsrc.rw[2] = 0;
     }
+#ifdef VC_4W_PREFETCH
+    {
+      // The column siblings of the next tile (same tm, the gw tiles of its column group) split its A panel by rows: sibling c takes
+      // rows c, c + gw, c + 2 gw ...; k-tile t of THIS tile requests RPS of them, whole rows (nk lines of 128 B: one DRAM page).
+      // lane -> (row within the chunk, line of the row)
+      const int gw_ = p.group_n < p.tiles_n ? p.group_n : p.tiles_n;
+#ifdef VC_4W_PF_ALL
+      const int gwe = 1, c_ = 0;
+#else
+      const int gwe = gw_, c_ = tn % gw_;
+#endif
+      const int share = (32 * MI - c_ + gwe - 1) / gwe;
+      const int rps = (share + nk - 1) / nk;
+      const int Lq = w * 64 + lane;
+      const int jr = (int)((float)Lq / (float)nk), line = Lq - jr * nk;       // exact for these magnitudes (Lq < 256, nk <= 48)
+      L.voff_pf = (jr < rps) ? (uint32_t)((c_ + jr * gwe) * p.lda * 2 + line * 128) : 0xfffffff0u;
+      pf_step = (uint32_t)(rps * gwe * p.lda * 2);
+    }
+#define PF_ARGS(t_) , nsrc, (uint32_t)(t_) * pf_step
+#else
+#define PF_ARGS(t_)
+#endif
     // k-tiles 0 .. nk-3 request k-tiles 2 .. nk-1 of this tile; k-tiles nk-2, nk-1 request k-tiles 0, 1 of the next tile (nk >= 3)
     STAMP_AT(pos, 0);
-    k_tile<MI, 1, true>(acc, f, L, src, cur, 2 * 128);
+    k_tile<MI, 1, true>(acc, f, L, src, cur, 2 * 128 PF_ARGS(0));
     cur = BUF_BYTES - cur;
     STAMP_AT(pos, 1);
     for (int t = 1; t < nk - 2; ++t) {
-      k_tile<MI, 1, false>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128);
+      k_tile<MI, 1, false>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128 PF_ARGS(t));
       cur = BUF_BYTES - cur;
     }
-    k_tile<MI, 1, false>(acc, f, L, nsrc, cur, 0);
+    k_tile<MI, 1, false>(acc, f, L, nsrc, cur, 0 PF_ARGS(nk - 2));
     cur = BUF_BYTES - cur;
-    k_tile<MI, 4, false>(acc, f, L, nsrc, cur, 128);
+    k_tile<MI, 4, false>(acc, f, L, nsrc, cur, 128 PF_ARGS(nk - 1));
+#undef PF_ARGS
     cur = BUF_BYTES - cur;
     fence_accumulators<MI>(acc);
     STAMP_AT(pos, 2);
@@ -815,7 +840,7 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
     VC_FUNC_SMEM(kern, smem);
     // VITCAP_GEMM_4W_TIGHT=1 (experiments): the fewest workgroups (a multiple of 8: every XCD the same number) that finish in the same
     // number of rounds as all CUs would -- 1305 tiles take 6 rounds on 256 CUs and on 224 -- leaving the other CUs to whatever else
-    // runs.  Measured: no gain alone (19.55 vs 19.59 ms, B = 512 124.3 vs 123.3), and inside the batch pipeline only a
+    // runs.  Measured (docs/LAB_r01_r04.md 4.3): no gain alone (19.55 vs 19.59 ms, B = 512 124.3 vs 123.3), and inside the batch pipeline only a
     // CONSTANT reservation helps the decode chain (VITCAP_GEMM_4W_RESERVE=32 ties the 8-wave kernel there), so the default is off
     static const int tight = [] { const char* e = getenv("VITCAP_GEMM_4W_TIGHT"); return e ? atoi(e) : 0; }();
     int grid = p.n_big < n_cu ? p.n_big : n_cu;

@@ -91,7 +91,7 @@ class BucketedAllReduce(object):
         self.rank = dist.get_rank() if self.exchange else 0
         self.cuda = flat.is_cuda
         # high priority: the collective's few workgroups (RCCL channels) must not queue behind GEMM grids that fill every CU --
-        # the dispatcher serves a higher-priority queue first whenever a workgroup slot frees
+        # the dispatcher serves a higher-priority queue first whenever a workgroup slot frees (docs/LAB_r01_r04.md section 7)
         self.comm = torch.cuda.Stream(device=flat.device, priority=-1) if (self.cuda and self.exchange) else None
         self.algo = algo or os.environ.get('VITCAP_DP_REDUCE', 'all_reduce')
         if self.algo not in ('all_reduce', 'rs_ag'):

@@ -44,7 +44,7 @@ def _build_tree(root, spec, tie_weights):
 
 
 def _encode_stream(dev):
-    """The pipeline's encoder stream.  VITCAP_ENC_CUS = n < 256 (experiment, DESIGN.md 4.2 vi) confines it to the CUs of the
+    """The pipeline's encoder stream.  VITCAP_ENC_CUS = n < 256 (experiment, docs/LAB_r01_r04.md 4.2 vi) confines it to the CUs of the
     low n mask bits (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8), which leaves 256 - n CUs that the encoder's GEMM
     workgroups never occupy for the decode chain's dependent launches to start on."""
     import os

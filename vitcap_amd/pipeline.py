@@ -431,6 +431,10 @@ class CaptionUniPipeline(object):
                           max_iter=max_iter, label_smoothing=float(self.cfg.label_smoothing), dist=dist,
                           attn_dropout=attn_drop, hidden_dropout=float(self.cfg.drop_out or 0), dropout_seed=int(self.cfg.random_seed or 0),
                           tag_loss='focal' if self.cfg.loss == 'focal' else 'bce')     # modeling_bert.py:713-717
+        # graph mode (train.py train_step_graph): the cross-entropy step replays hipGraph segments captured once per batch shape -- the
+        # host issues ~11 calls per step instead of ~750 (41.7 -> 0.9-8 ms of host time per step, profiles/r05_train_graph.txt), which is
+        # what keeps 8 ranks x (loader processes + launcher) on one host from serialising on Python.  `train_graph: false` keeps eager.
+        eng.use_graphs = self.cfg.train_graph is None or bool(self.cfg.train_graph)
         per_gpu = max(1, int(self.cfg.effective_batch_size) // self.world)
         ckpt = Checkpointer(model=_EngineState(eng), optimizer=_EngineState(eng, 'optimizer'),
                             scheduler=_EngineState(eng, 'scheduler'), save_dir=self.get_snapshot_dir(),

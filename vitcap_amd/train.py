@@ -34,7 +34,7 @@ from . import weights as W
 from ._lib import check, lib
 
 CH = 1024           # optimizer chunk (elements)
-_FUSE_BIAS = os.environ.get('VITCAP_TRAIN_FUSED_BIAS', '1') != '0'      # A/B switch of the measurement in DESIGN.md 7
+_FUSE_BIAS = os.environ.get('VITCAP_TRAIN_FUSED_BIAS', '1') != '0'      # A/B switch of the measurement in docs/LAB_r01_r04.md 7
 NV = 577
 SV = 578
 T = 20
