@@ -185,3 +185,13 @@ def test_recipe_is_reproducible():
     assert (st.mean(axis=(1, 2, 3)).std() > 0.15), 'the images must differ in their colour offsets'
     vb = W.gen_tensor('module.cls.predictions.bias', (30522,), 'vbias', 0, 0.25)     # the untied golden's vocabulary-bias sigma
     assert abs(float(vb.std()) - 0.25) < 1e-2 and (vb * 4 == a).all()
+
+
+def test_gemm_reserve_cus_host_state(L):
+    """vitcap_gemm_reserve_cus (host-side atomic, no launch): returns the previous value, rounds up to whole XCD rows of 8, clamps
+    negatives to 0 -- what BucketedAllReduce toggles around the buckets in flight."""
+    assert L.lib.vitcap_gemm_reserve_cus(0) >= 0
+    assert L.lib.vitcap_gemm_reserve_cus(13) == 0
+    assert L.lib.vitcap_gemm_reserve_cus(-5) == 16
+    assert L.lib.vitcap_gemm_reserve_cus(0) == 0
+    assert L.lib.vitcap_set_dropout_salt(None) == 0

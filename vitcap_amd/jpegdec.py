@@ -1,5 +1,6 @@
-"""Host-side image decode for loader worker PROCESSES: imports nothing but the standard library, numpy and Pillow, so that a spawned
-worker starts in a fraction of a second and never touches the GPU runtime (vitcap_amd.imageio imports torch and the HIP library).
+"""Host-side image decode for loader worker PROCESSES: this module imports nothing but the standard library, numpy and Pillow and never
+touches the GPU runtime (vitcap_amd.imageio imports torch and the HIP library).  Note that a SPAWNED worker re-imports the parent's
+`__main__` module as well (run.py / bench.py import torch: ~1.5 s and ~300 MB per worker at start-up, nothing per task).
 
 The reference decodes inside DataLoader worker processes (uni_pipeline.py:333-339, transform.py:106-136: cv2.imdecode); threads of
 one Python process top out near 2 000 images/s on the GPU box however many are started (base64 and the numpy copy hold the GIL:
@@ -88,3 +89,15 @@ def decode_rows(tsv_path, row_ids):
     """-> (keys, images): the pipe-return fallback (no shared memory)."""
     recs = _rows(tsv_path, row_ids)
     return [r[0] for r in recs], decode_many([r[-1] for r in recs])
+
+
+def pin_worker(counter, first, stride):
+    """Pool initializer (VITCAP_LOADER_CPUS): this worker takes the next CPU of the sequence first, first + stride, ..."""
+    import os
+    with counter.get_lock():
+        i = counter.value
+        counter.value += 1
+    try:
+        os.sched_setaffinity(0, {first + i * stride})
+    except OSError:
+        pass

@@ -518,7 +518,17 @@ class CaptionUniPipeline(object):
             else:
                 import multiprocessing as mp
                 from multiprocessing import shared_memory
-                pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))
+                ctx = mp.get_context('spawn')
+                # VITCAP_LOADER_CPUS=<first>[:<stride>] (experiment): worker i is pinned to CPU first + i * stride (default stride 1) -- under a
+                # CFS quota on a many-core host the scheduler otherwise migrates the decoders across the whole machine
+                pin = os.environ.get('VITCAP_LOADER_CPUS')
+                if pin:
+                    from .jpegdec import pin_worker
+                    first, _, stride = pin.partition(':')
+                    pool = ProcessPoolExecutor(max_workers=workers, mp_context=ctx, initializer=pin_worker,
+                                               initargs=(ctx.Value('i', 0), int(first), int(stride or 1)))
+                else:
+                    pool = ProcessPoolExecutor(max_workers=workers, mp_context=ctx)
                 # decoded pixels come back through shared memory (vitcap_amd/jpegdec.py); a slab holds one task's images and is reused
                 # two batches after the batch that read it went to the GPU
                 slab_bytes = int(self.cfg.loader_slab_mb or 24) << 20
