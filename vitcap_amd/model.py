@@ -518,7 +518,9 @@ class ImageCaptioning(nn.Module):
             ids, lp = self._out_buffers(B, opts, dev)
             check(lib.vitcap_engine_decode(self._engine, B, C.byref(opts), wp, need, C.c_void_p(ids.data_ptr()),
                                            C.c_void_p(lp.data_ptr()), None, C.c_void_p(pipe['dec'].cuda_stream)), 'engine_decode')
-            done = torch.cuda.Event()
+            # blocking: a host thread that waits for this batch SLEEPS (hipEventBlockingSync) instead of spinning on a core -- under a
+            # CPU quota (the GPU pool gives 16 cores) spinning waiters starve the JPEG decode workers of the loader
+            done = torch.cuda.Event(blocking=True)
             done.record(pipe['dec'])
         pipe['done'][slot] = done
         return _Pending(ids, lp, done, image)

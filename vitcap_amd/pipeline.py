@@ -94,9 +94,11 @@ def _prefetched(gen, device, depth=2):
         try:
             if device.type == 'cuda':
                 torch.cuda.set_device(device)
+            ev = torch.cuda.Event(blocking=True) if device.type == 'cuda' else None     # sleep, do not spin (see generate_async)
             for b in gen:
-                if device.type == 'cuda':
-                    torch.cuda.current_stream(device).synchronize()
+                if ev is not None:
+                    ev.record(torch.cuda.current_stream(device))
+                    ev.synchronize()
                 if not put(b):
                     break
             else:
@@ -707,7 +709,12 @@ class CaptionUniPipeline(object):
                     else:
                         out = model(batch)
                     pending.append((batch, out, flag, expect_n))
-                    while len(pending) > (1 if overlap else 0):
+                    # TWO batches stay in flight behind the one just submitted: batch k-2 is collected (its decode finished before
+                    # batch k-1's started) while k-1 decodes and k encodes, so the detokeniser / JSON / TSV work of this thread (~5 ms
+                    # per 64 captions) never sits between two submissions -- with one batch in flight the GPU ran batch k's decode
+                    # alone while this thread was still writing batch k-1's rows (round 5: 21 vs 16 ms per batch from disk).  The
+                    # outputs of a batch are its own tensors; its workspace slot is re-used by batch k+1 behind a stream-side wait.
+                    while len(pending) > (2 if overlap else 0):
                         for key, js in collect(pending.pop(0)):
                             yield key, js
                 for entry in pending:
