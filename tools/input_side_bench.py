@@ -112,8 +112,23 @@ def main():
     sweep = ((8, True), (6, False), (8, False), (10, False), (12, False), (14, False), (16, False))
     if os.environ.get('INPUT_SIDE_WORKERS'):
         sweep = tuple((int(w), False) for w in os.environ['INPUT_SIDE_WORKERS'].split(','))
+    def cpu_stat():
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open('/sys/fs/cgroup/cpu.stat').read().splitlines())}
+        except Exception:
+            return {}
+    res['cgroup_cpu'] = {}
     for workers, threads in sweep:
+        c0 = cpu_stat()
         st, wall = run_once('w%d%d' % (workers, threads), workers, threads)
+        c1 = cpu_stat()
+        if c0 and c1:      # whole run (model load included): CPU seconds used by the cgroup, periods in which the quota throttled it
+            res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')] = {
+                'wall_s': round(wall, 2), 'cpu_s': round((c1['usage_usec'] - c0['usage_usec']) / 1e6, 2),
+                'avg_cores': round((c1['usage_usec'] - c0['usage_usec']) / 1e6 / wall, 2),
+                'periods': c1.get('nr_periods', 0) - c0.get('nr_periods', 0), 'throttled_periods': c1.get('nr_throttled', 0) - c0.get('nr_throttled', 0),
+                'throttled_s': round((c1.get('throttled_usec', 0) - c0.get('throttled_usec', 0)) / 1e6, 2)}
+            print('cgroup cpu', res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')], flush=True)
         e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
         print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s)' % (
             workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall), flush=True)

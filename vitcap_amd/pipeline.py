@@ -510,7 +510,7 @@ class CaptionUniPipeline(object):
             from .jpegdec import decode_rows, decode_rows_into
             import numpy as np
             workers = max(1, int(self.cfg.num_workers or 1))
-            chunk = 8                                                  # images per worker task
+            chunk = int(os.environ.get('VITCAP_LOADER_CHUNK', 8))      # images per worker task
             per_batch = (bs + chunk - 1) // chunk
             ahead = max(2, (2 * workers + per_batch - 1) // per_batch + 1)   # batches in flight: two tasks per worker
             starts = list(range(0, len(mine), bs))
@@ -687,7 +687,7 @@ class CaptionUniPipeline(object):
         def gen_rows():
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
             with torch.no_grad():
-                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or 2)):
+                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or os.environ.get('VITCAP_LOADER_PREFETCH', 4))):
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
                     flag = None
