@@ -459,7 +459,7 @@ def test_two_process_data_parallel_step(tmp_path, path):
 def _rccl_one_rank_worker(port, out, tmp, algo):
     import os
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', VITCAP_DP_REDUCE=algo)
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VITCAP_DP_REDUCE='rs_ag' if algo == 'bf16' else algo)
     import torch
     from vitcap_amd import dist_util as D
     from vitcap_amd import weights as W
@@ -471,7 +471,10 @@ def _rccl_one_rank_worker(port, out, tmp, algo):
     dist = D.init('nccl', torch.device('cuda', 0))           # RCCL communicator of one rank, bound to the device as bench.py does
     assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
     eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda:0', max_iter=10, attn_dropout=0.0, dist=dist)
-    eng.reducer = BucketedAllReduce(eng.G, eng.reducer.buckets, eng.reducer.stages, dist, algo=algo, force_exchange=True)
+    wire = 'bf16' if algo == 'bf16' else 'f32'               # 'bf16': all-to-all of bf16 slices + fp32 accumulate + all-gather (dist_util.py)
+    eng.reducer = BucketedAllReduce(eng.G, eng.reducer.buckets, eng.reducer.stages, dist, algo='rs_ag' if algo == 'bf16' else algo,
+                                    force_exchange=True, wire=wire)
+    assert eng.reducer.wire == wire and eng.reducer.reserve_cus == 16
     assert eng.reducer.exchange and eng.reducer.comm is not None and eng.reducer._native_rs
     b = {k: v.cuda() for k, v in synthetic_train_inputs(2).items()}
     b['image'] = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
@@ -485,7 +488,7 @@ def _rccl_one_rank_worker(port, out, tmp, algo):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag'])
+@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag', 'bf16'])
 def test_rccl_exchange_one_rank_group(tmp_path, algo):
     """The `nccl` (= RCCL) branch of the gradient exchange on the one GPU a test box has: a process group of ONE rank, the exchange
     forced (BucketedAllReduce(force_exchange=True)): communicator creation with device_id, every bucket's collective enqueued on the
@@ -518,10 +521,12 @@ def test_rccl_exchange_one_rank_group(tmp_path, algo):
     want = eng.train_step(b)
     torch.cuda.synchronize()
     assert abs(loss - float(want['masked_loss'])) < 1e-5
-    assert abs(gnorm - eng.grad_norm()) < 1e-3 * gnorm
+    # 'bf16' (new in round 5: RCCL all_to_all_single + all_gather_into_tensor on bf16 staging buffers): the gradients come back rounded
+    # to bf16 (2^-9 relative per element), the clip coefficient and Adam's sign-like first step hardly notice
+    assert abs(gnorm - eng.grad_norm()) < (5e-3 if algo == 'bf16' else 1e-3) * gnorm
     got = torch.load(str(tmp_path / ('p_%s.pt' % algo)))
     d = (eng.P.cpu() - got).abs()
-    assert float(d.mean()) < 2e-6, float(d.mean())
+    assert float(d.mean()) < (5e-6 if algo == 'bf16' else 2e-6), float(d.mean())
 
 
 def test_scst_logprob_gradient_vs_oracle(sd_t):
