@@ -155,6 +155,33 @@ def test_fused_bias_gradients(ops):
         ops.gemm_ex(dy[:512], wt, colsum=torch.zeros(N, device='cuda'))
 
 
+@pytest.mark.parametrize('M', [2308, 36928])
+def test_gemm_4wave_training_extras_bit_identical(ops, M):
+    """The training extras of vitcap_gemm_ex (zout = gelu'(pre-activation) next to the activation; aux = the stored factor multiplied in;
+    colsum = bias gradient added by the epilogue) in the persistent 4-wave kernel's register epilogue (round 5; tile_hint 42)
+    against the 8-wave kernel that carries them by default (tile_hint 5): `out` and `zout` bit for bit, column sums to the fp32 atomics'
+    order; rows past M (a ragged last tile) add nothing to the sums."""
+    from vitcap_amd._lib import lib
+    N, K = 1024, 768
+    x = _bf(_rand((M, K), 51)).cuda()
+    w = _bf(_rand((N, K), 52, 0.05)).cuda()
+    bias = _rand((N,), 53).cuda()
+    z4 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    z8 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    g4 = ops.gemm_ex(x, w, bias=bias, act=1, zout=z4, tile_hint=42)         # 4-wave persistent + extras
+    g8 = ops.gemm_ex(x, w, bias=bias, act=1, zout=z8, tile_hint=5)          # 8-wave kernel
+    assert torch.equal(g4, g8) and torch.equal(z4, z8)
+    f = _bf(_rand((M, N), 54, 0.6) + 0.5).cuda()
+    for aux in (f, None):
+        c4 = torch.full((N,), 1.0, device='cuda')
+        c8 = torch.full((N,), 1.0, device='cuda')
+        d4 = ops.gemm_ex(x, w, aux=aux, colsum=c4, tile_hint=42)
+        d8 = ops.gemm_ex(x, w, aux=aux, colsum=c8, tile_hint=5)
+        assert torch.equal(d4, d8)
+        assert _rel(c4, c8) < 1e-5 and _rel(c4, 1.0 + d4.float().sum(0)) < 1e-5
+        assert torch.equal(ops.gemm_ex(x, w, aux=aux, tile_hint=42), d4)     # aux without the column sums
+
+
 @pytest.mark.parametrize('p_drop', [0.0, 0.1, 0.5])
 def test_attn_joint_causal_forward_backward(ops, p_drop):
     """The decoder's joint attention under teacher forcing in ONE pass of the dense MFMA kernels (causal_from = 578):

@@ -61,14 +61,16 @@ def main():
     t = TSVFile(os.path.join(tmp, 'data', 'toy', 'test.tsv'))
     recs = [t[i][1] for i in range(min(N, 1024))]
     dec = {}
-    for th in (1, 8, 16, 32, 64):
+    skip_dec = bool(os.environ.get('INPUT_SIDE_SKIP_DECODE'))       # the decode-only sweeps take a minute of box time
+    for th in (() if skip_dec else (1, 8, 16, 32, 64)):
         with ThreadPoolExecutor(th) as pool:
             list(pool.map(decode_image, recs[:64]))
             t0 = time.perf_counter()
             list(pool.map(decode_image, recs))
             dec[th] = round(len(recs) / (time.perf_counter() - t0), 1)
     res['decode_only_images_per_s_by_threads'] = dec
-    res['decode_ms_per_image_one_thread'] = round(1e3 / dec[1], 2)
+    if dec:
+        res['decode_ms_per_image_one_thread'] = round(1e3 / dec[1], 2)
     # ---- the pipeline from disk
     enc = os.path.join(tmp, 'enc')
     os.makedirs(enc)
@@ -83,7 +85,7 @@ def main():
     from concurrent.futures import ProcessPoolExecutor
     from vitcap_amd.jpegdec import decode_many
     decp = {}
-    for th in (8, 16, 32):
+    for th in (() if skip_dec else (8, 16, 32)):
         with ProcessPoolExecutor(th, mp_context=mp.get_context('spawn')) as pool:
             chunks = [recs[c:c + 8] for c in range(0, len(recs), 8)]
             list(pool.map(decode_many, chunks[:th]))
@@ -109,6 +111,43 @@ def main():
         getattr(run, kw.pop('type'))(**kw)
         torch.cuda.synchronize()
         return dict(P.LAST_PREDICT_STATS), time.perf_counter() - t0
+    def run_fed(name, make_batches):
+        """The same predict loop (2-slot caption pipeline, detokeniser, predict TSV) fed by `make_batches(pipeline)` instead of the
+        loader: what the GPU + this process sustain when JPEG decoding costs nothing."""
+        param = {'full_expid': name, 'max_iter': 10, 'model_file': ck, 'text_encoder_type': enc, 'tagemb': 'cls', 'test_batch_size': 64,
+                 'force_predict': True, 'crop_pct': 1.0, 'test_crop_size': 384, 'num_workers': 0, 'test_data': 'toy', 'test_split': 'test',
+                 'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}
+        pipe = run._build(param)[0]
+        pipe.cfg.test_batches = make_batches(pipe)
+        P.LAST_PREDICT_STATS.clear()
+        pipe.ensure_predict()
+        torch.cuda.synchronize()
+        return round(P.LAST_PREDICT_STATS['images_per_sec'], 1)
+
+    if os.environ.get('INPUT_SIDE_CEILING'):
+        from vitcap_amd.imageio import ImagePreprocessor
+        nb = N // 64
+        dev = torch.device('cuda', 0)
+        decoded = [np.ascontiguousarray(decode_image(r)) for r in recs[:256]]
+        pinned = [torch.from_numpy(a).pin_memory().numpy() for a in decoded]       # page-locked, as the loader's slabs are
+
+        def resident(pipe):
+            pre = ImagePreprocessor(dev, 384, 1.0)
+            img = pre(pinned[:64])
+            torch.cuda.synchronize()
+            for b in range(nb):
+                yield {'image': img, 'key': ['img%d' % (b * 64 + i) for i in range(64)]}
+
+        def decoded_host(pipe):
+            pre = ImagePreprocessor(dev, 384, 1.0)
+            for b in range(nb):
+                imgs = [pinned[(b * 64 + i) % 256] for i in range(64)]
+                yield {'image': pre(imgs), 'key': ['img%d' % (b * 64 + i) for i in range(64)]}
+        res['ceiling'] = {}
+        for rep in range(2):
+            res['ceiling']['resident_batches_through_predict_%d' % rep] = run_fed('res%d' % rep, resident)
+            res['ceiling']['decoded_pinned_host_images_through_predict_%d' % rep] = run_fed('dech%d' % rep, decoded_host)
+        print('ceiling', res['ceiling'], flush=True)
     sweep = ((8, True), (6, False), (8, False), (10, False), (12, False), (14, False), (16, False))
     if os.environ.get('INPUT_SIDE_WORKERS'):
         sweep = tuple((int(w), False) for w in os.environ['INPUT_SIDE_WORKERS'].split(','))
@@ -130,8 +169,10 @@ def main():
                 'throttled_s': round((c1.get('throttled_usec', 0) - c0.get('throttled_usec', 0)) / 1e6, 2)}
             print('cgroup cpu', res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')], flush=True)
         e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
-        print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s)' % (
-            workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall), flush=True)
+        print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s); loader seconds %s' % (
+            workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall,
+            st.get('loader_seconds')), flush=True)
+        res.setdefault('loader_seconds', {})['%d %s' % (workers, 'threads' if threads else 'processes')] = st.get('loader_seconds')
     res['pipeline_from_tsv_images_per_s'] = e2e
     res['note'] = ('run.py pipeline_eval_multi, batch 64, 2-slot caption pipeline, predictions written as the reference\'s predict TSV; '
                    'steady state = from the second batch\'s captions to the last row')

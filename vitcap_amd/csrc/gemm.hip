@@ -1796,6 +1796,10 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     VC_REQUIRE(d->out_dtype == VITCAP_OUT_BF16 && !residual && plain_rows && split_k == 1 && d->M >= 2048 && d->N % 8 == 0 && d->ldc % 8 == 0 &&
                    (!aux_bf16 || ldaux % 8 == 0) && (!zout_bf16 || ldz % 8 == 0) && d->act != VITCAP_ACT_TANH,
                "gemm(colsum): needs bf16 output, no residual / row remap / split-K, M >= 2048, N, ldc (ldaux, ldz) multiples of 8");
+    // the persistent 4-wave kernel's register epilogue carries the column sums too (round 5): on request (tile_hint 42), or where the
+    // automatic choice allows it (vc_4w_extras_auto: off by default, slower inside the training step)
+    if ((hint == 42 || (hint == 0 && vc_4w_extras_auto(a) && large_gemm_form(d->M, d->N, hint, false) == 2)) && vc_4w_supports(a, d->act))
+      return vc_dispatch_4w(a, d->act, d->out_dtype, s, 2);
     return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);
   }
   if (hint == 23 || hint == 24) {
@@ -1873,9 +1877,18 @@ extern "C" int vitcap_gemm_ex(const void* A, const void* W, const float* bias, c
     //   512-register workgroup leaves no room for a co-resident decode wave), at every size since round 5 (large_gemm_form).
     // VITCAP_GEMM_4W = "<form for tile_hint 5>,<form for auto>" overrides (-1 = 8-wave kernel, 0..2 = form; experiments).
     const int form = large_gemm_form(d->M, d->N, hint, d->out_dtype == VITCAP_OUT_F32 || residual != nullptr);
-    if (form >= 0 && form <= 2 && d->M >= 2048 && vc_4w_supports(a, d->act)) return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);
+    // training extras (aux / zout / colsum) ride in the persistent form's register epilogue only (round 5), and only where
+    // vc_4w_extras_auto says so
+    const bool extras = aux_bf16 || zout_bf16 || d->colsum;
+    if (form >= 0 && form <= 2 && d->M >= 2048 && (!extras || (form == 2 && d->out_dtype == VITCAP_OUT_BF16 && vc_4w_extras_auto(a))) &&
+        vc_4w_supports(a, d->act))
+      return vc_dispatch_4w(a, d->act, d->out_dtype, s, form);
   }
-  if (hint >= 40 && hint <= 42) return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent
+  if (hint >= 40 && hint <= 42) {
+    VC_REQUIRE(!(aux_bf16 || zout_bf16 || d->colsum) || (hint == 42 && d->out_dtype == VITCAP_OUT_BF16),
+               "gemm(4-wave): aux / zout / colsum need the persistent form (tile_hint 42) and a bf16 output");
+    return vc_dispatch_4w(a, d->act, d->out_dtype, s, hint - 40);
+  }   // 4 waves x 128x128, one wave per SIMD (gemm4w.hip): 40 LDS epilogue, 41 register epilogue, 42 persistent
   if (hint == 30) return dispatch_256<4>(a, d->act, d->out_dtype, s, 3);    // every tile 192 x 256 (tile-cost measurement)
   if (hint == 31) return dispatch_256<4>(a, d->act, d->out_dtype, s, 2);    // every tile 128 x 256
   if (hint == 5 || hint == 32) return dispatch_256<4>(a, d->act, d->out_dtype, s, 0);    // 256 x 256 tiles only (no short tail tiles)

@@ -427,6 +427,96 @@ __device__ __forceinline__ void epilogue_regs_fast(f32x4 (&acc)[MI][8], const Ge
   }
 }
 
+// ---- the same epilogue with the TRAINING extras of vitcap_gemm_ex (round 5; gemm.hip's 8-wave kernel carried them alone until now:
+// 16 % of a training step ran on its one-tile form only because of them):
+//   aux    : out = (acc + bias) * aux[m][n]            (the stored gelu' factor: fc2's input gradient)
+//   zout   : zout[m][n] = gelu'(acc + bias)            (next to out = gelu(acc + bias): fc1's forward; one erfc evaluation for both)
+//   colsum : colsum[n] += sum over the tile's valid rows of the ROUNDED outputs (the bias gradient of the layer `out` is the output
+//            gradient of; what vitcap_colsum_bf16 over the stored output would add)
+// Same arithmetic per element and the same order as gemm.hip's epilogue: bit-identical `out` / `zout`.  aux arrives in the MFMA layout
+// (8 bytes per lane and n-tile: the 4 columns the lane holds), requested one m-tile ahead.
+template <int ACT, int MI>
+__device__ __forceinline__ void epilogue_regs_fast_x(f32x4 (&acc)[MI][8], const GemmArgs& p, const int row_w, const int col_w, const int lane) {
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 bias4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias4[j] = p.bias ? *(const f32x4*)(p.bias + col_w + j * 16 + fk * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rc = rows_rsrc((const bf16_t*)p.C + (size_t)row_w * p.ldc, (long long)(p.M - row_w) * p.ldc * 2);
+  const __amdgpu_buffer_rsrc_t rz = rows_rsrc(p.zout ? p.zout + (size_t)row_w * p.ldz : nullptr, p.zout ? (long long)(p.M - row_w) * p.ldz * 2 : 0);
+  const __amdgpu_buffer_rsrc_t ra = rows_rsrc(p.aux ? p.aux + (size_t)row_w * p.ldaux : nullptr, p.aux ? (long long)(p.M - row_w) * p.ldaux * 2 : 0);
+  unsigned voff = (unsigned)(frow * p.ldc + col_w + (fk & 1) * 16 + (fk >> 1) * 8) * 2u;
+  unsigned voff_z = (unsigned)(frow * p.ldz + col_w + (fk & 1) * 16 + (fk >> 1) * 8) * 2u;
+  unsigned voff_a = (unsigned)(frow * p.ldaux + col_w + fk * 4) * 2u;
+  const unsigned istep = 16u * p.ldc * 2u, istep_z = 16u * p.ldz * 2u, istep_a = 16u * p.ldaux * 2u;
+  const bool has_aux = p.aux != nullptr, has_z = p.zout != nullptr, has_cs = p.colsum != nullptr;
+  u32x2_t ax[2][8];
+#define ISSUE_AUX(i_)                                                                                              \
+  if (has_aux) {                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
+      ax[(i_) & 1][j] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(ra, voff_a + j * 32, 0, 0)); \
+    voff_a += istep_a;                                                                                             \
+  }
+  ISSUE_AUX(0);
+  float cs[4][8];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[jj][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (i + 1 < MI) { ISSUE_AUX(i + 1); }
+    const bool row_ok = row_w + i * 16 + frow < p.M;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      f32x4 ve = acc[i][2 * jj] + bias4[2 * jj], vo = acc[i][2 * jj + 1] + bias4[2 * jj + 1];
+      if (has_aux) {
+        const u32x2_t ae = ax[i & 1][2 * jj], ao = ax[i & 1][2 * jj + 1];
+        ve *= f32x4{__uint_as_float(ae[0] << 16), __uint_as_float(ae[0] & 0xffff0000u), __uint_as_float(ae[1] << 16), __uint_as_float(ae[1] & 0xffff0000u)};
+        vo *= f32x4{__uint_as_float(ao[0] << 16), __uint_as_float(ao[0] & 0xffff0000u), __uint_as_float(ao[1] << 16), __uint_as_float(ao[1] & 0xffff0000u)};
+      }
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+        if (has_z) {
+          f32x4 de, dn;
+          ve = gelu_erf4_grad(ve, de);
+          vo = gelu_erf4_grad(vo, dn);
+          const u32x2_t z0 = __builtin_amdgcn_permlane16_swap(pack2bf(de[0], de[1]), pack2bf(dn[0], dn[1]), false, false);
+          const u32x2_t z1 = __builtin_amdgcn_permlane16_swap(pack2bf(de[2], de[3]), pack2bf(dn[2], dn[3]), false, false);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{z0[0], z1[0], z0[1], z1[1]}, rz, voff_z + jj * 64, 0, VC_4W_STORE_AUX);
+        } else {
+          ve = gelu_erf4(ve);
+          vo = gelu_erf4(vo);
+        }
+      }
+      const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[0], ve[1]), pack2bf(vo[0], vo[1]), false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[2], ve[3]), pack2bf(vo[2], vo[3]), false, false);
+      const u32x4_t o = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rc, voff + jj * 64, 0, VC_4W_STORE_AUX);
+      if (has_cs && row_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cs[jj][2 * q] += __uint_as_float(o[q] << 16);
+          cs[jj][2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u);
+        }
+      }
+    }
+    voff += istep;
+    voff_z += istep_z;
+  }
+#undef ISSUE_AUX
+  if (has_cs) {
+    // the 16 lanes frow = 0..15 of a lane group hold the same 32 columns: butterfly over lane bits 0..3, one atomic per column and group
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[jj][e];
+#pragma unroll
+        for (int o = 1; o <= 8; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (frow == 0) atomicAdd(p.colsum + col_w + jj * 32 + (fk & 1) * 16 + (fk >> 1) * 8 + e, v);
+      }
+  }
+}
+
 // fp32 output and / or residual: each m-tile through the wave's 8 KiB LDS patch (see epilogue_patch), loads and stores by buffer
 // instructions: lane -> columns (lane & 31) * 4 .. +3 of row 2 * it + (lane >> 5), two rows of 512 contiguous bytes per instruction
 template <int ACT, int OUT_F32, bool HAS_RES, int MI>
@@ -667,7 +757,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // tile (buffers keep alternating with the stream position), the register epilogue sits between two k-tiles, and the next tile's
 // k-half-0 fragments were read before it started -- no per-tile prologue (3-7k cycles of exposed DMA latency per tile in the
 // one-tile kernel, stamped), and the epilogue's stores drain behind the next tile's first MFMAs.
-template <int ACT, int OUT_F32, bool HAS_RES, int MI>
+template <int ACT, int OUT_F32, bool HAS_RES, int MI, bool EXTRAS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_4wp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -772,7 +862,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (OUT_F32 || HAS_RES)
       epilogue_patch_fast<ACT, OUT_F32, HAS_RES, MI>(acc, p, smem + 2 * BUF_BYTES + w * PATCH_BYTES, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
     else
-      epilogue_regs_fast<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+    {
+      if constexpr (EXTRAS) epilogue_regs_fast_x<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+      else epilogue_regs_fast<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+    }
 #endif
     STAMP_AT(pos, 3);
     if (!more) break;
@@ -831,7 +924,11 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
   p.n_big = p.tiles_m * p.tiles_n;
   if (form == 2) {
     const int n_cu = persistent_cus();
+    const bool extras = p.aux || p.zout || p.colsum;        // training extras: the bf16 register epilogue's second form (vc_4w_supports)
     auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
+    if constexpr (!OUT_F32 && !HAS_RES) {
+      if (extras) kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI, true>;
+    }
 #ifdef VC_4W_PREFETCH
     constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES + 1024;
 #else
@@ -897,10 +994,26 @@ extern "C" int vitcap_gemm_reserve_cus(int cus) {
 
 int vc_4w_pick_mi(int M, int tiles_n, int form) { return form == 0 ? 8 : pick_mi(M, tiles_n, form); }
 
+// Whether the AUTOMATIC choice hands a launch with training extras to the 4-wave kernel.  Measured inside the training step on one box
+// (profiles/r05_train_extras_ab.txt): every such launch on the 8-wave kernel 52.16 / 52.28 ms per step; zout launches (fc1 forward) on
+// the 4-wave kernel 52.47 / 52.44; aux + colsum launches (fc2 input gradient) as well 53.11 / 53.12 -- so the default is "none".
+// VITCAP_GEMM_4W_EXTRAS: bit 0 = launches with zout, bit 1 = with aux, bit 2 = with colsum may go (tile_hint 42 always does).
+bool vc_4w_extras_auto(const GemmArgs& a) {
+  static const int mask = [] { const char* e = getenv("VITCAP_GEMM_4W_EXTRAS"); return e ? atoi(e) : 0; }();
+  return !((a.zout && !(mask & 1)) || (a.aux && !(mask & 2)) || (a.colsum && !(mask & 4)));
+}
+
 bool vc_4w_supports(const GemmArgs& a, int act) {
 #ifdef VC_4W_STAMP
   if (a.rowstat) return true;
 #endif
+  if (a.aux || a.zout || a.colsum) {
+    // training extras: the PERSISTENT form's bf16 register epilogue only (no downgrade of the form inside launch_4w: the caller checks
+    // that the persistent form was chosen) -- plain rows, whole 256-column tiles, 16-byte aligned rows of every operand
+    return !a.res && !a.rowstat && !a.live && a.split_k <= 1 && a.K >= 192 && (a.N & 255) == 0 && a.row_group == 0 && (a.ldc & 7) == 0 &&
+           (!a.aux || (a.ldaux & 7) == 0) && (!a.zout || (a.ldz & 7) == 0) && a.M >= 2048 &&
+           (act == VITCAP_ACT_NONE || act == VITCAP_ACT_GELU_ERF);
+  }
   // a.live (decode loops: early exit once every sequence has finished) is honoured by the 8-wave kernels only: such launches stay there
   return !a.aux && !a.zout && !a.colsum && !a.rowstat && !a.live && a.split_k <= 1 && a.K >= 128 &&
          (act == VITCAP_ACT_NONE || act == VITCAP_ACT_GELU_ERF);

@@ -56,5 +56,6 @@ int vc_tile_group_n(int tiles_n);
 // form: 0 = one tile per workgroup + LDS epilogue, 1 = one tile per workgroup + register epilogue, 2 = persistent
 int vc_dispatch_4w(const GemmArgs& a, int act, int out_f32, hipStream_t s, int form);
 bool vc_4w_supports(const GemmArgs& a, int act);
+bool vc_4w_extras_auto(const GemmArgs& a);     // policy: may the automatic choice give a launch with aux / zout / colsum to the 4-wave kernel
 // m-tiles of 16 rows per wave (8 / 7 / 6 -> 256- / 224- / 192-row tiles) the 4-wave kernel picks for a launch
 int vc_4w_pick_mi(int M, int tiles_n, int form);

@@ -95,11 +95,17 @@ def _prefetched(gen, device, depth=2):
             if device.type == 'cuda':
                 torch.cuda.set_device(device)
             ev = torch.cuda.Event(blocking=True) if device.type == 'cuda' else None     # sleep, do not spin (see generate_async)
+            import time
             for b in gen:
+                t0 = time.perf_counter()
                 if ev is not None:
                     ev.record(torch.cuda.current_stream(device))
                     ev.synchronize()
-                if not put(b):
+                t1 = time.perf_counter()
+                ok = put(b)
+                LOADER_TIMES['copy_sync'] = LOADER_TIMES.get('copy_sync', 0.0) + t1 - t0
+                LOADER_TIMES['queue_full'] = LOADER_TIMES.get('queue_full', 0.0) + time.perf_counter() - t1
+                if not ok:
                     break
             else:
                 put(END)
@@ -115,8 +121,11 @@ def _prefetched(gen, device, depth=2):
     t = threading.Thread(target=work, daemon=True)
     t.start()
     try:
+        import time
         while True:
+            t0 = time.perf_counter()
             b = q.get()
+            LOADER_TIMES['queue_empty'] = LOADER_TIMES.get('queue_empty', 0.0) + time.perf_counter() - t0
             if b is END:
                 break
             if isinstance(b, BaseException):
@@ -127,6 +136,7 @@ def _prefetched(gen, device, depth=2):
         t.join(timeout=30)
 
 
+LOADER_TIMES = {}           # seconds, summed over the batches of the last predict: where the producer thread and the consumer waited
 LAST_PREDICT_STATS = {}     # filled by CaptionUniPipeline.predict: rows, steady-state images/sec of this rank (tools/input_side_bench.py)
 from .checkpoint import Checkpointer
 from .config import Config
@@ -509,6 +519,7 @@ class CaptionUniPipeline(object):
             from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
             from .jpegdec import decode_rows, decode_rows_into
             import numpy as np
+            import time
             workers = max(1, int(self.cfg.num_workers or 1))
             chunk = int(os.environ.get('VITCAP_LOADER_CHUNK', 8))      # images per worker task
             per_batch = (bs + chunk - 1) // chunk
@@ -581,6 +592,7 @@ class CaptionUniPipeline(object):
                     while inflight:
                         tasks = inflight.pop(0)
                         keys, imgs, used = [], [], []
+                        t_wait = time.perf_counter()
                         for sid, f in tasks:
                             ks, items = f.result()
                             keys.extend(ks)
@@ -592,8 +604,11 @@ class CaptionUniPipeline(object):
                                     imgs.append(item)
                             if sid is not None:
                                 used.append(sid)
+                        t_pre = time.perf_counter()
                         batch = {'image': pre(imgs), 'key': keys}       # host -> device copies of pageable memory return once staged
                         del imgs
+                        LOADER_TIMES['decode_wait'] = LOADER_TIMES.get('decode_wait', 0.0) + t_pre - t_wait
+                        LOADER_TIMES['transform_enqueue'] = LOADER_TIMES.get('transform_enqueue', 0.0) + time.perf_counter() - t_pre
                         retired.append(used)
                         if len(retired) > 2:
                             free.extend(retired.pop(0))
@@ -721,6 +736,7 @@ class CaptionUniPipeline(object):
                     for key, js in collect(entry):
                         yield key, js
         import time
+        LOADER_TIMES.clear()
         stats = {'rows': 0, 't_first': None, 'rows_first': 0}
 
         def timed_rows():
@@ -735,6 +751,7 @@ class CaptionUniPipeline(object):
         if stats['t_first'] is not None and stats['rows'] > stats['rows_first']:
             dt = time.perf_counter() - stats['t_first']
             LAST_PREDICT_STATS.update(rows=stats['rows'], steady_rows=stats['rows'] - stats['rows_first'], steady_seconds=dt,
+                                      loader_seconds={k: round(v, 3) for k, v in LOADER_TIMES.items()},
                                       images_per_sec=(stats['rows'] - stats['rows_first']) / dt)
             logging.info('predict: %d rows, steady state %.1f images/sec on rank %d', stats['rows'], LAST_PREDICT_STATS['images_per_sec'], self.rank)
         if self.world > 1:
