@@ -671,6 +671,11 @@ int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float
  * N and K multiples of 256. */
 int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
                    void* stream);
+/* The same with the sum over the splits done by the launch itself: out[N][K] (+)= sum_s C_slabs[s] in slab order (the result of
+ * vitcap_gemm_tn followed by vitcap_reduce_slabs, bit for bit; C_slabs is scratch).  The workgroups of a tile wait for each other,
+ * so tiles x splits must not exceed the number of CUs (an error otherwise). */
+int vitcap_gemm_tn_sum(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, float* out, int accumulate, int M, int N,
+                       int K, int splits, void* stream);
 /* bias gradient: out[n] += sum_m y[m][n]  (bf16 [M][ldy] -> fp32 [N], atomic accumulation into `out`) */
 int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream);
 /* fp32 master W[N][K] -> bf16 W and bf16 W^T[K][N] (the operands of the forward and the dgrad GEMMs) */

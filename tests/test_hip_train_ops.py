@@ -241,6 +241,32 @@ def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
     assert _rel(bias, y.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K,splits', [(36928, 2304, 768, 9), (36928, 768, 768, 28), (36928, 768, 3072, 7), (4099, 3072, 768, 7),
+                                          (1154, 768, 768, 5), (640, 256, 256, 2)])
+def test_gemm_tn_sum_equals_two_launches(ops, M, N, K, splits):
+    """vitcap_gemm_tn_sum (the splits of a tile add their slabs up inside the launch: tickets, write-through slabs, slab order) against
+    vitcap_gemm_tn + vitcap_reduce_slabs: bit for bit, plain and accumulating, on a scratch buffer that still holds an older launch's
+    slabs and through repeated launches (the tickets must be back at zero every time); more workgroups than CUs is an error."""
+    y = _bf(_rand((M, N), 61, 1.0)).cuda()
+    x = _bf(_rand((M, K), 62, 1.0)).cuda()
+    want = torch.empty(N, K, device='cuda')
+    ops.reduce_slabs(ops.gemm_tn(y, x, splits), want)
+    slabs = torch.full((splits, N, K), 7.0, device='cuda')
+    for rep in range(4):
+        got = torch.full((N, K), float('nan'), device='cuda')
+        ops.gemm_tn_sum(y, x, splits, got, slabs=slabs)
+        assert torch.equal(got, want), rep
+    base = _rand((N, K), 63).cuda()
+    acc = base.clone()
+    ops.gemm_tn_sum(y, x, splits, acc, accumulate=True)
+    want_acc = base.clone()
+    ops.reduce_slabs(ops.gemm_tn(y, x, splits), want_acc, accumulate=True)
+    assert torch.equal(acc, want_acc)
+    if N * K // 65536 * 40 > 256:
+        with pytest.raises(RuntimeError):
+            ops.gemm_tn_sum(y, x, 40, torch.empty(N, K, device='cuda'))
+
+
 def test_attn_probe_rows_forward_backward(ops):
     """[578 visual | 20 token rows | 19 [MASK] probe rows]: probe j sees visual + tokens 0..j + itself and nobody sees the
     probes (mask_from): forward and both backward kernels against autograd through the explicit mask."""

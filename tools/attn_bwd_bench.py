@@ -1,5 +1,6 @@
 """Attention backward (vitcap_attn_dense_bwd: dQ kernel + dK/dV kernel) per launch at the training shapes, and a checksum of the result
-so that two builds / forms can be compared bit for bit:  VITCAP_ATTN_BWD_DMA=0|1 python tools/attn_bwd_bench.py
+so that two builds can be compared bit for bit (round 5 compared the LDS-DMA pair with the first pair this way:
+profiles/r05_train_attn_bwd_ab.txt):  python tools/attn_bwd_bench.py
   encoder   B = 64, S = 577, no dropout          decoder   B = 64, S = 578 + 40 caption rows, causal_from = 578, dropout 0.1"""
 import hashlib
 import os
@@ -28,8 +29,8 @@ def run(name, B, S, iters=30, **kw):
     torch.cuda.synchronize()
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(5, iters))
     flops = 7 * 2.0 * B * 12 * S * S * 64
-    print('%-8s form %s: %.1f us per backward (median; min %.1f)  %.0f TFLOP/s over the 7 matmuls  sha %s' % (
-        name, os.environ.get('VITCAP_ATTN_BWD_DMA', '1'), ts[len(ts) // 2], ts[0], flops / ts[len(ts) // 2] / 1e6, digest), flush=True)
+    print('%-8s %.1f us per backward (median; min %.1f)  %.0f TFLOP/s over the 7 matmuls  sha %s' % (
+        name, ts[len(ts) // 2], ts[0], flops / ts[len(ts) // 2] / 1e6, digest), flush=True)
 
 
 if __name__ == '__main__':

@@ -40,6 +40,8 @@ def main():
     from vitcap_amd.model import ImageCaptioning
     from vitcap_amd.tsv import TSVFile, tsv_writer
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    if os.environ.get('INPUT_SIDE_SWITCH') == '1':
+        sys.setswitchinterval(0.0005)          # experiment: GIL hand-over between the launcher, the loader thread and the pool's threads
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
     tmp = tempfile.mkdtemp(prefix='vitcap_input_')
     os.chdir(tmp)
@@ -54,7 +56,8 @@ def main():
         quota = None if q == 'max' else round(int(q) / int(per), 1)
     except Exception:
         pass
-    res = {'images': N, 'mean_jpeg_bytes': int(np.mean([len(j) for j in jpegs])), 'sizes': SIZES, 'host_cores': os.cpu_count(),
+    import torch as _t
+    res = {'torch_threads': _t.get_num_threads(), 'images': N, 'mean_jpeg_bytes': int(np.mean([len(j) for j in jpegs])), 'sizes': SIZES, 'host_cores': os.cpu_count(),
            'host_cpu_quota_cores': quota,
            'build_s': round(time.perf_counter() - t0, 1)}
     # ---- decode only
@@ -157,10 +160,29 @@ def main():
         except Exception:
             return {}
     res['cgroup_cpu'] = {}
+    import threading
     for workers, threads in sweep:
         c0 = cpu_stat()
+        samples, stop = [], threading.Event()
+
+        def sampler():        # cgroup CPU accounting every 50 ms: which part of the throttling falls into the steady-state window
+            while not stop.is_set():
+                c = cpu_stat()
+                samples.append((time.perf_counter(), c.get('nr_throttled', 0), c.get('usage_usec', 0), c.get('nr_periods', 0)))
+                stop.wait(0.05)
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
         st, wall = run_once('w%d%d' % (workers, threads), workers, threads)
+        stop.set()
+        th.join()
         c1 = cpu_stat()
+        if samples and st.get('t_end'):
+            win = [x for x in samples if st['t_end'] - st['steady_seconds'] <= x[0] <= st['t_end']]
+            if len(win) > 1:
+                res.setdefault('cgroup_cpu_steady_window', {})['%d %s' % (workers, 'threads' if threads else 'processes')] = sw = {
+                    'seconds': round(win[-1][0] - win[0][0], 2), 'periods': win[-1][3] - win[0][3], 'throttled_periods': win[-1][1] - win[0][1],
+                    'avg_cores': round((win[-1][2] - win[0][2]) / 1e6 / max(1e-9, win[-1][0] - win[0][0]), 2)}
+                print('steady window cgroup cpu', sw, flush=True)
         if c0 and c1:      # whole run (model load included): CPU seconds used by the cgroup, periods in which the quota throttled it
             res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')] = {
                 'wall_s': round(wall, 2), 'cpu_s': round((c1['usage_usec'] - c0['usage_usec']) / 1e6, 2),

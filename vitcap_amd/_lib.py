@@ -132,6 +132,7 @@ _SIGS = {
     'vitcap_adamw_multi': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_size_t, vp]),
     'vitcap_gemm_tn': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'vitcap_gemm_tn_sum': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'vitcap_colsum_bf16': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'vitcap_image_preproc_workspace_bytes': (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
     'vitcap_image_preproc': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),

@@ -6,14 +6,19 @@
 //     dQ[q] = scale * sum_k dS[q][k] K[k]   dK[k] = scale * sum_q dS[q][k] Q[q]
 // Two kernels, both built like the forward (32x32x16 MFMA, transposed score tiles so per-row quantities are
 // lane-local, the MFMA C layout reused as the next B operand, no atomics):
-//   attn_bwd_dq_kernel  : a wave owns 32 queries and sweeps 64-key tiles:  S^T = K Q^T, dP^T = V dO^T,
-//                         dQ^T += K^T dS^T.  Also writes D[q] for the second kernel.
-//   attn_bwd_dkv_kernel : a wave owns 32 keys and sweeps 64-query tiles:   S = Q K^T, dP = dO V^T,
-//                         dV^T += dO^T P, dK^T += Q^T dS.
+//   attn_bwd_dq_dma_kernel  : a wave owns 32 queries and sweeps 64-key tiles:  S^T = K Q^T, dP^T = V dO^T,
+//                             dQ^T += K^T dS^T.  Also writes D[q] for the second kernel.
+//   attn_bwd_dkv_dma_kernel : a wave owns 32 keys and sweeps 64-query tiles:   S = Q K^T, dP = dO V^T,
+//                             dV^T += dO^T P, dK^T += Q^T dS.
 // P and dS are rounded to bf16 for the MFMAs (fp32 accumulation), like the forward's P.
 // Left-over rows (S = 577/578 leaves 1/2) are handled on the vector ALU.
-#include <stdlib.h>
-
+//
+// Data path (round 5; rounds 1-4 staged the tiles through VGPRs and built transposed copies with v_perm: 15-19 % slower per
+// launch, same bits -- profiles/r05_train_attn_bwd_ab.txt): tiles travel HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane,
+// no VGPR round trip, no ds_write), ROW-major (64 rows x 128 B) with XOR-swizzled 16-byte chunks, in a ring of three stages on
+// counted vmcnt waits; the row-major operands (S, dP) are read with ds_read_b128, the transposed ones (K^T, Q^T, dO^T) straight from
+// the same tiles with ds_read_b64_tr_b16 -- the two runs of 4 consecutive rows a lane needs per 16-row MFMA step are exactly the C
+// layout of the score tile (see attn.hip).
 #include "common.h"
 #include "rng.h"
 
@@ -23,494 +28,21 @@ constexpr int HD = 64;
 constexpr int NH = 12;
 constexpr int QKV_LD = 2304;
 constexpr int KT = 64;
-constexpr int LDS_ROW = 144;       // 64 bf16 + 16 B pad
-constexpr int TILE_B = KT * LDS_ROW;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// staging helpers --------------------------------------------------------------------------------
-// row-major tile: thread (tid>>2) = row, (tid&3)*16 = first of 16 columns (two 16-byte pieces)
-#define ROW_LOAD(r0_, r1_, src_, row_, ld_, col0_)                                   \
-  do {                                                                               \
-    const bf16_t* p_ = (src_) + (size_t)(row_) * (ld_) + (col0_) + (tid & 3) * 16;   \
-    r0_ = *(const uint4*)p_;                                                         \
-    r1_ = *(const uint4*)(p_ + 8);                                                   \
-  } while (0)
-#define ROW_STORE(lds_, r0_, r1_)                                                    \
-  do {                                                                               \
-    char* q_ = (lds_) + (tid >> 2) * LDS_ROW + (tid & 3) * 32;                       \
-    *(uint4*)q_ = r0_;                                                               \
-    *(uint4*)(q_ + 16) = r1_;                                                        \
-  } while (0)
-// transposed tile [64 d][64 slots]: thread loads 4 rows x 4 d (8 bytes each) and writes 4 x 8 bytes; the 4 rows
-// of each group of 16 are stored in the order 0-3,8-11,4-7,12-15 so a lane's 8 consecutive slots match the MFMA
-// C layout of the score tile (see attn.hip)
-#define TR_LOAD(v0_, v1_, v2_, v3_, src_, row0_, ld_, col0_, nrows_)                 \
-  do {                                                                               \
-    const int t0_ = (row0_) + v_kg * 4;                                              \
-    const int a0_ = t0_ < (nrows_) ? t0_ : (nrows_) - 1, a1_ = t0_ + 1 < (nrows_) ? t0_ + 1 : (nrows_) - 1; \
-    const int a2_ = t0_ + 2 < (nrows_) ? t0_ + 2 : (nrows_) - 1, a3_ = t0_ + 3 < (nrows_) ? t0_ + 3 : (nrows_) - 1; \
-    v0_ = *(const uint2*)((src_) + (size_t)a0_ * (ld_) + (col0_) + v_dg * 4);        \
-    v1_ = *(const uint2*)((src_) + (size_t)a1_ * (ld_) + (col0_) + v_dg * 4);        \
-    v2_ = *(const uint2*)((src_) + (size_t)a2_ * (ld_) + (col0_) + v_dg * 4);        \
-    v3_ = *(const uint2*)((src_) + (size_t)a3_ * (ld_) + (col0_) + v_dg * 4);        \
-  } while (0)
-#define TR_STORE(lds_, v0_, v1_, v2_, v3_)                                           \
-  do {                                                                               \
-    uint2 t0_, t1_, t2_, t3_;                                                        \
-    t0_.x = __builtin_amdgcn_perm(v1_.x, v0_.x, 0x05040100);                         \
-    t0_.y = __builtin_amdgcn_perm(v3_.x, v2_.x, 0x05040100);                         \
-    t1_.x = __builtin_amdgcn_perm(v1_.x, v0_.x, 0x07060302);                         \
-    t1_.y = __builtin_amdgcn_perm(v3_.x, v2_.x, 0x07060302);                         \
-    t2_.x = __builtin_amdgcn_perm(v1_.y, v0_.y, 0x05040100);                         \
-    t2_.y = __builtin_amdgcn_perm(v3_.y, v2_.y, 0x05040100);                         \
-    t3_.x = __builtin_amdgcn_perm(v1_.y, v0_.y, 0x07060302);                         \
-    t3_.y = __builtin_amdgcn_perm(v3_.y, v2_.y, 0x07060302);                         \
-    char* vp_ = (lds_) + (v_dg * 4) * LDS_ROW + v_pos * 2;                           \
-    *(uint2*)(vp_) = t0_;                                                            \
-    *(uint2*)(vp_ + LDS_ROW) = t1_;                                                  \
-    *(uint2*)(vp_ + 2 * LDS_ROW) = t2_;                                              \
-    *(uint2*)(vp_ + 3 * LDS_ROW) = t3_;                                              \
-  } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// dQ kernel.  grid = q-blocks(128 rows) x heads x B (1-D, XCD-aware like the forward).
-// ------------------------------------------------------------------------------------------------
-// DROP (both kernels): the forward multiplied P by keep/(1-p) before P.V, so dP = (dO.V) o keep/(1-p) and dV uses the
-// dropped P; D[q] = dO[q].O[q] is unchanged in form (O is the dropped output).
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
-                                                          int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                          uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
-                                                          int q_lo, int q_hi, const uint32_t* __restrict__ drop_salt) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_B];   // [buf][K rows | V rows | K^T]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int qi = lane & 31, half = lane >> 5;
-  const int nqb = (q_hi - q_lo + 127) / 128;     // query blocks covering rows [q_lo, q_hi), q_lo a multiple of 128
-  const int nwork = nqb * NH * B;
-  int wid = blockIdx.x;
-  {
-    const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
-    wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
-  }
-  const int qb = (q_lo >> 7) + wid % nqb;
-  const int h = (wid / nqb) % NH, b = wid / (nqb * NH);
-  const int q0 = qb * 128 + w * 32;
-  const bool active = q0 < S;
-  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
-  const int qr = (q0 + qi) < S ? (q0 + qi) : S - 1;
-  const uint32_t hq = DROP ? (vc_drop_stream(vc_salted(drop_seed, drop_salt), (uint32_t)b, (uint32_t)h) ^ ((uint32_t)(q0 + qi) << 10)) : 0u;
-
-  // B-operand fragments held for the whole kernel: Q^T and dO^T (lane: row q, dims ds*16 + half*8 ..)
-  bf16x8 qf[4], dof[4];
-  float dpart = 0.f;
-  {
-    const bf16_t* qp = base + (size_t)qr * QKV_LD + half * 8;
-    const bf16_t* dp = dout + ((size_t)b * ld_rows + qr) * 768 + h * HD + half * 8;
-    const bf16_t* op = o + ((size_t)b * ld_rows + qr) * 768 + h * HD + half * 8;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      qf[ds] = *(const bf16x8*)(qp + ds * 16);
-      dof[ds] = *(const bf16x8*)(dp + ds * 16);
-      const bf16x8 of = *(const bf16x8*)(op + ds * 16);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dpart += (float)dof[ds][j] * (float)of[j];
-    }
-  }
-  const float Dq = dpart + __shfl_xor(dpart, 32, 64);          // D[q] = dO[q] . O[q]
-  const float Lq = lse[((size_t)b * NH + h) * S + qr];
-  if (active && half == 0 && q0 + qi < S) dsum[((size_t)b * NH + h) * S + q0 + qi] = Dq;
-
-  const int v_kg = tid & 15, v_dg = tid >> 4;
-  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
-  const int nfull = S / KT, rem = S - nfull * KT;
-  const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);   // caption keys (>= causal_from) live in the masked tail tile
-  const int ntiles = nfull + (tail_tile ? 1 : 0);
-
-  uint4 k0, k1, v0, v1;
-  uint2 t0, t1, t2, t3;
-#define LOAD_TILE(t_)                                                                \
-  do {                                                                               \
-    int kr_ = (t_) * KT + (tid >> 2);                                                \
-    kr_ = kr_ < S ? kr_ : S - 1;                                                     \
-    ROW_LOAD(k0, k1, base, kr_, QKV_LD, 768);                                        \
-    ROW_LOAD(v0, v1, base, kr_, QKV_LD, 1536);                                       \
-    TR_LOAD(t0, t1, t2, t3, base, (t_) * KT, QKV_LD, 768, S);                        \
-  } while (0)
-#define STORE_TILE(buf_)                                                             \
-  do {                                                                               \
-    char* l_ = smem + (buf_) * 3 * TILE_B;                                           \
-    ROW_STORE(l_, k0, k1);                                                           \
-    ROW_STORE(l_ + TILE_B, v0, v1);                                                  \
-    TR_STORE(l_ + 2 * TILE_B, t0, t1, t2, t3);                                       \
-  } while (0)
-
-  f32x16 dqt[2], zero16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dqt[0][r] = 0.f;
-    dqt[1][r] = 0.f;
-    zero16[r] = 0.f;
-  }
-  if (ntiles > 0) {
-    LOAD_TILE(0);
-    STORE_TILE(0);
-  }
-  // all prologue loads provably complete on every path into the loop (see attn.hip: otherwise the waitcnt pass makes
-  // each iteration wait for the NEXT tile's loads before its first MFMAs)
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) LOAD_TILE(t + 1);
-    if (active) {
-      const char* kl = smem + buf * 3 * TILE_B;
-      const char* vl = kl + TILE_B;
-      const char* ktl = kl + 2 * TILE_B;
-      f32x16 st[2], dpt[2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const char* kr = kl + (kt * 32 + qi) * LDS_ROW + half * 16;
-        const char* vr = vl + (kt * 32 + qi) * LDS_ROW + half * 16;
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr), qf[0], zero16, 0, 0, 0);
-        dpt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vr), dof[0], zero16, 0, 0, 0);
-#pragma unroll
-        for (int ds = 1; ds < 4; ++ds) {
-          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kr + ds * 32), qf[ds], st[kt], 0, 0, 0);
-          dpt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vr + ds * 32), dof[ds], dpt[kt], 0, 0, 0);
-        }
-      }
-      const bool masked = t >= nfull;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p = fast_exp2(fmaf(st[kt][r], c_log2, -Lq));
-          if (masked) {
-            const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            p = joint_visible(q0 + qi, key, S, causal_from, mask_from) ? p : 0.f;
-          }
-          float dp = dpt[kt][r];
-          if (DROP) {
-            const uint32_t key = (uint32_t)(t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-            dp = vc_lowbias32(hq ^ key) >= drop_thr ? dp * drop_scale : 0.f;
-          }
-          st[kt][r] = p * (dp - Dq);        // dS^T
-        }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const int kt = kb >> 1, ks = kb & 1;
-        bf16x8 sf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sf[j] = (__bf16)st[kt][ks * 8 + j];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 kf = *(const bf16x8*)(ktl + (dt * 32 + qi) * LDS_ROW + (kb * 16 + half * 8) * 2);
-          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dqt[dt], 0, 0, 0);
-        }
-      }
-    }
-    if (t + 1 < ntiles) STORE_TILE(buf ^ 1);
-    __syncthreads();
-  }
-#undef LOAD_TILE
-#undef STORE_TILE
-  // left-over keys on the vector ALU
-  if (active && !tail_tile) {
-    for (int key = nfull * KT; key < S; ++key) {
-      const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
-      const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + half * 8;
-      float sp = 0.f, dp = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const bf16x8 kv = *(const bf16x8*)(kr + ds * 16);
-        const bf16x8 vv = *(const bf16x8*)(vr + ds * 16);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sp += (float)qf[ds][j] * (float)kv[j];
-          dp += (float)dof[ds][j] * (float)vv[j];
-        }
-      }
-      sp += __shfl_xor(sp, 32, 64);
-      dp += __shfl_xor(dp, 32, 64);
-      const float p = fast_exp2(fmaf(sp, c_log2, -Lq));
-      if (DROP) dp = vc_lowbias32(hq ^ (uint32_t)key) >= drop_thr ? dp * drop_scale : 0.f;
-      const float dsb = (float)(__bf16)(p * (dp - Dq));
-      const bf16_t* ko = base + (size_t)key * QKV_LD + 768 + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x4 kk = *(const bf16x4*)(ko + dt * 32 + g * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dqt[dt][g * 4 + e] = fmaf(dsb, (float)kk[e], dqt[dt][g * 4 + e]);
-        }
-    }
-  }
-  const int q = q0 + qi;
-  if (q < S) {
-    bf16_t* op = dqkv + ((size_t)b * ld_rows + q) * QKV_LD + h * HD + 4 * half;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack2bf(dqt[dt][g * 4 + 0] * scale, dqt[dt][g * 4 + 1] * scale);
-        ov.y = pack2bf(dqt[dt][g * 4 + 2] * scale, dqt[dt][g * 4 + 3] * scale);
-        *(uint2*)(op + dt * 32 + g * 8) = ov;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dK/dV kernel.  A wave owns 32 keys; grid = key-blocks(128 rows) x heads x B.
-// `extra` (optional, bf16 [B*S][2][768]) is added to the results: contributions of other queries
-// (the caption rows of the decoder) to these keys' K/V gradients.
-// ------------------------------------------------------------------------------------------------
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                           const bf16_t* __restrict__ extra, bf16_t* __restrict__ dqkv, int S,
-                                                           int B, int ld_rows, float c_log2, float scale, uint32_t drop_seed,
-                                                           uint32_t drop_thr, float drop_scale, int causal_from, int mask_from,
-                                                           int q_lo, int q_hi, const uint32_t* __restrict__ drop_salt) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (4 * TILE_B + 512)];   // [buf][Q | dO | Q^T | dO^T | L[64] D[64]]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int ki = lane & 31, half = lane >> 5;
-  const int nkb = (S + 127) / 128;
-  const int nwork = nkb * NH * B;
-  int wid = blockIdx.x;
-  {
-    const int qd = nwork >> 3, rm = nwork & 7, xcd = wid & 7;
-    wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (wid >> 3);
-  }
-  const int kb_ = wid % nkb;
-  const int h = (wid / nkb) % NH, b = wid / (nkb * NH);
-  const int key0 = kb_ * 128 + w * 32;
-  const bool active = key0 < S;
-  const bf16_t* base = qkv + (size_t)b * ld_rows * QKV_LD + h * HD;
-  const bf16_t* dob = dout + (size_t)b * ld_rows * 768 + h * HD;
-  const float* Lb = lse + ((size_t)b * NH + h) * S;
-  const float* Db = dsum + ((size_t)b * NH + h) * S;
-  const int kr = (key0 + ki) < S ? (key0 + ki) : S - 1;
-  const uint32_t hk = DROP ? (vc_drop_stream(vc_salted(drop_seed, drop_salt), (uint32_t)b, (uint32_t)h) ^ (uint32_t)(key0 + ki)) : 0u;
-
-  bf16x8 kf[4], vf[4];     // B operands: K^T and V^T columns of this lane's key
-  {
-    const bf16_t* kp = base + (size_t)kr * QKV_LD + 768 + half * 8;
-    const bf16_t* vp = base + (size_t)kr * QKV_LD + 1536 + half * 8;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      kf[ds] = *(const bf16x8*)(kp + ds * 16);
-      vf[ds] = *(const bf16x8*)(vp + ds * 16);
-    }
-  }
-  const int v_kg = tid & 15, v_dg = tid >> 4;
-  const int v_pos = (v_kg >> 2) * 16 + ((((v_kg & 1) << 1) | ((v_kg >> 1) & 1)) * 4);
-  const int nfull = S / KT, rem = S - nfull * KT;
-  const bool tail_tile = rem > 8 || (causal_from > 0 && rem > 0);
-  const int ntiles = nfull + (tail_tile ? 1 : 0);
-  // only the query tiles that intersect [q_lo, q_hi) are visited (rows of those tiles outside the range must carry dO = 0)
-  const int t_lo = q_lo / KT;
-  int t_hi = (q_hi + KT - 1) / KT;
-  t_hi = t_hi < ntiles ? t_hi : ntiles;
-  // a caption key (>= causal_from) only hears from caption queries q >= key: waves that own such keys mask every tile
-  const bool wave_causal = causal_from > 0 && key0 + 31 >= causal_from;
-  constexpr int BUF = 4 * TILE_B + 512;
-
-  uint4 q0r, q1r, d0r, d1r;
-  uint2 a0, a1, a2, a3, c0, c1, c2, c3;
-  float lreg = 0.f;
-#define LOAD_TILE(t_)                                                                \
-  do {                                                                               \
-    int qr_ = (t_) * KT + (tid >> 2);                                                \
-    qr_ = qr_ < S ? qr_ : S - 1;                                                     \
-    ROW_LOAD(q0r, q1r, base, qr_, QKV_LD, 0);                                        \
-    ROW_LOAD(d0r, d1r, dob, qr_, 768, 0);                                            \
-    TR_LOAD(a0, a1, a2, a3, base, (t_) * KT, QKV_LD, 0, S);                          \
-    TR_LOAD(c0, c1, c2, c3, dob, (t_) * KT, 768, 0, S);                              \
-    if (tid < 128) {                                                                 \
-      int i_ = (t_) * KT + (tid & 63);                                               \
-      i_ = i_ < S ? i_ : S - 1;                                                      \
-      lreg = tid < 64 ? Lb[i_] : Db[i_];                                             \
-    }                                                                                \
-  } while (0)
-#define STORE_TILE(buf_)                                                             \
-  do {                                                                               \
-    char* l_ = smem + (buf_) * BUF;                                                  \
-    ROW_STORE(l_, q0r, q1r);                                                         \
-    ROW_STORE(l_ + TILE_B, d0r, d1r);                                                \
-    TR_STORE(l_ + 2 * TILE_B, a0, a1, a2, a3);                                       \
-    TR_STORE(l_ + 3 * TILE_B, c0, c1, c2, c3);                                       \
-    if (tid < 128) ((float*)(l_ + 4 * TILE_B))[tid] = lreg;                          \
-  } while (0)
-
-  f32x16 dvt[2], dkt[2], zero16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dvt[0][r] = 0.f; dvt[1][r] = 0.f; dkt[0][r] = 0.f; dkt[1][r] = 0.f; zero16[r] = 0.f;
-  }
-  if (t_hi > t_lo) {
-    LOAD_TILE(t_lo);
-    STORE_TILE(0);
-  }
-  // all prologue loads provably complete on every path into the loop (see attn.hip: otherwise the waitcnt pass makes
-  // each iteration wait for the NEXT tile's loads before its first MFMAs)
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  __syncthreads();
-  for (int t = t_lo; t < t_hi; ++t) {
-    const int buf = (t - t_lo) & 1;
-    if (t + 1 < t_hi) LOAD_TILE(t + 1);
-    if (active) {
-      const char* ql = smem + buf * BUF;
-      const char* dl = ql + TILE_B;
-      const char* qtl = ql + 2 * TILE_B;
-      const char* dtl = ql + 3 * TILE_B;
-      const float* Ll = (const float*)(ql + 4 * TILE_B);
-      const float* Dl = Ll + 64;
-      // one 32-query half-tile at a time (keeps the register footprint at 2 waves per SIMD)
-      const bool masked = t >= nfull || wave_causal;
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        f32x16 st, dpt;
-        const char* qr = ql + (qt * 32 + ki) * LDS_ROW + half * 16;
-        const char* dr = dl + (qt * 32 + ki) * LDS_ROW + half * 16;
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr), kf[0], zero16, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr), vf[0], zero16, 0, 0, 0);
-#pragma unroll
-        for (int ds = 1; ds < 4; ++ds) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qr + ds * 32), kf[ds], st, 0, 0, 0);
-          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(dr + ds * 32), vf[ds], dpt, 0, 0, 0);
-        }
-        // lane holds, for its key, queries q = qt*32 + 8g + 4*half + e  (r = 4g + e)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 L4 = *(const f32x4*)(Ll + qt * 32 + g * 8 + 4 * half);
-          const f32x4 D4 = *(const f32x4*)(Dl + qt * 32 + g * 8 + 4 * half);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = g * 4 + e;
-            float p = fast_exp2(fmaf(st[r], c_log2, -L4[e]));
-            if (masked) {
-              const int q = t * KT + qt * 32 + g * 8 + 4 * half + e;
-              p = (q < S && joint_visible(q, key0 + ki, S, causal_from, mask_from)) ? p : 0.f;
-            }
-            float dp = dpt[r], pd = p;
-            if (DROP) {
-              const uint32_t q = (uint32_t)(t * KT + qt * 32 + g * 8 + 4 * half + e);
-              const bool keep = vc_lowbias32(hk ^ (q << 10)) >= drop_thr;
-              dp = keep ? dp * drop_scale : 0.f;
-              pd = keep ? p : 0.f;
-            }
-            st[r] = pd;                          // (dropped) P[q][key]
-            dpt[r] = p * (dp - D4[e]);           // dS[q][key]
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int qb4 = qt * 2 + ks;
-          bf16x8 pf, sf;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            pf[j] = (__bf16)st[ks * 8 + j];
-            sf[j] = (__bf16)dpt[ks * 8 + j];
-          }
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 dof = *(const bf16x8*)(dtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
-            const bf16x8 qtf = *(const bf16x8*)(qtl + (dt * 32 + ki) * LDS_ROW + (qb4 * 16 + half * 8) * 2);
-            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[dt], 0, 0, 0);
-            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dkt[dt], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (t + 1 < t_hi) STORE_TILE(buf ^ 1);
-    __syncthreads();
-  }
-#undef LOAD_TILE
-#undef STORE_TILE
-  // left-over queries on the vector ALU
-  if (active && !tail_tile) {
-    for (int q = (nfull * KT > q_lo ? nfull * KT : q_lo); q < (S < q_hi ? S : q_hi); ++q) {
-      const bf16_t* qr = base + (size_t)q * QKV_LD + half * 8;
-      const bf16_t* dr = dob + (size_t)q * 768 + half * 8;
-      float sp = 0.f, dp = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const bf16x8 qv = *(const bf16x8*)(qr + ds * 16);
-        const bf16x8 dv = *(const bf16x8*)(dr + ds * 16);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sp += (float)qv[j] * (float)kf[ds][j];
-          dp += (float)dv[j] * (float)vf[ds][j];
-        }
-      }
-      sp += __shfl_xor(sp, 32, 64);
-      dp += __shfl_xor(dp, 32, 64);
-      const float p = fast_exp2(fmaf(sp, c_log2, -Lb[q]));
-      float pb = (float)(__bf16)p;
-      if (DROP) {
-        const bool keep = vc_lowbias32(hk ^ ((uint32_t)q << 10)) >= drop_thr;
-        dp = keep ? dp * drop_scale : 0.f;
-        pb = keep ? pb : 0.f;
-      }
-      const float dsb = (float)(__bf16)(p * (dp - Db[q]));
-      const bf16_t* qo = base + (size_t)q * QKV_LD + 4 * half;
-      const bf16_t* dd = dob + (size_t)q * 768 + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x4 qq = *(const bf16x4*)(qo + dt * 32 + g * 8);
-          const bf16x4 dq = *(const bf16x4*)(dd + dt * 32 + g * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            dvt[dt][g * 4 + e] = fmaf(pb, (float)dq[e], dvt[dt][g * 4 + e]);
-            dkt[dt][g * 4 + e] = fmaf(dsb, (float)qq[e], dkt[dt][g * 4 + e]);
-          }
-        }
-    }
-  }
-  const int key = key0 + ki;
-  if (key < S) {
-    bf16_t* ok = dqkv + ((size_t)b * ld_rows + key) * QKV_LD + 768 + h * HD + 4 * half;
-    bf16_t* ov = ok + 768;
-    const bf16_t* ex = extra ? extra + ((size_t)b * ld_rows + key) * 1536 + h * HD + 4 * half : nullptr;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float kx[4] = {0.f, 0.f, 0.f, 0.f}, vx[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ex) {
-          const bf16x4 ek = *(const bf16x4*)(ex + dt * 32 + g * 8);
-          const bf16x4 ev = *(const bf16x4*)(ex + 768 + dt * 32 + g * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { kx[e] = (float)ek[e]; vx[e] = (float)ev[e]; }
-        }
-        uint2 o1, o2;
-        o1.x = pack2bf(dkt[dt][g * 4 + 0] * scale + kx[0], dkt[dt][g * 4 + 1] * scale + kx[1]);
-        o1.y = pack2bf(dkt[dt][g * 4 + 2] * scale + kx[2], dkt[dt][g * 4 + 3] * scale + kx[3]);
-        const float vs = DROP ? drop_scale : 1.0f;
-        o2.x = pack2bf(dvt[dt][g * 4 + 0] * vs + vx[0], dvt[dt][g * 4 + 1] * vs + vx[1]);
-        o2.y = pack2bf(dvt[dt][g * 4 + 2] * vs + vx[2], dvt[dt][g * 4 + 3] * vs + vx[3]);
-        *(uint2*)(ok + dt * 32 + g * 8) = o1;
-        *(uint2*)(ov + dt * 32 + g * 8) = o2;
-      }
-  }
-}
-
-
-// ================================================================================================
-// Round 5: the same two kernels on the forward's data path (attn.hip): tiles travel HBM/L2 -> LDS by LDS-DMA (global_load_lds,
-// 16 B per lane, no VGPR round trip, no ds_write, no register transposes), ROW-major (64 rows x 128 B) with XOR-swizzled 16-byte
-// chunks, in a ring of three stages on counted vmcnt waits; the row-major operands (S = Q K^T, dP = dO V^T) are read with
-// ds_read_b128, the transposed ones (K^T, Q^T, dO^T) straight from the same tiles with ds_read_b64_tr_b16 -- the two runs of 4
-// consecutive rows a lane needs per 16-row MFMA step are exactly the C layout of the score tile (see attn.hip).  The arithmetic
-// (and its order) is the first pair's: results are bit-identical.  VITCAP_ATTN_BWD_DMA=0 launches the first pair.
-// ================================================================================================
+// build knobs measured on one box against the shipped form (profiles/r05_train_attn_bwd_ab.txt): all within the run-to-run spread
+#ifndef VC_BWD_PRIO          // 1: s_setprio(1) around the MFMA bursts (two waves of different workgroups share a SIMD)
+#define VC_BWD_PRIO 0
+#endif
+#define VC_BWD_PRIO_ON() do { if (VC_BWD_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define VC_BWD_PRIO_OFF() do { if (VC_BWD_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#ifndef VC_BWD_PREFETCH      // 1: the row-major fragments of a tile's second half are requested behind the first half's S / dP MFMAs
+#define VC_BWD_PREFETCH 0
+#endif
+#ifndef VC_BWD_DQ_MINW       // waves per SIMD the dQ kernel is compiled for (3 = 168 registers: 52 spilled, not usable as written)
+#define VC_BWD_DQ_MINW 2
+#endif
 constexpr int DT_B = KT * 128;               // one row-major tile: 64 rows x 128 B
 constexpr int NSTG = 3;                      // ring: tile t+2 is in flight while tile t is multiplied
 constexpr int DQ_STG = 2 * DT_B;             // dq stage:  [K | V]
@@ -552,7 +84,7 @@ __device__ __forceinline__ bool visible_nb(int q, int k, int S, int cf, int mf) 
 #define VC_ZERO16 f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, VC_BWD_DQ_MINW) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                  float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
                                                                  int ld_rows, float c_log2, float scale, uint32_t drop_seed,
@@ -645,16 +177,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
 #define DQ_HALF(KT_, t_)                                                                                    \
   do {                                                                                                               \
     bf16x8 kfr[4], vfr[4];                                                                                           \
-    _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                               \
-      kfr[ds] = *(const bf16x8*)(kl + (KT_) * 4096 + koff[ds]);                                                      \
-      vfr[ds] = *(const bf16x8*)(kl + DT_B + (KT_) * 4096 + koff[ds]);                                               \
+    if (VC_BWD_PREFETCH && (KT_) == 1) {                                                                             \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) { kfr[ds] = knx[ds]; vfr[ds] = vnx[ds]; }                     \
+    } else {                                                                                                         \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                             \
+        kfr[ds] = *(const bf16x8*)(kl + (KT_) * 4096 + koff[ds]);                                                    \
+        vfr[ds] = *(const bf16x8*)(kl + DT_B + (KT_) * 4096 + koff[ds]);                                             \
+      }                                                                                                              \
     }                                                                                                                \
+    VC_BWD_PRIO_ON();                                                                                                \
     f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], VC_ZERO16, 0, 0, 0);                          \
     f32x16 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], VC_ZERO16, 0, 0, 0);                        \
     _Pragma("unroll") for (int ds = 1; ds < 4; ++ds) {                                                               \
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ds], qf[ds], st, 0, 0, 0);                                    \
       dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ds], dof[ds], dpt, 0, 0, 0);                                 \
     }                                                                                                                \
+    VC_BWD_PRIO_OFF();                                                                                               \
     /* the transposed K fragments of this half go out now: their latency hides behind the elementwise part */       \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     s16x4 ktr[2][2][2];                                                                                              \
@@ -663,23 +201,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
         ktr[0][dt][rd] = lds_tr_read<(KT_) * 4096>(kb_ + (uint32_t)toff[rd][dt]);                                    \
         ktr[1][dt][rd] = lds_tr_read<(KT_) * 4096 + 2048>(kb_ + (uint32_t)toff[rd][dt]);                             \
       }                                                                                                              \
+    if (VC_BWD_PREFETCH && (KT_) == 0) {      /* the second half's row-major fragments: in flight during this half's elementwise part */ \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                             \
+        knx[ds] = *(const bf16x8*)(kl + 4096 + koff[ds]);                                                            \
+        vnx[ds] = *(const bf16x8*)(kl + DT_B + 4096 + koff[ds]);                                                     \
+      }                                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
     if (masked_) DQ_ELEM(KT_, t_, true);          /* wave-uniform: only the elementwise part exists twice */          \
     else DQ_ELEM(KT_, t_, false);                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \
                  : "+v"(ktr[0][0][0]), "+v"(ktr[0][0][1]), "+v"(ktr[0][1][0]), "+v"(ktr[0][1][1]),                   \
                    "+v"(ktr[1][0][0]), "+v"(ktr[1][0][1]), "+v"(ktr[1][1][0]), "+v"(ktr[1][1][1]));                  \
+    VC_BWD_PRIO_ON();                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
       bf16x8 sf;                                                                                                     \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) sf[j] = (__bf16)st[ks * 8 + j];                                  \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                               \
         dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(ktr[ks][dt][0], ktr[ks][dt][1]), sf, dqt[dt], 0, 0, 0); \
     }                                                                                                                \
+    VC_BWD_PRIO_OFF();                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   } while (0)
 #define DQ_TILE(stg_, t_)                                                                                   \
   do {                                                                                                               \
     const char* kl = smem + (stg_) * DQ_STG;                                                                         \
     const uint32_t kb_ = lds_addr(kl);                                                                               \
+    bf16x8 knx[4], vnx[4];                                                                                           \
     DQ_HALF(0, t_);                                                                                                  \
     DQ_HALF(1, t_);                                                                                                  \
   } while (0)
@@ -856,16 +404,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const bf16_t* 
 #define DKV_HALF(QT_, t_)                                                                                   \
   do {                                                                                                               \
     bf16x8 qfr[4], dfr[4];                                                                                           \
-    _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                               \
-      qfr[ds] = *(const bf16x8*)(ql + (QT_) * 4096 + koff[ds]);                                                      \
-      dfr[ds] = *(const bf16x8*)(ql + DT_B + (QT_) * 4096 + koff[ds]);                                               \
+    if (VC_BWD_PREFETCH && (QT_) == 1) {                                                                             \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) { qfr[ds] = qnx[ds]; dfr[ds] = dnx[ds]; }                     \
+    } else {                                                                                                         \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                             \
+        qfr[ds] = *(const bf16x8*)(ql + (QT_) * 4096 + koff[ds]);                                                    \
+        dfr[ds] = *(const bf16x8*)(ql + DT_B + (QT_) * 4096 + koff[ds]);                                             \
+      }                                                                                                              \
     }                                                                                                                \
+    VC_BWD_PRIO_ON();                                                                                                \
     f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[0], kf[0], VC_ZERO16, 0, 0, 0);                          \
     f32x16 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[0], vf[0], VC_ZERO16, 0, 0, 0);                         \
     _Pragma("unroll") for (int ds = 1; ds < 4; ++ds) {                                                               \
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ds], kf[ds], st, 0, 0, 0);                                    \
       dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[ds], vf[ds], dpt, 0, 0, 0);                                  \
     }                                                                                                                \
+    VC_BWD_PRIO_OFF();                                                                                               \
     /* the transposed Q / dO fragments of this half go out now: their latency hides behind the elementwise part */  \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     s16x4 qtr[2][2], dtr[2][2];          /* [dt][rd] of one 16-query block at a time */                              \
@@ -874,8 +428,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const bf16_t* 
         dtr[dt][rd] = lds_tr_read<DT_B + (QT_) * 4096>(qb_ + (uint32_t)toff[rd][dt]);                                \
         qtr[dt][rd] = lds_tr_read<(QT_) * 4096>(qb_ + (uint32_t)toff[rd][dt]);                                       \
       }                                                                                                              \
+    if (VC_BWD_PREFETCH && (QT_) == 0) {      /* the second half's row-major fragments: in flight during this half's elementwise part */ \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                             \
+        qnx[ds] = *(const bf16x8*)(ql + 4096 + koff[ds]);                                                            \
+        dnx[ds] = *(const bf16x8*)(ql + DT_B + 4096 + koff[ds]);                                                     \
+      }                                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
     if (masked_) DKV_ELEM(QT_, t_, true);         /* wave-uniform: only the elementwise part exists twice */          \
     else DKV_ELEM(QT_, t_, false);                                                                                   \
+    VC_BWD_PRIO_ON();                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
       bf16x8 pf, sf;                                                                                                 \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
@@ -902,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const bf16_t* 
         dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[dt], sf, dkt[dt], 0, 0, 0);                             \
       }                                                                                                              \
     }                                                                                                                \
+    VC_BWD_PRIO_OFF();                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   } while (0)
 #define DKV_TILE(stg_, t_)                                                                                  \
@@ -909,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const bf16_t* 
     const char* ql = smem + (stg_) * DKV_STG;                                                                        \
     const float* Ll = (const float*)(ql + 2 * DT_B);                                                                 \
     const uint32_t qb_ = lds_addr(ql);                                                                               \
+    bf16x8 qnx[4], dnx[4];                                                                                           \
     DKV_HALF(0, t_);                                                                                                 \
     DKV_HALF(1, t_);                                                                                                 \
   } while (0)
@@ -1019,17 +583,6 @@ extern "C" int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, cons
   dim3 grid_q(((q_hi - q_lo + 127) / 128) * NH * B);     // dQ: the query blocks of the range
   const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
   const float rs = 1.0f / (1.0f - p_drop);
-#define VC_BWD_LAUNCH(DROP_)                                                                                              \
-  do {                                                                                                                    \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP_>, grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,            \
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);                        \
-    VC_LAUNCH_CHECK("attn_bwd_dq");                                                                                       \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,           \
-                       (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
-                       ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);     \
-    VC_LAUNCH_CHECK("attn_bwd_dkv");                                                                                      \
-  } while (0)
 #define VC_BWD_LAUNCH_DMA(DROP_)                                                                                          \
   do {                                                                                                                    \
     hipLaunchKernelGGL(attn_bwd_dq_dma_kernel<DROP_>, grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,        \
@@ -1041,16 +594,9 @@ extern "C" int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, cons
                        ld_rows, c, scale, drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);     \
     VC_LAUNCH_CHECK("attn_bwd_dkv_dma");                                                                                  \
   } while (0)
-  static const int dma = [] { const char* e = getenv("VITCAP_ATTN_BWD_DMA"); return e ? atoi(e) : 1; }();   // 0: the first pair (A/B)
-  if (dma) {
-    if (p_drop > 0.f) VC_BWD_LAUNCH_DMA(true);
-    else VC_BWD_LAUNCH_DMA(false);
-  } else {
-    if (p_drop > 0.f) VC_BWD_LAUNCH(true);
-    else VC_BWD_LAUNCH(false);
-  }
+  if (p_drop > 0.f) VC_BWD_LAUNCH_DMA(true);
+  else VC_BWD_LAUNCH_DMA(false);
 #undef VC_BWD_LAUNCH_DMA
-#undef VC_BWD_LAUNCH
   return VITCAP_OK;
 }
 

@@ -17,6 +17,8 @@
 // chunk C ^ f(m), f(m) = 4*((m>>3)&3) + (m&3).  One transpose read touches rows {8g + j} (g = lane group, j = 0..3):
 // 16 different f values, 8 per half-wave -> 8 distinct bank groups per LDS cycle.  The swizzle is applied by choosing
 // which global 16-byte chunk each DMA lane fetches (the LDS side of the DMA is lane-linear).
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -39,6 +41,9 @@ struct TnArgs {
   const bf16_t* zeros;   // >= 512 B of zeros (rows past M)
   int M, N, K, ldy, ldx;
   int tiles_n, tiles_k, splits, stages_per_split;
+  float* out;        // != nullptr: the workgroups of a tile add their slabs up themselves (below), out[N][K] (+)= sum over splits
+  int* cnt;          // [tiles][2] arrive / depart tickets, zero between launches
+  int accumulate;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
@@ -283,13 +288,61 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   // ---- store the slab: with the operands swapped the lane holds 4 consecutive k of ONE n (16-byte stores)
   float* cs = p.C + (size_t)split * p.N * p.K;
   const int nl = lane & 15, kq = (lane >> 4) * 4;
+  if (!p.out) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = n0 + wn * 128 + i * 16 + nl;
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + wn * 128 + i * 16 + nl;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + wk * 64 + j * 16 + kq;
-      if (n < p.N && k < p.K) *(f32x4*)(cs + (size_t)n * p.K + k) = acc[i][j];
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + kq;
+        if (n < p.N && k < p.K) *(f32x4*)(cs + (size_t)n * p.K + k) = acc[i][j];
+      }
+    }
+    return;
+  }
+  // ---- the splits of a tile add themselves up (round 5; was one reduce_slabs launch behind every weight gradient).  The grid is at
+  // most one workgroup per CU (the launcher checks), so the `splits` workgroups of a tile are resident together: each stores its slab
+  // write-through (sc1), draws an arrive ticket, waits until all of them have, and then sums ITS share of the tile's rows over the
+  // slabs in slab order -- the order reduce_slabs_kernel used: bit-identical results, no atomics on data.  The last to leave puts the
+  // two tickets back to zero for the next launch.
+  {
+    const __amdgpu_buffer_rsrc_t rc = vc_rsrc(cs, (long long)p.N * p.K * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + wn * 128 + i * 16 + nl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + kq;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vc_u32x4, acc[i][j]), rc, (unsigned)(n * p.K + k) * 4u, 0, 16);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* arrive = p.cnt + 2 * tile;
+  if (tid == 0) {
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.splits) __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the other slabs sit in memory; drop what this CU / XCD may hold of their lines
+  }
+  __syncthreads();
+  {
+    const int rp = (TBN + p.splits - 1) / p.splits;        // rows of the tile per split
+    const int r0 = split * rp;
+    const int r1 = r0 + rp < TBN ? r0 + rp : TBN;
+    const size_t slab = (size_t)p.N * p.K;
+    for (int r = r0 + w; r < r1; r += 8) {                 // a wave per row: 64 lanes x 4 floats = the tile's 256 columns
+      const size_t off = (size_t)(n0 + r) * p.K + k0 + lane * 4;
+      f32x4 a = p.accumulate ? *(const f32x4*)(p.out + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int sp = 0; sp < p.splits; ++sp) a += *(const f32x4*)(p.C + sp * slab + off);
+      *(f32x4*)(p.out + off) = a;
+    }
+  }
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == p.splits - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -329,17 +382,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 }  // namespace
 
-extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
-                              void* stream) {
+static int launch_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, float* out, int accumulate, int M, int N, int K,
+                     int splits, void* stream) {
   VC_REQUIRE(Y && X && C_slabs && M > 0 && N > 0 && K > 0 && splits >= 1, "gemm_tn: bad arguments");
   VC_REQUIRE(N % 256 == 0 && K % 256 == 0, "gemm_tn: N=%d and K=%d must be multiples of 256", N, K);
   VC_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gemm_tn: misaligned operands");
   static bf16_t* zeros[64] = {nullptr};
+  static int* tickets[64] = {nullptr};
+  constexpr int SLOTS = 64, SLOT_INTS = 512;       // ticket blocks handed out round-robin: launches in flight on other streams get their own
+  static std::atomic<unsigned> seq{0};
   int dev = 0;
   VC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "gemm_tn: bad device");
   if (!zeros[dev]) {
     VC_REQUIRE(hipMalloc(&zeros[dev], 1024) == hipSuccess && hipMemset(zeros[dev], 0, 1024) == hipSuccess,
                "gemm_tn: zero page allocation failed");
+    VC_REQUIRE(hipMalloc(&tickets[dev], SLOTS * SLOT_INTS * sizeof(int)) == hipSuccess &&
+                   hipMemset(tickets[dev], 0, SLOTS * SLOT_INTS * sizeof(int)) == hipSuccess, "gemm_tn: ticket allocation failed");
   }
   constexpr int smem = 2 * STAGE_BYTES;
   VC_FUNC_SMEM(gemm_tn_kernel, smem);
@@ -349,9 +407,31 @@ extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
   p.tiles_n = N / TBN; p.tiles_k = K / TBK; p.splits = splits;
   const int total_stages = (M + TBM - 1) / TBM;
   p.stages_per_split = (total_stages + splits - 1) / splits;
+  p.out = nullptr; p.cnt = nullptr; p.accumulate = accumulate;
+  if (out) {
+    // the in-kernel sum waits for the other splits of its tile: every workgroup of the launch must be resident at once (one per CU:
+    // the kernel owns 128 KiB of LDS)
+    int cus = 0;
+    VC_REQUIRE(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "gemm_tn: device query failed");
+    VC_REQUIRE(p.tiles_n * p.tiles_k * splits <= cus && p.tiles_n * p.tiles_k * 2 <= SLOT_INTS && (size_t)N * K * 4 < (1ull << 31),
+               "gemm_tn(sum): %d tiles x %d splits must fit the %d CUs at once", p.tiles_n * p.tiles_k, splits, cus);
+    p.out = out;
+    p.cnt = tickets[dev] + (seq.fetch_add(1, std::memory_order_relaxed) % SLOTS) * SLOT_INTS;
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * splits), dim3(512), smem, (hipStream_t)stream, p);
   VC_LAUNCH_CHECK("gemm_tn");
   return VITCAP_OK;
+}
+
+extern "C" int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
+                              void* stream) {
+  return launch_tn(Y, ldy, X, ldx, C_slabs, nullptr, 0, M, N, K, splits, stream);
+}
+
+extern "C" int vitcap_gemm_tn_sum(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, float* out, int accumulate, int M,
+                                  int N, int K, int splits, void* stream) {
+  VC_REQUIRE(out, "gemm_tn_sum: out is null");
+  return launch_tn(Y, ldy, X, ldx, C_slabs, out, accumulate, M, N, K, splits, stream);
 }
 
 extern "C" int vitcap_colsum_bf16(const void* y, int ldy, int M, int N, float* out, void* stream) {

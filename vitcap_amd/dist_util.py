@@ -27,6 +27,34 @@ def init(backend, device=None):
     return dist
 
 
+def host_cpu_budget():
+    """Cores this process (with its children) may use: the cgroup-v2 CPU bandwidth (cpu.max) where one is set, else the scheduler
+    affinity mask, else the machine.  On the GPU pool a box shows 256 hardware threads and grants 16 cores: a library that sizes
+    its thread pool by cpu_count() (torch's intra-op pool: 128 threads) burns the quota of a whole 100 ms period in a few
+    milliseconds, and the kernel then stops EVERY thread of the job -- launcher and decode workers included -- until the period ends."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cap_host_threads(reserved=0):
+    """Lowers (never raises) torch's intra-op thread count to the CPU budget minus `reserved` cores (decode workers, launch threads).
+    With WORLD_SIZE ranks on one host the budget is shared: each rank takes its share (host budget)."""
+    world_local = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', 1)) or 1)
+    n = max(1, host_cpu_budget() // max(1, world_local) - int(reserved))
+    if n < torch.get_num_threads():
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def shard_seed(base_seed, rank):
     """Each rank captions different synthetic images (the reference shards with DistributedSampler(shuffle=False),
     uni_pipeline.py:782-850)."""

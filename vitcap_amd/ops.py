@@ -380,6 +380,21 @@ def gemm_tn(y, x, splits, slabs=None):
     return slabs
 
 
+def gemm_tn_sum(y, x, splits, out, accumulate=False, slabs=None):
+    """out[N][K] (+)= y^T x with the sum over the `splits` pieces of M done inside the launch (vitcap_gemm_tn_sum): the result of
+    gemm_tn + reduce_slabs bit for bit, one launch; tiles x splits must fit the CUs."""
+    _dev_bf16(y); _dev_bf16(x); _dev_f32(out)
+    M, N = y.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and tuple(out.shape) == (N, K) and out.is_contiguous()
+    if slabs is None:
+        slabs = torch.empty((splits, N, K), device=y.device, dtype=torch.float32)
+    with _Timed('gemm_tn (weight gradients)', 2.0 * M * N * K, True):
+        check(lib.vitcap_gemm_tn_sum(_p(y), y.stride(0), _p(x), x.stride(0), _p(slabs), _p(out), int(accumulate), M, N, K, splits,
+                                     _stream()), 'gemm_tn_sum')
+    return out
+
+
 def colsum_bf16(y, out):
     """out[n] += sum_m y[m][n]"""
     _dev_bf16(y); _dev_f32(out)

@@ -20,6 +20,7 @@ import json
 import logging
 import os
 import os.path as op
+import time
 
 import torch
 
@@ -95,7 +96,6 @@ def _prefetched(gen, device, depth=2):
             if device.type == 'cuda':
                 torch.cuda.set_device(device)
             ev = torch.cuda.Event(blocking=True) if device.type == 'cuda' else None     # sleep, do not spin (see generate_async)
-            import time
             for b in gen:
                 t0 = time.perf_counter()
                 if ev is not None:
@@ -121,7 +121,6 @@ def _prefetched(gen, device, depth=2):
     t = threading.Thread(target=work, daemon=True)
     t.start()
     try:
-        import time
         while True:
             t0 = time.perf_counter()
             b = q.get()
@@ -300,6 +299,9 @@ class CaptionUniPipeline(object):
             D.init(backend, torch.device('cuda', self.local_rank) if backend == 'nccl' else None)
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local_rank)
+        # host threads sized by what the job may use, not by what the machine shows (D.host_cpu_budget); the loader's decode
+        # processes keep their cores
+        D.cap_host_threads(reserved=int(self.cfg.num_workers or 0))
         self._initialized = True
 
     # ------------------------------------------------------------------ model / tokenizer
@@ -404,7 +406,6 @@ class CaptionUniPipeline(object):
         """do_train_dict (trainer.py:33-213) on the HIP training engine: per-GPU batch = effective_batch_size // world,
         AdamW on the reference's parameter groups, linear LR decay, snapshot every snapshot_steps and at max_iter."""
         check_model_config(self.cfg, training=True)
-        import time
         self._ensure_initialized()
         last = self.get_checkpoint_file()
         if op.isfile(last) and not self.cfg.force_train:
@@ -519,11 +520,14 @@ class CaptionUniPipeline(object):
             from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
             from .jpegdec import decode_rows, decode_rows_into
             import numpy as np
-            import time
             workers = max(1, int(self.cfg.num_workers or 1))
             chunk = int(os.environ.get('VITCAP_LOADER_CHUNK', 8))      # images per worker task
             per_batch = (bs + chunk - 1) // chunk
-            ahead = max(2, (2 * workers + per_batch - 1) // per_batch + 1)   # batches in flight: two tasks per worker
+            # batches being decoded ahead of the one handed out: ten tasks per worker.  Decode times jitter (image sizes, a host shared
+            # with other tenants) and the consumer can never run faster than the GPU to make up for a gap, so every gap is lost for good:
+            # with 3 batches ahead + 4 queued 0.93-0.94 of the resident rate, with 10 + 24 0.96-0.975 (profiles/r05_input_side.json)
+            ahead = max(3, (10 * workers + per_batch - 1) // per_batch)
+            ahead = int(os.environ.get('VITCAP_LOADER_AHEAD', ahead))
             starts = list(range(0, len(mine), bs))
             slabs, free = [], []
             if self.cfg.loader_threads:
@@ -683,7 +687,9 @@ class CaptionUniPipeline(object):
 
         def collect(entry):
             b, out, flag, expect_n = entry
+            t_c0 = time.perf_counter()
             out = out.result() if overlap else out          # synchronises with the batch's decode stream
+            LOADER_TIMES['consumer_wait_gpu'] = LOADER_TIMES.get('consumer_wait_gpu', 0.0) + time.perf_counter() - t_c0
             if flag is not None and not bool(flag):
                 # the device-side comparison against the count of the earlier batches failed: either this batch's (valid) mask shows
                 # another number of visible tag slots -- then it is decoded again with the options of ITS count, as a host-resident
@@ -697,12 +703,15 @@ class CaptionUniPipeline(object):
                 logging.info('visible tag slots changed from %s to %d: batch decoded again with its own options', expect_n, n_tag)
                 seen['n'] = n_tag
                 out = model.generate_async(b['image'], opts=opts_for(n_tag)).result()
-            return self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu()))
+            t_c1 = time.perf_counter()
+            rows = list(self.predict_output_to_tsv_row(b, (out[0].cpu(), out[1].cpu())))
+            LOADER_TIMES['consumer_rows'] = LOADER_TIMES.get('consumer_rows', 0.0) + time.perf_counter() - t_c1
+            return rows
 
         def gen_rows():
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
             with torch.no_grad():
-                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or os.environ.get('VITCAP_LOADER_PREFETCH', 4))):
+                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or os.environ.get('VITCAP_LOADER_PREFETCH', 24))):
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
                     flag = None
@@ -720,7 +729,9 @@ class CaptionUniPipeline(object):
                             n_tag = model.check_text_inputs(batch, base.max_length)
                             if am is not None and am.is_cuda:
                                 seen['n'] = n_tag
+                        t_s0 = time.perf_counter()
                         out = model.generate_async(batch['image'], opts=opts_for(n_tag))
+                        LOADER_TIMES['consumer_submit'] = LOADER_TIMES.get('consumer_submit', 0.0) + time.perf_counter() - t_s0
                     else:
                         out = model(batch)
                     pending.append((batch, out, flag, expect_n))
@@ -735,7 +746,6 @@ class CaptionUniPipeline(object):
                 for entry in pending:
                     for key, js in collect(entry):
                         yield key, js
-        import time
         LOADER_TIMES.clear()
         stats = {'rows': 0, 't_first': None, 'rows_first': 0}
 
@@ -750,7 +760,7 @@ class CaptionUniPipeline(object):
         tsv_writer(timed_rows(), sub)               # .tsv + .lineidx + .lineidx.8b (tsv_io.py:959-998)
         if stats['t_first'] is not None and stats['rows'] > stats['rows_first']:
             dt = time.perf_counter() - stats['t_first']
-            LAST_PREDICT_STATS.update(rows=stats['rows'], steady_rows=stats['rows'] - stats['rows_first'], steady_seconds=dt,
+            LAST_PREDICT_STATS.update(rows=stats['rows'], steady_rows=stats['rows'] - stats['rows_first'], steady_seconds=dt, t_end=time.perf_counter(),
                                       loader_seconds={k: round(v, 3) for k, v in LOADER_TIMES.items()},
                                       images_per_sec=(stats['rows'] - stats['rows_first']) / dt)
             logging.info('predict: %d rows, steady state %.1f images/sec on rank %d', stats['rows'], LAST_PREDICT_STATS['images_per_sec'], self.rank)

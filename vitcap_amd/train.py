@@ -35,6 +35,9 @@ from ._lib import check, lib
 
 CH = 1024           # optimizer chunk (elements)
 _FUSE_BIAS = os.environ.get('VITCAP_TRAIN_FUSED_BIAS', '1') != '0'      # A/B switch of the measurement in docs/LAB_r01_r04.md 7
+_TN_SUM = os.environ.get('VITCAP_TRAIN_TN_SUM', '0') != '0'             # 1: the splits of a weight gradient add themselves up inside the launch
+# (vitcap_gemm_tn_sum, bit-identical) instead of a reduce_slabs launch each -- measured SLOWER inside the graph-replayed step (48.85 vs 49.3 ms:
+# profiles/r05_train_attn_bwd_ab.txt): the ticket wait and the write-through slabs cost more than 80 cheap launches save
 NV = 577
 SV = 578
 T = 20
@@ -484,6 +487,8 @@ class TrainEngine(object):
         S = max(1, min(stages, 256 // tiles))
         if S == 1:
             ops.gemm_tn(dy, x, 1, slabs=gview.view(1, N, Kin))
+        elif _TN_SUM and gview.is_contiguous():
+            ops.gemm_tn_sum(dy, x, S, gview)                     # the splits add themselves up inside the launch (round 5)
         else:
             ops.reduce_slabs(ops.gemm_tn(dy, x, S), gview)
         if bias_grad is not None:
