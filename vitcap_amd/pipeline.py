@@ -526,7 +526,7 @@ class CaptionUniPipeline(object):
             # batches being decoded ahead of the one handed out: ten tasks per worker.  Decode times jitter (image sizes, a host shared
             # with other tenants) and the consumer can never run faster than the GPU to make up for a gap, so every gap is lost for good:
             # with 3 batches ahead + 4 queued 0.93-0.94 of the resident rate, with 10 + 24 0.96-0.975 (profiles/r05_input_side.json)
-            ahead = max(3, (10 * workers + per_batch - 1) // per_batch)
+            ahead = min(12, max(3, (10 * workers + per_batch - 1) // per_batch))     # <= 15 batches of slabs (2.9 GB nominal) however many workers
             ahead = int(os.environ.get('VITCAP_LOADER_AHEAD', ahead))
             starts = list(range(0, len(mine), bs))
             slabs, free = [], []
