@@ -163,6 +163,7 @@ def main():
     import threading
     for workers, threads in sweep:
         c0 = cpu_stat()
+        m0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
         samples, stop = [], threading.Event()
 
         def sampler():        # cgroup CPU accounting every 50 ms: which part of the throttling falls into the steady-state window
@@ -190,6 +191,8 @@ def main():
                 'periods': c1.get('nr_periods', 0) - c0.get('nr_periods', 0), 'throttled_periods': c1.get('nr_throttled', 0) - c0.get('nr_throttled', 0),
                 'throttled_s': round((c1.get('throttled_usec', 0) - c0.get('throttled_usec', 0)) / 1e6, 2)}
             print('cgroup cpu', res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')], flush=True)
+        print('device allocations (hipMalloc) during the run: %d; reserved %.1f GB' % (
+            torch.cuda.memory_stats().get('num_device_alloc', 0) - m0, torch.cuda.memory_reserved() / 2**30), flush=True)
         e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
         print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s); loader seconds %s' % (
             workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall,
