@@ -1053,6 +1053,25 @@ def test_generate_async_pipeline_equals_generate(model):
     assert torch.equal(ids.clone(), want[0][0])
 
 
+def test_pipeline_streams_belong_to_the_process(model):
+    """A second model object of the process runs its 2-slot pipeline on the SAME encoder / decode streams as the first (model.role_stream)
+    and gives the same results: with a fresh stream pair per model every new model drew another stream -> hardware-queue arrangement, and
+    some of them halved the pipeline's rate (profiles/r05_hw_queue_aliasing.txt)."""
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning, role_stream
+    imgs = [torch.from_numpy(W.gen_image_batch(8, 300 + i)).cuda().to(torch.bfloat16) for i in range(3)]
+    want = [model.generate_async(im).result() for im in imgs]
+    other = ImageCaptioning(tie_weights=True, tagemb='cls').load_recipe(0).eval()
+    other.pack('cuda')
+    got = [other.generate_async(im).result() for im in imgs]
+    for (a, b), (c, d) in zip(want, got):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    pa, pb = model._pipes[0], other._pipes[0]
+    assert pa['enc'] is pb['enc'] and pa['dec'] is pb['dec']
+    dev = torch.device('cuda', torch.cuda.current_device())
+    assert role_stream(dev, 'enc0', lambda: None) is pa['enc']
+
+
 def test_generate_async_beam_equals_generate_beam(model):
     from vitcap_amd import weights as W
     imgs = [torch.from_numpy(W.gen_image_batch(3, 200 + i)).cuda().to(torch.bfloat16) for i in range(3)]

@@ -500,6 +500,24 @@ extern "C" int vitcap_engine_create(vitcap_engine** out) {
   }
   return *out ? VITCAP_OK : VITCAP_EINVAL;
 }
+// The engine's helper streams are PROCESS-wide, one per role and device, created on first use and never destroyed.  HIP maps streams onto a
+// few hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order, and two chains that share a queue block each other at every
+// event wait.  With streams owned by the engine object, every new model of a process (pipeline_eval_multi over several test sets) drew a
+// new arrangement: some put the encoder and the decode chain on one queue and the 2-slot pipeline ran at HALF its rate (measured: the
+// second and third predict() of a process 1 935 instead of 3 750 images/s, all fine with 8 queues; profiles/r05_hw_queue_aliasing.txt).
+// Shared streams add ordering between two engines used at the same time from two threads, never a hazard: every use is fenced by the
+// engine's own events.
+enum { ROLE_SIDE = 0, ROLE_DEC2 = 1, ROLE_PART0 = 2 /* .. +2 */, ROLE_COUNT = 5 };
+static hipStream_t role_stream(int role) {
+  static std::mutex mu;
+  static hipStream_t pool[64][ROLE_COUNT] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || role < 0 || role >= ROLE_COUNT) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!pool[dev][role] && hipStreamCreateWithFlags(&pool[dev][role], hipStreamNonBlocking) != hipSuccess) pool[dev][role] = nullptr;
+  return pool[dev][role];
+}
+
 extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
   if (!e) return;
   for (auto& t : e->pool) {
@@ -509,13 +527,10 @@ extern "C" void vitcap_engine_destroy(vitcap_engine* e) {
   drop_graphs(e);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->side) (void)hipStreamDestroy(e->side);
-  if (e->cap) (void)hipStreamDestroy(e->cap);
-  if (e->dec2) (void)hipStreamDestroy(e->dec2);
+  if (e->cap) (void)hipStreamDestroy(e->cap);          // side / dec2 / part streams belong to the process (role_stream)
   if (e->ev_dfork) (void)hipEventDestroy(e->ev_dfork);
   if (e->ev_djoin) (void)hipEventDestroy(e->ev_djoin);
   for (int i = 0; i < 3; ++i) {
-    if (e->part[i]) (void)hipStreamDestroy(e->part[i]);
     if (e->ev_pjoin[i]) (void)hipEventDestroy(e->ev_pjoin[i]);
   }
   if (e->ev_pfork) (void)hipEventDestroy(e->ev_pfork);
@@ -745,7 +760,7 @@ static int encode_part(vitcap_engine* e, const void* image, int image_is_bf16, i
     if (i == 8 && fork) {
       // fork: the tag branch depends only on x (the output of block 7), which nobody writes from here on
       if (!e->side) {
-        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        if ((e->side = role_stream(ROLE_SIDE)) == nullptr ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
           vitcap_set_error("encode: side stream creation failed");
@@ -793,7 +808,7 @@ static int encode_parts(const vitcap_gen_opts& o, int B, const Layout& lo) {
 
 static int ensure_dec2(vitcap_engine* e) {
   if (!e->dec2) {
-    if (hipStreamCreateWithFlags(&e->dec2, hipStreamNonBlocking) != hipSuccess ||
+    if ((e->dec2 = role_stream(ROLE_DEC2)) == nullptr ||
         hipEventCreateWithFlags(&e->ev_dfork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_djoin, hipEventDisableTiming) != hipSuccess) {
       vitcap_set_error("engine: second stream creation failed");
@@ -816,7 +831,7 @@ static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16,
     if (!e->ev_pfork) HIPCK(hipEventCreateWithFlags(&e->ev_pfork, hipEventDisableTiming), "encode: event");
     for (int i = 0; i < np - 1; ++i)
       if (!e->part[i]) {
-        HIPCK(hipStreamCreateWithFlags(&e->part[i], hipStreamNonBlocking), "encode: part stream");
+        if ((e->part[i] = role_stream(ROLE_PART0 + i)) == nullptr) { vitcap_set_error("encode: part stream creation failed"); return VITCAP_ELAUNCH; }
         HIPCK(hipEventCreateWithFlags(&e->ev_pjoin[i], hipEventDisableTiming), "encode: event");
       }
     HIPCK(hipEventRecord(e->ev_pfork, (hipStream_t)s), "encode: split fork record");
@@ -1118,7 +1133,7 @@ static int greedy_loop(vitcap_engine* e, const Layout& lo, const vitcap_gen_opts
     parts[0] = Part{0, b0 * K, 0};
     parts[1] = Part{b0 * K, (B - b0) * K, b0};
     if (!e->dec2) {
-      if (hipStreamCreateWithFlags(&e->dec2, hipStreamNonBlocking) != hipSuccess ||
+      if ((e->dec2 = role_stream(ROLE_DEC2)) == nullptr ||
           hipEventCreateWithFlags(&e->ev_dfork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&e->ev_djoin, hipEventDisableTiming) != hipSuccess) {
         vitcap_set_error("decode: second stream creation failed");

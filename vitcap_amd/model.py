@@ -43,6 +43,22 @@ def _build_tree(root, spec, tie_weights):
     return params
 
 
+_ROLE_STREAMS = {}
+
+
+def role_stream(dev, role, make):
+    """One stream per (device, role) for the life of the PROCESS.  torch hands out its pool streams round-robin and HIP maps streams onto
+    a few hardware queues (GPU_MAX_HW_QUEUES, default 4): with a fresh pair of streams per model object, every new model of a process drew
+    another arrangement, and the ones that put the encoder chain and the decode chain (or the loader's copies) on one queue ran the 2-slot
+    pipeline at half its rate (profiles/r05_hw_queue_aliasing.txt).  Streams are only ever added, never handed back."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    s = _ROLE_STREAMS.get(key)
+    if s is None:
+        s = _ROLE_STREAMS[key] = make()
+    return s
+
+
 def _encode_stream(dev):
     """The pipeline's encoder stream.  VITCAP_ENC_CUS = n < 256 (experiment, docs/LAB_r01_r04.md 4.2 vi) confines it to the CUs of the
     low n mask bits (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8), which leaves 256 - n CUs that the encoder's GEMM
@@ -492,7 +508,8 @@ class ImageCaptioning(nn.Module):
         if pipe is None:
             import os
             prio = int(os.environ.get('VITCAP_DECODE_PRIORITY', '-1'))     # -1 = high: the latency-bound chain goes first
-            pipe = pipes[lane] = {'enc': _encode_stream(dev), 'dec': torch.cuda.Stream(dev, priority=prio),
+            pipe = pipes[lane] = {'enc': role_stream(dev, 'enc%d' % lane, lambda: _encode_stream(dev)),
+                                  'dec': role_stream(dev, 'dec%d' % lane, lambda: torch.cuda.Stream(dev, priority=prio)),
                                   'done': [None, None], 'n': 0}
         slot = pipe['n'] % 2
         pipe['n'] += 1

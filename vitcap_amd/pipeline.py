@@ -96,6 +96,14 @@ def _prefetched(gen, device, depth=2):
             if device.type == 'cuda':
                 torch.cuda.set_device(device)
             ev = torch.cuda.Event(blocking=True) if device.type == 'cuda' else None     # sleep, do not spin (see generate_async)
+            # the producer's copies and transform kernels go to a stream of their own: on the (per-process) default stream they shared a
+            # queue with the consumer's blocking device -> host copies of the finished captions, and each side waited behind the other's
+            # work -- with 24 batches of prefetch a `.cpu()` of 5 KB could sit behind a whole batch of host -> device copies
+            # (docs/LAB_r05.md 5: the 22 ms-per-batch mode of the round script's input-side runs)
+            from .model import role_stream
+            side = role_stream(device, 'loader', lambda: torch.cuda.Stream(device)) if device.type == 'cuda' else None
+            if side is not None:
+                torch.cuda.set_stream(side)          # thread-local: this thread only
             for b in gen:
                 t0 = time.perf_counter()
                 if ev is not None:
