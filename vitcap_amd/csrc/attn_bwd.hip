@@ -40,8 +40,13 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 #ifndef VC_BWD_PREFETCH      // 1: the row-major fragments of a tile's second half are requested behind the first half's S / dP MFMAs
 #define VC_BWD_PREFETCH 0
 #endif
-#ifndef VC_BWD_DQ_MINW       // waves per SIMD the dQ kernel is compiled for (3 = 168 registers: 52 spilled, not usable as written)
-#define VC_BWD_DQ_MINW 2
+// waves per SIMD the dQ kernel is compiled for.  3 = 168 registers: reached with the S^T and the dP^T MFMA chains one after the other (one set
+// of row-major fragments live at a time) and the tail mode as a template parameter (an instantiation holds either the left-over-key loop or
+// the masked tail tile); what the allocator still spills (13 registers in the encoder's instantiation) is stored once in front of the loop
+// and re-read once behind it -- checked in the ISA, no scratch access inside the loop.  Per launch -2.4 % (encoder) / -3.5 % (decoder)
+// against two waves, the training step within its spread (profiles/r05_train_attn_bwd_ab.txt).
+#ifndef VC_BWD_DQ_MINW
+#define VC_BWD_DQ_MINW 3
 #endif
 constexpr int DT_B = KT * 128;               // one row-major tile: 64 rows x 128 B
 constexpr int NSTG = 3;                      // ring: tile t+2 is in flight while tile t is multiplied
@@ -83,7 +88,7 @@ __device__ __forceinline__ bool visible_nb(int q, int k, int S, int cf, int mf) 
 }
 #define VC_ZERO16 f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 
-template <bool DROP>
+template <bool DROP, bool TAIL>
 __global__ __launch_bounds__(256, VC_BWD_DQ_MINW) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                  float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int S, int B,
@@ -176,23 +181,20 @@ __global__ __launch_bounds__(256, VC_BWD_DQ_MINW) void attn_bwd_dq_dma_kernel(co
   // one 32-key half of a tile: S^T = K Q^T, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T (KT_ literal: the transpose reads take immediates)
 #define DQ_HALF(KT_, t_)                                                                                    \
   do {                                                                                                               \
-    bf16x8 kfr[4], vfr[4];                                                                                           \
-    if (VC_BWD_PREFETCH && (KT_) == 1) {                                                                             \
-      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) { kfr[ds] = knx[ds]; vfr[ds] = vnx[ds]; }                     \
-    } else {                                                                                                         \
-      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                             \
-        kfr[ds] = *(const bf16x8*)(kl + (KT_) * 4096 + koff[ds]);                                                    \
-        vfr[ds] = *(const bf16x8*)(kl + DT_B + (KT_) * 4096 + koff[ds]);                                             \
-      }                                                                                                              \
+    f32x16 st, dpt;                                                                                                  \
+    {                                                                                                                \
+      bf16x8 kfr[4];                                                                                                 \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) kfr[ds] = *(const bf16x8*)(kl + (KT_) * 4096 + koff[ds]);     \
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], VC_ZERO16, 0, 0, 0);                               \
+      _Pragma("unroll") for (int ds = 1; ds < 4; ++ds) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ds], qf[ds], st, 0, 0, 0); \
     }                                                                                                                \
-    VC_BWD_PRIO_ON();                                                                                                \
-    f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], VC_ZERO16, 0, 0, 0);                          \
-    f32x16 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], VC_ZERO16, 0, 0, 0);                        \
-    _Pragma("unroll") for (int ds = 1; ds < 4; ++ds) {                                                               \
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ds], qf[ds], st, 0, 0, 0);                                    \
-      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ds], dof[ds], dpt, 0, 0, 0);                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    {                                                                                                                \
+      bf16x8 vfr[4];                                                                                                 \
+      _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) vfr[ds] = *(const bf16x8*)(kl + DT_B + (KT_) * 4096 + koff[ds]); \
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], VC_ZERO16, 0, 0, 0);                             \
+      _Pragma("unroll") for (int ds = 1; ds < 4; ++ds) dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ds], dof[ds], dpt, 0, 0, 0); \
     }                                                                                                                \
-    VC_BWD_PRIO_OFF();                                                                                               \
     /* the transposed K fragments of this half go out now: their latency hides behind the elementwise part */       \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     s16x4 ktr[2][2][2];                                                                                              \
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, VC_BWD_DQ_MINW) void attn_bwd_dq_dma_kernel(co
       }                                                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
     }                                                                                                                \
-    if (masked_) DQ_ELEM(KT_, t_, true);          /* wave-uniform: only the elementwise part exists twice */          \
+    if (TAIL && masked_) DQ_ELEM(KT_, t_, true);  /* wave-uniform: only the elementwise part exists twice */          \
     else DQ_ELEM(KT_, t_, false);                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \
                  : "+v"(ktr[0][0][0]), "+v"(ktr[0][0][1]), "+v"(ktr[0][1][0]), "+v"(ktr[0][1][1]),                   \
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(256, VC_BWD_DQ_MINW) void attn_bwd_dq_dma_kernel(co
 #undef DQ_HALF
 #undef DQ_ELEM
 #undef STAGE_TILE
-  // left-over keys on the vector ALU
-  if (active && !tail_tile) {
+  // left-over keys on the vector ALU (TAIL = false: the host picks the instantiation by the same rule as tail_tile)
+  if (!TAIL && active && !tail_tile) {
     for (int key = nfull * KT; key < S; ++key) {
       const bf16_t* kr = base + (size_t)key * QKV_LD + 768 + half * 8;
       const bf16_t* vr = base + (size_t)key * QKV_LD + 1536 + half * 8;
@@ -583,11 +585,18 @@ extern "C" int vitcap_attn_dense_bwd_rows(const void* qkv, const void* out, cons
   dim3 grid_q(((q_hi - q_lo + 127) / 128) * NH * B);     // dQ: the query blocks of the range
   const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
   const float rs = 1.0f / (1.0f - p_drop);
+  const int rem_ = S % KT;
+  const bool tail_tile_ = rem_ > 8 || (causal_from > 0 && rem_ > 0);      // the kernels' own rule: masked tail tile or left-over keys
 #define VC_BWD_LAUNCH_DMA(DROP_)                                                                                          \
   do {                                                                                                                    \
-    hipLaunchKernelGGL(attn_bwd_dq_dma_kernel<DROP_>, grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,        \
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,        \
-                       drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);                        \
+    if (tail_tile_)                                                                                                       \
+      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DROP_, true>), grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, \
+                         (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,      \
+                         drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);                      \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DROP_, false>), grid_q, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, \
+                         (const bf16_t*)out, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, S, B, ld_rows, c, scale,      \
+                         drop_seed, thr, rs, causal_from, mask_from, q_lo, q_hi, vc_tls_drop_salt);                      \
     VC_LAUNCH_CHECK("attn_bwd_dq_dma");                                                                                   \
     hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel<DROP_>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,       \
                        (const bf16_t*)dout, lse, (const float*)dsum, (const bf16_t*)extra_dkv, (bf16_t*)dqkv, S, B,       \
