@@ -3,7 +3,9 @@
   (b) decode only (isolated chain),
   (c) the full 2-slot pipeline (bench.py's timed loop).
 (c) - (a) = what the decode chain still costs per batch although it overlaps the next batch's encoder.
-Usage: python tools/encode_only_bench.py [B=64] [steps=60]"""
+Usage: python tools/encode_only_bench.py [B=64] [steps=60] [phase]
+phase = enc | dec | pipe: only that phase, `steps` times (for tools/power_during.py: board power of each phase on its own -> the
+energy balance of the pipeline, profiles/r05_energy_balance.txt)."""
 import ctypes as C
 import os
 import sys
@@ -21,6 +23,7 @@ from vitcap_amd.model import ImageCaptioning
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    phase = sys.argv[3] if len(sys.argv) > 3 else None
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:0')
     img = torch.from_numpy(W.gen_image_batch(B, 1234)).cuda().to(torch.bfloat16).contiguous()
@@ -50,8 +53,16 @@ def main():
                 fn()
             stream.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
-        t_enc = timed(enc, steps)
-        t_dec = timed(dec, steps)
+        if phase in ('enc', 'dec'):
+            if phase == 'dec':
+                enc()                      # the decode chain needs a prefilled workspace
+            t = timed(enc if phase == 'enc' else dec, steps)
+            print('B=%d | %s alone %.3f ms x %d' % (B, 'encode+prefill' if phase == 'enc' else 'decode', t, steps))
+            return
+        t_enc = t_dec = 0.0
+        if phase is None:
+            t_enc = timed(enc, steps)
+            t_dec = timed(dec, steps)
         model.prime_pipeline(B, dev, opts=popts)
         for _ in range(3):
             model.generate_async(img, opts=popts).result()
@@ -64,6 +75,9 @@ def main():
         pend.result()
         torch.cuda.synchronize()
         t_pipe = (time.perf_counter() - t0) / steps * 1e3
+    if phase == 'pipe':
+        print('B=%d | 2-slot pipeline %.3f ms/batch x %d' % (B, t_pipe, steps))
+        return
     print('B=%d | encode+prefill alone %.3f ms | decode alone %.3f ms | sum %.3f | 2-slot pipeline %.3f ms/batch (%.0f img/s) | '
           'decode cost not hidden %.3f ms (%.1f %% of the pipeline step)' % (
               B, t_enc, t_dec, t_enc + t_dec, t_pipe, B / t_pipe * 1e3, t_pipe - t_enc, (t_pipe - t_enc) / t_pipe * 100))
