@@ -24,10 +24,11 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     phase = sys.argv[3] if len(sys.argv) > 3 else None
+    max_length = int(sys.argv[4]) if len(sys.argv) > 4 else 20          # decode steps = max_length - 1 (marginal cost of a step inside the pipeline)
     model = ImageCaptioning().load_recipe(0).eval()
     model.pack('cuda:0')
     img = torch.from_numpy(W.gen_image_batch(B, 1234)).cuda().to(torch.bfloat16).contiguous()
-    popts = model.gen_options(gemm_mode=L.GEMM_TILES, num_beams=1, num_keep_best=1, do_sample=False, num_return_sequences=1)
+    popts = model.gen_options(gemm_mode=L.GEMM_TILES, num_beams=1, num_keep_best=1, do_sample=False, num_return_sequences=1, max_length=max_length)
     dev = img.device
     ws, need = model._workspace(B, dev, 'eo', popts)
     wp = C.c_void_p(ws.data_ptr())
@@ -76,7 +77,7 @@ def main():
         torch.cuda.synchronize()
         t_pipe = (time.perf_counter() - t0) / steps * 1e3
     if phase == 'pipe':
-        print('B=%d | 2-slot pipeline %.3f ms/batch x %d' % (B, t_pipe, steps))
+        print('B=%d | max_length %d | 2-slot pipeline %.3f ms/batch x %d' % (B, max_length, t_pipe, steps))
         return
     print('B=%d | encode+prefill alone %.3f ms | decode alone %.3f ms | sum %.3f | 2-slot pipeline %.3f ms/batch (%.0f img/s) | '
           'decode cost not hidden %.3f ms (%.1f %% of the pipeline step)' % (
