@@ -186,6 +186,44 @@ def test_bucketed_exchange_bf16_wire_vs_fp32(world):
         assert torch.equal(f[~inside], m[~inside])
 
 
+def _bcast_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from vitcap_amd import dist_util as D
+    dist = D.init('gloo')
+    g = torch.Generator().manual_seed(7)
+    P = torch.randn(5000, generator=g)
+    M, V = torch.zeros(5000), torch.ones(5000)
+    if rank != 0:                      # a replica built from another file: perturbed parameters, stale moments
+        P += 0.1 * (rank + 1)
+        M += rank
+        V *= 3.0
+    n = D.broadcast_from_rank0([P, M, V], dist, chunk_elems=2048)      # 3 pieces per tensor: the chunked path
+    out.put((rank, n, P.clone(), M.clone(), V.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_broadcast_from_rank0_gloo():
+    """DDP's wrap-time broadcast (uni_pipeline.py:497-505): rank 1 starts from perturbed weights / moments and ends equal to rank 0
+    (TrainEngine.__init__ and sync_from_rank0 call this helper on the flat parameter / moment buffers)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = torch.randn(5000, generator=torch.Generator().manual_seed(7))
+    for rank, n, P, M, V in res:
+        assert n == 3 * 5000 * 4
+        assert torch.equal(P, want) and torch.equal(M, torch.zeros(5000)) and torch.equal(V, torch.ones(5000)), rank
+    from vitcap_amd import dist_util as D
+    assert D.broadcast_from_rank0([torch.zeros(3)], None) == 0         # no process group: nothing to do
+
+
 def test_bench_self_launches_eight_ranks():
     """The driver's widest launch: `python bench.py --gpus 8` starts eight ranks (child torch.distributed.run), every rank takes
     part in the barriers and the max-over-ranks, rank 0 prints the ONE line (CPU stand-in workload, gloo)."""

@@ -459,7 +459,7 @@ def test_two_process_data_parallel_step(tmp_path, path):
 def _rccl_one_rank_worker(port, out, tmp, algo):
     import os
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', VITCAP_DP_REDUCE='rs_ag' if algo == 'bf16' else algo)
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VITCAP_DP_REDUCE={'bf16': 'rs_ag', 'graph': 'all_reduce'}.get(algo, algo))
     import torch
     from vitcap_amd import dist_util as D
     from vitcap_amd import weights as W
@@ -472,13 +472,25 @@ def _rccl_one_rank_worker(port, out, tmp, algo):
     assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
     eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda:0', max_iter=10, attn_dropout=0.0, dist=dist)
     wire = 'bf16' if algo == 'bf16' else 'f32'               # 'bf16': all-to-all of bf16 slices + fp32 accumulate + all-gather (dist_util.py)
-    eng.reducer = BucketedAllReduce(eng.G, eng.reducer.buckets, eng.reducer.stages, dist, algo='rs_ag' if algo == 'bf16' else algo,
-                                    force_exchange=True, wire=wire)
+    eng.reducer = BucketedAllReduce(eng.G, eng.reducer.buckets, eng.reducer.stages, dist,
+                                    algo={'bf16': 'rs_ag', 'graph': 'all_reduce'}.get(algo, algo), force_exchange=True, wire=wire)
     assert eng.reducer.wire == wire and eng.reducer.reserve_cus == 16
     assert eng.reducer.exchange and eng.reducer.comm is not None and eng.reducer._native_rs
     b = {k: v.cuda() for k, v in synthetic_train_inputs(2).items()}
     b['image'] = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+    if algo == 'graph':
+        # graph mode + gradient exchange (the default of pipeline.train on > 1 rank): 4 captured segments, the buckets of a segment's
+        # stages start behind its replay; segments 1..3 are captured with the reducer's CUs reserved (frozen into their grids)
+        eng.use_graphs = True
+        from vitcap_amd._lib import lib
+        assert lib.vitcap_gemm_reserve_cus(0) == 0
     res = eng.train_step(b)
+    if algo == 'graph':
+        entry, = eng._graphs.values()
+        assert [st for _, st in entry['segs']] == [['cls', 'dec1', 'dec0'], ['emb', 'tag1', 'tag0'], ['blk5', 'blk4', 'blk3'],
+                                                   ['blk2', 'blk1', 'blk0', 'patch']]
+        assert entry['reserved_cus'] == 16
+        assert lib.vitcap_gemm_reserve_cus(0) == 0           # nothing left reserved behind the capture / the step
     torch.cuda.synchronize()
     t = torch.ones(1, device='cuda')
     dist.all_reduce(t)                                        # the bench's barrier / max-over-ranks primitives on RCCL
@@ -488,7 +500,7 @@ def _rccl_one_rank_worker(port, out, tmp, algo):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag', 'bf16'])
+@pytest.mark.parametrize('algo', ['all_reduce', 'rs_ag', 'bf16', 'graph'])
 def test_rccl_exchange_one_rank_group(tmp_path, algo):
     """The `nccl` (= RCCL) branch of the gradient exchange on the one GPU a test box has: a process group of ONE rank, the exchange
     forced (BucketedAllReduce(force_exchange=True)): communicator creation with device_id, every bucket's collective enqueued on the
@@ -527,6 +539,37 @@ def test_rccl_exchange_one_rank_group(tmp_path, algo):
     got = torch.load(str(tmp_path / ('p_%s.pt' % algo)))
     d = (eng.P.cpu() - got).abs()
     assert float(d.mean()) < (5e-6 if algo == 'bf16' else 2e-6), float(d.mean())
+
+
+def test_nan_watch_raises_and_dumps_context(tmp_path):
+    """trainer.py:134-137: a NaN loss saves `NaN_context_<rank>` and raises RuntimeError('NaN encountered!').  The device-side flag
+    (loss or gradient norm not finite) is read at the periodic host synchronisation: a clean step passes the check, a step on an image
+    with an Inf pixel trips it -- in eager and in graph mode."""
+    import os
+    from vitcap_amd import weights as W
+    from vitcap_amd.model import ImageCaptioning
+    from vitcap_amd.synthetic import synthetic_train_inputs
+    from vitcap_amd.train import TrainEngine
+    for graph in (False, True):
+        eng = TrainEngine(ImageCaptioning().load_recipe(0), 'cuda', max_iter=10, attn_dropout=0.0)
+        eng.use_graphs = graph
+        eng.nan_dump_dir = str(tmp_path)
+        b = {k: v.cuda() for k, v in synthetic_train_inputs(2).items()}
+        b['image'] = torch.from_numpy(W.gen_image_batch(2, 1234)).cuda()
+        eng.train_step(b)
+        eng.flush_text_check()                                  # clean: no exception, no file
+        assert not os.path.exists(str(tmp_path / 'NaN_context_0.pt'))
+        bad = dict(b)
+        bad['image'] = b['image'].clone()
+        bad['image'][1, 0, 5, 7] = float('inf')
+        eng.train_step(bad)
+        eng.train_step(b)                                       # the flag survives later steps until it is read
+        with pytest.raises(RuntimeError, match='NaN encountered'):
+            eng.flush_text_check()
+        ctx = torch.load(str(tmp_path / 'NaN_context_0.pt'), weights_only=False)
+        assert ctx['first_bad_step'] == 2 and ctx['iteration'] == 3 and 'optimizer' in ctx and len(ctx['model']) == 288
+        os.remove(str(tmp_path / 'NaN_context_0.pt'))
+        eng.flush_text_check()                                  # the flag was consumed
 
 
 def test_scst_logprob_gradient_vs_oracle(sd_t):

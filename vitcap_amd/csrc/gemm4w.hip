@@ -57,7 +57,7 @@ __device__ __forceinline__ void dma16(uint32_t lds, uint32_t voff, const i32x4& 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-// VC_4W_PREFETCH probe: one dword per lane into an LDS scratch line -- pulls the 128-byte lines of 64 rows of a LATER k-tile's A slice
+// A-panel prefetch (template parameter PF of the persistent kernel): one dword per lane into an LDS scratch line -- pulls 128-byte lines of the NEXT tile's A panel
 // into this XCD's L2 (no VGPR destination: nothing for the compiler to reuse while the load is in flight)
 __device__ __forceinline__ void pf64(uint32_t lds, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -90,7 +90,7 @@ struct Loop {
   uint32_t voff_a, voff_w;        // per-lane global byte offset inside a piece
   uint32_t soff_a, soff_w;        // wave's first piece (scalar byte offset)
   uint32_t pstep_a, pstep_w;      // 8 rows
-  uint32_t voff_pf, lds_pf;       // VC_4W_PREFETCH probe: this lane's row of the A tile (or out of range), 256 B of LDS scratch
+  uint32_t voff_pf, lds_pf;       // A-panel prefetch: this lane's row / line of the next tile's panel (or out of range), 256 B of LDS scratch per wave
 };
 // buffer descriptors of one output tile's operand panels (base = the tile's first row, range-checked to the matrix end: rows past
 // M / N read as out-of-range -- no fault, and their outputs are never stored)
@@ -253,14 +253,17 @@ __device__ __forceinline__ void k_tile_e(f32x4 (&acc)[MI][8], Frags& f, const Lo
 
 // One k-tile t (cur = its buffer's byte offset): k-half 0, the mid-tile rendezvous, k-half 1 (whose DMA, MODE1 == 1, requests the
 // k-tile at byte offset kb2 of the panels `src` -- two k-tiles ahead in the stream, possibly the NEXT output tile's -- into `cur`).
-template <int MI, int MODE1, bool FIRST>
+template <int MI, int MODE1, bool FIRST, bool PF = false>
 __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2,
                                        const Src& pf, uint32_t pf_soff);
 template <int MI, int MODE1, bool FIRST>
 __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2) {
-  k_tile<MI, MODE1, FIRST>(acc, f, L, src, cur, kb2, src, 0xfffffff0u);
+  k_tile<MI, MODE1, FIRST, false>(acc, f, L, src, cur, kb2, src, 0xfffffff0u);
 }
-template <int MI, int MODE1, bool FIRST>
+// PF (persistent bf16-output kernel at M >= 64k rows, round 6): every k-tile issues exactly ONE more memory instruction behind its DMA
+// pieces -- whole rows of the NEXT output tile's A panel into a scratch line (lanes without a row are out of range: no fetch) -- and
+// the mid-tile wait counts it (vmcnt(1): the prefetch stays in flight across the rendezvous).
+template <int MI, int MODE1, bool FIRST, bool PF>
 __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2,
                                        const Src& pf, uint32_t pf_soff) {
 #ifdef VC_4W_EARLY
@@ -273,17 +276,12 @@ __device__ __forceinline__ void k_tile(f32x4 (&acc)[MI][8], Frags& f, const Loop
   // `cur` may be overwritten and buffer `nxt` may be read
 #if defined(VC_LOOP_ABL) && (VC_LOOP_ABL & 4)     // probe ablation: no mid-tile barrier (wrong results)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(VC_4W_PREFETCH)                       // the prefetch issued behind the awaited pieces stays in flight
-  asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (PF) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
   half_steps<MI, MODE1, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
-#ifdef VC_4W_PREFETCH
-  // whole rows of the NEXT output tile's A panel (this workgroup's share of them), a few rows per k-tile: every k-tile issues exactly
-  // one instruction (keeps the counted wait exact); lanes without a line and the one-tile kernel's calls are out of range (no fetch)
-  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, pf.ra, pf_soff);
-#endif
+  if constexpr (PF) pf64(L.lds_pf, L.voff_pf, pf.ra, pf_soff);
   if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -757,8 +755,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // tile (buffers keep alternating with the stream position), the register epilogue sits between two k-tiles, and the next tile's
 // k-half-0 fragments were read before it started -- no per-tile prologue (3-7k cycles of exposed DMA latency per tile in the
 // one-tile kernel, stamped), and the epilogue's stores drain behind the next tile's first MFMAs.
-template <int ACT, int OUT_F32, bool HAS_RES, int MI, bool EXTRAS = false>
+template <int ACT, int OUT_F32, bool HAS_RES, int MI, bool EXTRAS = false, bool PF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_4wp_kernel(GemmArgs p) {
+  static_assert(!PF || (!OUT_F32 && !HAS_RES), "the A-panel prefetch needs a scratch line behind the k-tile buffers: bf16-output forms only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -780,11 +779,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int tm, tn;
   tile_of(p, pos, tm, tn);
   Src src = make_src(p, tm * (32 * MI), tn * 256);
-#ifdef VC_4W_PREFETCH
-  // (probe: the fp32 / residual forms own all 160 KiB of LDS already -- no scratch line, no prefetch, their timing is not the question)
-  L.lds_pf = (OUT_F32 || HAS_RES) ? 0u : lds_addr(smem) + 2 * BUF_BYTES + w * 256;
+  // (the fp32 / residual forms own all 160 KiB of LDS already: no scratch line, no prefetch)
+  if constexpr (PF) L.lds_pf = lds_addr(smem) + 2 * BUF_BYTES + w * 256;
   uint32_t pf_step = 0;      // byte offset between the row chunks of consecutive k-tiles
-#endif
+  (void)pf_step;
   f32x4 acc[MI][8];
   Frags f;
   const int nk = p.K / 64;      // >= 2 (launcher)
@@ -792,12 +790,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the only prologue: k-tiles 0 and 1 of the first tile
   dma_tile<MI>(L, src, 0, 0, PIECES);
   dma_tile<MI>(L, src, BUF_BYTES, 128, PIECES);
-#ifdef VC_4W_PREFETCH
-  if (L.lds_pf) pf64(L.lds_pf, L.voff_pf, src.ra, 0);      // out of range: no fetch, one instruction for the counted wait
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8 + 1) : "memory");
-#else
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
-#endif
+  if constexpr (PF) {
+    pf64(L.lds_pf, L.voff_pf, src.ra, 0);      // out of range: no fetch, one instruction for the counted wait
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8 + 1) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MI + 8) : "memory");
+  }
   read_frags<MI, 0>(f, L.a_rd[0], L.w_rd[0], PIECES);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   uint32_t cur = 0;
@@ -815,8 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       nsrc.ra[2] = 0;
       nsrc.rw[2] = 0;
     }
-#ifdef VC_4W_PREFETCH
-    {
+    if constexpr (PF) {
       // The column siblings of the next tile (same tm, the gw tiles of its column group) split its A panel by rows: sibling c takes
       // rows c, c + gw, c + 2 gw ...; k-tile t of THIS tile requests RPS of them, whole rows (nk lines of 128 B: one DRAM page).
       // lane -> (row within the chunk, line of the row)
@@ -834,21 +831,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       pf_step = (uint32_t)(rps * gwe * p.lda * 2);
     }
 #define PF_ARGS(t_) , nsrc, (uint32_t)(t_) * pf_step
-#else
-#define PF_ARGS(t_)
-#endif
     // k-tiles 0 .. nk-3 request k-tiles 2 .. nk-1 of this tile; k-tiles nk-2, nk-1 request k-tiles 0, 1 of the next tile (nk >= 3)
     STAMP_AT(pos, 0);
-    k_tile<MI, 1, true>(acc, f, L, src, cur, 2 * 128 PF_ARGS(0));
+    k_tile<MI, 1, true, PF>(acc, f, L, src, cur, 2 * 128 PF_ARGS(0));
     cur = BUF_BYTES - cur;
     STAMP_AT(pos, 1);
     for (int t = 1; t < nk - 2; ++t) {
-      k_tile<MI, 1, false>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128 PF_ARGS(t));
+      k_tile<MI, 1, false, PF>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128 PF_ARGS(t));
       cur = BUF_BYTES - cur;
     }
-    k_tile<MI, 1, false>(acc, f, L, nsrc, cur, 0 PF_ARGS(nk - 2));
+    k_tile<MI, 1, false, PF>(acc, f, L, nsrc, cur, 0 PF_ARGS(nk - 2));
     cur = BUF_BYTES - cur;
-    k_tile<MI, 4, false>(acc, f, L, nsrc, cur, 128 PF_ARGS(nk - 1));
+    k_tile<MI, 4, false, PF>(acc, f, L, nsrc, cur, 128 PF_ARGS(nk - 1));
 #undef PF_ARGS
     cur = BUF_BYTES - cur;
     fence_accumulators<MI>(acc);
@@ -904,7 +898,7 @@ int persistent_cus() {
 
 int pick_mi(int M, int tiles_n, int form) {
   static const int env_mi = [] { const char* e = getenv("VITCAP_GEMM4W_MI"); return e ? atoi(e) : 0; }();
-  if (env_mi >= 6 && env_mi <= 8) return env_mi;
+  if (env_mi >= 4 && env_mi <= 8 && env_mi != 5) return env_mi;
   const int n_cu = form == 2 ? persistent_cus() : device_cus();
   const float fixed = form == 2 ? 0.3f : 0.9f;       // per-tile cost that does not shrink with the tile: pipeline fill, barriers' skew, W traffic
   int best = 8;
@@ -925,16 +919,7 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
   if (form == 2) {
     const int n_cu = persistent_cus();
     const bool extras = p.aux || p.zout || p.colsum;        // training extras: the bf16 register epilogue's second form (vc_4w_supports)
-    auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
-    if constexpr (!OUT_F32 && !HAS_RES) {
-      if (extras) kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI, true>;
-    }
-#ifdef VC_4W_PREFETCH
-    constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES + 1024;
-#else
     constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
-#endif
-    VC_FUNC_SMEM(kern, smem);
     // VITCAP_GEMM_4W_TIGHT=1 (experiments): the fewest workgroups (a multiple of 8: every XCD the same number) that finish in the same
     // number of rounds as all CUs would -- 1305 tiles take 6 rounds on 256 CUs and on 224 -- leaving the other CUs to whatever else
     // runs.  Measured (docs/LAB_r01_r04.md 4.3): no gain alone (19.55 vs 19.59 ms, B = 512 124.3 vs 123.3), and inside the batch pipeline only a
@@ -946,7 +931,36 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
       const int need = ((p.n_big + rounds - 1) / rounds + 7) & ~7;
       if (need < grid) grid = need;
     }
-    VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
+    // one call site per kernel: VC_FUNC_SMEM remembers per call site that the attribute was set
+    bool launched = false;
+    if constexpr (!OUT_F32 && !HAS_RES) {
+      if (extras) {
+        auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI, true>;
+        VC_FUNC_SMEM(kern, smem);
+        VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
+        launched = true;
+      }
+      // A-panel prefetch one tile ahead (round 5's measured probe, shipped in round 6): from ~64k rows on the A panel streams from
+      // HBM and the same loop takes 32-37k instead of 25.4k cycles per tile; whole rows of the NEXT tile's panel, split over the column
+      // siblings, requested one per k-tile bring it to 29.7k (qkv +3.6 %, fc1 +2.1 % wall at M = 295 424, docs/LAB_r05.md section 1).
+      // Below the threshold the operands are cache-resident and the extra instruction only costs (+0.8 % loop cycles): plain form.
+      // VITCAP_GEMM_4W_PF: 0 = never, N > 1 = from N rows on (default 65536).
+      if constexpr (MI == 8) {
+        static const int pf_rows = [] { const char* e = getenv("VITCAP_GEMM_4W_PF"); return e ? atoi(e) : 65536; }();
+        if (!launched && pf_rows > 0 && p.M >= pf_rows && p.tiles_m > 1) {
+          auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI, false, true>;
+          constexpr int smem_pf = 2 * BUF_BYTES + 1024;
+          VC_FUNC_SMEM(kern, smem_pf);
+          VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem_pf, s, p);
+          launched = true;
+        }
+      }
+    }
+    if (!launched) {
+      auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI>;
+      VC_FUNC_SMEM(kern, smem);
+      VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
+    }
   } else {
     auto kern = gemm_nt_4w_kernel<ACT, OUT_F32, HAS_RES, 1, MI>;
     constexpr int smem = (OUT_F32 || HAS_RES) ? SMEM_4WP : 2 * BUF_BYTES;
@@ -980,6 +994,7 @@ int launch_4w(const GemmArgs& a, hipStream_t s, int form) {
   switch (pick_mi(a.M, p.tiles_n, form)) {
     case 7: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 7>(p, s, form);
     case 6: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 6>(p, s, form);
+    case 4: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 4>(p, s, form);
     default: return launch_4w_mi<ACT, OUT_F32, HAS_RES, 8>(p, s, form);
   }
 }

@@ -74,6 +74,24 @@ def whole_job_rate(units_per_rank_per_step, steps, world, elapsed_max):
     return units_per_rank_per_step * world * steps / elapsed_max
 
 
+def broadcast_from_rank0(tensors, dist, chunk_elems=64 << 20):
+    """Every rank ends with rank 0's values of `tensors` (in place) -- what DistributedDataParallel does to a module's parameters and
+    buffers when it wraps it (uni_pipeline.py:497-505 -> torch DDP's _sync_module_states): replicas that were built from different
+    files, seeds or a stale snapshot cannot train as if they were one model.  Large flat buffers travel in `chunk_elems` pieces (the
+    0.87 GB parameter vector as 4 messages; gloo stages CUDA tensors through the host).  Returns the number of bytes broadcast; a
+    no-op (0) without an initialised process group or with one rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() < 2:
+        return 0
+    sent = 0
+    for t in tensors:
+        flat = t.view(-1)
+        for a in range(0, flat.numel(), chunk_elems):
+            piece = flat[a:a + chunk_elems]
+            dist.broadcast(piece, src=0)
+            sent += piece.numel() * piece.element_size()
+    return sent
+
+
 class BucketedAllReduce(object):
     """Gradient mean over ranks, overlapped with backward.
 

@@ -9,8 +9,9 @@ get_raw_model 566-618, predict_output_to_tsv_row 620-630) for what the hot path 
 * ``ensure_predict``: builds the HIP ``ImageCaptioning`` model, loads ``basemodel`` / the latest snapshot with the
   reference's suffix-matching loader, captions the test split, writes ``<model>.…predict.tsv`` rows
   ``key \\t json([{"caption": str, "conf": exp(logprob)}])`` per rank and merges them on rank 0;
-* the input side (TSV + JPEG decode) is not built: batches come from
-  ``data: synthetic`` (seeded uniform(-1,1) images) or from an iterable passed as ``test_batches``;
+* the input side: ``test_data`` names a TSV of (key, base64 JPEG) rows read through ``.lineidx``
+  (tsv.py), decoded by worker processes on the host (jpegdec.py) and resized / cropped / normalised on the GPU bit-identical to
+  Pillow (csrc/preproc.hip); ``data: synthetic`` (seeded uniform(-1,1) images) and an iterable passed as ``test_batches`` remain;
 * ``ensure_train`` runs the HIP training engine (vitcap_amd/train.py) on synthetic or caller-provided batches and
   writes reference-format snapshots; ``ensure_evaluate`` needs the external
   coco-caption tools the reference does not vendor either and is a logged no-op without them.
@@ -466,7 +467,22 @@ class CaptionUniPipeline(object):
         if ckpt.has_checkpoint() and not self.cfg.force_train:
             extra = ckpt.load()
             start_iter = int(extra.get('iteration', 0))
+            eng.sync_from_rank0()       # every rank continues from rank 0's parameters and moments, whatever file it found
             logging.info('resuming from %s at iteration %d', ckpt.get_checkpoint_file(), start_iter)
+        # trainer.py:134-137: a NaN loss saves `NaN_context_<rank>` through the checkpointer and raises (TrainEngine.flush_nan_check)
+        def nan_dump(name):
+            # every rank writes its own context (the file name carries the rank); `last_checkpoint` keeps naming the last good
+            # snapshot -- the reference's save() re-tags it to the NaN context on rank 0, which a resume would then load
+            c = Checkpointer(model=_EngineState(eng), optimizer=_EngineState(eng, 'optimizer'), scheduler=_EngineState(eng, 'scheduler'),
+                             save_dir=self.get_snapshot_dir(), save_to_disk=True)
+            prev = c.get_checkpoint_file() if c.has_checkpoint() else None
+            f = c.save(name, iteration=eng.step_no)
+            if prev:
+                c.tag_last_checkpoint(prev)
+            elif op.isfile(op.join(c.save_dir, 'last_checkpoint')):
+                os.remove(op.join(c.save_dir, 'last_checkpoint'))
+            logging.info('NaN context saved to %s', f)
+        eng.nan_dump = nan_dump
         t0, log_step = time.time(), int(self.cfg.log_step)
         batches = self.iter_train_batches(per_gpu, start_iter=start_iter)
         scst = None

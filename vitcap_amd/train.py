@@ -262,8 +262,17 @@ class TrainEngine(object):
         self.loss_buf = torch.zeros(2, device=self.dev)      # [masked_loss, tag_loss]
         self._gemm_w = {}
         self._ct_table = None
+        # DDP's wrap broadcasts rank 0's parameters and buffers to every replica (uni_pipeline.py:497-505): ranks that loaded different
+        # files (or none) must not train as one model.  The Adam moments follow after a resume (sync_from_rank0).
+        from .dist_util import BucketedAllReduce, broadcast_from_rank0
+        self.synced_bytes = broadcast_from_rank0([self.P], dist)
+        # device-side NaN / Inf watch on the loss and the gradient norm (trainer.py:134-137 raises on `losses != losses` every step;
+        # here the flag is read at the host synchronisations that exist anyway: every 50 steps, before a snapshot, after the last step)
+        self._nan_bad = torch.zeros((), dtype=torch.int32, device=self.dev)
+        self._nan_first = torch.full((), -1, dtype=torch.int32, device=self.dev)
+        self.nan_dump = None              # callable(name) that saves the context (the pipeline passes its Checkpointer.save); default: torch.save here
+        self.nan_dump_dir = '.'
         self.refresh_weights()
-        from .dist_util import BucketedAllReduce
         self.reducer = BucketedAllReduce(self.G, grad_buckets(order, self.off, self.shape), GRAD_STAGES, dist)
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self._pending = False
@@ -302,10 +311,48 @@ class TrainEngine(object):
         if self.step_no % 50 == 49:
             self.flush_text_check()
 
+    def sync_from_rank0(self):
+        """Parameters AND Adam moments of every rank := rank 0's (after a resume: a rank that read a stale or different snapshot would
+        otherwise keep its own moments); bf16 operand copies rebuilt.  No-op without a process group."""
+        from .dist_util import broadcast_from_rank0
+        n = broadcast_from_rank0([self.P, self.M, self.V], self.dist)
+        if n:
+            self.refresh_weights()
+        return n
+
+    def _watch_nan(self):
+        """Enqueued once per step behind vitcap_sumsq: counts the steps whose loss or gradient norm is not finite (no host read)."""
+        bad = ~(torch.isfinite(self.loss_buf[0]) & torch.isfinite(self.gsumsq[0]))
+        self._nan_first.copy_(torch.where(bad & (self._nan_first < 0), torch.full_like(self._nan_first, self.step_no), self._nan_first))
+        self._nan_bad += bad.to(torch.int32)
+
+    def flush_nan_check(self):
+        """trainer.py:134-137: `if losses != losses: checkpointer.save("NaN_context_{rank}"); raise RuntimeError('NaN encountered!')`.
+        The reference tests the loss on the host after every step; here the device-side flag of _watch_nan (loss OR gradient norm not
+        finite -- an Inf gradient reaches the parameters one step before the loss shows it) is read where the host waits anyway."""
+        if int(self._nan_bad) == 0:
+            return
+        first, n = int(self._nan_first), int(self._nan_bad)
+        self._nan_bad.zero_()
+        self._nan_first.fill_(-1)
+        rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
+        name = 'NaN_context_{}'.format(rank)
+        import logging
+        logging.info('NaN encountered! (first at step %d, %d step(s) since the last check)', first, n)
+        if self.nan_dump is not None:
+            self.nan_dump(name)
+        else:
+            torch.save({'model': self.state_dict(), 'iteration': self.step_no, 'first_bad_step': first,
+                        'optimizer': self.optimizer_state_dict(), 'scheduler': self.scheduler_state_dict()},
+                       os.path.join(self.nan_dump_dir, name + '.pt'))
+        raise RuntimeError('NaN encountered!')
+
     def flush_text_check(self):
-        """Reads the device-side counter of batches whose text tensors the kernels do not implement (one host synchronisation).
+        """Reads the device-side counter of batches whose text tensors the kernels do not implement (one host synchronisation) and
+        the NaN watch (flush_nan_check).
         Called every 50 steps, and by the pipeline before every checkpoint it saves and after the last step (otherwise a
         snapshot could be written from up to 49 steps trained on the hard-wired mask, and the final steps were never reported)."""
+        self.flush_nan_check()
         bad = getattr(self, '_text_bad', None)
         if bad is not None and int(bad) != 0:
             self._text_bad = None
@@ -764,7 +811,10 @@ class TrainEngine(object):
             rows_all = (torch.arange(B, device=dev).view(B, 1) * TT + tpos).view(-1)
             used = (mids != 0).view(-1)
             # a batch whose masked_pos and masked_ids disagree is reported like a bad mask (device counter, TrainEngine.flush_text_check)
-            bad = (mpos.sum(1) != (mids != 0).sum(1)).any()
+            # (counts equal AND the used slots are the leading ones: dataset.py:321-324 pads masked_ids behind the real ids; a zero in
+            # front of a real id would pair targets with the wrong rows -- ADVICE r5)
+            nm = mpos.sum(1, keepdim=True)
+            bad = (nm.view(-1) != (mids != 0).sum(1)).any() | ((mids != 0) != (torch.arange(J, device=dev).view(1, J) < nm)).any()
             if getattr(self, '_text_bad', None) is None:
                 self._text_bad = torch.zeros((), dtype=torch.int32, device=dev)
             self._text_bad += bad.to(torch.int32)
@@ -967,6 +1017,7 @@ class TrainEngine(object):
         self.step_no += 1
         self.gsumsq.zero_()
         check(lib.vitcap_sumsq(_p(self.G), self.nflat, _p(self.gsumsq), _s()), 'sumsq')
+        self._watch_nan()
         check(lib.vitcap_adamw_multi(_p(self.P), _p(self.G), _p(self.M), _p(self.V), _p(self.chunk_lr), _p(self.chunk_wd),
                                      _p(self.gsumsq), self.clip, self.lr_scale, self.step_no, 0.9, 0.999, 1e-8,
                                      self.nflat // CH, _s()), 'adamw')
@@ -979,6 +1030,8 @@ class TrainEngine(object):
         loss, tag_loss = self.forward_backward(batch)
         self.all_reduce_grads()
         self.optimizer_step()
+        if self.step_no % 50 == 0:
+            self.flush_nan_check()
         return {'masked_loss': loss, 'tag_loss': tag_loss}
 
     # ------------------------------------------------------------------ graph mode: the step as a few host calls
@@ -1001,20 +1054,35 @@ class TrainEngine(object):
         dev = self.dev
         static = {k: batch[k].to(dev).clone().contiguous() for k in self._GRAPH_KEYS if k in batch}
         salt = torch.zeros(1, dtype=torch.int32, device=dev)
-        # one eager pass on the static buffers first: every kernel's launch attributes exist, the caching allocator is warm, and (multi-
-        # rank) every rank runs the same collectives -- it changes gradients and the loss buffer only
-        self.forward_backward(static)
-        self.all_reduce_grads()
+        # one eager pass on the static buffers first: every kernel's launch attributes exist and the caching allocator is warm.  It runs
+        # WITHOUT the gradient exchange: a rank that meets a new batch shape -- a ragged last batch, or a batch that stays
+        # eager on another rank -- must not issue one more round of collectives than its peers (RCCL would hang); the pass only
+        # changes gradients and the loss buffer, both rewritten by the step that follows
+        exchange = self.reducer.exchange
+        self.reducer.exchange = False
+        try:
+            self.forward_backward(static)
+            self.all_reduce_grads()
+        finally:
+            self.reducer.exchange = exchange
         torch.cuda.synchronize(dev)
         segs = []
         pool = torch.cuda.graph_pool_handle()
         gen = self._fb_gen(static, capture=True)
         done = False
+        last = GRAD_STAGES[-1]
         check(lib.vitcap_set_dropout_salt(C.c_void_p(salt.data_ptr())), 'set_dropout_salt')
+        # The grid of a persistent GEMM is fixed when its launch is RECORDED (vitcap_gemm_reserve_cus is read by the launcher, on the
+        # host): a replayed segment keeps whatever reservation was set while it was captured.  The first bucket's collective starts
+        # behind segment 0, so every later segment is captured with the reducer's CUs left free (captured after finish()
+        # had set the reservation back to 0, the graphs froze all-CU grids and the reservation was a no-op in graph mode).
+        reserve = self.reducer.reserve_cus if exchange else 0
         try:
             while not done:
                 g = torch.cuda.CUDAGraph()
                 stages = []
+                if reserve and segs:
+                    lib.vitcap_gemm_reserve_cus(reserve)
                 with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):     # a loader thread may copy meanwhile
                     while True:
                         try:
@@ -1023,12 +1091,15 @@ class TrainEngine(object):
                             done = True
                             break
                         stages.append(st)
-                        if self.reducer.exchange and st in self.GRAPH_SEGMENT_ENDS:
+                        # the last stage is followed by nothing but the generator's return: it stays in this segment
+                        if exchange and st in self.GRAPH_SEGMENT_ENDS and st != last:
                             break
                 segs.append((g, stages))
         finally:
+            if reserve:
+                lib.vitcap_gemm_reserve_cus(0)
             check(lib.vitcap_set_dropout_salt(None), 'set_dropout_salt')
-        entry = {'static': static, 'salt': salt, 'segs': segs}
+        entry = {'static': static, 'salt': salt, 'segs': segs, 'reserved_cus': reserve}
         self._graphs[key] = entry
         return entry
 
@@ -1046,7 +1117,8 @@ class TrainEngine(object):
                 self.reducer.stage_done(st)
         self.all_reduce_grads()
         self.optimizer_step()
-        if self.step_no % 50 == 0:
+        if self.step_no % 50 == 0 or not entry.get('checked'):     # the first replay of a shape as well: a bad batch layout is reported at once
+            entry['checked'] = True
             self.flush_text_check()
         return {'masked_loss': self.loss_buf[0], 'tag_loss': self.loss_buf[1]}
 
