@@ -129,6 +129,61 @@ def cpu_baseline(budget_s=60.0):
             'leg_seconds': round(time.time() - t_all, 1)}
 
 
+class PowerSampler(object):
+    """Board power / shader clock read by rocm-smi in a side thread (a child process per reading: this thread never touches the GPU).
+    The pipeline runs at the board's power cap, so joules per step is the number a kernel change has to move."""
+
+    def __init__(self, period=0.02):
+        import threading
+        self.samples, self._stop, self.period = [], threading.Event(), period
+        self._t = threading.Thread(target=self._loop, daemon=True)
+
+    @staticmethod
+    def read():
+        import subprocess
+        try:
+            out = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=5).stdout
+            card = json.loads(out)
+            card = card[sorted(card.keys())[0]]
+            sclk = pw = None
+            for k, v in card.items():
+                kl = k.lower()
+                if 'sclk' in kl and 'clock' in kl and sclk is None:
+                    sclk = float(str(v).strip('()').lower().replace('mhz', ''))
+                if 'power' in kl and '(w)' in kl and pw is None:
+                    pw = float(v)
+            return (sclk, pw) if (sclk is not None and pw is not None) else None
+        except Exception:       # noqa  (no rocm-smi, no permission: the fields stay null)
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            r = self.read()
+            if r:
+                self.samples.append(r)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join()
+
+    def summary(self, ms_per_step):
+        if len(self.samples) < 3:
+            return None
+        sc = sorted(s[0] for s in self.samples)
+        pw = sorted(s[1] for s in self.samples)
+        med_p = pw[len(pw) // 2]
+        return {'board_power_w_median': med_p, 'board_power_w_max': pw[-1], 'sclk_mhz_median': sc[len(sc) // 2],
+                'joules_per_step': round(med_p * ms_per_step * 1e-3, 3), 'energy_pass_ms_per_step': round(ms_per_step, 3),
+                'samples': len(self.samples),
+                'note': 'rocm-smi readings during an UNTIMED pass of the same steps (>= 2 s) right after the timed regions; joules_per_step = '
+                        'median board power x that pass\'s time per step'}
+
+
 TRAIN_FLOP_PER_SAMPLE = 569.3e9     # fwd+bwd, SURVEY.md section 8d (algorithmic)
 # executed: rows nobody reads are not computed -- rows 1..576 of the last tag block (7.6 GF forward) and the 578 visual rows
 # of the last decoder layer's attention / output / MLP (6.9 GF forward), forward + backward = 3x
@@ -329,6 +384,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--power', type=int, default=1, help='1: an untimed pass of >= 2 s after the timed regions with rocm-smi sampled beside it (extra.board_power_w_median, sclk_mhz_median, joules_per_step); 0 skips it')
     ap.add_argument('--single-region', action='store_true', help='time ONE region of K steps even when it is shorter than 2 s (profiling runs)')
     ap.add_argument('--mode', default='caption', choices=['caption', 'train', 'scst'],
                     help="'caption' = the headline metric; 'train' = cross-entropy training step (BASELINE configs[3])")
@@ -463,6 +519,21 @@ def main():
         check(lib.vitcap_engine_timing_end_kernel(model._engine, ms, fl, ln, busy, kms, kbusy), 'timing_end')
         if unarmed == 'pending':
             unarmed, _ = region(False)
+        # ---- energy pass (rank 0 samples; every rank runs the steps): >= 2 s of the same steps, untimed for `value`
+        energy = None
+        if args.power:
+            n_e = max(args.steps, int(2.0 / max(elapsed / args.steps, 1e-4)) + 1)
+            n_e = int(D.max_over_ranks(n_e, dist, device='cuda'))
+            save_steps, args.steps = args.steps, n_e
+            try:
+                if rank == 0:
+                    with PowerSampler() as ps:
+                        e_s, _ = region(False)
+                    energy = ps.summary(e_s / n_e * 1e3)
+                else:
+                    region(False)
+            finally:
+                args.steps = save_steps
         # With the batch pipeline the GEMMs of the timed region share the chip with the other slot's decode kernels, so
         # their launch durations are longer than the kernel alone needs.  A second, untimed pass of (at most 20 of) the same
         # steps on ONE stream gives the kernel's own rate (reported next to, not instead of, the timed-region figure).
@@ -545,6 +616,7 @@ def main():
                              (', decode loop replayed from an engine-owned hipGraph' if args.graph else ', eager launches'),
                    'streams_per_gpu': 2 if piped else 1},
         'decode_phase_ms_per_batch': None if dec_ms is None else round(dec_ms, 3),
+        'extra': energy,
         'end_to_end_tflops_algorithmic': round(value / world * FLOP_PER_IMAGE / 1e12, 2),
         'end_to_end_tflops_executed': round(value / world * (FLOP_EXECUTED_PER_IMAGE if args.beams == 1 else FLOP_EXECUTED_PER_IMAGE + 13.35e9) / 1e12, 2),
         'end_to_end_frac_of_bf16_peak': round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -21,6 +21,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include "vitcap_jpeg.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -757,6 +758,26 @@ typedef struct vitcap_train_aug {
 size_t vitcap_image_train_preproc_workspace_bytes(const vitcap_image* imgs, const vitcap_train_aug* aug, int B, int size);
 int vitcap_image_train_preproc(const vitcap_image* imgs, const vitcap_train_aug* aug, int B, int size, int out_bf16,
                                void* out, uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device back half of the JPEG decoder ("rocJPEG + HIP resize" -- built as own kernels because the parity bar is
+ * bit-exact pixels): replaces the part of cv2.imdecode (src/tools/common.py:23-31 img_from_base64, src/data_layer/transform.py:106-136)
+ * that follows the entropy decoder.  The host front half (include/vitcap_jpeg.h, libvitcap_jpeg.so: vitcap_jpeg_parse /
+ * vitcap_jpeg_decode_coefs, run by the loader's worker processes) yields a vitcap_jpeg_info and int16 coefficient blocks; this call
+ * dequantises them, runs libjpeg's ISLOW 8x8 inverse DCT, the "fancy" h2v1 / h2v2 chroma upsampling and the fixed-point YCbCr -> RGB
+ * conversion, and writes the uint8 HWC RGB image that vitcap_image_preproc takes.  Bit-identical to Pillow's decoder (libjpeg-turbo,
+ * default settings) on every stream vitcap_jpeg_parse accepts; other streams never reach this call (the caller decodes them with Pillow).
+ *   imgs: host array; `coefs` (info.nblocks * 64 int16, as vitcap_jpeg_decode_coefs wrote them) and `rgb` (height rows of `pitch`
+ *   >= 3 * width bytes) are DEVICE pointers.  Enqueue-only on `stream`; the workspace holds the component planes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vitcap_jpeg_image {
+  vitcap_jpeg_info info;
+  const int16_t* coefs;
+  uint8_t* rgb;
+  int32_t pitch;
+} vitcap_jpeg_image;
+size_t vitcap_jpeg_backhalf_workspace_bytes(const vitcap_jpeg_image* imgs, int B);
+int vitcap_jpeg_backhalf(const vitcap_jpeg_image* imgs, int B, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ for M in [int(x) for x in sys.argv[1:]] or [128]:
     for name, N, K, act, f32 in (('qkv', 2304, 768, L.ACT_NONE, 0), ('fc1', 3072, 768, L.ACT_GELU_ERF, 0), ('ao', 768, 768, L.ACT_NONE, 1),
                                  ('fc2', 768, 3072, L.ACT_NONE, 1)):
         row = []
-        for h in (20, 21, 22, 1, 13, 14, 15):
+        for h in (20, 21, 22, 1, 13, 14, 15, 2, 3, 0):
             try:
                 row.append('h%d %.1f' % (h, bench(M, N, K, act, f32, h)))
             except Exception as e:

@@ -101,11 +101,11 @@ def main():
     from vitcap_amd import pipeline as P
     e2e = {}
 
-    def run_once(name, workers, threads):
+    def run_once(name, workers, threads, device_jpeg=True):
         cfg = {'type': 'pipeline_eval_multi', 'all_test_data': [{'test_data': 'toy', 'test_split': 'test'}],
                'param': {'full_expid': name, 'max_iter': 10, 'model_file': ck, 'text_encoder_type': enc, 'tagemb': 'cls',
                          'test_batch_size': 64, 'force_predict': True, 'crop_pct': 1.0, 'test_crop_size': 384, 'num_workers': workers,
-                         'loader_threads': threads, 'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
+                         'loader_threads': threads, 'device_jpeg': bool(device_jpeg), 'pipeline_type': {'from': 'vitcap_amd.pipeline', 'import': 'CaptionUniPipeline'}}}
         yf = os.path.join(tmp, name + '.yaml')
         open(yf, 'w').write(yaml.safe_dump(cfg))
         kw = run.parse_general_args(['-c', yf])
@@ -154,6 +154,10 @@ def main():
     sweep = ((8, True), (6, False), (8, False), (10, False), (12, False), (14, False), (16, False))
     if os.environ.get('INPUT_SIDE_WORKERS'):
         sweep = tuple((int(w), False) for w in os.environ['INPUT_SIDE_WORKERS'].split(','))
+    # INPUT_SIDE_DEVICE_JPEG = comma list aligned with the sweep (round 6): 1 = the workers only entropy-decode, the GPU finishes the JPEG
+    # (csrc/jpeg.hip; the default of the pipeline), 0 = Pillow decodes everything in the workers (rounds 1-5)
+    dj = [int(x) for x in os.environ.get('INPUT_SIDE_DEVICE_JPEG', '').split(',') if x != '']
+    sweep = tuple((w, t, (dj[i] if i < len(dj) else 1)) for i, (w, t) in enumerate(sweep))
     def cpu_stat():
         try:
             return {k: int(v) for k, v in (ln.split() for ln in open('/sys/fs/cgroup/cpu.stat').read().splitlines())}
@@ -161,7 +165,7 @@ def main():
             return {}
     res['cgroup_cpu'] = {}
     import threading
-    for workers, threads in sweep:
+    for run_i, (workers, threads, device_jpeg) in enumerate(sweep):
         c0 = cpu_stat()
         m0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
         samples, stop = [], threading.Event()
@@ -173,7 +177,7 @@ def main():
                 stop.wait(0.05)
         th = threading.Thread(target=sampler, daemon=True)
         th.start()
-        st, wall = run_once('w%d%d' % (workers, threads), workers, threads)
+        st, wall = run_once('w%d%d_%d' % (workers, threads, run_i), workers, threads, device_jpeg)
         stop.set()
         th.join()
         c1 = cpu_stat()
@@ -193,9 +197,9 @@ def main():
             print('cgroup cpu', res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')], flush=True)
         print('device allocations (hipMalloc) during the run: %d; reserved %.1f GB' % (
             torch.cuda.memory_stats().get('num_device_alloc', 0) - m0, torch.cuda.memory_reserved() / 2**30), flush=True)
-        e2e['%d %s' % (workers, 'threads' if threads else 'processes')] = round(st['images_per_sec'], 1)
-        print('num_workers %d (%s): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s); loader seconds %s' % (
-            workers, 'threads' if threads else 'processes', st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall,
+        e2e['run %d: %d %s, %s' % (run_i, workers, 'threads' if threads else 'processes', 'device JPEG back half' if device_jpeg else 'Pillow in the workers')] = round(st['images_per_sec'], 1)
+        print('num_workers %d (%s, device_jpeg %d): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s); loader seconds %s' % (
+            workers, 'threads' if threads else 'processes', device_jpeg, st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall,
             st.get('loader_seconds')), flush=True)
         res.setdefault('loader_seconds', {})['%d %s' % (workers, 'threads' if threads else 'processes')] = st.get('loader_seconds')
     res['pipeline_from_tsv_images_per_s'] = e2e

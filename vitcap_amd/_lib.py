@@ -76,6 +76,13 @@ class Image(C.Structure):
     _fields_ = [('rgb', C.c_void_p), ('height', C.c_int), ('width', C.c_int), ('pitch', C.c_int)]
 
 
+class JpegImage(C.Structure):
+    """vitcap_jpeg_image: vitcap_jpeg_info (vitcap_amd/jpegdec.py JpegInfo, include/vitcap_jpeg.h) + device pointers of the coefficient
+    blocks and of the RGB image the back half writes."""
+    from .jpegdec import JpegInfo as _Info
+    _fields_ = [('info', _Info), ('coefs', C.c_void_p), ('rgb', C.c_void_p), ('pitch', C.c_int32)]
+
+
 class TrainAug(C.Structure):
     """vitcap_train_aug: RandomResizedCrop box, ColorJitter operations in order (0 brightness, 1 contrast, 2 saturation,
     -1 none) with their factors, horizontal flip."""
@@ -138,6 +145,8 @@ _SIGS = {
     'vitcap_image_preproc': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'vitcap_image_train_preproc_workspace_bytes': (C.c_size_t, [vp, vp, C.c_int, C.c_int]),
     'vitcap_image_train_preproc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    'vitcap_jpeg_backhalf_workspace_bytes': (C.c_size_t, [vp, C.c_int]),
+    'vitcap_jpeg_backhalf': (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
     'vitcap_resample_coeffs': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     'vitcap_resized_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'vitcap_cast_transpose': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -330,6 +330,7 @@ struct Layout {
 
 thread_local vitcap_engine* g_cur = nullptr;   // engine whose launches are being enqueued (timing hook)
 thread_local int g_gemm_mode = VITCAP_GEMM_AUTO; // vitcap_gen_opts.gemm_mode of the call being enqueued
+thread_local bool g_light_decode = false;        // the other stream's decode chain is a plain greedy / sampling loop of <= 512 sequences
 thread_local const int32_t* g_live = nullptr;    // live counter handed to the decode-step GEMMs (vitcap_gemm_desc.live)
 
 // sets the per-call context (timing hook, GEMM launch form, early-exit counter) for the duration of one engine call
@@ -354,6 +355,7 @@ struct CallScope {
     g_gemm_mode = gemm_mode;
     g_live = live;
     vc_tls_live = live;
+    g_light_decode = o && o->num_beams <= 1 && o->cbs_states <= 1;
     if (o) vc_tls_eos_extra = VcEosExtra{{o->eos_extra[0], o->eos_extra[1], o->eos_extra[2]}};
   }
   ~CallScope() {
@@ -361,6 +363,7 @@ struct CallScope {
     vc_tls_live = nullptr;
     vc_tls_eos_extra = VcEosExtra{{-1, -1, -1}};
     g_gemm_mode = VITCAP_GEMM_AUTO;
+    g_light_decode = false;
   }
 };
 
@@ -375,7 +378,17 @@ int gemm_desc(const void* A, const void* W, const float* bias, const float* res,
   const bool timed = eligible && e->timing_this_step && e->used < e->pool.size();
   GemmTiming* t = timed ? &e->pool[e->used++] : nullptr;
   // one tile per workgroup for the large GEMMs when the caller overlaps a second stream (vitcap_gen_opts.gemm_mode)
-  if (d.tile_hint == 0 && g_gemm_mode == VITCAP_GEMM_TILES && d.M >= 2048 && d.act != VITCAP_ACT_TANH && d.split_k <= 1) d.tile_hint = 5;
+  if (d.tile_hint == 0 && g_gemm_mode == VITCAP_GEMM_TILES && d.M >= 2048 && d.act != VITCAP_ACT_TANH && d.split_k <= 1) {
+    d.tile_hint = 5;
+    // Round 6: from 64k rows per launch on (B = 512) the bf16-output GEMMs (qkv, fc1) run the PERSISTENT 4-wave form, whose A-panel
+    // prefetch exists for that size class (gemm4w.hip PF) -- +0.4-0.9 % images/s, -1 % joules per step at B = 512
+    // (profiles/r06_prefetch_ab_b512.txt) -- but only next to a greedy decode chain: beside the 1 280-sequence chain of beam 5 x 256 the
+    // persistent grids cost -3.4 % (3 688 -> 3 562 img/s, profiles/r06_decode_forms_and_beam_ab.txt).  VITCAP_GEMM_4W_MIX_BIG=0 turns it off.
+    static const int mix_big = [] { const char* v = getenv("VITCAP_GEMM_4W_MIX_BIG"); return v ? atoi(v) : 1; }();
+    if (mix_big && g_light_decode && d.M >= 65536 && d.out_dtype == VITCAP_OUT_BF16 && !res && (d.N & 255) == 0 && d.K >= 192 && d.row_group == 0 &&
+        !d.colsum && !d.rowstat)
+      d.tile_hint = 42;
+  }
   if (d.M <= 4096) d.live = g_live;           // decode-step shapes only; the encoder / prefill GEMMs never carry it
   if (t) {
     t->variant = d.act * 4 + d.out_dtype * 2 + (res ? 1 : 0);
@@ -821,7 +834,7 @@ static int ensure_dec2(vitcap_engine* e) {
 static int encode_locked(vitcap_engine* e, const void* image, int image_is_bf16, int B, const vitcap_gen_opts& o, const Layout& lo,
                          char* ws, void* s) {
   if (!image) { vitcap_set_error("encode: null image"); return VITCAP_EINVAL; }
-  CallScope scope(e, o.gemm_mode, nullptr);
+  CallScope scope(e, o.gemm_mode, nullptr, &o);
   WalkScope walk;
   // timing runs: a step is sampled WHOLE (its encoder and prefill launches), so that the union of the sampled launches' intervals
   // still sees which of them ran next to each other (tag branch beside caption blocks 8-11, batch parts)
@@ -941,7 +954,7 @@ static int prefill_tags(vitcap_engine* e, int B, const vitcap_gen_opts& o, const
 }
 
 static int prefill_locked(vitcap_engine* e, int B, const vitcap_gen_opts& o, const Layout& lo, char* ws, void* s) {
-  CallScope scope(e, o.gemm_mode, nullptr);
+  CallScope scope(e, o.gemm_mode, nullptr, &o);
   WalkScope walk;
   if (encode_parts(o, B, lo) >= 2) return VITCAP_OK;       // done by encode_locked, per part
   return prefill_part(e, B, o, lo, ws, s);

@@ -1,0 +1,254 @@
+// Device back half of the JPEG decoder (include/vitcap_hip.h: vitcap_jpeg_backhalf): coefficient blocks from the host
+// entropy decoder (jpeg_host.cpp) -> dequantisation + 8x8 inverse DCT -> component planes -> chroma upsampling + YCbCr -> RGB -> the
+// uint8 HWC image that vitcap_image_preproc resizes.  It restates libjpeg(-turbo)'s DEFAULT decompression path, which is integer
+// arithmetic end to end, so the pixels are bit-identical to Pillow's decoder (tests/test_hip_jpeg.py):
+//   jidctint.c jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2, range-limit table), jdsample.c h2v1 / h2v2 fancy upsampling with
+//   jdmainct.c's replicated context rows at the top / bottom edge, jdcolor.c ycc_rgb_convert (SCALEBITS 16).
+// HBM-bound byte work: 3 B per pixel of coefficients in, 1.5 B of planes out and back in, 3 B of RGB out; a 640 x 480 image is 7 200
+// independent blocks, a batch of 64 half a million threads -- no tiling to speak of, coalescing is what matters (adjacent threads take
+// adjacent blocks of a block row: the 8-byte row segments they store are contiguous).
+#include "common.h"
+#include "../../include/vitcap_jpeg.h"
+
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+struct JpegPlan {
+  const int16_t* coefs;
+  uint8_t* rgb;
+  long long plane_off[3];       // byte offsets of the component planes in the workspace (pitch = 8 * blocks_w)
+  int pitch;                    // output row pitch in bytes
+  int width, height, ncomp, hs0, vs0;
+  int blocks_w[3], blocks_h[3], samp_w[3], samp_h[3], block0[3], nblocks;
+  unsigned short qt[3][64];
+};
+
+constexpr int CONST_BITS = 13, PASS1_BITS = 2;
+constexpr int F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+              F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
+              F_2_562915447 = 20995, F_3_072711026 = 25172;
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// one 1-D pass of jpeg_idct_islow: inputs i0..i7 -> o[0..7] descaled by SHIFT
+template <int SHIFT>
+__device__ __forceinline__ void idct_1d(int i0, int i1, int i2, int i3, int i4, int i5, int i6, int i7, int (&o)[8]) {
+  int z2 = i2, z3 = i6;
+  int z1 = (z2 + z3) * F_0_541196100;
+  int tmp2 = z1 + z3 * (-F_1_847759065);
+  int tmp3 = z1 + z2 * F_0_765366865;
+  int tmp0 = (i0 + i4) * (1 << CONST_BITS);
+  int tmp1 = (i0 - i4) * (1 << CONST_BITS);
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = i7; tmp1 = i5; tmp2 = i3; tmp3 = i1;
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  const int z5 = (z3 + z4) * F_1_175875602;
+  tmp0 *= F_0_298631336; tmp1 *= F_2_053119869; tmp2 *= F_3_072711026; tmp3 *= F_1_501321110;
+  z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  o[0] = descale(tmp10 + tmp3, SHIFT); o[7] = descale(tmp10 - tmp3, SHIFT);
+  o[1] = descale(tmp11 + tmp2, SHIFT); o[6] = descale(tmp11 - tmp2, SHIFT);
+  o[2] = descale(tmp12 + tmp1, SHIFT); o[5] = descale(tmp12 - tmp1, SHIFT);
+  o[3] = descale(tmp13 + tmp0, SHIFT); o[4] = descale(tmp13 - tmp0, SHIFT);
+}
+
+// sample_range_limit + CENTERJSAMPLE indexed by (x & RANGE_MASK): jdmaster.c prepare_range_limit_table
+__device__ __forceinline__ unsigned range_limit(int x) {
+  const int v = x & 1023;
+  return (unsigned)(v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896)));
+}
+
+// one thread per 8x8 block: grid (ceil(max blocks / 256), images)
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegPlan* __restrict__ plans, uint8_t* __restrict__ ws) {
+  const JpegPlan& P = plans[blockIdx.y];
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  if (blk >= P.nblocks) return;
+  const int c = (P.ncomp == 3 && blk >= P.block0[2]) ? 2 : ((P.ncomp == 3 && blk >= P.block0[1]) ? 1 : 0);
+  const int local = blk - P.block0[c];
+  const int brow = local / P.blocks_w[c], bcol = local - brow * P.blocks_w[c];
+  const uint4* src = (const uint4*)(P.coefs + (size_t)blk * 64);
+  int ws_[8][8];       // workspace after pass 1: [row][col]
+  {
+    int in[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint4 v = src[r];
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        in[r][2 * k] = (int)(short)(w4[k] & 0xffffu) * (int)P.qt[c][r * 8 + 2 * k];
+        in[r][2 * k + 1] = (int)(short)(w4[k] >> 16) * (int)P.qt[c][r * 8 + 2 * k + 1];
+      }
+    }
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+      int o[8];
+      idct_1d<CONST_BITS - PASS1_BITS>(in[0][col], in[1][col], in[2][col], in[3][col], in[4][col], in[5][col], in[6][col], in[7][col], o);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ws_[r][col] = o[r];
+    }
+  }
+  const int pitch = P.blocks_w[c] * 8;
+  uint8_t* dst = ws + P.plane_off[c] + (size_t)(brow * 8) * pitch + bcol * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    int o[8];
+    idct_1d<CONST_BITS + PASS1_BITS + 3>(ws_[r][0], ws_[r][1], ws_[r][2], ws_[r][3], ws_[r][4], ws_[r][5], ws_[r][6], ws_[r][7], o);
+    uint2 px;
+    px.x = range_limit(o[0]) | (range_limit(o[1]) << 8) | (range_limit(o[2]) << 16) | (range_limit(o[3]) << 24);
+    px.y = range_limit(o[4]) | (range_limit(o[5]) << 8) | (range_limit(o[6]) << 16) | (range_limit(o[7]) << 24);
+    *(uint2*)(dst + (size_t)r * pitch) = px;
+  }
+}
+
+// chroma sample of output pixel (r, col) from the downsampled plane p (sw x sh real samples, pitch bytes per row)
+template <int HS, int VS>
+__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int pitch, int sw, int sh, int r, int col) {
+  if (HS == 1) return p[(size_t)r * pitch + col];
+  const int cc = col >> 1, pc = col & 1;
+  if (VS == 1) {          // jdsample.c h2v1_fancy_upsample
+    const uint8_t* row = p + (size_t)r * pitch;
+    const int v = row[cc];
+    if (pc == 0) return cc == 0 ? v : (3 * v + row[cc - 1] + 1) >> 2;
+    return cc == sw - 1 ? v : (3 * v + row[cc + 1] + 2) >> 2;
+  }
+  // h2v2_fancy_upsample: nearest row weighs 3, the next nearest (above for even output rows, below for odd ones) 1; the rows above
+  // the first and below the last real row are copies of that row (jdmainct.c context rows)
+  const int cr = r >> 1;
+  int other = (r & 1) ? cr + 1 : cr - 1;
+  other = other < 0 ? 0 : (other > sh - 1 ? sh - 1 : other);
+  const uint8_t* r0 = p + (size_t)cr * pitch;
+  const uint8_t* r1 = p + (size_t)other * pitch;
+  const int cs = 3 * r0[cc] + r1[cc];
+  if (pc == 0) return cc == 0 ? (cs * 4 + 8) >> 4 : (cs * 3 + (3 * r0[cc - 1] + r1[cc - 1]) + 8) >> 4;
+  return cc == sw - 1 ? (cs * 4 + 7) >> 4 : (cs * 3 + (3 * r0[cc + 1] + r1[cc + 1]) + 7) >> 4;
+}
+
+__device__ __forceinline__ unsigned clamp255(int v) { return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// one thread per output pixel: grid (ceil(max pixels / 256), images)
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegPlan* __restrict__ plans, const uint8_t* __restrict__ ws) {
+  const JpegPlan& P = plans[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P.width * P.height) return;
+  const int r = idx / P.width, col = idx - r * P.width;
+  const int y = ws[P.plane_off[0] + (size_t)r * (P.blocks_w[0] * 8) + col];
+  uint8_t* out = P.rgb + (size_t)r * P.pitch + (size_t)col * 3;
+  if (P.ncomp == 1) {
+    out[0] = out[1] = out[2] = (uint8_t)y;
+    return;
+  }
+  int cb, cr;
+  const uint8_t* pb = ws + P.plane_off[1];
+  const uint8_t* pr = ws + P.plane_off[2];
+  const int pitch = P.blocks_w[1] * 8, sw = P.samp_w[1], sh = P.samp_h[1];
+  if (P.hs0 == 1) {
+    cb = chroma_at<1, 1>(pb, pitch, sw, sh, r, col);
+    cr = chroma_at<1, 1>(pr, pitch, sw, sh, r, col);
+  } else if (P.vs0 == 1) {
+    cb = chroma_at<2, 1>(pb, pitch, sw, sh, r, col);
+    cr = chroma_at<2, 1>(pr, pitch, sw, sh, r, col);
+  } else {
+    cb = chroma_at<2, 2>(pb, pitch, sw, sh, r, col);
+    cr = chroma_at<2, 2>(pr, pitch, sw, sh, r, col);
+  }
+  // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert: FIX(x) = (int)(x * 65536 + 0.5)
+  const int xb = cb - 128, xr = cr - 128;
+  const int R = y + ((91881 * xr + 32768) >> 16);
+  const int B = y + ((116130 * xb + 32768) >> 16);
+  const int G = y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+  out[0] = (uint8_t)clamp255(R);
+  out[1] = (uint8_t)clamp255(G);
+  out[2] = (uint8_t)clamp255(B);
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+bool info_ok(const vitcap_jpeg_info& I) {
+  if (I.abi != VITCAP_JPEG_ABI || I.width <= 0 || I.height <= 0 || (I.ncomp != 1 && I.ncomp != 3) || I.nblocks <= 0) return false;
+  int nb = 0;
+  for (int c = 0; c < I.ncomp; ++c) {
+    if (I.blocks_w[c] <= 0 || I.blocks_h[c] <= 0 || I.block0[c] != nb || I.samp_w[c] <= 0 || I.samp_h[c] <= 0 ||
+        I.samp_w[c] > 8 * I.blocks_w[c] || I.samp_h[c] > 8 * I.blocks_h[c])
+      return false;
+    nb += I.blocks_w[c] * I.blocks_h[c];
+  }
+  if (nb != I.nblocks || I.width > 8 * I.blocks_w[0] || I.height > 8 * I.blocks_h[0]) return false;
+  if (I.ncomp == 3) {
+    const bool s444 = I.hs[0] == 1 && I.vs[0] == 1, s422 = I.hs[0] == 2 && I.vs[0] == 1, s420 = I.hs[0] == 2 && I.vs[0] == 2;
+    if (!(s444 || s422 || s420) || I.hs[1] != 1 || I.vs[1] != 1 || I.hs[2] != 1 || I.vs[2] != 1) return false;
+    if (I.hs[0] == 2 && (I.samp_w[1] <= 2 || I.samp_w[2] != I.samp_w[1] || 2 * I.samp_w[1] < I.width)) return false;
+    if (I.vs[0] == 2 && 2 * I.samp_h[1] < I.height) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t vitcap_jpeg_backhalf_workspace_bytes(const vitcap_jpeg_image* imgs, int B) {
+  if (!imgs || B <= 0) return 0;
+  size_t tot = align256((size_t)B * sizeof(JpegPlan));
+  for (int i = 0; i < B; ++i) {
+    const vitcap_jpeg_info& I = imgs[i].info;
+    for (int c = 0; c < (I.ncomp == 3 ? 3 : 1); ++c) tot += align256((size_t)I.blocks_w[c] * 8 * I.blocks_h[c] * 8);
+  }
+  return tot + 256;
+}
+
+extern "C" int vitcap_jpeg_backhalf(const vitcap_jpeg_image* imgs, int B, void* workspace, size_t workspace_bytes, void* stream) {
+  VC_REQUIRE(imgs && B > 0 && workspace, "jpeg_backhalf: bad arguments");
+  VC_REQUIRE(workspace_bytes >= vitcap_jpeg_backhalf_workspace_bytes(imgs, B), "jpeg_backhalf: workspace too small");
+  std::vector<JpegPlan> plans(B);
+  size_t off = align256((size_t)B * sizeof(JpegPlan));
+  int max_blocks = 0;
+  long long max_px = 0;
+  for (int i = 0; i < B; ++i) {
+    const vitcap_jpeg_info& I = imgs[i].info;
+    VC_REQUIRE(info_ok(I), "jpeg_backhalf: image %d carries an inconsistent vitcap_jpeg_info (not from vitcap_jpeg_parse?)", i);
+    VC_REQUIRE(imgs[i].coefs && imgs[i].rgb && imgs[i].pitch >= 3 * I.width, "jpeg_backhalf: image %d has a bad descriptor", i);
+    JpegPlan& p = plans[i];
+    memset(&p, 0, sizeof(p));
+    p.coefs = imgs[i].coefs;
+    p.rgb = imgs[i].rgb;
+    p.pitch = imgs[i].pitch;
+    p.width = I.width; p.height = I.height; p.ncomp = I.ncomp; p.hs0 = I.hs[0]; p.vs0 = I.vs[0]; p.nblocks = I.nblocks;
+    for (int c = 0; c < I.ncomp; ++c) {
+      p.blocks_w[c] = I.blocks_w[c]; p.blocks_h[c] = I.blocks_h[c]; p.samp_w[c] = I.samp_w[c]; p.samp_h[c] = I.samp_h[c];
+      p.block0[c] = I.block0[c];
+      p.plane_off[c] = (long long)off;
+      off += align256((size_t)I.blocks_w[c] * 8 * I.blocks_h[c] * 8);
+      memcpy(p.qt[c], I.qt[c], sizeof(p.qt[c]));
+    }
+    max_blocks = I.nblocks > max_blocks ? I.nblocks : max_blocks;
+    const long long px = (long long)I.width * I.height;
+    max_px = px > max_px ? px : max_px;
+  }
+  VC_REQUIRE(off <= workspace_bytes, "jpeg_backhalf: workspace too small (%zu > %zu)", off, workspace_bytes);
+  // pinned staging for the plan table (reused; an event guards reuse by the next call on this thread)
+  static thread_local char* stage = nullptr;
+  static thread_local size_t stage_cap = 0;
+  static thread_local hipEvent_t stage_ev = nullptr;
+  const size_t up = (size_t)B * sizeof(JpegPlan);
+  if (stage_ev) (void)hipEventSynchronize(stage_ev);
+  if (up > stage_cap) {
+    if (stage) (void)hipHostFree(stage);
+    VC_REQUIRE(hipHostMalloc((void**)&stage, up, hipHostMallocDefault) == hipSuccess, "jpeg_backhalf: pinned staging alloc failed");
+    stage_cap = up;
+  }
+  if (!stage_ev) VC_REQUIRE(hipEventCreateWithFlags(&stage_ev, hipEventDisableTiming) == hipSuccess, "jpeg_backhalf: event");
+  memcpy(stage, plans.data(), up);
+  hipStream_t s = (hipStream_t)stream;
+  VC_REQUIRE(hipMemcpyAsync(workspace, stage, up, hipMemcpyHostToDevice, s) == hipSuccess, "jpeg_backhalf: plan upload failed");
+  (void)hipEventRecord(stage_ev, s);
+  const JpegPlan* dplans = (const JpegPlan*)workspace;
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)(max_blocks + 255) / 256, B), dim3(256), 0, s, dplans, (uint8_t*)workspace);
+  VC_LAUNCH_CHECK("jpeg_idct");
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((max_px + 255) / 256), B), dim3(256), 0, s, dplans, (const uint8_t*)workspace);
+  VC_LAUNCH_CHECK("jpeg_color");
+  return VITCAP_OK;
+}

@@ -18,6 +18,45 @@ from ._lib import check, lib
 
 
 from .jpegdec import decode_image      # noqa: E402,F401  (kept importable from here; the loader's worker processes import jpegdec alone)
+from ._lib import JpegImage as _JpegImage
+
+
+class CoefImage(object):
+    """A JPEG the host has only ENTROPY-decoded (vitcap_amd/jpegdec.py decode_coefs / the loader's workers): vitcap_jpeg_info + int16
+    coefficient blocks.  ImagePreprocessor finishes the decode on the GPU (csrc/jpeg.hip: dequantisation, inverse DCT, chroma
+    upsampling, YCbCr -> RGB -- Pillow's pixels bit for bit) in front of its resize."""
+    __slots__ = ('info', 'coefs')
+
+    def __init__(self, info, coefs):
+        self.info, self.coefs = info, coefs
+
+    @property
+    def shape(self):
+        return (int(self.info.height), int(self.info.width), 3)
+
+
+def jpeg_backhalf(items, dev, keep):
+    """[CoefImage] -> list of uint8 (H, W, 3) device tensors (enqueued on the current stream).  `keep` collects every buffer that must
+    outlive the kernels."""
+    B = len(items)
+    desc = (_JpegImage * B)()
+    outs = []
+    for i, it in enumerate(items):
+        co = it.coefs
+        src = co if (co.flags.writeable and co.flags.c_contiguous) else np.array(co, copy=True, order='C')
+        t = torch.from_numpy(src).to(dev, non_blocking=True)
+        h, w = int(it.info.height), int(it.info.width)
+        o = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+        desc[i].info = it.info
+        desc[i].coefs, desc[i].rgb, desc[i].pitch = t.data_ptr(), o.data_ptr(), w * 3
+        keep.append(t)
+        outs.append(o)
+    need = lib.vitcap_jpeg_backhalf_workspace_bytes(desc, B)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    keep.append(ws)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.vitcap_jpeg_backhalf(desc, B, C.c_void_p(ws.data_ptr()), need, s), 'jpeg_backhalf')
+    return outs
 
 
 class ImagePreprocessor(object):
@@ -35,9 +74,17 @@ class ImagePreprocessor(object):
     def __call__(self, images, want_u8=False):
         B = len(images)
         dev_imgs, desc = [], (_ImageDesc * B)()
+        # entropy-decoded JPEGs (CoefImage) are finished on the GPU first: one back-half launch for all of them
+        coef_idx = [i for i, im in enumerate(images) if isinstance(im, CoefImage)]
+        decoded = dict(zip(coef_idx, jpeg_backhalf([images[i] for i in coef_idx], self.dev, dev_imgs))) if coef_idx else {}
         for i, im in enumerate(images):
+            if i in decoded:
+                t = decoded[i]
+                dev_imgs.append(t)
+                desc[i] = _ImageDesc(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1] * 3)
+                continue
             if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
-                raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
+                raise ValueError('image %d: expected uint8 (H,W,3) RGB or a CoefImage' % i)
             # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
             # loader's shared-memory slabs -- goes to the device as it is
             src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')

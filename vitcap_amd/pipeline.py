@@ -542,7 +542,12 @@ class CaptionUniPipeline(object):
             # context) and import vitcap_amd.jpegdec only.  `loader_threads: true` keeps the decode in threads of this process.
             # Rows are read by the WORKERS (round 5: a task names the file and its row numbers), batches come back in order.
             from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
-            from .jpegdec import decode_rows, decode_rows_into
+            from .jpegdec import coef_item, decode_rows, decode_rows_into, jpeg_lib
+            from .imageio import CoefImage
+            # device JPEG back half (round 6): the workers only entropy-decode baseline JPEGs (libvitcap_jpeg.so); dequantisation, inverse
+            # DCT, upsampling and the colour conversion run on the GPU in front of the resize, bit-identical to Pillow.  `device_jpeg:
+            # false` (or a missing library) keeps the whole decode in the workers.
+            device_jpeg = (self.cfg.device_jpeg is None or bool(self.cfg.device_jpeg)) and jpeg_lib() is not None and not self.cfg.loader_threads
             import numpy as np
             workers = max(1, int(self.cfg.num_workers or 1))
             chunk = int(os.environ.get('VITCAP_LOADER_CHUNK', 8))      # images per worker task
@@ -573,7 +578,14 @@ class CaptionUniPipeline(object):
                 # decoded pixels come back through shared memory (vitcap_amd/jpegdec.py); a slab holds one task's images and is reused
                 # two batches after the batch that read it went to the GPU
                 slab_bytes = int(self.cfg.loader_slab_mb or 24) << 20
+                # the slabs are page-locked shared memory (x ranks on one host): the decode-ahead depth is capped in BYTES, not batches
+                # (at test_batch_size 512 the batch-count rule asked for 9-23 GB per rank).  `loader_shm_gb` (default 4); the
+                # floor is one batch ahead + the three in retirement.
+                budget = int(float(self.cfg.loader_shm_gb or os.environ.get('VITCAP_LOADER_SHM_GB', 4)) * 2**30)
+                ahead = max(1, min(ahead, budget // (per_batch * slab_bytes) - 3))
                 n_slabs = (ahead + 3) * per_batch
+                logging.info('loader: %d slabs x %d MB = %.1f GB of page-locked shared memory (%d batches ahead)', n_slabs, slab_bytes >> 20,
+                             n_slabs * slab_bytes / 2**30, ahead)
                 # a /dev/shm too small for the slabs (container default: 64 MB) would kill the workers with SIGBUS on first touch:
                 # check the free space first and fall back to returning the pixels through the pool's pipe (decode_many)
                 try:
@@ -609,7 +621,7 @@ class CaptionUniPipeline(object):
                         for c in range(0, len(ids), chunk):
                             if slabs:
                                 sid = free.pop()
-                                tasks.append((sid, pool.submit(decode_rows_into, slabs[sid].name, tsv, ids[c:c + chunk])))
+                                tasks.append((sid, pool.submit(decode_rows_into, slabs[sid].name, tsv, ids[c:c + chunk], device_jpeg)))
                             else:
                                 tasks.append((None, pool.submit(decode_rows, tsv, ids[c:c + chunk])))
                         inflight.append(tasks)
@@ -625,7 +637,9 @@ class CaptionUniPipeline(object):
                             ks, items = f.result()
                             keys.extend(ks)
                             for item in items:
-                                if sid is not None and isinstance(item, tuple):
+                                if sid is not None and isinstance(item, tuple) and item[0] == 'coef':
+                                    imgs.append(CoefImage(*coef_item(item, slabs[sid].buf)))     # the GPU finishes the decode (csrc/jpeg.hip)
+                                elif sid is not None and isinstance(item, tuple):
                                     off, h, w = item
                                     imgs.append(np.ndarray((h, w, 3), dtype=np.uint8, buffer=slabs[sid].buf, offset=off))
                                 else:
@@ -735,7 +749,10 @@ class CaptionUniPipeline(object):
         def gen_rows():
             pending = []                          # greedy / beam: batch i decodes while batch i+1 is encoded (generate_async)
             with torch.no_grad():
-                for batch in _prefetched(self.iter_test_batches(), dev, depth=int(self.cfg.loader_prefetch or os.environ.get('VITCAP_LOADER_PREFETCH', 24))):
+                # batches queued on the device: capped in IMAGES (24 batches of 64 = 1 536 images = 1.4 GB of bf16 crops; the same count of
+                # 512-image batches would be 11 GB)
+                depth = int(self.cfg.loader_prefetch or os.environ.get('VITCAP_LOADER_PREFETCH', 0)) or max(2, min(24, 1536 // max(1, int(self.cfg.test_batch_size))))
+                for batch in _prefetched(self.iter_test_batches(), dev, depth=depth):
                     batch = dict(batch)
                     batch['image'] = batch['image'].to(dev, non_blocking=True).contiguous()
                     flag = None
