@@ -673,8 +673,11 @@ int vitcap_adamw_multi(float* p, const float* g, float* m, float* v, const float
 int vitcap_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, int M, int N, int K, int splits,
                    void* stream);
 /* The same with the sum over the splits done by the launch itself: out[N][K] (+)= sum_s C_slabs[s] in slab order (the result of
- * vitcap_gemm_tn followed by vitcap_reduce_slabs, bit for bit; C_slabs is scratch).  The workgroups of a tile wait for each other,
- * so tiles x splits must not exceed the number of CUs (an error otherwise). */
+ * vitcap_gemm_tn followed by vitcap_reduce_slabs, bit for bit; C_slabs is scratch).  The workgroups of a tile wait for each other
+ * (slabs published by write-through `sc1` stores + drained vmcnt + a relaxed agent-scope ticket; the readers take an agent-scope
+ * acquire), so tiles x splits must not exceed the number of CUs (an error otherwise) AND the launch needs those CUs to itself: a caller
+ * must not run it beside kernels of another stream that hold CUs for long (a collective, a persistent GEMM grid) -- a workgroup that is
+ * not resident yet is waited for by its resident siblings.  Off in the training step (measured slower than reduce_slabs, LAB r05 4). */
 int vitcap_gemm_tn_sum(const void* Y, int ldy, const void* X, int ldx, float* C_slabs, float* out, int accumulate, int M, int N,
                        int K, int splits, void* stream);
 /* bias gradient: out[n] += sum_m y[m][n]  (bf16 [M][ldy] -> fp32 [N], atomic accumulation into `out`) */

@@ -184,24 +184,24 @@ def main():
         if samples and st.get('t_end'):
             win = [x for x in samples if st['t_end'] - st['steady_seconds'] <= x[0] <= st['t_end']]
             if len(win) > 1:
-                res.setdefault('cgroup_cpu_steady_window', {})['%d %s' % (workers, 'threads' if threads else 'processes')] = sw = {
+                res.setdefault('cgroup_cpu_steady_window', {})['run %d: %d %s, device_jpeg %d' % (run_i, workers, 'threads' if threads else 'processes', device_jpeg)] = sw = {
                     'seconds': round(win[-1][0] - win[0][0], 2), 'periods': win[-1][3] - win[0][3], 'throttled_periods': win[-1][1] - win[0][1],
                     'avg_cores': round((win[-1][2] - win[0][2]) / 1e6 / max(1e-9, win[-1][0] - win[0][0]), 2)}
                 print('steady window cgroup cpu', sw, flush=True)
         if c0 and c1:      # whole run (model load included): CPU seconds used by the cgroup, periods in which the quota throttled it
-            res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')] = {
+            res['cgroup_cpu']['run %d: %d %s, device_jpeg %d' % (run_i, workers, 'threads' if threads else 'processes', device_jpeg)] = {
                 'wall_s': round(wall, 2), 'cpu_s': round((c1['usage_usec'] - c0['usage_usec']) / 1e6, 2),
                 'avg_cores': round((c1['usage_usec'] - c0['usage_usec']) / 1e6 / wall, 2),
                 'periods': c1.get('nr_periods', 0) - c0.get('nr_periods', 0), 'throttled_periods': c1.get('nr_throttled', 0) - c0.get('nr_throttled', 0),
                 'throttled_s': round((c1.get('throttled_usec', 0) - c0.get('throttled_usec', 0)) / 1e6, 2)}
-            print('cgroup cpu', res['cgroup_cpu']['%d %s' % (workers, 'threads' if threads else 'processes')], flush=True)
+            print('cgroup cpu', res['cgroup_cpu']['run %d: %d %s, device_jpeg %d' % (run_i, workers, 'threads' if threads else 'processes', device_jpeg)], flush=True)
         print('device allocations (hipMalloc) during the run: %d; reserved %.1f GB' % (
             torch.cuda.memory_stats().get('num_device_alloc', 0) - m0, torch.cuda.memory_reserved() / 2**30), flush=True)
         e2e['run %d: %d %s, %s' % (run_i, workers, 'threads' if threads else 'processes', 'device JPEG back half' if device_jpeg else 'Pillow in the workers')] = round(st['images_per_sec'], 1)
         print('num_workers %d (%s, device_jpeg %d): %.1f images/s from disk in the steady state (%d rows in %.2f s; whole run %.1f s); loader seconds %s' % (
             workers, 'threads' if threads else 'processes', device_jpeg, st['images_per_sec'], st['steady_rows'], st['steady_seconds'], wall,
             st.get('loader_seconds')), flush=True)
-        res.setdefault('loader_seconds', {})['%d %s' % (workers, 'threads' if threads else 'processes')] = st.get('loader_seconds')
+        res.setdefault('loader_seconds', {})['run %d: %d %s, device_jpeg %d' % (run_i, workers, 'threads' if threads else 'processes', device_jpeg)] = st.get('loader_seconds')
     res['pipeline_from_tsv_images_per_s'] = e2e
     res['note'] = ('run.py pipeline_eval_multi, batch 64, 2-slot caption pipeline, predictions written as the reference\'s predict TSV; '
                    'steady state = from the second batch\'s captions to the last row')
