@@ -83,3 +83,22 @@ def test_preprocessor_accepts_entropy_decoded_jpegs():
     b, b8 = pre(new_imgs, want_u8=True)
     torch.cuda.synchronize()
     assert torch.equal(a8, b8) and torch.equal(a, b)
+
+
+def test_train_preprocessor_accepts_entropy_decoded_jpegs():
+    """Training input side (dataset.CaptionTrainSet.sample with device_jpeg): the same drawn augmentation applied to a CoefImage and to
+    the Pillow-decoded array gives the same bytes and the same normalised tensor."""
+    from vitcap_amd import jpegdec as J
+    from vitcap_amd.augment import TrainAugmentation
+    from vitcap_amd.imageio import CoefImage, TrainImagePreprocessor
+    datas = [jpeg_bytes(synth(w, h, 5 * i + 1), quality=88, subsampling=(2 - i % 3)) for i, (w, h) in enumerate([(640, 480), (480, 640), (500, 375), (333, 500)])]
+    ref = [J.decode_image(d) for d in datas]
+    new = [CoefImage(*J.decode_coefs(d)) for d in datas]
+    aug = TrainAugmentation(seed=11)
+    params = [aug.params(im.shape[0], im.shape[1], index=i, epoch=2) for i, im in enumerate(ref)]
+    assert [n.shape for n in new] == [r.shape for r in ref]
+    pre = TrainImagePreprocessor('cuda', out_dtype=torch.float32)
+    a, a8 = pre(ref, params, want_u8=True)
+    b, b8 = pre(new, params, want_u8=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a8, b8) and torch.equal(a, b)

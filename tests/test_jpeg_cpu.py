@@ -147,3 +147,40 @@ def test_worker_hand_off_through_a_shared_memory_slab():
         J._SHM.pop(shm.name, None)
         shm.close()
         shm.unlink()
+
+
+@needs_lib
+def test_front_half_survives_corrupt_streams():
+    """Bit flips, truncations, spliced garbage, header damage: the front half either refuses the stream or fills the coefficient array --
+    it never reads or writes out of bounds (a crash would take a loader worker down)."""
+    import random
+    rnd = random.Random(1)
+    base = [jpeg_bytes(synth(160, 120, i), quality=q, subsampling=s) for i, (q, s) in enumerate([(85, 2), (60, 1), (95, 0)])]
+    try:
+        rst = jpeg_bytes(synth(160, 120, 9), quality=75, restart_marker_blocks=4)
+        if b'\xff\xdd' in rst:
+            base.append(rst)
+    except TypeError:
+        pass
+    decoded = refused = 0
+    for it in range(800):
+        d = bytearray(rnd.choice(base))
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rnd.randint(1, 8)):
+                d[rnd.randrange(len(d))] = rnd.randrange(256)
+        elif mode == 1:
+            d = d[:rnd.randrange(2, len(d))]
+        elif mode == 2:
+            i = rnd.randrange(len(d))
+            d[i:i + rnd.randint(1, 40)] = bytes(rnd.randrange(256) for _ in range(rnd.randint(0, 40)))
+        else:
+            d[rnd.randrange(2, min(700, len(d)))] = rnd.randrange(256)       # header region
+        got = J.decode_coefs(bytes(d))
+        if got is None:
+            refused += 1
+        else:
+            decoded += 1
+            info, coefs = got
+            assert coefs.size == info.nblocks * 64 and 0 < info.width * info.height <= 1 << 26
+    assert decoded > 0 and refused > 0

@@ -150,6 +150,7 @@ int parse(const uint8_t* d, size_t n, Parsed& P) {
         P.info.width = be16(s + 3);
         P.info.ncomp = s[5];
         if (P.info.height <= 0 || P.info.width <= 0) return fail(VITCAP_JPEG_EUNSUPPORTED, "frame without a size (DNL)");
+        if ((long long)P.info.height * P.info.width > (1ll << 26)) return fail(VITCAP_JPEG_EUNSUPPORTED, "more than 64 Mpixel");
         if (P.info.ncomp != 1 && P.info.ncomp != 3) return fail(VITCAP_JPEG_EUNSUPPORTED, "%d components", P.info.ncomp);
         if (sl < 6 + 3 * P.info.ncomp) return fail(VITCAP_JPEG_EINVAL, "bad SOF length");
         for (int c = 0; c < P.info.ncomp; ++c) {

@@ -30,7 +30,8 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 from .augment import TrainAugmentation
-from .imageio import decode_image
+from .imageio import CoefImage, decode_image
+from .jpegdec import decode_coefs, jpeg_lib
 from .tsv import TSVFile
 
 
@@ -117,7 +118,9 @@ def resolve_nltk_tagger():
 
 class CaptionTrainSet(object):
     def __init__(self, root, data, tensorizer, tagger, split='train', caption_version=None, label_version=None,
-                 augmentation=None):
+                 augmentation=None, device_jpeg=None):
+        # device_jpeg: None = on when the host front half (libvitcap_jpeg.so) is built
+        self.device_jpeg = (jpeg_lib() is not None) if device_jpeg is None else (bool(device_jpeg) and jpeg_lib() is not None)
         self.idx = CaptionIdx(root, data, split, caption_version)
         self.images = TSVFile(data_file(root, data, split))
         self.captions = TSVFile(data_file(root, data, split, 'caption', caption_version))
@@ -142,7 +145,10 @@ class CaptionTrainSet(object):
             img_row = self.images[idx_img]
             cap_row = self.captions[idx_img]
             lab_row = self.labels[idx_img] if self.labels is not None else None
-        rgb = decode_image(img_row[-1])
+        # device JPEG back half (round 6): a baseline JPEG is only entropy-decoded here (ctypes call: the GIL is released, like inside
+        # Pillow's decoder); the GPU finishes it in front of the crop / resize (imageio.TrainImagePreprocessor)
+        got = decode_coefs(img_row[-1]) if self.device_jpeg else None
+        rgb = CoefImage(*got) if got is not None else decode_image(img_row[-1])
         caption = json.loads(cap_row[1])[idx_cap]['caption']
         labels = json.loads(lab_row[1]) if lab_row is not None else []
         # the masking draws of tensorize_ab come from Python's global `random` in the reference; here a per-sample generator

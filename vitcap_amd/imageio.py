@@ -59,6 +59,28 @@ def jpeg_backhalf(items, dev, keep):
     return outs
 
 
+def _device_images(images, dev, keep, desc):
+    """Fills the vitcap_image descriptors `desc` for a list of decoded arrays and / or CoefImage items: arrays are copied to the device,
+    entropy-decoded JPEGs are finished there first (one back-half launch for all of them).  `keep` collects the buffers that must
+    outlive the enqueued kernels."""
+    coef_idx = [i for i, im in enumerate(images) if isinstance(im, CoefImage)]
+    decoded = dict(zip(coef_idx, jpeg_backhalf([images[i] for i in coef_idx], dev, keep))) if coef_idx else {}
+    for i, im in enumerate(images):
+        if i in decoded:
+            t = decoded[i]
+            keep.append(t)
+            desc[i] = _ImageDesc(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1] * 3)
+            continue
+        if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+            raise ValueError('image %d: expected uint8 (H,W,3) RGB or a CoefImage' % i)
+        # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
+        # loader's shared-memory slabs -- goes to the device as it is
+        src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')
+        t = torch.from_numpy(src).to(dev, non_blocking=True)
+        keep.append(t)
+        desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
+
+
 class ImagePreprocessor(object):
     """get_transform_vit_default(is_train=False) (uni_pipeline.py:1233-1256) for a list of decoded images."""
 
@@ -74,23 +96,7 @@ class ImagePreprocessor(object):
     def __call__(self, images, want_u8=False):
         B = len(images)
         dev_imgs, desc = [], (_ImageDesc * B)()
-        # entropy-decoded JPEGs (CoefImage) are finished on the GPU first: one back-half launch for all of them
-        coef_idx = [i for i, im in enumerate(images) if isinstance(im, CoefImage)]
-        decoded = dict(zip(coef_idx, jpeg_backhalf([images[i] for i in coef_idx], self.dev, dev_imgs))) if coef_idx else {}
-        for i, im in enumerate(images):
-            if i in decoded:
-                t = decoded[i]
-                dev_imgs.append(t)
-                desc[i] = _ImageDesc(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1] * 3)
-                continue
-            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
-                raise ValueError('image %d: expected uint8 (H,W,3) RGB or a CoefImage' % i)
-            # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
-            # loader's shared-memory slabs -- goes to the device as it is
-            src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')
-            t = torch.from_numpy(src).to(self.dev, non_blocking=True)
-            dev_imgs.append(t)
-            desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
+        _device_images(images, self.dev, dev_imgs, desc)
         need = lib.vitcap_image_preproc_workspace_bytes(desc, B, self.resize_short, self.crop)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
@@ -120,15 +126,8 @@ class TrainImagePreprocessor(object):
         B = len(images)
         assert len(params) == B
         dev_imgs, desc, aug = [], (_ImageDesc * B)(), (_TrainAug * B)()
+        _device_images(images, self.dev, dev_imgs, desc)
         for i, (im, pr) in enumerate(zip(images, params)):
-            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
-                raise ValueError('image %d: expected uint8 (H,W,3) RGB' % i)
-            # Pillow hands out read-only arrays (torch wants a writable one: private copy); a writable C-contiguous view -- the
-            # loader's shared-memory slabs -- goes to the device as it is
-            src = im if (im.flags.writeable and im.flags.c_contiguous) else np.array(im, copy=True, order='C')
-            t = torch.from_numpy(src).to(self.dev, non_blocking=True)
-            dev_imgs.append(t)
-            desc[i] = _ImageDesc(t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3)
             top, left, h, w = pr['box']
             a = aug[i]
             a.top, a.left, a.height, a.width, a.flip = int(top), int(left), int(h), int(w), int(bool(pr['flip']))

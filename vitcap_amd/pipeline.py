@@ -406,7 +406,7 @@ class CaptionUniPipeline(object):
         seed = int(c.random_seed or 0)
         ds = CaptionTrainSet(c.data_root or 'data', c.data, tz, tagger, split='train', caption_version=c.train_version,
                              label_version=c.train_label_version,
-                             augmentation=TrainAugmentation(seed=seed, small_scale=c.input_small_scale))
+                             augmentation=TrainAugmentation(seed=seed, small_scale=c.input_small_scale), device_jpeg=c.device_jpeg)
         tf = TrainImagePreprocessor(torch.device('cuda', self.local_rank), train_crop_size=int(c.train_crop_size))
         return TrainBatchLoader(ds, per_gpu, tf, rank=self.rank, world=self.world, seed=seed, workers=int(c.num_workers),
                                 want_captions=bool(c.scst), start_iter=start_iter)
