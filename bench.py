@@ -31,7 +31,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r05_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r06_hbm_traffic_pmc.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
 FLOP_PER_IMAGE = 187.95e9          # SURVEY.md section 8d / BASELINE.md section 3 (algorithmic)
 # What the engine executes per greedy image: of the 4th tag block only the CLS row is ever read (pooler input and first
 # visual token), so its Q / attention / proj / MLP run for that row alone: 9.19 GF -> K|V projections 1.36 + one 128-row
@@ -521,7 +521,9 @@ def main():
             unarmed, _ = region(False)
         # ---- energy pass (rank 0 samples; every rank runs the steps): >= 2 s of the same steps, untimed for `value`
         energy = None
-        if args.power:
+        # (never under a profiler: its preloaded library would be inherited by the rocm-smi children of the sampler thread)
+        profiled = any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'ROCPROFILER_LIBRARY_PATH'))
+        if args.power and not profiled:
             n_e = max(args.steps, int(2.0 / max(elapsed / args.steps, 1e-4)) + 1)
             n_e = int(D.max_over_ranks(n_e, dist, device='cuda'))
             save_steps, args.steps = args.steps, n_e

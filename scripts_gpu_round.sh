@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of BASELINE configs[1..4], rocprof summaries, PMC traffic.
 # Usage: bash scripts_gpu_round.sh [tag] [notests]
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
@@ -27,13 +27,13 @@ python bench.py --steps 200 --warmup 5 --batch 1 --pipeline 0 --graph 1 --no-cpu
 (python tools/library_yardstick.py; python tools/library_yardstick.py 295424) 2>&1 | grep -v amdgpu.ids > gpurun_out/library_yardstick_$TAG.txt
 python bench.py --steps 30 --warmup 3 --mode train --train-graph 0 > gpurun_out/bench_train_eager_$TAG.json 2>> gpurun_out/bench_$TAG.err
 python tools/exact_rate.py 2>&1 | grep EXACT > gpurun_out/exact_rate_$TAG.txt
-INPUT_SIDE_CEILING=1 INPUT_SIDE_WORKERS=8,10,8,10 python tools/input_side_bench.py 24576 gpurun_out/input_side_$TAG.json > gpurun_out/input_side_$TAG.log 2>&1
+INPUT_SIDE_SKIP_DECODE=1 INPUT_SIDE_CEILING=1 INPUT_SIDE_WORKERS=8,8,6,6,8,8 INPUT_SIDE_DEVICE_JPEG=1,0,1,0,1,0 python tools/input_side_bench.py 24576 gpurun_out/input_side_$TAG.json > gpurun_out/input_side_$TAG.log 2>&1
 bash tools/pmc_hot.sh $TAG > gpurun_out/pmc_hot_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline --single-region > $R/gpurun_out/prof_$TAG.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline --single-region >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o pipe -- python3 $R/bench.py --steps 20 --warmup 3 --isolated 0 --no-cpu-baseline --single-region --power 0 > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o seq -- python3 $R/bench.py --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline --single-region --power 0 >> $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o train -- python3 $R/bench.py --steps 3 --warmup 1 --mode train >> $R/gpurun_out/prof_$TAG.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o b512 -- python3 $R/bench.py --steps 6 --warmup 2 --batch 512 --isolated 0 --no-cpu-baseline --single-region >> $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o b512 -- python3 $R/bench.py --steps 6 --warmup 2 --batch 512 --isolated 0 --no-cpu-baseline --single-region --power 0 >> $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 for k in pipe seq train b512; do
 DB=$(find gpurun_out/prof_$TAG -name "${k}_results.db" | head -1)

@@ -11,7 +11,7 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES"
 P3="SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
 for wl in greedy train; do
-  if [ $wl = greedy ]; then ARGS="--steps 2 --warmup 1 --pipeline 0 --isolated 0 --no-cpu-baseline --single-region"; else ARGS="--mode train --steps 1 --warmup 1"; fi
+  if [ $wl = greedy ]; then ARGS="--steps 2 --warmup 1 --pipeline 0 --isolated 0 --no-cpu-baseline --single-region --power 0"; else ARGS="--mode train --steps 1 --warmup 1"; fi
   i=0
   for P in "$P1" "$P2" "$P3"; do
     i=$((i+1))

@@ -5,7 +5,7 @@ EXTRA="$2"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic_${TAG}_$c -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --single-region $EXTRA > $R/gpurun_out/traffic_${TAG}_$c.log 2>&1
+rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic_${TAG}_$c -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --single-region --power 0 $EXTRA > $R/gpurun_out/traffic_${TAG}_$c.log 2>&1
 done
 cd $R
 python3 - $TAG <<'PY'
