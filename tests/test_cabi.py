@@ -30,6 +30,29 @@ def test_header_symbols_exported(L):
     assert names == set(L.EXPORTS), names ^ set(L.EXPORTS)
 
 
+def test_jpeg_header_symbols_exported():
+    """include/vitcap_jpeg.h (host front half of the JPEG decoder): every declared function is exported by libvitcap_jpeg.so, the ABI number
+    matches the binding, and the ctypes mirror of vitcap_jpeg_info has the C struct's size (the device back half in libvitcap_hip.so
+    takes the same struct inside vitcap_jpeg_image)."""
+    import __graft_entry__ as g
+    from vitcap_amd import jpegdec as J
+    path = os.path.join(REPO, 'vitcap_amd', 'libvitcap_jpeg.so')
+    if not os.path.exists(path):
+        g.build()
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(REPO, 'include', 'vitcap_jpeg.h')).read(), flags=re.S)
+    names = set(re.findall(r'\b(vitcap_jpeg_[a-z0-9_]+)\s*\(', hdr))
+    assert names == {'vitcap_jpeg_abi', 'vitcap_jpeg_parse', 'vitcap_jpeg_decode_coefs', 'vitcap_jpeg_last_error'}
+    raw = C.CDLL(path)
+    for n in names:
+        assert hasattr(raw, n), n
+    assert raw.vitcap_jpeg_abi() == J.JPEG_ABI == int(re.search(r'#define VITCAP_JPEG_ABI (\d+)', hdr).group(1))
+    # int32: abi, width, height, ncomp, hs[3], vs[3], blocks_w[3], blocks_h[3], samp_w[3], samp_h[3], block0[3], nblocks; uint16 qt[3][64]
+    assert C.sizeof(J.JpegInfo) == 4 * (4 + 7 * 3 + 1) + 2 * 3 * 64
+    lib = J.jpeg_lib()
+    info = J.JpegInfo()
+    assert lib.vitcap_jpeg_parse(b'not a jpeg', 10, C.byref(info)) == J.JPEG_EINVAL and b'SOI' in lib.vitcap_jpeg_last_error()
+
+
 def test_argument_validation_without_gpu(L):
     d = L.GemmDesc(M=8, N=16, K=96, lda=96, ldw=96, ldc=16)
     rc = L.lib.vitcap_gemm_bias_act(None, None, None, None, None, C.byref(d), None)
@@ -41,6 +64,11 @@ def test_argument_validation_without_gpu(L):
     assert L.lib.vitcap_layernorm_fwd(a, 768, a, a, 1e-6, a, None, 4, 512, None) == -1      # D != 768
     assert L.lib.vitcap_attn_decode_step(a, a, a, a, 2, 578, 20, 20, 1, 0.125, None) == -1  # t out of range
     assert L.lib.vitcap_sigmoid_topk(a, 30592, 30522, 65, 0.2, a, a, a, 1, None) == -1      # k > 64
+    # device JPEG back half: null arguments, then a descriptor whose vitcap_jpeg_info did not come from vitcap_jpeg_parse
+    assert L.lib.vitcap_jpeg_backhalf(None, 0, None, 0, None) == -1
+    img = (L.JpegImage * 1)()
+    img[0].coefs, img[0].rgb, img[0].pitch = a.value, a.value, 24
+    assert L.lib.vitcap_jpeg_backhalf(img, 1, a, 1 << 20, None) == -1 and b'vitcap_jpeg_info' in L.lib.vitcap_last_error()
 
 
 def test_abi_version_is_checked(L):
