@@ -39,8 +39,7 @@ def test_backhalf_equals_pillow_bit_for_bit(sub):
     torch.cuda.synchronize()
     for d, o in zip(datas, outs):
         want = pillow_rgb(d)
-        got = o.cpu().numpy()
-        assert got.shape == want.shape
+        got = o.cpu().numpy()[:, :want.shape[1] * 3].reshape(want.shape)       # rows are padded to a multiple of 4 bytes
         assert np.array_equal(got, want), 'pixels differ: %d of %d (max |d| %d)' % (
             int((got != want).sum()), want.size, int(np.abs(got.astype(int) - want.astype(int)).max()))
 
@@ -62,7 +61,8 @@ def test_grey_restart_markers_and_extreme_coefficients():
     outs = jpeg_backhalf(_coef_images(datas), torch.device('cuda'), keep)
     torch.cuda.synchronize()
     for d, o in zip(datas, outs):
-        assert np.array_equal(o.cpu().numpy(), pillow_rgb(d))
+        want = pillow_rgb(d)
+        assert np.array_equal(o.cpu().numpy()[:, :want.shape[1] * 3].reshape(want.shape), want)
 
 
 def test_preprocessor_accepts_entropy_decoded_jpegs():

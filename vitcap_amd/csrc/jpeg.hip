@@ -131,40 +131,55 @@ __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int pitc
 
 __device__ __forceinline__ unsigned clamp255(int v) { return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-// one thread per output pixel: grid (ceil(max pixels / 256), images)
+// one thread per FOUR horizontally consecutive output pixels: grid (ceil(max groups / 256), images).  The luma bytes arrive as one aligned
+// dword; with a row pitch that is a multiple of 4 (what vitcap_amd.imageio allocates) the 12 output bytes leave as three dword stores,
+// otherwise -- and for the last, partial group of a row -- byte by byte.
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegPlan* __restrict__ plans, const uint8_t* __restrict__ ws) {
   const JpegPlan& P = plans[blockIdx.y];
+  const int w4 = (P.width + 3) >> 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P.width * P.height) return;
-  const int r = idx / P.width, col = idx - r * P.width;
-  const int y = ws[P.plane_off[0] + (size_t)r * (P.blocks_w[0] * 8) + col];
-  uint8_t* out = P.rgb + (size_t)r * P.pitch + (size_t)col * 3;
-  if (P.ncomp == 1) {
-    out[0] = out[1] = out[2] = (uint8_t)y;
-    return;
-  }
-  int cb, cr;
+  if (idx >= w4 * P.height) return;
+  const int r = idx / w4, col0 = (idx - r * w4) * 4;
+  const int npx = P.width - col0 < 4 ? P.width - col0 : 4;
+  const unsigned y4 = *(const unsigned*)(ws + P.plane_off[0] + (size_t)r * (P.blocks_w[0] * 8) + col0);      // plane pitch is a multiple of 8
+  uint8_t* out = P.rgb + (size_t)r * P.pitch + (size_t)col0 * 3;
+  unsigned char px[12];
   const uint8_t* pb = ws + P.plane_off[1];
   const uint8_t* pr = ws + P.plane_off[2];
   const int pitch = P.blocks_w[1] * 8, sw = P.samp_w[1], sh = P.samp_h[1];
-  if (P.hs0 == 1) {
-    cb = chroma_at<1, 1>(pb, pitch, sw, sh, r, col);
-    cr = chroma_at<1, 1>(pr, pitch, sw, sh, r, col);
-  } else if (P.vs0 == 1) {
-    cb = chroma_at<2, 1>(pb, pitch, sw, sh, r, col);
-    cr = chroma_at<2, 1>(pr, pitch, sw, sh, r, col);
-  } else {
-    cb = chroma_at<2, 2>(pb, pitch, sw, sh, r, col);
-    cr = chroma_at<2, 2>(pr, pitch, sw, sh, r, col);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = (int)((y4 >> (8 * k)) & 0xffu);
+    if (P.ncomp == 1) {
+      px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (unsigned char)y;
+      continue;
+    }
+    const int col = col0 + k < P.width ? col0 + k : P.width - 1;       // (lanes of a partial group recompute the last pixel: never stored)
+    int cb, cr;
+    if (P.hs0 == 1) {
+      cb = chroma_at<1, 1>(pb, pitch, sw, sh, r, col);
+      cr = chroma_at<1, 1>(pr, pitch, sw, sh, r, col);
+    } else if (P.vs0 == 1) {
+      cb = chroma_at<2, 1>(pb, pitch, sw, sh, r, col);
+      cr = chroma_at<2, 1>(pr, pitch, sw, sh, r, col);
+    } else {
+      cb = chroma_at<2, 2>(pb, pitch, sw, sh, r, col);
+      cr = chroma_at<2, 2>(pr, pitch, sw, sh, r, col);
+    }
+    // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert: FIX(x) = (int)(x * 65536 + 0.5)
+    const int xb = cb - 128, xr = cr - 128;
+    px[3 * k] = (unsigned char)clamp255(y + ((91881 * xr + 32768) >> 16));
+    px[3 * k + 1] = (unsigned char)clamp255(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
+    px[3 * k + 2] = (unsigned char)clamp255(y + ((116130 * xb + 32768) >> 16));
   }
-  // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert: FIX(x) = (int)(x * 65536 + 0.5)
-  const int xb = cb - 128, xr = cr - 128;
-  const int R = y + ((91881 * xr + 32768) >> 16);
-  const int B = y + ((116130 * xb + 32768) >> 16);
-  const int G = y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
-  out[0] = (uint8_t)clamp255(R);
-  out[1] = (uint8_t)clamp255(G);
-  out[2] = (uint8_t)clamp255(B);
+  if (npx == 4 && (P.pitch & 3) == 0 && ((uintptr_t)P.rgb & 3) == 0) {
+    unsigned* o32 = (unsigned*)out;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      o32[q] = (unsigned)px[4 * q] | ((unsigned)px[4 * q + 1] << 8) | ((unsigned)px[4 * q + 2] << 16) | ((unsigned)px[4 * q + 3] << 24);
+  } else {
+    for (int i = 0; i < 3 * npx; ++i) out[i] = px[i];
+  }
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -206,7 +221,7 @@ extern "C" int vitcap_jpeg_backhalf(const vitcap_jpeg_image* imgs, int B, void* 
   std::vector<JpegPlan> plans(B);
   size_t off = align256((size_t)B * sizeof(JpegPlan));
   int max_blocks = 0;
-  long long max_px = 0;
+  long long max_groups = 0;
   for (int i = 0; i < B; ++i) {
     const vitcap_jpeg_info& I = imgs[i].info;
     VC_REQUIRE(info_ok(I), "jpeg_backhalf: image %d carries an inconsistent vitcap_jpeg_info (not from vitcap_jpeg_parse?)", i);
@@ -225,8 +240,8 @@ extern "C" int vitcap_jpeg_backhalf(const vitcap_jpeg_image* imgs, int B, void* 
       memcpy(p.qt[c], I.qt[c], sizeof(p.qt[c]));
     }
     max_blocks = I.nblocks > max_blocks ? I.nblocks : max_blocks;
-    const long long px = (long long)I.width * I.height;
-    max_px = px > max_px ? px : max_px;
+    const long long groups = (long long)((I.width + 3) / 4) * I.height;
+    max_groups = groups > max_groups ? groups : max_groups;
   }
   VC_REQUIRE(off <= workspace_bytes, "jpeg_backhalf: workspace too small (%zu > %zu)", off, workspace_bytes);
   // pinned staging for the plan table (reused; an event guards reuse by the next call on this thread)
@@ -248,7 +263,7 @@ extern "C" int vitcap_jpeg_backhalf(const vitcap_jpeg_image* imgs, int B, void* 
   const JpegPlan* dplans = (const JpegPlan*)workspace;
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)(max_blocks + 255) / 256, B), dim3(256), 0, s, dplans, (uint8_t*)workspace);
   VC_LAUNCH_CHECK("jpeg_idct");
-  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((max_px + 255) / 256), B), dim3(256), 0, s, dplans, (const uint8_t*)workspace);
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((max_groups + 255) / 256), B), dim3(256), 0, s, dplans, (const uint8_t*)workspace);
   VC_LAUNCH_CHECK("jpeg_color");
   return VITCAP_OK;
 }

@@ -36,8 +36,8 @@ class CoefImage(object):
 
 
 def jpeg_backhalf(items, dev, keep):
-    """[CoefImage] -> list of uint8 (H, W, 3) device tensors (enqueued on the current stream).  `keep` collects every buffer that must
-    outlive the kernels."""
+    """[CoefImage] -> list of uint8 (H, pitch) device tensors holding the RGB rows (pitch = 3 W rounded up to 4 bytes; enqueued on the
+    current stream).  `keep` collects every buffer that must outlive the kernels."""
     B = len(items)
     desc = (_JpegImage * B)()
     outs = []
@@ -46,9 +46,10 @@ def jpeg_backhalf(items, dev, keep):
         src = co if (co.flags.writeable and co.flags.c_contiguous) else np.array(co, copy=True, order='C')
         t = torch.from_numpy(src).to(dev, non_blocking=True)
         h, w = int(it.info.height), int(it.info.width)
-        o = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+        pitch = (3 * w + 3) & ~3                  # rows start on a dword: the colour kernel stores 12 bytes as three dwords
+        o = torch.empty((h, pitch), dtype=torch.uint8, device=dev)
         desc[i].info = it.info
-        desc[i].coefs, desc[i].rgb, desc[i].pitch = t.data_ptr(), o.data_ptr(), w * 3
+        desc[i].coefs, desc[i].rgb, desc[i].pitch = t.data_ptr(), o.data_ptr(), pitch
         keep.append(t)
         outs.append(o)
     need = lib.vitcap_jpeg_backhalf_workspace_bytes(desc, B)
@@ -69,7 +70,7 @@ def _device_images(images, dev, keep, desc):
         if i in decoded:
             t = decoded[i]
             keep.append(t)
-            desc[i] = _ImageDesc(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1] * 3)
+            desc[i] = _ImageDesc(t.data_ptr(), int(im.info.height), int(im.info.width), t.shape[1])
             continue
         if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
             raise ValueError('image %d: expected uint8 (H,W,3) RGB or a CoefImage' % i)
