@@ -32,23 +32,26 @@ constexpr int F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, 
               F_2_562915447 = 20995, F_3_072711026 = 25172;
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// v_mul_i32_i24 runs at the full VALU rate (v_mul_lo_u32 at a quarter of it); exact while both operands fit 24 signed bits: constants
+// are < 2^15, dequantised coefficients and first-pass results of a valid stream < 2^16 (libjpeg-turbo's SIMD path keeps them in int16)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
 // one 1-D pass of jpeg_idct_islow: inputs i0..i7 -> o[0..7] descaled by SHIFT
 template <int SHIFT>
 __device__ __forceinline__ void idct_1d(int i0, int i1, int i2, int i3, int i4, int i5, int i6, int i7, int (&o)[8]) {
   int z2 = i2, z3 = i6;
-  int z1 = (z2 + z3) * F_0_541196100;
-  int tmp2 = z1 + z3 * (-F_1_847759065);
-  int tmp3 = z1 + z2 * F_0_765366865;
+  int z1 = mul24(z2 + z3, F_0_541196100);
+  int tmp2 = z1 + mul24(z3, -F_1_847759065);
+  int tmp3 = z1 + mul24(z2, F_0_765366865);
   int tmp0 = (i0 + i4) * (1 << CONST_BITS);
   int tmp1 = (i0 - i4) * (1 << CONST_BITS);
   const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
   tmp0 = i7; tmp1 = i5; tmp2 = i3; tmp3 = i1;
   z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
   int z4 = tmp1 + tmp3;
-  const int z5 = (z3 + z4) * F_1_175875602;
-  tmp0 *= F_0_298631336; tmp1 *= F_2_053119869; tmp2 *= F_3_072711026; tmp3 *= F_1_501321110;
-  z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
+  const int z5 = mul24(z3 + z4, F_1_175875602);
+  tmp0 = mul24(tmp0, F_0_298631336); tmp1 = mul24(tmp1, F_2_053119869); tmp2 = mul24(tmp2, F_3_072711026); tmp3 = mul24(tmp3, F_1_501321110);
+  z1 = mul24(z1, -F_0_899976223); z2 = mul24(z2, -F_2_562915447); z3 = mul24(z3, -F_1_961570560); z4 = mul24(z4, -F_0_390180644);
   z3 += z5; z4 += z5;
   tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
   o[0] = descale(tmp10 + tmp3, SHIFT); o[7] = descale(tmp10 - tmp3, SHIFT);
@@ -63,15 +66,32 @@ __device__ __forceinline__ unsigned range_limit(int x) {
   return (unsigned)(v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896)));
 }
 
-// one thread per 8x8 block: grid (ceil(max blocks / 256), images)
+// one thread per 8x8 block: grid (ceil(max blocks / 256), images).  The 256 blocks of a workgroup are 32 KB of CONTIGUOUS coefficients:
+// they are fetched with fully coalesced 16-byte loads (lane l of an instruction takes chunk l of a 4 KiB run) into LDS, block b at byte
+// 144 b -- the 16 bytes of padding spread a 16-lane group's 16-byte reads of one row over all 64 banks -- and each thread then reads its
+// own block back.  (First form: every lane loaded straight from its own 128-byte line, 64 lines per instruction: 145 us per batch of 64.)
+constexpr int BLK_LDS = 144;
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegPlan* __restrict__ plans, uint8_t* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) char stage[256 * BLK_LDS];
   const JpegPlan& P = plans[blockIdx.y];
-  const int blk = blockIdx.x * 256 + threadIdx.x;
+  const int blk0 = blockIdx.x * 256;
+  if (blk0 >= P.nblocks) return;
+  const int nb = P.nblocks - blk0 < 256 ? P.nblocks - blk0 : 256;
+  {
+    const uint4* src = (const uint4*)(P.coefs + (size_t)blk0 * 64);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int chunk = it * 256 + threadIdx.x;         // 16-byte chunk of the workgroup's run: block chunk / 8, row chunk % 8
+      if (chunk < nb * 8) *(uint4*)(stage + (chunk >> 3) * BLK_LDS + (chunk & 7) * 16) = src[chunk];
+    }
+  }
+  __syncthreads();
+  const int blk = blk0 + threadIdx.x;
   if (blk >= P.nblocks) return;
   const int c = (P.ncomp == 3 && blk >= P.block0[2]) ? 2 : ((P.ncomp == 3 && blk >= P.block0[1]) ? 1 : 0);
   const int local = blk - P.block0[c];
   const int brow = local / P.blocks_w[c], bcol = local - brow * P.blocks_w[c];
-  const uint4* src = (const uint4*)(P.coefs + (size_t)blk * 64);
+  const uint4* src = (const uint4*)(stage + threadIdx.x * BLK_LDS);
   int ws_[8][8];       // workspace after pass 1: [row][col]
   {
     int in[8][8];
@@ -81,8 +101,8 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegPlan* __restri
       const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        in[r][2 * k] = (int)(short)(w4[k] & 0xffffu) * (int)P.qt[c][r * 8 + 2 * k];
-        in[r][2 * k + 1] = (int)(short)(w4[k] >> 16) * (int)P.qt[c][r * 8 + 2 * k + 1];
+        in[r][2 * k] = mul24((int)(short)(w4[k] & 0xffffu), (int)P.qt[c][r * 8 + 2 * k]);
+        in[r][2 * k + 1] = mul24((int)(short)(w4[k] >> 16), (int)P.qt[c][r * 8 + 2 * k + 1]);
       }
     }
 #pragma unroll
@@ -106,34 +126,57 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegPlan* __restri
   }
 }
 
-// chroma sample of output pixel (r, col) from the downsampled plane p (sw x sh real samples, pitch bytes per row)
+__device__ __forceinline__ unsigned clamp255(int v) { return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// Chroma samples of the FOUR output pixels (r, col0 .. col0 + 3), col0 a multiple of 4, from the downsampled plane p (sw x sh real
+// samples).  jdsample.c's first / last column special cases are the general formulas with the missing neighbour replaced by the sample
+// itself -- (3 v + v + 1) >> 2 = v, (3 s + s + 8) >> 4 = (4 s + 8) >> 4 -- so neighbour indices are simply clamped; the rows above the
+// first and below the last real row are copies of that row (jdmainct.c context rows): the row index is clamped as well.
 template <int HS, int VS>
-__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int pitch, int sw, int sh, int r, int col) {
-  if (HS == 1) return p[(size_t)r * pitch + col];
-  const int cc = col >> 1, pc = col & 1;
+__device__ __forceinline__ void chroma4(const uint8_t* __restrict__ p, int pitch, int sw, int sh, int r, int col0, int (&out)[4]) {
+  if (HS == 1) {
+    const unsigned v = *(const unsigned*)(p + (size_t)r * pitch + col0);       // plane pitch is a multiple of 8, col0 of 4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (int)((v >> (8 * k)) & 0xffu);
+    return;
+  }
+  const int cc0 = col0 >> 1;                      // the pixels use chroma columns cc0, cc0 + 1 and their outer neighbours
+  int idx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cc0 - 1 + j;
+    idx[j] = c < 0 ? 0 : (c > sw - 1 ? sw - 1 : c);
+  }
   if (VS == 1) {          // jdsample.c h2v1_fancy_upsample
     const uint8_t* row = p + (size_t)r * pitch;
-    const int v = row[cc];
-    if (pc == 0) return cc == 0 ? v : (3 * v + row[cc - 1] + 1) >> 2;
-    return cc == sw - 1 ? v : (3 * v + row[cc + 1] + 2) >> 2;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = row[idx[j]];
+    // a column past the last real one (odd widths: col0 + 2, + 3 beyond the image) is never stored; its index was clamped
+    out[0] = (3 * v[1] + v[0] + 1) >> 2;
+    out[1] = (3 * v[1] + (cc0 >= sw - 1 ? v[1] : v[2]) + 2) >> 2;
+    out[2] = (3 * v[2] + v[1] + 1) >> 2;
+    out[3] = (3 * v[2] + v[3] + 2) >> 2;
+    return;
   }
-  // h2v2_fancy_upsample: nearest row weighs 3, the next nearest (above for even output rows, below for odd ones) 1; the rows above
-  // the first and below the last real row are copies of that row (jdmainct.c context rows)
+  // h2v2_fancy_upsample: the nearest row weighs 3, the next nearest (above for even output rows, below for odd ones) 1
   const int cr = r >> 1;
   int other = (r & 1) ? cr + 1 : cr - 1;
   other = other < 0 ? 0 : (other > sh - 1 ? sh - 1 : other);
   const uint8_t* r0 = p + (size_t)cr * pitch;
   const uint8_t* r1 = p + (size_t)other * pitch;
-  const int cs = 3 * r0[cc] + r1[cc];
-  if (pc == 0) return cc == 0 ? (cs * 4 + 8) >> 4 : (cs * 3 + (3 * r0[cc - 1] + r1[cc - 1]) + 8) >> 4;
-  return cc == sw - 1 ? (cs * 4 + 7) >> 4 : (cs * 3 + (3 * r0[cc + 1] + r1[cc + 1]) + 7) >> 4;
+  int cs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = 3 * r0[idx[j]] + r1[idx[j]];
+  out[0] = (cs[1] * 3 + cs[0] + 8) >> 4;
+  out[1] = (cs[1] * 3 + (cc0 >= sw - 1 ? cs[1] : cs[2]) + 7) >> 4;
+  out[2] = (cs[2] * 3 + cs[1] + 8) >> 4;
+  out[3] = (cs[2] * 3 + cs[3] + 7) >> 4;
 }
 
-__device__ __forceinline__ unsigned clamp255(int v) { return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
-
 // one thread per FOUR horizontally consecutive output pixels: grid (ceil(max groups / 256), images).  The luma bytes arrive as one aligned
-// dword; with a row pitch that is a multiple of 4 (what vitcap_amd.imageio allocates) the 12 output bytes leave as three dword stores,
-// otherwise -- and for the last, partial group of a row -- byte by byte.
+// dword, the chroma neighbourhood is loaded once for the four pixels; with a row pitch that is a multiple of 4 (what vitcap_amd.imageio
+// allocates) the 12 output bytes leave as three dword stores, otherwise -- and for the last, partial group of a row -- byte by byte.
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegPlan* __restrict__ plans, const uint8_t* __restrict__ ws) {
   const JpegPlan& P = plans[blockIdx.y];
   const int w4 = (P.width + 3) >> 2;
@@ -144,33 +187,32 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegPlan* __restr
   const unsigned y4 = *(const unsigned*)(ws + P.plane_off[0] + (size_t)r * (P.blocks_w[0] * 8) + col0);      // plane pitch is a multiple of 8
   uint8_t* out = P.rgb + (size_t)r * P.pitch + (size_t)col0 * 3;
   unsigned char px[12];
-  const uint8_t* pb = ws + P.plane_off[1];
-  const uint8_t* pr = ws + P.plane_off[2];
-  const int pitch = P.blocks_w[1] * 8, sw = P.samp_w[1], sh = P.samp_h[1];
+  if (P.ncomp == 1) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = (int)((y4 >> (8 * k)) & 0xffu);
-    if (P.ncomp == 1) {
-      px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (unsigned char)y;
-      continue;
-    }
-    const int col = col0 + k < P.width ? col0 + k : P.width - 1;       // (lanes of a partial group recompute the last pixel: never stored)
-    int cb, cr;
+    for (int k = 0; k < 4; ++k) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (unsigned char)((y4 >> (8 * k)) & 0xffu);
+  } else {
+    const uint8_t* pb = ws + P.plane_off[1];
+    const uint8_t* pr = ws + P.plane_off[2];
+    const int pitch = P.blocks_w[1] * 8, sw = P.samp_w[1], sh = P.samp_h[1];
+    int cb[4], cr[4];
     if (P.hs0 == 1) {
-      cb = chroma_at<1, 1>(pb, pitch, sw, sh, r, col);
-      cr = chroma_at<1, 1>(pr, pitch, sw, sh, r, col);
+      chroma4<1, 1>(pb, pitch, sw, sh, r, col0, cb);
+      chroma4<1, 1>(pr, pitch, sw, sh, r, col0, cr);
     } else if (P.vs0 == 1) {
-      cb = chroma_at<2, 1>(pb, pitch, sw, sh, r, col);
-      cr = chroma_at<2, 1>(pr, pitch, sw, sh, r, col);
+      chroma4<2, 1>(pb, pitch, sw, sh, r, col0, cb);
+      chroma4<2, 1>(pr, pitch, sw, sh, r, col0, cr);
     } else {
-      cb = chroma_at<2, 2>(pb, pitch, sw, sh, r, col);
-      cr = chroma_at<2, 2>(pr, pitch, sw, sh, r, col);
+      chroma4<2, 2>(pb, pitch, sw, sh, r, col0, cb);
+      chroma4<2, 2>(pr, pitch, sw, sh, r, col0, cr);
     }
-    // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert: FIX(x) = (int)(x * 65536 + 0.5)
-    const int xb = cb - 128, xr = cr - 128;
-    px[3 * k] = (unsigned char)clamp255(y + ((91881 * xr + 32768) >> 16));
-    px[3 * k + 1] = (unsigned char)clamp255(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
-    px[3 * k + 2] = (unsigned char)clamp255(y + ((116130 * xb + 32768) >> 16));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert: FIX(x) = (int)(x * 65536 + 0.5)
+      const int y = (int)((y4 >> (8 * k)) & 0xffu), xb = cb[k] - 128, xr = cr[k] - 128;
+      px[3 * k] = (unsigned char)clamp255(y + ((91881 * xr + 32768) >> 16));
+      px[3 * k + 1] = (unsigned char)clamp255(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
+      px[3 * k + 2] = (unsigned char)clamp255(y + ((116130 * xb + 32768) >> 16));
+    }
   }
   if (npx == 4 && (P.pitch & 3) == 0 && ((uintptr_t)P.rgb & 3) == 0) {
     unsigned* o32 = (unsigned*)out;
