@@ -134,6 +134,31 @@ def test_gemm_256_tile_heights_bit_identical(ops, variant):
         assert torch.equal(outs[hint], outs[32]), 'tile_hint %d differs from 256-row tiles (%s)' % (hint, variant)
 
 
+@pytest.mark.parametrize('shape', [(36928, 2304, 768, 0), (1000, 256, 768, 0), (20000, 3072, 3072, 1), (73856, 768, 2304, 0), (5000, 3072, 768, 1)],
+                         ids=lambda t: '%dx%dx%d_act%d' % t)
+def test_gemm_4wave_deferred_stores_bit_identical(ops, shape, monkeypatch):
+    """DEFER form of the persistent 4-wave kernel (round 6): the upper half of every wave tile's bf16 stores is parked in registers and
+    issued behind the NEXT tile's first MFMAs (a workgroup's first tile stores nothing parked: zero-record descriptor; its last tile
+    flushes its own half).  Same values to the same addresses: the output must equal the 8-wave kernel's bit for bit -- six rounds of
+    tiles per workgroup, one tile per workgroup (flush path only), K = 3072 with GELU, a ragged last m-tile, and a wider output buffer
+    whose other columns (and the rows behind M) must keep their sentinel."""
+    from vitcap_amd import _lib as L
+    M, N, K, act = shape
+    monkeypatch.setenv('VITCAP_GEMM_4W_DEFER', '2')          # every bf16 shape (the default policy defers plain outputs below 64k rows only)
+    a = _bf(_rand((M, K), 91)).cuda()
+    w = _bf(_rand((N, K), 92, 0.05)).cuda()
+    bias = _rand((N,), 93, 0.1).cuda()
+    outs = {}
+    for hint in (32, 42):
+        big = torch.full((M + 300, N + 64), -7.0, device='cuda', dtype=torch.bfloat16)        # sentinel around the output window
+        ops.gemm_bias_act(a, w, bias, act=L.ACT_GELU_ERF if act else L.ACT_NONE, out=big[:M, :N], tile_hint=hint)
+        outs[hint] = big
+    torch.cuda.synchronize()
+    assert torch.equal(outs[42], outs[32]), 'max |d| %g' % float((outs[42].float() - outs[32].float()).abs().max())
+    assert bool((outs[42][M:] == -7.0).all()) and bool((outs[42][:, N:] == -7.0).all())
+    assert not bool((outs[42][:M, :N] == -7.0).all())
+
+
 @pytest.mark.parametrize('variant', ['bias_bf16', 'gelu_bf16', 'res_f32', 'rowmap_res_f32', 'bias_f32', 'res_bf16', 'k128', 'k3072_res_f32',
                                      'ragged_n', 'strided'])
 def test_gemm_4wave_bit_identical(ops, variant):

@@ -515,6 +515,93 @@ __device__ __forceinline__ void epilogue_regs_fast_x(f32x4 (&acc)[MI][8], const 
   }
 }
 
+// ---- deferred stores (round 6, DEFER forms of the persistent kernel).  The bf16 epilogue spends 6k of its 8.7k (qkv) / 15.5k (fc1)
+// cycles at the ISSUE of its 32 stores per wave (without the stores the same epilogue takes 4.4k and the kernel 140 -> 116 us,
+// docs/LAB_r01_r04.md 4.3).  Here the upper half of the wave tile's m-tiles is converted, packed and PARKED in VGPRs (4 x 16 B per
+// m-tile and lane) instead of being stored, and its stores are issued four per k-tile in the NEXT tile's first k-tiles: same values,
+// same addresses, same order per address -- bit-identical outputs (tests/test_hip_ops.py::test_gemm_4wave_deferred_stores_bit_identical).
+// A workgroup's first tile finds a descriptor of zero records (stores dropped by the range check), its last tile flushes its own
+// parked half.  What it buys is small (see the launcher's policy note): with one wave per SIMD a store's issue stalls the wave -- and
+// the matrix pipe with it -- wherever in the stream it stands.
+template <int MI>
+struct Park {
+  static constexpr int NP = MI / 2;          // parked m-tiles (the upper ones)
+  u32x4_t v[NP * 4];
+  unsigned voff[NP];
+};
+// (the buffer descriptor of the parked stores travels beside the struct, in a variable of its own: inside it hipcc hands the asm
+// statement a VGPR quad for the "s" operand)
+// descriptor of the parked tile's rows, rebuilt where it is used from ONE carried integer (the wave tile's first row, -1 = nothing
+// parked: zero records, every store dropped): a descriptor carried across the tile loop ends up in VGPRs (the kernel runs out of
+// SGPRs) and cannot be an "s" operand
+__device__ __forceinline__ i32x4 park_rsrc(const GemmArgs& p, int park_row) {
+  const int row = __builtin_amdgcn_readfirstlane(park_row);
+  const uint64_t cb = (uint64_t)((const bf16_t*)p.C + (size_t)(row < 0 ? 0 : row) * p.ldc);
+  const long long cbytes = row < 0 ? 0 : (long long)(p.M - row) * p.ldc * 2;
+  const unsigned rec = cbytes <= 0 ? 0u : (cbytes > 0xffffffffll ? 0xffffffffu : (unsigned)cbytes);
+  return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)cb), __builtin_amdgcn_readfirstlane((int)(uint32_t)(cb >> 32)),
+               __builtin_amdgcn_readfirstlane((int)rec), 0x00020000};
+}
+template <int MI, int N>
+__device__ __forceinline__ void store_parked(const Park<MI>& pk, const i32x4& prc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3" ::"v"(pk.v[N]), "v"(pk.voff[N / 4]), "s"(prc), "n"((N % 4) * 64) : "memory");
+}
+template <int MI, int... N>
+__device__ __forceinline__ void store_parked_all(const Park<MI>& pk, const i32x4& prc, std::integer_sequence<int, N...>) {
+  (store_parked<MI, N>(pk, prc), ...);
+}
+
+template <int ACT, int MI>
+__device__ __forceinline__ void epilogue_regs_fast_defer(f32x4 (&acc)[MI][8], const GemmArgs& p, const int row_w, const int col_w, const int lane,
+                                                         Park<MI>& pk) {
+  constexpr int NP = Park<MI>::NP, NI = MI - NP;
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 bias4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias4[j] = p.bias ? *(const f32x4*)(p.bias + col_w + j * 16 + fk * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* cbase = (const bf16_t*)p.C + (size_t)row_w * p.ldc;
+  const long long cbytes = (long long)(p.M - row_w) * p.ldc * 2;
+  const __amdgpu_buffer_rsrc_t rc = rows_rsrc(cbase, cbytes);
+  unsigned voff = (unsigned)(frow * p.ldc + col_w + (fk & 1) * 16 + (fk >> 1) * 8) * 2u;
+  const unsigned istep = 16u * p.ldc * 2u;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (i >= NI) pk.voff[i - NI] = voff;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      f32x4 ve = acc[i][2 * jj] + bias4[2 * jj], vo = acc[i][2 * jj + 1] + bias4[2 * jj + 1];
+      if (ACT == VITCAP_ACT_GELU_ERF) {
+        ve = gelu_erf4(ve);
+        vo = gelu_erf4(vo);
+      }
+      const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[0], ve[1]), pack2bf(vo[0], vo[1]), false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pack2bf(ve[2], ve[3]), pack2bf(vo[2], vo[3]), false, false);
+      const u32x4_t o = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+      if (i < NI) __builtin_amdgcn_raw_buffer_store_b128(o, rc, voff + jj * 64, 0, VC_4W_STORE_AUX);
+      else pk.v[(i - NI) * 4 + jj] = o;
+    }
+    voff += istep;
+  }
+}
+
+// k-tile of the DEFER kernel that issues the parked stores ST0 .. ST0 + 3 of the PREVIOUS output tile behind its first half's MFMAs;
+// the mid-tile wait leaves exactly those four in flight (gfx9 retires VMEM operations in order: everything older -- the pieces of
+// k-tile t + 1 that this rendezvous is about -- has completed when only the four youngest are outstanding)
+template <int MI, int MODE1, bool FIRST, int ST0>
+__device__ __forceinline__ void k_tile_st(f32x4 (&acc)[MI][8], Frags& f, const Loop& L, const Src& src, uint32_t cur, uint32_t kb2, const Park<MI>& pk,
+                                          const GemmArgs& p, int park_row) {
+  const uint32_t nxt = BUF_BYTES - cur;
+  const i32x4 prc = park_rsrc(p, park_row);
+  half_steps<MI, 0, FIRST>(acc, f, L, src, L.a_rd[1] + cur, L.w_rd[1] + cur, 0, 0, std::make_integer_sequence<int, MI * 8>{});
+  store_parked<MI, ST0>(pk, prc);
+  store_parked<MI, ST0 + 1>(pk, prc);
+  store_parked<MI, ST0 + 2>(pk, prc);
+  store_parked<MI, ST0 + 3>(pk, prc);
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  half_steps<MI, MODE1, false>(acc, f, L, src, L.a_rd[0] + nxt, L.w_rd[0] + nxt, cur, kb2, std::make_integer_sequence<int, MI * 8>{});
+  if constexpr (MODE1 != 3 && MODE1 != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // fp32 output and / or residual: each m-tile through the wave's 8 KiB LDS patch (see epilogue_patch), loads and stores by buffer
 // instructions: lane -> columns (lane & 31) * 4 .. +3 of row 2 * it + (lane >> 5), two rows of 512 contiguous bytes per instruction
 template <int ACT, int OUT_F32, bool HAS_RES, int MI>
@@ -755,9 +842,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // tile (buffers keep alternating with the stream position), the register epilogue sits between two k-tiles, and the next tile's
 // k-half-0 fragments were read before it started -- no per-tile prologue (3-7k cycles of exposed DMA latency per tile in the
 // one-tile kernel, stamped), and the epilogue's stores drain behind the next tile's first MFMAs.
-template <int ACT, int OUT_F32, bool HAS_RES, int MI, bool EXTRAS = false, bool PF = false>
+template <int ACT, int OUT_F32, bool HAS_RES, int MI, bool EXTRAS = false, bool PF = false, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_4wp_kernel(GemmArgs p) {
   static_assert(!PF || (!OUT_F32 && !HAS_RES), "the A-panel prefetch needs a scratch line behind the k-tile buffers: bf16-output forms only");
+  static_assert(!DEFER || (!OUT_F32 && !HAS_RES && !EXTRAS && !PF), "deferred stores: plain bf16-output form only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -785,7 +873,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   (void)pf_step;
   f32x4 acc[MI][8];
   Frags f;
-  const int nk = p.K / 64;      // >= 2 (launcher)
+  Park<MI> pk;                  // DEFER: the previous tile's parked stores (first tile: zero records -> every store is dropped)
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int n = 0; n < Park<MI>::NP * 4; ++n) pk.v[n] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int n = 0; n < Park<MI>::NP; ++n) pk.voff[n] = 0u;
+  }
+  int park_row = -1;            // first row of the wave tile whose upper half is parked (-1: nothing parked yet)
+  (void)park_row;
+  const int nk = p.K / 64;      // >= 2 (launcher; DEFER: >= Park::NP + 3)
   constexpr auto PIECES = std::make_integer_sequence<int, MI + 8>{};
   // the only prologue: k-tiles 0 and 1 of the first tile
   dma_tile<MI>(L, src, 0, 0, PIECES);
@@ -833,10 +930,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define PF_ARGS(t_) , nsrc, (uint32_t)(t_) * pf_step
     // k-tiles 0 .. nk-3 request k-tiles 2 .. nk-1 of this tile; k-tiles nk-2, nk-1 request k-tiles 0, 1 of the next tile (nk >= 3)
     STAMP_AT(pos, 0);
-    k_tile<MI, 1, true, PF>(acc, f, L, src, cur, 2 * 128 PF_ARGS(0));
-    cur = BUF_BYTES - cur;
-    STAMP_AT(pos, 1);
-    for (int t = 1; t < nk - 2; ++t) {
+    int t_plain = 1;
+    if constexpr (DEFER) {
+      // k-tiles 0 .. NP-1 issue the previous tile's parked stores, one m-tile (4 stores) each
+      constexpr int NP = Park<MI>::NP;
+      k_tile_st<MI, 1, true, 0>(acc, f, L, src, cur, 2 * 128, pk, p, park_row);
+      cur = BUF_BYTES - cur;
+      STAMP_AT(pos, 1);
+      if constexpr (NP > 1) { k_tile_st<MI, 1, false, 4>(acc, f, L, src, cur, 3 * 128, pk, p, park_row); cur = BUF_BYTES - cur; }
+      if constexpr (NP > 2) { k_tile_st<MI, 1, false, 8>(acc, f, L, src, cur, 4 * 128, pk, p, park_row); cur = BUF_BYTES - cur; }
+      if constexpr (NP > 3) { k_tile_st<MI, 1, false, 12>(acc, f, L, src, cur, 5 * 128, pk, p, park_row); cur = BUF_BYTES - cur; }
+      t_plain = NP;
+    } else {
+      k_tile<MI, 1, true, PF>(acc, f, L, src, cur, 2 * 128 PF_ARGS(0));
+      cur = BUF_BYTES - cur;
+      STAMP_AT(pos, 1);
+    }
+    for (int t = t_plain; t < nk - 2; ++t) {
       k_tile<MI, 1, false, PF>(acc, f, L, src, cur, (uint32_t)(t + 2) * 128 PF_ARGS(t));
       cur = BUF_BYTES - cur;
     }
@@ -858,11 +968,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else
     {
       if constexpr (EXTRAS) epilogue_regs_fast_x<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
+      else if constexpr (DEFER) {
+        park_row = m0 + (w >> 1) * (16 * MI);
+        epilogue_regs_fast_defer<ACT, MI>(acc, p, park_row, n0 + (w & 1) * 128, lane, pk);
+      }
       else epilogue_regs_fast<ACT, MI>(acc, p, m0 + (w >> 1) * (16 * MI), n0 + (w & 1) * 128, lane);
     }
 #endif
     STAMP_AT(pos, 3);
-    if (!more) break;
+    if (!more) {
+      if constexpr (DEFER) store_parked_all<MI>(pk, park_rsrc(p, park_row), std::make_integer_sequence<int, Park<MI>::NP * 4>{});      // the last tile flushes its own parked half
+      break;
+    }
     pos = npos;
     src = nsrc;
     // the next tile's k-tile 0 landed before the last mid-tile barrier: its k-half-0 fragments
@@ -945,6 +1062,24 @@ int launch_4w_mi(GemmArgs& p, hipStream_t s, int form) {
       // siblings, requested one per k-tile bring it to 29.7k (qkv +3.6 %, fc1 +2.1 % wall at M = 295 424, docs/LAB_r05.md section 1).
       // Below the threshold the operands are cache-resident and the extra instruction only costs (+0.8 % loop cycles): plain form.
       // VITCAP_GEMM_4W_PF: 0 = never, N > 1 = from N rows on (default 65536).
+      // deferred stores (round 6): the upper half of every wave tile's stores ride behind the next tile's first k-tiles.  Measured
+      // (profiles/r06_deferred_stores.txt): the epilogue shrinks as priced (qkv 8.7k -> 6.2k cycles per tile), but with ONE wave per
+      // SIMD a store's issue (~150 cycles each) stalls the wave wherever it stands, so the next tile's loop pays what the epilogue
+      // saved (25.3k -> 27.2k + 0.7k): a tie without an activation (qkv 138.9 -> 138.3 us, the training step 49.63 -> 49.23 ms),
+      // a loss with GELU (fc1 211.8 -> 221.0 us: its stores were already hidden behind the activation's arithmetic) and from 64k rows
+      // on, where the parked stores compete with the A panel's HBM stream (qkv 1 080 -> 1 153 us; B = 512 pipeline 4 160 -> 4 064
+      // img/s).  Policy: plain bf16 outputs below 64k rows.  VITCAP_GEMM_4W_DEFER: 0 = never, 1 = that policy (default), 2 = always.
+      {
+        const char* de = getenv("VITCAP_GEMM_4W_DEFER");      // read per launch (not cached): the parity test switches it
+        const int defer = de ? atoi(de) : 1;
+        const bool want = defer == 2 || (defer == 1 && ACT == VITCAP_ACT_NONE && p.M < 65536);
+        if (!launched && want && p.K / 64 >= Park<MI>::NP + 3) {
+          auto kern = gemm_nt_4wp_kernel<ACT, OUT_F32, HAS_RES, MI, false, false, true>;
+          VC_FUNC_SMEM(kern, smem);
+          VC_LAUNCH_GEMM(kern, dim3(grid), dim3(256), smem, s, p);
+          launched = true;
+        }
+      }
       if constexpr (MI == 8) {
         static const int pf_rows = [] { const char* e = getenv("VITCAP_GEMM_4W_PF"); return e ? atoi(e) : 65536; }();
         if (!launched && pf_rows > 0 && p.M >= pf_rows && p.tiles_m > 1) {
