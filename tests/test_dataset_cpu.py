@@ -56,9 +56,20 @@ def test_samples_and_loader(tmp_path, with_num):
     idx = CaptionIdx(str(tmp_path), 'toy', 'train')
     assert len(idx) == n and idx[0] == ('k0', 0, 0) and idx[2] == ('k1', 1, 1)
     tz = CaptionTensorizer(tok, max_seq_length=70, max_seq_a_length=20, is_train=True)
-    ds = CaptionTrainSet(str(tmp_path), 'toy', tz, TagLabelTensorizer(tok, encode='bert'), label_version='vinvl')
+    ds = CaptionTrainSet(str(tmp_path), 'toy', tz, TagLabelTensorizer(tok, encode='bert'), label_version='vinvl', device_jpeg=False)
     s = ds.sample(2, epoch=0)
     assert s['rgb'].dtype == np.uint8 and s['rgb'].ndim == 3 and s['key'] == 'k1'
+    # default (round 6): a baseline JPEG leaves the sample only ENTROPY-decoded (the GPU finishes it, imageio.TrainImagePreprocessor);
+    # the augmentation is drawn from the same image size, so every other field of the sample is unchanged
+    from vitcap_amd.imageio import CoefImage
+    from vitcap_amd.jpegdec import jpeg_lib
+    if jpeg_lib() is not None:
+        ds_c = CaptionTrainSet(str(tmp_path), 'toy', tz, TagLabelTensorizer(tok, encode='bert'), label_version='vinvl')
+        sc = ds_c.sample(2, epoch=0)
+        assert isinstance(sc['rgb'], CoefImage) and sc['rgb'].shape == s['rgb'].shape and sc['aug'] == s['aug']
+        assert torch.equal(sc['input_ids'], s['input_ids']) and torch.equal(sc['label'], s['label'])
+        from oracle import jpeg_backhalf as JO
+        assert np.array_equal(JO.backhalf(sc['rgb'].info, sc['rgb'].coefs), s['rgb'])
     assert s['input_ids'].shape == (70,) and s['attention_mask'].shape == (70, 70) and s['masked_ids'].shape == (3,)
     assert s['token_type_ids'].shape == (70,) and 'segment_ids' not in s
     assert int(s['input_ids'][0]) == tok.vocab['[CLS]'] and int(s['masked_pos'].sum()) == int((s['masked_ids'] != 0).sum())
