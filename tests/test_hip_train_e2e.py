@@ -396,6 +396,13 @@ def _dp_worker(rank, world, port, out, tmp, path='train_step'):
     b['image'] = img[sl].contiguous().cuda()
     if path == 'train_step':
         res = eng.train_step(b)
+    elif path == 'graph':
+        # graph mode under a REAL gradient exchange (2 ranks): the warm-up pass runs without collectives, the step replays 4 captured
+        # segments and starts each segment's buckets behind it -- both ranks must issue the same collectives (a mismatch hangs the test)
+        eng.use_graphs = True
+        res = eng.train_step(b)
+        entry, = eng._graphs.values()
+        assert len(entry['segs']) == 4 and entry['reserved_cus'] == eng.reducer.reserve_cus
     else:
         # the documented trainer contract (do_train_dict, trainer.py:112-131): loss_dict = model(data); losses.backward();
         # optimizer.step() -- backward() must join the bucketed all-reduce before anything else touches the gradients
@@ -414,7 +421,7 @@ def _dp_worker(rank, world, port, out, tmp, path='train_step'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('path', ['train_step', 'loss_dict'])
+@pytest.mark.parametrize('path', ['train_step', 'loss_dict', 'graph'])
 def test_two_process_data_parallel_step(tmp_path, path):
     """The DP path as the driver launches it (one process per rank, bucketed all-reduce on the side stream behind the
     backward pass), here with 2 ranks on ONE GPU over gloo: after one step both ranks hold the same parameters, equal
