@@ -30,6 +30,15 @@ constexpr int KT = 64;          // keys per tile
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+typedef __attribute__((ext_vector_type(4))) int attn_i32x4;
+// one LDS-DMA piece through a buffer descriptor: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS byte address `lds`; global address =
+// descriptor base + per-lane voff + scalar soff.  Against glds16 (64-bit per-lane addresses) the per-tile address arithmetic moves from
+// 8 v_lshl_add_u64 + 2 v_mad_i64_i32 per key tile to scalar adds (round 6: the loop is bound by vector-ALU issue and by the board's power).
+__device__ __forceinline__ void bufdma16(uint32_t lds, uint32_t voff, const attn_i32x4& rsrc, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
@@ -123,15 +132,19 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
   const int srow = w * 8 + (lane >> 3);                          // (row + 32 has the same swizzle)
   const uint32_t s_off = (uint32_t)(srow * QKV_LD + 768) * 2u + (uint32_t)(((lane & 7) ^ kv_swz(srow)) * 16);
   const char* gbase = (const char*)base;
+  // descriptor over this (image, head)'s rows (unbounded range: full tiles never leave the image's rows)
+  const uint64_t gb64 = (uint64_t)gbase;
+  const attn_i32x4 kv_rsrc = attn_i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)gb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(gb64 >> 32)),
+                                        -1, 0x00020000};
 #define STAGE_TILE(t_, stg_)                                                                                    \
   do {                                                                                                          \
     char* sb_ = smem + (stg_) * STG_B + w * 1024;                                                               \
     if ((t_) < nfull) {                                                                                         \
-      const char* tb_ = gbase + (size_t)(t_) * (KT * QKV_LD * 2) + s_off;                                       \
-      glds16(tb_, sb_);                                                                                         \
-      glds16(tb_ + 32 * QKV_LD * 2, sb_ + 4096);                                                                \
-      glds16(tb_ + 768 * 2, sb_ + TILE_B);                                                                      \
-      glds16(tb_ + 768 * 2 + 32 * QKV_LD * 2, sb_ + TILE_B + 4096);                                             \
+      const uint32_t so_ = (uint32_t)(t_) * (uint32_t)(KT * QKV_LD * 2), sl_ = lds_addr(sb_);                   \
+      bufdma16(sl_, s_off, kv_rsrc, so_);                                                                       \
+      bufdma16(sl_ + 4096, s_off, kv_rsrc, so_ + 32 * QKV_LD * 2);                                              \
+      bufdma16(sl_ + TILE_B, s_off, kv_rsrc, so_ + 768 * 2);                                                    \
+      bufdma16(sl_ + TILE_B + 4096, s_off, kv_rsrc, so_ + 768 * 2 + 32 * QKV_LD * 2);                           \
     } else { /* tail tile: rows past the sequence re-read its last row (their scores are masked) */            \
       const int r0_ = (t_) * KT + srow, r1_ = r0_ + 32;                                                         \
       const uint32_t c_ = (uint32_t)(768 * 2 + ((lane & 7) ^ kv_swz(srow)) * 16);                               \
@@ -279,12 +292,15 @@ __global__ __launch_bounds__(256, VC_ATTN_MINW) void attn_dense_kernel(const bf1
         }                                                                                                       \
     }                                                                                                           \
     /* running max on the raw scores (scale > 0), integer ceiling in the log2 domain */                         \
-    float mx0 = fmaxf(st[0][0], st[1][0]), mx1 = fmaxf(st[0][1], st[1][1]);                                     \
-    _Pragma("unroll") for (int r = 2; r < 16; r += 2) {                                                         \
-      mx0 = fmaxf(mx0, fmaxf(st[0][r], st[1][r]));                                                              \
-      mx1 = fmaxf(mx1, fmaxf(st[0][r + 1], st[1][r + 1]));                                                      \
+    /* 32 scores -> 16 v_max3 / v_max in a tree (max is exact: any order gives the same value) */               \
+    float ma_[5], mb_[5];                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                                          \
+      ma_[i_] = max3f(st[0][3 * i_], st[0][3 * i_ + 1], st[0][3 * i_ + 2]);                                     \
+      mb_[i_] = max3f(st[1][3 * i_], st[1][3 * i_ + 1], st[1][3 * i_ + 2]);                                     \
     }                                                                                                           \
-    float mx = fmaxf(mx0, mx1);                                                                                 \
+    const float mc0_ = max3f(ma_[0], ma_[1], ma_[2]), mc1_ = max3f(ma_[3], ma_[4], st[0][15]);                   \
+    const float mc2_ = max3f(mb_[0], mb_[1], mb_[2]), mc3_ = max3f(mb_[3], mb_[4], st[1][15]);                   \
+    float mx = fmaxf(max3f(mc0_, mc1_, mc2_), mc3_);                                                            \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                     \
     const float m_new = fmaxf(m_i, ceilf(mx * c_log2));                                                         \
     if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0) { /* rare after the first tiles: integer steps */       \
