@@ -43,9 +43,7 @@ PMC_KERNEL = {3: 'void gemm_nt_256_kernel<0, 1, true, 4, 0>', 0: 'void gemm_nt_2
               4: 'void gemm_nt_256_kernel<1, 0, false, 4, 0>'}
 # the 4-wave persistent kernels of the same variants (one-stream runs, and the pipeline from 8 rounds of tiles on): <activation, fp32
 # output, residual, m-tiles of 16 rows per wave> -- the B = 64 file holds the 224-row forms, the B = 512 file the 256-row ones
-PMC_KERNEL_4W = {3: ['void gemm_nt_4wp_kernel<0, 1, true, 7>', 'void gemm_nt_4wp_kernel<0, 1, true, 8>'],
-                 0: ['void gemm_nt_4wp_kernel<0, 0, false, 7>', 'void gemm_nt_4wp_kernel<0, 0, false, 8>'],
-                 4: ['void gemm_nt_4wp_kernel<1, 0, false, 8>']}
+PMC_KERNEL_4W = {3: 'void gemm_nt_4wp_kernel<0, 1, true, ', 0: 'void gemm_nt_4wp_kernel<0, 0, false, ', 4: 'void gemm_nt_4wp_kernel<1, 0, false, '}      # name prefixes
 VARIANT_NAMES = {0: 'gemm_nt_256<256x256x64,bias,bf16>', 1: 'gemm_nt_256<256x256x64,bias+res,bf16>',
                  2: 'gemm_nt_256<256x256x64,bias,f32>', 3: 'gemm_nt_256<256x256x64,bias+residual,f32>',
                  4: 'gemm_nt_256<256x256x64,bias+gelu,bf16>', 6: 'gemm_nt_256<256x256x64,bias+gelu,f32>'}
@@ -592,7 +590,7 @@ def main():
         tfile = TRAFFIC_FILE if B < 256 else TRAFFIC_FILE.replace('.json', '_b512.json')
         with open(tfile) as f:
             tab = json.load(f)
-        names = PMC_KERNEL_4W[dom] if four_wave else [PMC_KERNEL[dom]]
+        names = [n for n in tab if n.startswith(PMC_KERNEL_4W[dom])] if four_wave else [PMC_KERNEL[dom]]
         traffic = max((tab[n] for n in names if n in tab), key=lambda e: e['launches'])['hbm_bytes_per_launch_corrected']
         if B not in (64, 512):
             traffic = None          # the committed passes are B = 64 and B = 512 runs

@@ -37,20 +37,50 @@ class CoefImage(object):
 
 def jpeg_backhalf(items, dev, keep):
     """[CoefImage] -> list of uint8 (H, pitch) device tensors holding the RGB rows (pitch = 3 W rounded up to 4 bytes; enqueued on the
-    current stream).  `keep` collects every buffer that must outlive the kernels."""
+    current stream).  `keep` collects every buffer that must outlive the kernels.
+    Host work per batch is kept small (the loader's producer thread shares the GIL with the caption launcher): coefficient arrays that sit
+    back to back in host memory -- the images of one worker task inside its shared-memory slab -- travel in ONE host -> device copy, and
+    the RGB images are slices of one allocation."""
     B = len(items)
     desc = (_JpegImage * B)()
-    outs = []
-    for i, it in enumerate(items):
-        co = it.coefs
-        src = co if (co.flags.writeable and co.flags.c_contiguous) else np.array(co, copy=True, order='C')
+    # ---- host -> device: runs of adjacent arrays (gaps < 64 B: the slab's 16-byte alignment padding) as single copies
+    addr = [it.coefs.ctypes.data for it in items]
+    nbyt = [it.coefs.nbytes for it in items]
+    dptr = [0] * B
+    i = 0
+    while i < B:
+        j = i
+        ok = items[i].coefs.flags.c_contiguous
+        while ok and j + 1 < B and items[j + 1].coefs.flags.c_contiguous and 0 <= addr[j + 1] - (addr[j] + nbyt[j]) < 64:
+            j += 1
+        if not ok:
+            src = np.array(items[i].coefs, copy=True, order='C').view(np.uint8).reshape(-1)
+        elif j == i and items[i].coefs.flags.writeable:
+            src = items[i].coefs.view(np.uint8).reshape(-1)
+        else:       # one flat view over the whole run (the memory belongs to the items' base buffer, which the caller keeps alive)
+            span = addr[j] + nbyt[j] - addr[i]
+            src = np.ctypeslib.as_array((C.c_uint8 * span).from_address(addr[i]))
+            keep.append([it.coefs for it in items[i:j + 1]])
         t = torch.from_numpy(src).to(dev, non_blocking=True)
+        keep.append(t)
+        base = t.data_ptr()
+        for k in range(i, j + 1):
+            dptr[k] = base + (addr[k] - addr[i])
+        i = j + 1
+    # ---- outputs: one allocation, 256-byte aligned slices
+    geo, total = [], 0
+    for it in items:
         h, w = int(it.info.height), int(it.info.width)
         pitch = (3 * w + 3) & ~3                  # rows start on a dword: the colour kernel stores 12 bytes as three dwords
-        o = torch.empty((h, pitch), dtype=torch.uint8, device=dev)
-        desc[i].info = it.info
-        desc[i].coefs, desc[i].rgb, desc[i].pitch = t.data_ptr(), o.data_ptr(), pitch
-        keep.append(t)
+        geo.append((total, h, pitch))
+        total += (h * pitch + 255) & ~255
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    keep.append(buf)
+    outs = []
+    for k, (it, (off, h, pitch)) in enumerate(zip(items, geo)):
+        o = buf[off:off + h * pitch].view(h, pitch)
+        desc[k].info = it.info
+        desc[k].coefs, desc[k].rgb, desc[k].pitch = dptr[k], o.data_ptr(), pitch
         outs.append(o)
     need = lib.vitcap_jpeg_backhalf_workspace_bytes(desc, B)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
