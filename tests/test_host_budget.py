@@ -50,3 +50,16 @@ def test_role_streams_are_created_once_per_device_and_role():
     b = role_stream('cuda:3', 'test-role-b', make)
     c = role_stream('cuda:4', 'test-role-a', make)
     assert b is not a and c is not a and len(made) == 3
+
+
+def test_bench_power_sampler_summary():
+    """bench.py's energy fields: joules_per_step = median board power x the energy pass's time per step; fewer than three
+    rocm-smi readings (no tool, no permission) leave the object null instead of inventing a number."""
+    import bench
+    ps = bench.PowerSampler()
+    assert ps.summary(16.0) is None
+    ps.samples = [(2100.0, 1350.0), (2150.0, 1380.0), (2200.0, 1400.0), (2000.0, 1300.0), (2180.0, 1379.0)]
+    s = ps.summary(16.0)
+    assert s['board_power_w_median'] == 1379.0 and s['board_power_w_max'] == 1400.0 and s['sclk_mhz_median'] == 2150.0
+    assert abs(s['joules_per_step'] - 1379.0 * 16.0e-3) < 1e-3 and s['samples'] == 5
+    assert bench.PowerSampler.read() is None or len(bench.PowerSampler.read()) == 2      # no rocm-smi here -> None, never an exception
